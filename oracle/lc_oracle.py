@@ -1,0 +1,669 @@
+"""CPU oracle for the libcluster variational E-step / suff-stat hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing in the product path (``libcluster_amd/``,
+the C-ABI library) may import, call or link this file.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg use it, and
+only as the checker.
+
+PARITY UNPINNED: the reference (dsteinberg/libcluster) cannot be compiled in
+this image (every translation unit needs Eigen 3 and Boost.Math, neither is
+installed and there is no network) and its tests hold no golden values or
+assertions (test/cluster_test.cpp:38-69 only prints).  This file is a numpy /
+scipy *restatement* of the reference arithmetic, line by line, each function
+citing the reference file:line it follows.  What pins it instead:
+  * ``scikit-learn``'s ``BayesianGaussianMixture`` private E-step, which
+    implements the same Bishop PRML 10.2 expectations
+    (tests/test_oracle.py::test_eloglike_matches_sklearn);
+  * ``scipy.special.digamma/gammaln`` for the special functions Boost.Math
+    provides in the reference;
+  * the reference's own test data (test/testdata.h, re-typed as
+    tests/golden/xcat.json) with end-to-end traces committed as fixtures.
+
+All arithmetic is IEEE double, like the reference.  Matrices are numpy
+row-major ``(N, D)`` arrays; groups are python lists of such arrays.
+"""
+from __future__ import annotations
+
+import math
+import sys
+
+import numpy as np
+from scipy.special import digamma, gammaln
+
+# --- constants: include/libcluster.h:122-127 (note the *float* literals) ---
+PRIORVAL = 1.0
+TRUNC = 100
+SPLITITER = 15
+CONVERGE = float(np.float32(1e-5))
+FENGYDEL = CONVERGE / 10
+ZEROCUTOFF = float(np.float32(0.1))
+# include/distributions.h:39-43
+BETAPRIOR = 1.0
+NUPRIOR = 1.0
+ALPHA1PRIOR = 1.0
+ALPHA2PRIOR = 1.0
+# src/probutils.cpp:39-40
+EIGCONTHRESH = float(np.float32(1.0e-8))
+MAXITER = 100
+
+
+# ---------------------------------------------------------------------------
+# probutils
+# ---------------------------------------------------------------------------
+
+def logdet(A):
+    """ln det(A) for SPD A -- src/probutils.cpp:189-202 (LDLT diag there)."""
+    A = np.asarray(A, dtype=np.float64)
+    if A.shape[0] != A.shape[1]:
+        raise ValueError("Matrix A must be square!")
+    try:
+        L = np.linalg.cholesky(A)
+    except np.linalg.LinAlgError as e:  # reference: domain_error
+        raise ArithmeticError("Matrix A is not positive definite.") from e
+    return 2.0 * float(np.sum(np.log(np.diag(L))))
+
+
+def mahaldist(X, mu, A):
+    """(x-mu)^T A^-1 (x-mu) per row -- src/probutils.cpp:113-138."""
+    X = np.atleast_2d(np.asarray(X, dtype=np.float64))
+    mu = np.asarray(mu, dtype=np.float64).reshape(-1)
+    A = np.asarray(A, dtype=np.float64)
+    if X.shape[1] != mu.shape[0] or X.shape[1] != A.shape[1]:
+        raise ValueError("Arguments do not have the same dimensionality")
+    if A.shape[0] != A.shape[1]:
+        raise ValueError("Matrix A must be square!")
+    try:
+        L = np.linalg.cholesky(A)
+    except np.linalg.LinAlgError as e:
+        raise ValueError("Matrix A is not positive definite") from e
+    X_mu = (X - mu).T  # D x N, probutils.cpp:135
+    sol = np.linalg.solve(L.T, np.linalg.solve(L, X_mu))  # A^-1 X_mu, :136
+    return np.sum(X_mu * sol, axis=0)
+
+
+def logsumexp(X):
+    """Row-wise log-sum-exp -- src/probutils.cpp:141-150."""
+    X = np.asarray(X, dtype=np.float64)
+    if X.shape[0] == 0:
+        return np.zeros(0)
+    mx = X.max(axis=1)
+    se = np.exp(X - mx[:, None]).sum(axis=1)
+    return np.log(se) + mx
+
+
+def eigpower(A):
+    """Power method principal eigenpair -- src/probutils.cpp:153-186."""
+    A = np.asarray(A, dtype=np.float64)
+    if A.shape[0] != A.shape[1]:
+        raise ValueError("Matrix A must be square!")
+    n = A.shape[0]
+    if n == 1:
+        return float(A[0, 0]), np.ones(1)
+    v = np.linspace(-1.0, 1.0, n)
+    eigval = float(np.linalg.norm(v))
+    eigvec = v / eigval
+    vdist = math.inf
+    i = 0
+    while vdist > EIGCONTHRESH and i < MAXITER:
+        oeigvec = eigvec
+        v = A @ oeigvec
+        eigval = float(np.linalg.norm(v))
+        eigvec = v / eigval
+        vdist = float(np.linalg.norm(eigvec - oeigvec))
+        i += 1
+    return eigval, eigvec
+
+
+def enumdims(D):
+    """1..D -- src/distributions.cpp:66-76."""
+    return np.arange(1, D + 1, dtype=np.float64) if D > 1 else np.ones(1)
+
+
+# ---------------------------------------------------------------------------
+# weight distributions
+# ---------------------------------------------------------------------------
+
+class Dirichlet:
+    """src/distributions.cpp:222-266, include/distributions.h:163-189."""
+
+    def __init__(self, alpha=ALPHA1PRIOR):
+        if alpha <= 0:
+            raise ValueError("Alpha prior must be > 0!")
+        self.alpha_p = float(alpha)
+        self.alpha = np.full(1, self.alpha_p)
+        self.E_logpi = np.zeros(1)
+        self.Nk = np.zeros(1)  # WeightDist(), distributions.h:94
+
+    def update(self, Nk):  # :242-256
+        Nk = np.asarray(Nk, dtype=np.float64).reshape(-1)
+        self.Nk = Nk.copy()
+        self.alpha = self.alpha_p + Nk
+        self.E_logpi = digamma(self.alpha) - digamma(self.alpha.sum())
+
+    def Elogweight(self):
+        return self.E_logpi
+
+    def getNk(self):
+        return self.Nk
+
+    def fenergy(self):  # :259-266
+        K = self.alpha.size
+        return float(
+            gammaln(self.alpha.sum())
+            - (self.alpha_p - 1) * self.E_logpi.sum()
+            + ((self.alpha - 1) * self.E_logpi - gammaln(self.alpha)).sum()
+            - gammaln(K * self.alpha_p)
+            + K * gammaln(self.alpha_p)
+        )
+
+
+class StickBreak:
+    """src/distributions.cpp:83-179, include/distributions.h:103-140."""
+
+    def __init__(self, concentration=ALPHA1PRIOR):
+        if concentration <= 0:
+            raise ValueError("Concentration parameter has to be > 0!")
+        self.alpha1_p = float(concentration)
+        self.alpha2_p = ALPHA2PRIOR
+        self.alpha1 = np.full(1, self.alpha1_p)
+        self.alpha2 = np.full(1, self.alpha2_p)
+        self.E_logv = np.zeros(1)
+        self.E_lognv = np.zeros(1)
+        self.E_logpi = np.zeros(1)
+        self.order = [0]
+        self.Nk = np.zeros(1)
+        # priorfcalc, :116-121
+        self.F_p = float(
+            gammaln(self.alpha1_p) + gammaln(self.alpha2_p)
+            - gammaln(self.alpha1_p + self.alpha2_p)
+        )
+
+    def update(self, Nk):  # :124-168
+        Nk = np.asarray(Nk, dtype=np.float64).reshape(-1)
+        K = Nk.size
+        self.Nk = Nk.copy()
+        self.alpha1 = self.alpha1_p + Nk
+        self.alpha2 = np.empty(K)
+        self.E_logv = np.empty(K)
+        self.E_lognv = np.empty(K)
+        self.E_logpi = np.empty(K)
+        # descending by size (:141-146).  std::sort is unstable in the
+        # reference; a stable sort is used here, ties keep index order.
+        self.order = sorted(range(K), key=lambda k: -Nk[k])
+        N = Nk.sum()
+        cumNk = 0.0
+        cumE_lognv = 0.0
+        for k in self.order:
+            cumNk += Nk[k]
+            self.alpha2[k] = self.alpha2_p + (N - cumNk)
+            psisum = digamma(self.alpha1[k] + self.alpha2[k])
+            self.E_logv[k] = digamma(self.alpha1[k]) - psisum
+            self.E_lognv[k] = digamma(self.alpha2[k]) - psisum
+            self.E_logpi[k] = self.E_logv[k] + cumE_lognv
+            cumE_lognv += self.E_lognv[k]
+
+    def Elogweight(self):
+        return self.E_logpi
+
+    def getNk(self):
+        return self.Nk
+
+    def fenergy(self):  # :171-179
+        K = self.alpha1.size
+        return float(
+            K * self.F_p
+            + (
+                gammaln(self.alpha1 + self.alpha2)
+                - gammaln(self.alpha1)
+                - gammaln(self.alpha2)
+                + (self.alpha1 - self.alpha1_p) * self.E_logv
+                + (self.alpha2 - self.alpha2_p) * self.E_lognv
+            ).sum()
+        )
+
+
+class GDirichlet(StickBreak):
+    """src/distributions.cpp:186-215 (default-constructed only)."""
+
+    def __init__(self):
+        super().__init__()
+
+    def update(self, Nk):  # :186-196
+        super().update(Nk)
+        smallk = self.order[-1]
+        self.E_logpi[smallk] = self.E_logpi[smallk] - self.E_logv[smallk]
+        self.E_logv[smallk] = 0.0
+        self.E_lognv[smallk] = 0.0
+
+    def fenergy(self):  # :199-215
+        K = len(self.order)
+        Fpi = 0.0
+        for k in self.order[: K - 1]:
+            Fpi += (
+                gammaln(self.alpha1[k] + self.alpha2[k])
+                - gammaln(self.alpha1[k])
+                - gammaln(self.alpha2[k])
+                + (self.alpha1[k] - self.alpha1_p) * self.E_logv[k]
+                + (self.alpha2[k] - self.alpha2_p) * self.E_lognv[k]
+            )
+        return float((K - 1) * self.F_p + Fpi)
+
+
+# ---------------------------------------------------------------------------
+# cluster distribution
+# ---------------------------------------------------------------------------
+
+class GaussWish:
+    """src/distributions.cpp:273-399, include/distributions.h:279-337."""
+
+    def __init__(self, clustwidth, D):
+        if clustwidth <= 0:
+            raise ValueError("clustwidth must be > 0!")
+        self.D = int(D)
+        self.prior = float(clustwidth)
+        self.N = 0.0
+        self.nu_p = float(D)
+        self.beta_p = BETAPRIOR
+        self.m_p = np.zeros(D)
+        self.iW_p = self.nu_p * self.prior * np.eye(D)  # :286
+        self.logdW_p = -logdet(self.iW_p)
+        self.F_p = float(gammaln((self.nu_p + 1 - enumdims(D)) / 2).sum())  # :294
+        self.clearobs()
+
+    def clearobs(self):  # :340-353
+        self.nu = self.nu_p
+        self.beta = self.beta_p
+        self.m = self.m_p.copy()
+        self.iW = self.iW_p.copy()
+        self.logdW = self.logdW_p
+        self.N_s = 0.0
+        self.x_s = np.zeros(self.D)
+        self.xx_s = np.zeros((self.D, self.D))
+
+    def addobs(self, qZk, X):  # :301-313
+        X = np.asarray(X, dtype=np.float64)
+        qZk = np.asarray(qZk, dtype=np.float64).reshape(-1)
+        if X.shape[1] != self.D:
+            raise ValueError("Mismatched dims. of cluster params and obs.!")
+        if qZk.shape[0] != X.shape[0]:
+            raise ValueError("qZk and X ar not the same length!")
+        qZkX = qZk[:, None] * X
+        self.N_s += qZk.sum()
+        self.x_s = self.x_s + qZkX.sum(axis=0)
+        self.xx_s = self.xx_s + qZkX.T @ X
+
+    def addstats(self, N_s, x_s, xx_s):
+        """Not in the reference: inject already-reduced statistics (what the
+        device kernels return); equals a sequence of addobs calls."""
+        self.N_s += float(N_s)
+        self.x_s = self.x_s + np.asarray(x_s, dtype=np.float64)
+        self.xx_s = self.xx_s + np.asarray(xx_s, dtype=np.float64)
+
+    def update(self):  # :316-337
+        xk = np.zeros(self.D)
+        if self.N_s > 0:
+            xk = self.x_s / self.N_s
+        Sk = self.xx_s - np.outer(xk, self.x_s)
+        xk_m = xk - self.m_p
+        self.N = self.N_s
+        self.nu = self.nu_p + self.N
+        self.beta = self.beta_p + self.N
+        self.m = (self.beta_p * self.m_p + self.x_s) / self.beta
+        self.iW = self.iW_p + Sk + (self.beta_p * self.N / self.beta) * np.outer(xk_m, xk_m)
+        try:
+            self.logdW = -logdet(self.iW)
+        except ArithmeticError as e:
+            raise RuntimeError("Calc log(det(W)): " + str(e)) from e
+
+    def sumpsi(self):
+        return float(digamma((self.nu + 1 - enumdims(self.D)) / 2).sum())
+
+    def Eloglike(self, X):  # :356-370
+        X = np.atleast_2d(np.asarray(X, dtype=np.float64))
+        return 0.5 * (
+            self.sumpsi()
+            + self.logdW
+            - self.D * (1 / self.beta + math.log(math.pi))
+            - self.nu * mahaldist(X, self.m, self.iW)
+        )
+
+    def splitobs(self, X):  # :373-385
+        _, eigvec = eigpower(self.iW)
+        X = np.atleast_2d(np.asarray(X, dtype=np.float64)).reshape(-1, self.D)
+        return ((X - self.m) * eigvec).sum(axis=1) >= 0
+
+    def fenergy(self):  # :388-399
+        l = enumdims(self.D)
+        sumpsi = float(digamma((self.nu + 1 - l) / 2).sum())
+        tr = float(np.trace(np.linalg.solve(self.iW, self.iW_p)))
+        maha = float(mahaldist(self.m[None, :], self.m_p, self.iW)[0])
+        return float(
+            self.F_p
+            + (
+                self.D * (self.beta_p / self.beta - 1 - self.nu - math.log(self.beta_p / self.beta))
+                + self.nu * (tr + self.beta_p * maha)
+                + self.nu_p * (self.logdW_p - self.logdW)
+                + self.N * sumpsi
+            )
+            / 2
+            - gammaln((self.nu + 1 - l) / 2).sum()
+        )
+
+    def getN(self):
+        return self.N
+
+    def getprior(self):
+        return self.prior
+
+    def getmean(self):
+        return self.m
+
+    def getcov(self):
+        return self.iW / self.nu
+
+
+# ---------------------------------------------------------------------------
+# comutils
+# ---------------------------------------------------------------------------
+
+def partobs(X, Xpart):
+    """src/comutils.cpp:56-72 -> (pidx, Xk)."""
+    pidx = np.flatnonzero(Xpart)
+    return pidx, np.asarray(X)[pidx, :].copy()
+
+
+def auglabels(k, mapidx, Zsplit, qZ):
+    """src/comutils.cpp:75-104."""
+    Zsplit = np.asarray(Zsplit, dtype=bool)
+    if Zsplit.size != mapidx.size:
+        raise ValueError("map and split must be the same size!")
+    N, K = qZ.shape
+    qZaug = np.zeros((N, K + 1))
+    qZaug[:, :K] = qZ
+    rows = mapidx[Zsplit]
+    qZaug[rows, K] = qZ[rows, k]
+    qZaug[rows, k] = 0.0
+    return qZaug
+
+
+def anyempty(clusters):
+    """src/comutils.h:114-123."""
+    return any(c.getN() <= 1 for c in clusters)
+
+
+# ---------------------------------------------------------------------------
+# cluster.cpp
+# ---------------------------------------------------------------------------
+
+def _kful(K, sparse, Nk):
+    """Active-cluster selection shared by updateSS/vbexpectation
+    (src/cluster.cpp:63-70, 106-112)."""
+    if not sparse:
+        return np.arange(K) if K > 1 else np.zeros(1, dtype=int), np.zeros(0, dtype=int)
+    mask = np.asarray(Nk) >= ZEROCUTOFF
+    return np.flatnonzero(mask), np.flatnonzero(~mask)
+
+
+def updateSS(Xj, qZj, clusters, sparse=False):
+    """src/cluster.cpp:53-82."""
+    K = qZj.shape[1]
+    Njk = qZj.sum(axis=0)
+    Kful, _ = _kful(K, sparse, Njk)
+    for k in Kful:
+        clusters[k].addobs(qZj[:, k], Xj)
+    return Njk
+
+
+def vbexpectation(Xj, weights, clusters, sparse=False):
+    """src/cluster.cpp:91-138 -> (qZj, -sum(logZ))."""
+    K = len(clusters)
+    Nj = Xj.shape[0]
+    E_logZ = weights.Elogweight()
+    Kful, Kemp = _kful(K, sparse, weights.getNk())
+    logqZj = np.empty((Nj, Kful.size))
+    for i, k in enumerate(Kful):
+        logqZj[:, i] = E_logZ[k] + clusters[k].Eloglike(Xj)
+    logZzj = logsumexp(logqZj)
+    qZj = np.zeros((Nj, K))
+    for i, k in enumerate(Kful):
+        qZj[:, k] = np.exp(logqZj[:, i] - logZzj)
+    return qZj, -float(logZzj.sum())
+
+
+def fenergy(weights, clusters, Fxz):
+    """src/cluster.cpp:145-165."""
+    Fw = 0.0
+    for w in weights:
+        Fw += w.fenergy()
+    Fc = 0.0
+    for c in clusters:
+        Fc += c.fenergy()
+    return Fc + Fw + Fxz
+
+
+def vbem(X, qZ, weights, clusters, clusterprior, maxit=-1, sparse=False,
+         verbose=False, wfactory=None, trace=None):
+    """src/cluster.cpp:177-239.  ``qZ``, ``weights``, ``clusters`` are lists
+    mutated in place (the reference takes them by mutable reference).
+    ``trace`` (optional list) receives F after every iteration."""
+    J = len(X)
+    K = qZ[0].shape[1]
+    D = X[0].shape[1]
+    while len(weights) < J:  # weights.resize(J, W()) :192
+        weights.append(wfactory())
+    while len(clusters) < K:  # clusters.resize(K, C(prior, D)) :193
+        clusters.append(GaussWish(clusterprior, D))
+    # (resize also shrinks)
+    del weights[J:]
+    del clusters[K:]
+
+    F = sys.float_info.max
+    i = 0
+    while True:
+        Fold = F
+        for k in range(K):
+            clusters[k].clearobs()
+        for j in range(J):
+            Njk = updateSS(X[j], qZ[j], clusters, sparse)
+            weights[j].update(Njk)
+        for k in range(K):
+            clusters[k].update()
+        Fz = 0.0
+        for j in range(J):
+            qZ[j], fz = vbexpectation(X[j], weights[j], clusters, sparse)
+            Fz += fz
+        F = fenergy(weights, clusters, Fz)
+        if trace is not None:
+            trace.append(F)
+        if (F - Fold) / abs(Fold) > FENGYDEL:
+            raise RuntimeError("Free energy increase!")
+        if verbose:
+            print("-", end="", flush=True)
+        # while (|dF/F| > CONVERGE) && ((i++ < maxit) || (maxit < 0)) :235-236
+        if not (abs((Fold - F) / Fold) > CONVERGE):
+            break
+        cont = (i < maxit) or (maxit < 0)
+        i += 1
+        if not cont:
+            break
+    return F
+
+
+def prune_clusters(qZ, weights, clusters, verbose=False):
+    """src/cluster.cpp:505-552."""
+    K = len(clusters)
+    Nk = np.array([c.getN() for c in clusters])
+    empty = Nk < ZEROCUTOFF
+    if not empty.any():
+        return False
+    if verbose:
+        print("*", end="", flush=True)
+    fidx = np.flatnonzero(~empty)
+    for i in sorted(np.flatnonzero(empty), reverse=True):
+        del clusters[i]
+    for j in range(len(qZ)):
+        qZ[j] = qZ[j][:, fidx].copy()
+        weights[j].update(qZ[j].sum(axis=0))
+    return True
+
+
+def split_gr(X, weights, clusters, qZ, tally, F, maxclusters, sparse, verbose,
+             wfactory, events=None):
+    """src/cluster.cpp:366-495."""
+    J = len(X)
+    K = len(clusters)
+    if maxclusters >= 0 and K >= maxclusters:
+        return False
+    while len(tally) < K:
+        tally.append(0)
+    del tally[K:]
+
+    Fk = np.array([c.fenergy() for c in clusters])
+    for j in range(J):
+        logpi = weights[j].Elogweight()
+        for k in range(K):
+            LL = float(qZ[j][:, k] @ (logpi[k] + clusters[k].Eloglike(X[j])))
+            Fk[k] -= LL
+    # greedcomp: tally ascending, then Fk descending (src/comutils.h:60-68)
+    order = sorted(range(K), key=lambda k: (tally[k], -Fk[k]))
+    if events is not None:
+        events.append(("order", list(order), Fk.tolist()))
+
+    for k in order:
+        tally[k] += 1
+        if clusters[k].getN() < 4:
+            continue
+        scount = 0
+        Mtot = 0
+        mapidx, Xk, qZref = [], [], []
+        for j in range(J):
+            idx, xk = partobs(X[j], qZ[j][:, k] > 0.5)
+            mapidx.append(idx)
+            Xk.append(xk)
+            Mtot += xk.shape[0]
+            splitk = clusters[k].splitobs(xk) if xk.shape[0] else np.zeros(0, dtype=bool)
+            q = np.zeros((xk.shape[0], 2))
+            q[:, 0] = splitk.astype(np.float64)
+            q[:, 1] = (~splitk).astype(np.float64)
+            qZref.append(q)
+            scount += int(splitk.sum())
+        if scount < 2 or scount > Mtot - 2:
+            continue
+        wspl, cspl = [], []
+        vbem(Xk, qZref, wspl, cspl, clusters[0].getprior(), SPLITITER, sparse,
+             wfactory=wfactory)
+        if anyempty(cspl):
+            continue
+        qZaug = [auglabels(k, mapidx[j], qZref[j][:, 1] > 0.5, qZ[j]) for j in range(J)]
+        Fsplit = vbem(X, qZaug, wspl, cspl, clusters[0].getprior(), 1, sparse,
+                      wfactory=wfactory)
+        if anyempty(cspl):
+            continue
+        if verbose:
+            print("=", end="", flush=True)
+        if events is not None:
+            events.append(("candidate", int(k), float(Fsplit)))
+        if Fsplit < F and abs((F - Fsplit) / F) > CONVERGE:
+            for j in range(J):
+                qZ[j] = qZaug[j]
+            tally[k] = 0
+            return True
+    return False
+
+
+def cluster(X, weights, clusters, clusterprior, maxclusters, sparse, verbose,
+            wfactory, trace=None, events=None):
+    """src/cluster.cpp:564-629 -> (F, qZ)."""
+    J = len(X)
+    qZ = [np.ones((X[j].shape[0], 1)) for j in range(J)]
+    tally = []
+    issplit = True
+    F = None
+    while issplit:
+        rtrace = [] if trace is not None else None
+        F = vbem(X, qZ, weights, clusters, clusterprior, -1, sparse, verbose,
+                 wfactory=wfactory, trace=rtrace)
+        if trace is not None:
+            trace.append((len(clusters), rtrace))
+        prune_clusters(qZ, weights, clusters, verbose)
+        if verbose:
+            print("<", end="", flush=True)
+        issplit = split_gr(X, weights, clusters, qZ, tally, F, maxclusters,
+                           sparse, verbose, wfactory, events=events)
+        if verbose:
+            print(">")
+    if verbose:
+        print("Finished!")
+        print("Number of clusters =", len(clusters))
+        print("Free energy =", F)
+    return F, qZ
+
+
+def learnVDP(X, clusterprior=PRIORVAL, maxclusters=-1, verbose=False,
+             weights=None, trace=None, events=None):
+    """src/cluster.cpp:636-664 -> (F, qZ, weights, clusters)."""
+    w = [weights if weights is not None else StickBreak()]
+    clusters = []
+    F, qZ = cluster([np.asarray(X, dtype=np.float64)], w, clusters, clusterprior,
+                    maxclusters, False, verbose, StickBreak, trace, events)
+    return F, qZ[0], w[0], clusters
+
+
+def learnBGMM(X, clusterprior=PRIORVAL, maxclusters=-1, verbose=False,
+              weights=None, trace=None, events=None):
+    """src/cluster.cpp:667-695 -> (F, qZ, weights, clusters)."""
+    w = [weights if weights is not None else Dirichlet()]
+    clusters = []
+    F, qZ = cluster([np.asarray(X, dtype=np.float64)], w, clusters, clusterprior,
+                    maxclusters, False, verbose, Dirichlet, trace, events)
+    return F, qZ[0], w[0], clusters
+
+
+def learnGMC(X, clusterprior=PRIORVAL, maxclusters=-1, sparse=False,
+             verbose=False, trace=None, events=None):
+    """src/cluster.cpp:763-784 -> (F, qZ, weights, clusters)."""
+    w, clusters = [], []
+    Xl = [np.asarray(x, dtype=np.float64) for x in X]
+    F, qZ = cluster(Xl, w, clusters, clusterprior, maxclusters, sparse, verbose,
+                    GDirichlet, trace, events)
+    return F, qZ, w, clusters
+
+
+# ---------------------------------------------------------------------------
+# fixed-K harness (no reference entry point: vbem is file-static there,
+# cluster.cpp:177).  Used by parity tests and bench.py's cpu_baseline check.
+# ---------------------------------------------------------------------------
+
+def suffstats(X, qZ):
+    """Dense restatement of K addobs calls: (Nk[K], xs[K,D], xxs[K,D,D])."""
+    Nk = qZ.sum(axis=0)
+    xs = qZ.T @ X
+    xxs = np.einsum("nk,ni,nj->kij", qZ, X, X, optimize=True)
+    return Nk, xs, xxs
+
+
+def vbem_fixed(X, qZ0, wfactory, clusterprior, iters, sparse=False):
+    """``iters`` VBEM iterations from the given qZ with the convergence test
+    disabled (same body as vbem, cluster.cpp:198-234).  Returns
+    (F trace, Fz trace, qZ list, weights, clusters)."""
+    J = len(X)
+    K = qZ0[0].shape[1]
+    D = X[0].shape[1]
+    qZ = [q.copy() for q in qZ0]
+    weights = [wfactory() for _ in range(J)]
+    clusters = [GaussWish(clusterprior, D) for _ in range(K)]
+    Ftrace, Fztrace = [], []
+    for _ in range(iters):
+        for c in clusters:
+            c.clearobs()
+        for j in range(J):
+            weights[j].update(updateSS(X[j], qZ[j], clusters, sparse))
+        for c in clusters:
+            c.update()
+        Fz = 0.0
+        for j in range(J):
+            qZ[j], fz = vbexpectation(X[j], weights[j], clusters, sparse)
+            Fz += fz
+        Fztrace.append(Fz)
+        Ftrace.append(fenergy(weights, clusters, Fz))
+    return Ftrace, Fztrace, qZ, weights, clusters
