@@ -1,0 +1,170 @@
+/* libcluster_hip.h -- C ABI of the MI355X (gfx950) implementation of
+ * libcluster's variational E-step / sufficient-statistic hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.
+ * Every entry point names the reference (dsteinberg/libcluster) interface it
+ * replaces.  All functions return an lc_status; on failure lc_last_error()
+ * (thread-local) holds the message.  The C++ facade (include/libcluster.h,
+ * include/distributions.h) re-throws the reference's exception classes:
+ *   LC_EINVAL  -> std::invalid_argument   LC_ERUNTIME -> std::runtime_error
+ *   LC_EDOMAIN -> std::domain_error       LC_EHIP     -> std::runtime_error
+ *
+ * There is NO CPU fallback: without a HIP device every data-path call fails
+ * with LC_EHIP.  Host-only entry points (lc_mstep_*, lc_weights_*, lc_digamma)
+ * work anywhere.
+ *
+ * Matrices are described as (pointer, row_stride, col_stride) in elements, so
+ * both Eigen storage orders (column-major default, row-major when the
+ * reference is built with -DEIGEN_DEFAULT_TO_ROW_MAJOR, CMakeLists.txt:59-61)
+ * are accepted without a copy on the caller's side.
+ */
+#ifndef LIBCLUSTER_HIP_H
+#define LIBCLUSTER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { LC_OK = 0, LC_EINVAL = 1, LC_ERUNTIME = 2, LC_EHIP = 3, LC_EDOMAIN = 4 } lc_status;
+
+/* weight distribution kinds: include/distributions.h:163 (Dirichlet), :103 (StickBreak), :147 (GDirichlet) */
+typedef enum { LC_W_DIRICHLET = 0, LC_W_STICKBREAK = 1, LC_W_GDIRICHLET = 2 } lc_weight_kind;
+/* learners: include/libcluster.h:177 (learnVDP), :218 (learnBGMM), :356 (learnGMC) */
+typedef enum { LC_ALGO_VDP = 0, LC_ALGO_BGMM = 1, LC_ALGO_GMC = 2 } lc_algo;
+
+typedef struct lc_ctx lc_ctx;     /* device-resident data set + qZ + workspaces */
+typedef struct lc_model lc_model; /* weights + clusters (+ the context that holds qZ) */
+
+const char* lc_last_error(void);
+int lc_version(void);
+/* number of visible HIP devices (0 on a host without a GPU; never fails) */
+int lc_device_count(void);
+
+/* ---- constants: include/libcluster.h:122-127, include/distributions.h:39-43 */
+double lc_const_converge(void);   /* CONVERGE   = (double)1e-5f */
+double lc_const_fengydel(void);   /* FENGYDEL   = CONVERGE/10   */
+double lc_const_zerocutoff(void); /* ZEROCUTOFF = (double)0.1f  */
+int lc_const_splititer(void);     /* SPLITITER  = 15            */
+
+/* ======================================================================== *
+ * Device context.  `stream` is a hipStream_t (NULL = the null stream).
+ * ======================================================================== */
+int lc_ctx_create(int device, void* stream, lc_ctx** out);
+int lc_ctx_destroy(lc_ctx* ctx);
+int lc_ctx_set_stream(lc_ctx* ctx, void* stream);
+int lc_ctx_synchronize(lc_ctx* ctx);
+int lc_ctx_dims(lc_ctx* ctx, int* J, int* D, int64_t* Ntotal, int* K);
+
+/* Upload J groups of observations (the `const vMatrixXd& X` of
+ * cluster.cpp:564-566; learnVDP/learnBGMM pass J = 1, cluster.cpp:651/682).
+ * Element (n,d) of group j is Xj[j][n*row_stride + d*col_stride]. */
+int lc_ctx_set_data(lc_ctx* ctx, int J, const double* const* Xj, const int64_t* Nj, int D, int64_t row_stride,
+                    int64_t col_stride);
+/* Synthetic K-component full-covariance Gaussian mixture generated on the
+ * device (bench workload): x = mu_z + L_z eps, z uniform,
+ * Philox-4x32-10 keyed by `seed`, counter = row_offset + row.  Also writes the
+ * initial qZ (true label = `hard`, rest (1-hard)/(K-1)).  mu: K x D, L: K x D x D
+ * row-major lower Cholesky factors (host pointers). */
+int lc_ctx_synth(lc_ctx* ctx, int64_t N, int D, int K, const double* mu, const double* L, uint64_t seed,
+                 int64_t row_offset, double hard);
+/* rows [row0,row0+n) of group j -> row-major n x D host buffer */
+int lc_ctx_get_rows(lc_ctx* ctx, int j, int64_t row0, int64_t n, double* out);
+
+/* qZ (the `vMatrixXd& qZ` of cluster.cpp:179): host <-> device, any strides. */
+int lc_ctx_set_qz(lc_ctx* ctx, int j, const double* q, int K, int64_t row_stride, int64_t col_stride);
+int lc_ctx_get_qz(lc_ctx* ctx, int j, double* q, int64_t row_stride, int64_t col_stride);
+int lc_ctx_fill_qz(lc_ctx* ctx, int K, double value); /* qZ[j].setOnes(N,1): cluster.cpp:583-585 */
+
+/* ---- the hot path ------------------------------------------------------ */
+/* vbexpectation (cluster.cpp:91-138) for ALL groups, from the posterior
+ * hyper-parameters the reference keeps inside GaussWish (distributions.h:
+ * 325-330) and the weights' Elogweight() (distributions.h:113/173):
+ *   nu[K], beta[K], m[K*D], iW[K*D*D] row-major, logdW[K], Elogpi[J*K],
+ *   active[J*K] (sparse mask: 0 => column zeroed, cluster.cpp:109-112/134-135)
+ *   or NULL.  Overwrites the context's qZ with the new responsibilities.
+ * Fz  <- -sum_n logZ_n  (cluster.cpp:137, summed over groups as in :221-223)
+ * LLk <- K values sum_n q_nk * Eloglike_k(x_n) (data term of cluster.cpp:409-410) or NULL. */
+int lc_estep_posterior(lc_ctx* ctx, int K, const double* nu, const double* beta, const double* m, const double* iW,
+                       const double* logdW, const double* Elogpi, const unsigned char* active, double* Fz,
+                       double* LLk);
+/* Same kernel, kernel-level parameters: A[K*D*D] row-major lower-triangular
+ * with nu*maha_k(x) = ||A_k (x - m_k)||^2, m[K*D], c[J*K] = Elogpi_jk +
+ * 0.5*(sum psi + logdW - D/beta - D ln pi).  LLk here excludes the constant:
+ * LLk = sum_n q_nk (log q~_nk - c_jk). */
+int lc_estep(lc_ctx* ctx, int K, const double* A, const double* m, const double* c, double* Fz, double* LLk);
+/* updateSS (cluster.cpp:53-82) + K x GaussWish::addobs (distributions.cpp:301-313)
+ * for ALL groups on the current qZ: Nk[K], xs[K*D], xxs[K*D*D] (row-major),
+ * Njk[J*K] (the returned `Njk` of every group).  smask[J*K]: sparse updates,
+ * 0 => group j contributes nothing to cluster k (cluster.cpp:67-79); NULL = dense.
+ * Any output pointer may be NULL. */
+int lc_suffstat(lc_ctx* ctx, const unsigned char* smask, double* Nk, double* xs, double* xxs, double* Njk);
+/* qZ[j].colwise().sum() for every group (cluster.cpp:62, 546) */
+int lc_colsums(lc_ctx* ctx, double* Njk);
+
+/* ---- multi-GPU: rows are sharded one context per rank; the two per-iteration
+ * reductions (packed suff-stats, [Fz; LLk]) call this hook on a device buffer.
+ * fn must sum `count` doubles in place across ranks, ordered after work already
+ * enqueued on `stream`; return 0 on success. */
+typedef int (*lc_allreduce_fn)(void* user, void* device_buf, int64_t count, void* stream);
+int lc_ctx_set_allreduce(lc_ctx* ctx, lc_allreduce_fn fn, void* user);
+
+/* ---- kernel timing (hipEvents on the context's stream) ------------------ */
+int lc_ctx_timing_enable(lc_ctx* ctx, int on);
+int lc_ctx_timing_reset(lc_ctx* ctx);
+int lc_ctx_timing_get(lc_ctx* ctx, double* estep_ms, int64_t* estep_calls, double* suffstat_ms,
+                      int64_t* suffstat_calls);
+
+/* ======================================================================== *
+ * Variational Bayes EM on a context (vbem, cluster.cpp:177-239).
+ * The model is created on first use (*model == NULL) with `wkind` weights of
+ * prior `wprior` and Gauss-Wishart clusters of prior `clusterprior`.
+ * fixed_iters >= 0 runs exactly that many iterations without the convergence
+ * and free-energy-increase tests (bench / parity harness: the reference has no
+ * public fixed-K entry point).  Ftrace (may be NULL) gets
+ * up to ntrace values of F, one per iteration; *niter the iterations run.
+ * ======================================================================== */
+int lc_vbem(lc_ctx* ctx, lc_model** model, int wkind, double wprior, double clusterprior, int maxit, int sparse,
+            int fixed_iters, int verbose, unsigned nthreads, double* F, int* niter, double* Ftrace, int ntrace);
+
+/* learnVDP / learnBGMM / learnGMC (cluster.cpp:636-695, 763-784): uploads X,
+ * runs the model-selection loop, returns the model (which owns its context so
+ * qZ can be fetched).  wprior: StickBreak concentration / Dirichlet alpha the
+ * caller's `weights` argument carried (1.0 = default-constructed); ignored
+ * for GMC (default-constructed GDirichlet per group, cluster.cpp:192). */
+int lc_learn(int algo, int J, const double* const* Xj, const int64_t* Nj, int D, int64_t row_stride,
+             int64_t col_stride, double wprior, double clusterprior, int maxclusters, int sparse, int verbose,
+             unsigned nthreads, int device, lc_model** out, double* F);
+
+/* ---- model accessors ----------------------------------------------------- */
+int lc_model_free(lc_model* m);
+int lc_model_dims(lc_model* m, int* J, int* K, int* D);
+int lc_model_rounds(lc_model* m, int* nrounds);                       /* vbem rounds of cluster() */
+int lc_model_round(lc_model* m, int r, int* K, int* niter, double* F, int nF); /* F trace of round r */
+int lc_model_get_qz(lc_model* m, int j, double* q, int64_t row_stride, int64_t col_stride);
+/* WeightDist::Elogweight() / getNk() of group j (K values each; may be NULL) */
+int lc_model_weights(lc_model* m, int j, double* Elogweight, double* Nk);
+/* GaussWish k: getN(), getmean() [D], getcov() [D*D row-major] and the posterior
+ * hyper-parameters nu, beta, iW [D*D], logdW (any pointer may be NULL) */
+int lc_model_cluster(lc_model* m, int k, double* N, double* mean, double* cov, double* nu, double* beta, double* iW,
+                     double* logdW);
+int lc_model_fenergy(lc_model* m, double* Fw /*[J]*/, double* Fc /*[K]*/);
+
+/* ======================================================================== *
+ * Host-only pieces of the path (no GPU needed; used by the C++ facade classes
+ * and by tests of the host arithmetic).
+ * ======================================================================== */
+double lc_digamma(double x); /* boost::math::digamma in the reference (probutils.cpp:213) */
+/* WeightDist::update(Nk) + Elogweight() + fenergy(): distributions.cpp:124-168, 186-196, 242-266 */
+int lc_weights_update(int wkind, double wprior, const double* Nk, int K, double* Elogweight, double* fenergy);
+/* GaussWish: clearobs + addobs-sums + update (distributions.cpp:316-337) from
+ * reduced statistics; outputs the posterior, the free energy (:388-399), the
+ * E-step whitener A (D*D) and Eloglike constant.  Any output may be NULL. */
+int lc_gw_mstep(double clustwidth, int D, double Ns, const double* xs, const double* xxs, double* nu, double* beta,
+                double* m, double* iW, double* logdW, double* fenergy, double* A, double* eloglike_const);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIBCLUSTER_HIP_H */

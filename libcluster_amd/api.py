@@ -1,0 +1,45 @@
+"""learnVDP / learnBGMM / learnGMC over the C-ABI, with the return shape of the
+reference's Python binding (python/libclusterpy.cpp:135-213:
+``(F, qZ, weights, means, covariances)``).  Argument meaning and error
+behaviour follow include/libcluster.h:177-186, 218-227, 356-366."""
+from __future__ import annotations
+
+import numpy as np
+
+from . import capi
+
+
+def _result(F, model, rows, grouped):
+    J, K, D = model.dims()
+    qZ = [model.qz(j, rows[j]) for j in range(J)]
+    w = [np.exp(model.weights(j)[0]) for j in range(J)]
+    cl = [model.cluster(k) for k in range(K)]
+    means = [c["mean"] for c in cl]
+    covs = [c["cov"] for c in cl]
+    info = {"K": K, "N": [c["N"] for c in cl], "rounds": model.rounds(), "clusters": cl,
+            "Elogweight": [model.weights(j)[0] for j in range(J)]}
+    model.close()
+    if grouped:
+        return F, qZ, w, means, covs, info
+    return F, qZ[0], w[0], means, covs, info
+
+
+def learnVDP(X, prior=1.0, maxclusters=-1, verbose=False, nthreads=1, concentration=1.0, device=0):
+    """include/libcluster.h:177-186.  Returns (F, qZ, weights, means, covs, info)."""
+    F, m, rows = capi.learn(capi.ALGO_VDP, np.asarray(X, dtype=np.float64), concentration, prior, maxclusters,
+                            False, verbose, nthreads, device)
+    return _result(F, m, rows, False)
+
+
+def learnBGMM(X, prior=1.0, maxclusters=-1, verbose=False, nthreads=1, alpha=1.0, device=0):
+    """include/libcluster.h:218-227."""
+    F, m, rows = capi.learn(capi.ALGO_BGMM, np.asarray(X, dtype=np.float64), alpha, prior, maxclusters, False,
+                            verbose, nthreads, device)
+    return _result(F, m, rows, False)
+
+
+def learnGMC(X, prior=1.0, maxclusters=-1, sparse=False, verbose=False, nthreads=1, device=0):
+    """include/libcluster.h:356-366.  X is a list of (N_j, D) arrays."""
+    F, m, rows = capi.learn(capi.ALGO_GMC, [np.asarray(x, dtype=np.float64) for x in X], 1.0, prior, maxclusters,
+                            sparse, verbose, nthreads, device)
+    return _result(F, m, rows, True)

@@ -1,0 +1,67 @@
+"""Build the C-ABI shared library (HIP kernels + host C++) in-tree.
+
+    python -m libcluster_amd.build            # incremental
+    python -m libcluster_amd.build --force
+
+hipcc cross-compiles for gfx950 without a GPU.  Output:
+libcluster_amd/lib/libcluster_hip.so (git-ignored; travels with gpurun).
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+CSRC = PKG / "csrc"
+OBJ = PKG / "lib" / "obj"
+LIB = PKG / "lib" / "libcluster_hip.so"
+ARCH = "gfx950"
+
+SOURCES = ["lc_kernels.hip", "lc_ctx.cpp", "lc_engine.cpp", "lc_capi.cpp"]
+HEADERS = ["lc_kernels.h", "lc_ctx.hpp", "lc_engine.hpp", "lc_host.hpp", "../../include/libcluster_hip.h"]
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _newer(target: Path, deps) -> bool:
+    if not target.exists():
+        return True
+    t = target.stat().st_mtime
+    return any(Path(d).stat().st_mtime > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    OBJ.mkdir(parents=True, exist_ok=True)
+    hipcc = _hipcc()
+    hdrs = [CSRC / h for h in HEADERS]
+    common = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", f"-I{PKG.parent / 'include'}"]
+    objs = []
+    for src in SOURCES:
+        s = CSRC / src
+        o = OBJ / (Path(src).stem + ".o")
+        objs.append(o)
+        if force or _newer(o, [s, *hdrs]):
+            cmd = [hipcc, *common, "-c", str(s), "-o", str(o)]
+            if src.endswith(".hip"):
+                cmd[1:1] = [f"--offload-arch={ARCH}"]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.run(cmd, check=True)
+    if force or _newer(LIB, objs):
+        cmd = [hipcc, "-shared", "-o", str(LIB), *map(str, objs), "-lpthread"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    p = build(force="--force" in sys.argv, verbose=True)
+    print("built", p)

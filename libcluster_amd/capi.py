@@ -1,0 +1,396 @@
+"""ctypes binding of include/libcluster_hip.h (plumbing only: every function
+here forwards to the C-ABI; there is no Python or CPU implementation of the
+data path).  Loading fails loudly if the shared library has not been built."""
+from __future__ import annotations
+
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+
+PKG = Path(__file__).resolve().parent
+LIB_PATH = PKG / "lib" / "libcluster_hip.so"
+HEADER = PKG.parent / "include" / "libcluster_hip.h"
+
+LC_OK, LC_EINVAL, LC_ERUNTIME, LC_EHIP, LC_EDOMAIN = range(5)
+W_DIRICHLET, W_STICKBREAK, W_GDIRICHLET = 0, 1, 2
+ALGO_VDP, ALGO_BGMM, ALGO_GMC = 0, 1, 2
+
+c_double_p = C.POINTER(C.c_double)
+c_int64_p = C.POINTER(C.c_int64)
+c_int_p = C.POINTER(C.c_int)
+c_ubyte_p = C.POINTER(C.c_ubyte)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+
+
+class HipError(RuntimeError):
+    """HIP runtime failure (including: no GPU -- there is no CPU fallback)."""
+
+
+class DomainError(ArithmeticError):
+    pass
+
+
+_lib = None
+
+
+def declared_symbols() -> list[str]:
+    """Every function the public header declares (used by the symbol test)."""
+    txt = HEADER.read_text()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    names = re.findall(r"\b(lc_[a-z0-9_]+)\s*\(", txt)
+    return sorted(set(n for n in names if n != "lc_allreduce_fn"))
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m libcluster_amd.build` "
+            "(hipcc, --offload-arch=gfx950).  There is no Python/CPU fallback for the E-step."
+        )
+    L = C.CDLL(str(LIB_PATH))
+    L.lc_last_error.restype = C.c_char_p
+    for f in ("lc_const_converge", "lc_const_fengydel", "lc_const_zerocutoff"):
+        getattr(L, f).restype = C.c_double
+    L.lc_digamma.restype = C.c_double
+    L.lc_digamma.argtypes = [C.c_double]
+    L.lc_ctx_create.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+    L.lc_ctx_destroy.argtypes = [C.c_void_p]
+    L.lc_ctx_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    L.lc_ctx_synchronize.argtypes = [C.c_void_p]
+    L.lc_ctx_dims.argtypes = [C.c_void_p, c_int_p, c_int_p, c_int64_p, c_int_p]
+    L.lc_ctx_set_data.argtypes = [C.c_void_p, C.c_int, C.POINTER(c_double_p), c_int64_p, C.c_int, C.c_int64, C.c_int64]
+    L.lc_ctx_synth.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, c_double_p, c_double_p, C.c_uint64,
+                               C.c_int64, C.c_double]
+    L.lc_ctx_get_rows.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, c_double_p]
+    L.lc_ctx_set_qz.argtypes = [C.c_void_p, C.c_int, c_double_p, C.c_int, C.c_int64, C.c_int64]
+    L.lc_ctx_get_qz.argtypes = [C.c_void_p, C.c_int, c_double_p, C.c_int64, C.c_int64]
+    L.lc_ctx_fill_qz.argtypes = [C.c_void_p, C.c_int, C.c_double]
+    L.lc_estep.argtypes = [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]
+    L.lc_estep_posterior.argtypes = [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
+                                     c_double_p, c_ubyte_p, c_double_p, c_double_p]
+    L.lc_suffstat.argtypes = [C.c_void_p, c_ubyte_p, c_double_p, c_double_p, c_double_p, c_double_p]
+    L.lc_colsums.argtypes = [C.c_void_p, c_double_p]
+    L.lc_ctx_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p]
+    L.lc_ctx_timing_enable.argtypes = [C.c_void_p, C.c_int]
+    L.lc_ctx_timing_reset.argtypes = [C.c_void_p]
+    L.lc_ctx_timing_get.argtypes = [C.c_void_p, c_double_p, c_int64_p, c_double_p, c_int64_p]
+    L.lc_vbem.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_double, C.c_double, C.c_int, C.c_int,
+                          C.c_int, C.c_int, C.c_uint, c_double_p, c_int_p, c_double_p, C.c_int]
+    L.lc_learn.argtypes = [C.c_int, C.c_int, C.POINTER(c_double_p), c_int64_p, C.c_int, C.c_int64, C.c_int64,
+                           C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_int,
+                           C.POINTER(C.c_void_p), c_double_p]
+    L.lc_model_free.argtypes = [C.c_void_p]
+    L.lc_model_dims.argtypes = [C.c_void_p, c_int_p, c_int_p, c_int_p]
+    L.lc_model_rounds.argtypes = [C.c_void_p, c_int_p]
+    L.lc_model_round.argtypes = [C.c_void_p, C.c_int, c_int_p, c_int_p, c_double_p, C.c_int]
+    L.lc_model_get_qz.argtypes = [C.c_void_p, C.c_int, c_double_p, C.c_int64, C.c_int64]
+    L.lc_model_weights.argtypes = [C.c_void_p, C.c_int, c_double_p, c_double_p]
+    L.lc_model_cluster.argtypes = [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
+                                   c_double_p, c_double_p]
+    L.lc_model_fenergy.argtypes = [C.c_void_p, c_double_p, c_double_p]
+    L.lc_weights_update.argtypes = [C.c_int, C.c_double, c_double_p, C.c_int, c_double_p, c_double_p]
+    L.lc_gw_mstep.argtypes = [C.c_double, C.c_int, C.c_double, c_double_p, c_double_p, c_double_p, c_double_p,
+                              c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]
+    _lib = L
+    return L
+
+
+def check(rc: int) -> None:
+    """Map lc_status to the exception classes the reference throws."""
+    if rc == LC_OK:
+        return
+    msg = lib().lc_last_error().decode("utf-8", "replace")
+    if rc == LC_EINVAL:
+        raise ValueError(msg)  # std::invalid_argument
+    if rc == LC_EHIP:
+        raise HipError(msg)
+    if rc == LC_EDOMAIN:
+        raise DomainError(msg)  # std::domain_error
+    raise RuntimeError(msg)  # std::runtime_error
+
+
+def dptr(a):
+    if a is None:
+        return None
+    assert a.dtype == np.float64
+    return a.ctypes.data_as(c_double_p)
+
+
+def _strides(a: np.ndarray):
+    assert a.ndim == 2 and a.dtype == np.float64
+    return a.strides[0] // 8, a.strides[1] // 8
+
+
+class Context:
+    """lc_ctx: device-resident observations + qZ (one per data set / rank)."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self._h = C.c_void_p()
+        self._cb = None
+        check(lib().lc_ctx_create(device, C.c_void_p(stream or 0), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().lc_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- data ---------------------------------------------------------------
+    def set_data(self, X):
+        """X: (N, D) array or list of (N_j, D) arrays, any strides (no copy)."""
+        Xs = [X] if isinstance(X, np.ndarray) else list(X)
+        Xs = [np.asarray(x, dtype=np.float64) for x in Xs]
+        D = Xs[0].shape[1]
+        for x in Xs:
+            if x.ndim != 2 or x.shape[1] != D:
+                raise ValueError("X dimensions are inconsistent between groups!")
+        st = {_strides(x) for x in Xs}
+        if len(st) == 1 and all(x.shape[0] > 1 for x in Xs) and min(next(iter(st))) > 0:
+            rs, cs = next(iter(st))  # e.g. all column-major (Eigen default) or all row-major: no copy
+        else:
+            Xs = [np.ascontiguousarray(x) for x in Xs]
+            rs, cs = D, 1
+        J = len(Xs)
+        ptrs = (c_double_p * J)(*[dptr(x) for x in Xs])
+        Nj = (C.c_int64 * J)(*[x.shape[0] for x in Xs])
+        check(lib().lc_ctx_set_data(self._h, J, ptrs, Nj, D, rs, cs))
+        self._X = Xs  # keep alive
+
+    def synth(self, N, D, K, mu, L, seed, row_offset=0, hard=0.9):
+        mu = np.ascontiguousarray(mu, dtype=np.float64)
+        L = np.ascontiguousarray(L, dtype=np.float64)
+        assert mu.shape == (K, D) and L.shape == (K, D, D)
+        check(lib().lc_ctx_synth(self._h, N, D, K, dptr(mu), dptr(L), seed, row_offset, hard))
+
+    def dims(self):
+        J, D, K, N = C.c_int(), C.c_int(), C.c_int(), C.c_int64()
+        check(lib().lc_ctx_dims(self._h, C.byref(J), C.byref(D), C.byref(N), C.byref(K)))
+        return J.value, D.value, N.value, K.value
+
+    def get_rows(self, j, row0, n):
+        _, D, _, _ = self.dims()
+        out = np.empty((n, D))
+        check(lib().lc_ctx_get_rows(self._h, j, row0, n, dptr(out)))
+        return out
+
+    def set_qz(self, qZ):
+        qs = [qZ] if isinstance(qZ, np.ndarray) else list(qZ)
+        K = qs[0].shape[1]
+        for j, q in enumerate(qs):
+            q = np.asarray(q, dtype=np.float64)
+            if q.shape[1] != K:
+                raise ValueError("qZ groups must have the same number of columns")
+            if q.shape[0] == 0:
+                q = np.zeros((1, K))[:0]
+                check(lib().lc_ctx_set_qz(self._h, j, dptr(np.zeros(1)), K, K, 1))
+                continue
+            rs, cs = _strides(q)
+            check(lib().lc_ctx_set_qz(self._h, j, dptr(q), K, rs, cs))
+
+    def get_qz(self, rows_per_group):
+        _, _, _, K = self.dims()
+        out = []
+        for j, n in enumerate(rows_per_group):
+            q = np.empty((n, K))
+            if n:
+                check(lib().lc_ctx_get_qz(self._h, j, dptr(q), K, 1))
+            out.append(q)
+        return out
+
+    def fill_qz(self, K, value=1.0):
+        check(lib().lc_ctx_fill_qz(self._h, K, value))
+
+    # -- hot path -------------------------------------------------------------
+    def estep_posterior(self, nu, beta, m, iW, logdW, Elogpi, active=None, want_ll=True):
+        K = len(nu)
+        nu, beta, m, iW, logdW, Elogpi = (np.ascontiguousarray(a, dtype=np.float64)
+                                          for a in (nu, beta, m, iW, logdW, Elogpi))
+        Fz = C.c_double()
+        ll = np.zeros(K) if want_ll else None
+        act = None
+        if active is not None:
+            active = np.ascontiguousarray(active, dtype=np.uint8)
+            act = active.ctypes.data_as(c_ubyte_p)
+        check(lib().lc_estep_posterior(self._h, K, dptr(nu), dptr(beta), dptr(m), dptr(iW), dptr(logdW),
+                                       dptr(Elogpi), act, C.byref(Fz), dptr(ll)))
+        return Fz.value, ll
+
+    def estep(self, A, m, c):
+        A, m, c = (np.ascontiguousarray(a, dtype=np.float64) for a in (A, m, c))
+        K = A.shape[0]
+        Fz = C.c_double()
+        ll = np.zeros(K)
+        check(lib().lc_estep(self._h, K, dptr(A), dptr(m), dptr(c), C.byref(Fz), dptr(ll)))
+        return Fz.value, ll
+
+    def suffstat(self, smask=None):
+        J, D, _, K = self.dims()
+        Nk, xs, xxs, Njk = np.zeros(K), np.zeros((K, D)), np.zeros((K, D, D)), np.zeros((J, K))
+        sm = None
+        if smask is not None:
+            smask = np.ascontiguousarray(smask, dtype=np.uint8)
+            sm = smask.ctypes.data_as(c_ubyte_p)
+        check(lib().lc_suffstat(self._h, sm, dptr(Nk), dptr(xs), dptr(xxs), dptr(Njk)))
+        return Nk, xs, xxs, Njk
+
+    def colsums(self):
+        J, _, _, K = self.dims()
+        out = np.zeros((J, K))
+        check(lib().lc_colsums(self._h, dptr(out)))
+        return out
+
+    def set_allreduce(self, fn):
+        """fn(device_ptr:int, count:int, stream:int) -> None; sums in place across ranks."""
+        if fn is None:
+            self._cb = None
+            check(lib().lc_ctx_set_allreduce(self._h, C.cast(None, ALLREDUCE_FN), None))
+            return
+
+        def tramp(user, buf, count, stream):
+            try:
+                fn(buf or 0, count, stream or 0)
+                return 0
+            except Exception as e:  # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        self._cb = ALLREDUCE_FN(tramp)
+        check(lib().lc_ctx_set_allreduce(self._h, self._cb, None))
+
+    def timing_enable(self, on=True):
+        check(lib().lc_ctx_timing_enable(self._h, int(on)))
+
+    def timing_reset(self):
+        check(lib().lc_ctx_timing_reset(self._h))
+
+    def timing_get(self):
+        a, b = C.c_double(), C.c_double()
+        na, nb = C.c_int64(), C.c_int64()
+        check(lib().lc_ctx_timing_get(self._h, C.byref(a), C.byref(na), C.byref(b), C.byref(nb)))
+        return {"estep_ms": a.value, "estep_calls": na.value, "suffstat_ms": b.value, "suffstat_calls": nb.value}
+
+    def synchronize(self):
+        check(lib().lc_ctx_synchronize(self._h))
+
+    def vbem(self, wkind, wprior=1.0, clusterprior=1.0, maxit=-1, sparse=False, fixed_iters=-1, verbose=False,
+             nthreads=1, model=None, ntrace=4096):
+        mh = model._h if model is not None else C.c_void_p()
+        F, nit = C.c_double(), C.c_int()
+        tr = np.zeros(ntrace)
+        check(lib().lc_vbem(self._h, C.byref(mh), wkind, wprior, clusterprior, maxit, int(sparse), fixed_iters,
+                            int(verbose), nthreads, C.byref(F), C.byref(nit), dptr(tr), ntrace))
+        if model is None:
+            model = Model(mh, ctx=self)
+        return F.value, tr[: nit.value].copy(), model
+
+
+class Model:
+    """lc_model: weights + clusters (+ access to the context's qZ)."""
+
+    def __init__(self, handle, ctx=None):
+        self._h = handle
+        self._ctx = ctx  # keep a borrowed context alive
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().lc_model_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def dims(self):
+        J, K, D = C.c_int(), C.c_int(), C.c_int()
+        check(lib().lc_model_dims(self._h, C.byref(J), C.byref(K), C.byref(D)))
+        return J.value, K.value, D.value
+
+    def rounds(self):
+        n = C.c_int()
+        check(lib().lc_model_rounds(self._h, C.byref(n)))
+        out = []
+        for r in range(n.value):
+            K, ni = C.c_int(), C.c_int()
+            check(lib().lc_model_round(self._h, r, C.byref(K), C.byref(ni), None, 0))
+            F = np.zeros(ni.value)
+            check(lib().lc_model_round(self._h, r, None, None, dptr(F), ni.value))
+            out.append((K.value, F.tolist()))
+        return out
+
+    def qz(self, j, n):
+        _, K, _ = self.dims()
+        q = np.empty((n, K))
+        if n:
+            check(lib().lc_model_get_qz(self._h, j, dptr(q), K, 1))
+        return q
+
+    def weights(self, j):
+        _, K, _ = self.dims()
+        e, n = np.zeros(K), np.zeros(K)
+        check(lib().lc_model_weights(self._h, j, dptr(e), dptr(n)))
+        return e, n
+
+    def cluster(self, k):
+        _, _, D = self.dims()
+        N, nu, beta, logdW = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+        mean, cov, iW = np.zeros(D), np.zeros((D, D)), np.zeros((D, D))
+        check(lib().lc_model_cluster(self._h, k, C.byref(N), dptr(mean), dptr(cov), C.byref(nu), C.byref(beta),
+                                     dptr(iW), C.byref(logdW)))
+        return {"N": N.value, "mean": mean, "cov": cov, "nu": nu.value, "beta": beta.value, "iW": iW,
+                "logdW": logdW.value}
+
+    def fenergy(self):
+        J, K, _ = self.dims()
+        Fw, Fc = np.zeros(J), np.zeros(K)
+        check(lib().lc_model_fenergy(self._h, dptr(Fw), dptr(Fc)))
+        return Fw, Fc
+
+
+def learn(algo, X, wprior=1.0, clusterprior=1.0, maxclusters=-1, sparse=False, verbose=False, nthreads=1, device=0):
+    Xs = [X] if isinstance(X, np.ndarray) else list(X)
+    Xs = [np.ascontiguousarray(x, dtype=np.float64) for x in Xs]
+    J, D = len(Xs), Xs[0].shape[1]
+    ptrs = (c_double_p * J)(*[dptr(x) for x in Xs])
+    Nj = (C.c_int64 * J)(*[x.shape[0] for x in Xs])
+    mh, F = C.c_void_p(), C.c_double()
+    check(lib().lc_learn(algo, J, ptrs, Nj, D, D, 1, wprior, clusterprior, maxclusters, int(sparse), int(verbose),
+                         nthreads, device, C.byref(mh), C.byref(F)))
+    return F.value, Model(mh), [x.shape[0] for x in Xs]
+
+
+def weights_update(wkind, Nk, wprior=1.0):
+    Nk = np.ascontiguousarray(Nk, dtype=np.float64)
+    e, f = np.zeros(Nk.size), C.c_double()
+    check(lib().lc_weights_update(wkind, wprior, dptr(Nk), Nk.size, dptr(e), C.byref(f)))
+    return e, f.value
+
+
+def gw_mstep(clustwidth, Ns, xs, xxs):
+    xs = np.ascontiguousarray(xs, dtype=np.float64)
+    xxs = np.ascontiguousarray(xxs, dtype=np.float64)
+    D = xs.size
+    nu, beta, logdW, fe, cst = (C.c_double() for _ in range(5))
+    m, iW, A = np.zeros(D), np.zeros((D, D)), np.zeros((D, D))
+    check(lib().lc_gw_mstep(clustwidth, D, Ns, dptr(xs), dptr(xxs), C.byref(nu), C.byref(beta), dptr(m), dptr(iW),
+                            C.byref(logdW), C.byref(fe), dptr(A), C.byref(cst)))
+    return {"nu": nu.value, "beta": beta.value, "m": m, "iW": iW, "logdW": logdW.value, "fenergy": fe.value,
+            "A": A, "eloglike_const": cst.value}

@@ -1,0 +1,472 @@
+// extern "C" boundary (include/libcluster_hip.h).  Nothing throws across it.
+#include <cmath>
+#include <cstring>
+#include <iostream>
+#include <limits>
+#include <memory>
+#include <new>
+#include <string>
+
+#include "../../include/libcluster_hip.h"
+#include "lc_ctx.hpp"
+#include "lc_engine.hpp"
+#include "lc_host.hpp"
+
+struct lc_ctx {
+  lcc::Context impl;
+  lc_ctx(int device, hipStream_t s) : impl(device, s) {}
+};
+
+struct lc_model {
+  std::unique_ptr<lc_ctx> owned_ctx;  // set by lc_learn
+  lc_ctx* ctx = nullptr;              // context holding qZ (owned or borrowed)
+  lce::Model model;
+  std::vector<std::pair<int, std::vector<double>>> rounds;
+  int D = 0;
+};
+
+namespace {
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+template <typename F>
+int guarded(F f) {
+  try {
+    f();
+    return LC_OK;
+  } catch (const lcc::HipFailure& e) {
+    return fail(LC_EHIP, e.what());
+  } catch (const std::invalid_argument& e) {
+    return fail(LC_EINVAL, e.what());
+  } catch (const std::domain_error& e) {
+    return fail(LC_EDOMAIN, e.what());
+  } catch (const std::bad_alloc&) {
+    return fail(LC_ERUNTIME, "out of host memory");
+  } catch (const std::exception& e) {
+    return fail(LC_ERUNTIME, e.what());
+  } catch (...) {
+    return fail(LC_ERUNTIME, "unknown error");
+  }
+}
+
+void need(const void* p, const char* what) {
+  if (!p) throw std::invalid_argument(std::string(what) + " must not be NULL");
+}
+}  // namespace
+
+extern "C" {
+
+const char* lc_last_error(void) { return g_err.c_str(); }
+int lc_version(void) { return 100; }
+
+int lc_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+double lc_const_converge(void) { return lch::CONVERGE; }
+double lc_const_fengydel(void) { return lch::FENGYDEL; }
+double lc_const_zerocutoff(void) { return lch::ZEROCUTOFF; }
+int lc_const_splititer(void) { return (int)lch::SPLITITER; }
+
+// ---------------------------------------------------------------------------
+int lc_ctx_create(int device, void* stream, lc_ctx** out) {
+  return guarded([&] {
+    need(out, "out");
+    *out = new lc_ctx(device, (hipStream_t)stream);
+  });
+}
+
+int lc_ctx_destroy(lc_ctx* ctx) {
+  return guarded([&] { delete ctx; });
+}
+
+int lc_ctx_set_stream(lc_ctx* ctx, void* stream) {
+  return guarded([&] {
+    need(ctx, "ctx");
+    ctx->impl.set_stream((hipStream_t)stream);
+  });
+}
+
+int lc_ctx_synchronize(lc_ctx* ctx) {
+  return guarded([&] {
+    need(ctx, "ctx");
+    ctx->impl.synchronize();
+  });
+}
+
+int lc_ctx_dims(lc_ctx* ctx, int* J, int* D, int64_t* Ntotal, int* K) {
+  return guarded([&] {
+    need(ctx, "ctx");
+    if (J) *J = ctx->impl.J();
+    if (D) *D = ctx->impl.D();
+    if (Ntotal) *Ntotal = ctx->impl.Ntotal();
+    if (K) *K = ctx->impl.K();
+  });
+}
+
+int lc_ctx_set_data(lc_ctx* ctx, int J, const double* const* Xj, const int64_t* Nj, int D, int64_t rs, int64_t cs) {
+  return guarded([&] {
+    need(ctx, "ctx");
+    need(Xj, "Xj");
+    need(Nj, "Nj");
+    ctx->impl.set_data(J, Xj, Nj, D, rs, cs);
+  });
+}
+
+int lc_ctx_synth(lc_ctx* ctx, int64_t N, int D, int K, const double* mu, const double* L, uint64_t seed,
+                 int64_t row_offset, double hard) {
+  return guarded([&] {
+    need(ctx, "ctx");
+    need(mu, "mu");
+    need(L, "L");
+    ctx->impl.synth(N, D, K, mu, L, seed, row_offset, hard);
+  });
+}
+
+int lc_ctx_get_rows(lc_ctx* ctx, int j, int64_t row0, int64_t n, double* out) {
+  return guarded([&] {
+    need(ctx, "ctx");
+    need(out, "out");
+    ctx->impl.get_rows(j, row0, n, out);
+  });
+}
+
+int lc_ctx_set_qz(lc_ctx* ctx, int j, const double* q, int K, int64_t rs, int64_t cs) {
+  return guarded([&] {
+    need(ctx, "ctx");
+    need(q, "q");
+    ctx->impl.qz_set(j, q, K, rs, cs);
+  });
+}
+
+int lc_ctx_get_qz(lc_ctx* ctx, int j, double* q, int64_t rs, int64_t cs) {
+  return guarded([&] {
+    need(ctx, "ctx");
+    need(q, "q");
+    ctx->impl.qz_get(j, q, rs, cs);
+  });
+}
+
+int lc_ctx_fill_qz(lc_ctx* ctx, int K, double value) {
+  return guarded([&] {
+    need(ctx, "ctx");
+    ctx->impl.qz_fill(K, value);
+    ctx->impl.synchronize();
+  });
+}
+
+// ---------------------------------------------------------------------------
+int lc_estep(lc_ctx* ctx, int K, const double* A, const double* m, const double* c, double* Fz, double* LLk) {
+  return guarded([&] {
+    need(ctx, "ctx");
+    need(A, "A");
+    need(m, "m");
+    need(c, "c");
+    ctx->impl.estep(K, A, m, c, Fz, LLk);
+  });
+}
+
+int lc_estep_posterior(lc_ctx* ctx, int K, const double* nu, const double* beta, const double* m, const double* iW,
+                       const double* logdW, const double* Elogpi, const unsigned char* active, double* Fz,
+                       double* LLk) {
+  return guarded([&] {
+    need(ctx, "ctx");
+    need(nu, "nu");
+    need(beta, "beta");
+    need(m, "m");
+    need(iW, "iW");
+    need(logdW, "logdW");
+    need(Elogpi, "Elogpi");
+    if (K < 1) throw std::invalid_argument("K must be >= 1");
+    const int D = ctx->impl.D(), J = ctx->impl.J();
+    std::vector<double> A((size_t)K * D * D), c((size_t)J * K), cst(K);
+    for (int k = 0; k < K; ++k) {
+      std::vector<double> L(iW + (size_t)k * D * D, iW + (size_t)(k + 1) * D * D);
+      // mahaldist's PD check, probutils.cpp:131-132
+      if (!lch::cholesky(L, D)) throw std::invalid_argument("Matrix A is not positive definite");
+      std::vector<double> Li = lch::tril_inverse(L, D);
+      const double s = std::sqrt(nu[k]);
+      for (size_t t = 0; t < Li.size(); ++t) A[(size_t)k * D * D + t] = s * Li[t];
+      double sumpsi = 0.0;
+      for (int d = 1; d <= D; ++d) sumpsi += lch::digamma((nu[k] + 1 - d) / 2);
+      cst[k] = 0.5 * (sumpsi + logdW[k] - D * (1.0 / beta[k] + std::log(lch::PI)));  // distributions.cpp:360-364
+    }
+    for (int j = 0; j < J; ++j)
+      for (int k = 0; k < K; ++k) {
+        double v = Elogpi[(size_t)j * K + k] + cst[k];
+        if (active && !active[(size_t)j * K + k]) v = -std::numeric_limits<double>::infinity();
+        c[(size_t)j * K + k] = v;
+      }
+    std::vector<double> ll(K);
+    ctx->impl.estep(K, A.data(), m, c.data(), Fz, ll.data());
+    if (LLk) {
+      std::vector<double> Njk((size_t)J * K);
+      ctx->impl.colsums(Njk.data());
+      for (int k = 0; k < K; ++k) {
+        double nk = 0.0;
+        for (int j = 0; j < J; ++j) nk += Njk[(size_t)j * K + k];
+        LLk[k] = ll[k] + cst[k] * nk;
+      }
+    }
+  });
+}
+
+int lc_suffstat(lc_ctx* ctx, const unsigned char* smask, double* Nk, double* xs, double* xxs, double* Njk) {
+  return guarded([&] {
+    need(ctx, "ctx");
+    ctx->impl.suffstat(smask, Nk, xs, xxs, Njk);
+  });
+}
+
+int lc_colsums(lc_ctx* ctx, double* Njk) {
+  return guarded([&] {
+    need(ctx, "ctx");
+    need(Njk, "Njk");
+    ctx->impl.colsums(Njk);
+  });
+}
+
+int lc_ctx_set_allreduce(lc_ctx* ctx, lc_allreduce_fn fn, void* user) {
+  return guarded([&] {
+    need(ctx, "ctx");
+    ctx->impl.set_allreduce(fn, user);
+  });
+}
+
+int lc_ctx_timing_enable(lc_ctx* ctx, int on) {
+  return guarded([&] {
+    need(ctx, "ctx");
+    ctx->impl.timing_enable(on != 0);
+  });
+}
+
+int lc_ctx_timing_reset(lc_ctx* ctx) {
+  return guarded([&] {
+    need(ctx, "ctx");
+    ctx->impl.timing_reset();
+  });
+}
+
+int lc_ctx_timing_get(lc_ctx* ctx, double* estep_ms, int64_t* estep_calls, double* suffstat_ms,
+                      int64_t* suffstat_calls) {
+  return guarded([&] {
+    need(ctx, "ctx");
+    const lcc::KernelTimes t = ctx->impl.timing_get();
+    if (estep_ms) *estep_ms = t.estep_ms;
+    if (estep_calls) *estep_calls = t.estep_calls;
+    if (suffstat_ms) *suffstat_ms = t.suffstat_ms;
+    if (suffstat_calls) *suffstat_calls = t.suffstat_calls;
+  });
+}
+
+// ---------------------------------------------------------------------------
+int lc_vbem(lc_ctx* ctx, lc_model** model, int wkind, double wprior, double clusterprior, int maxit, int sparse,
+            int fixed_iters, int verbose, unsigned nthreads, double* F, int* niter, double* Ftrace, int ntrace) {
+  return guarded([&] {
+    need(ctx, "ctx");
+    need(model, "model");
+    if (wkind < 0 || wkind > 2) throw std::invalid_argument("unknown weight kind");
+    if (nthreads < 1) throw std::invalid_argument("Must specify at least one thread for execution!");
+    std::unique_ptr<lc_model> fresh;
+    lc_model* m = *model;
+    if (!m) {
+      fresh.reset(new lc_model());
+      m = fresh.get();
+      m->model.wkind = wkind;
+      m->D = ctx->impl.D();
+      for (int j = 0; j < ctx->impl.J(); ++j) m->model.weights.emplace_back(wkind, wprior);
+    }
+    m->ctx = ctx;
+    std::vector<double> tr;
+    lce::VbemOptions vo;
+    vo.clusterprior = clusterprior;
+    vo.maxit = maxit;
+    vo.sparse = sparse != 0;
+    vo.verbose = verbose != 0;
+    vo.fixed_iters = fixed_iters;
+    vo.nthreads = nthreads;
+    vo.trace = &tr;
+    const double f = lce::vbem(ctx->impl, m->model, vo);
+    m->rounds.emplace_back((int)m->model.clusters.size(), tr);
+    if (F) *F = f;
+    if (niter) *niter = (int)tr.size();
+    if (Ftrace)
+      for (int i = 0; i < ntrace && i < (int)tr.size(); ++i) Ftrace[i] = tr[(size_t)i];
+    if (fresh) *model = fresh.release();
+  });
+}
+
+int lc_learn(int algo, int J, const double* const* Xj, const int64_t* Nj, int D, int64_t rs, int64_t cs,
+             double wprior, double clusterprior, int maxclusters, int sparse, int verbose, unsigned nthreads,
+             int device, lc_model** out, double* F) {
+  return guarded([&] {
+    need(Xj, "Xj");
+    need(Nj, "Nj");
+    need(out, "out");
+    if (algo < 0 || algo > 2) throw std::invalid_argument("unknown algorithm");
+    if ((algo == LC_ALGO_VDP || algo == LC_ALGO_BGMM) && J != 1)
+      throw std::invalid_argument("learnVDP/learnBGMM take a single observation matrix");
+    if (nthreads < 1) throw std::invalid_argument("Must specify at least one thread for execution!");  // cluster.cpp:576-577
+    std::unique_ptr<lc_model> m(new lc_model());
+    m->owned_ctx.reset(new lc_ctx(device, nullptr));
+    m->ctx = m->owned_ctx.get();
+    m->D = D;
+    lcc::Context& ctx = m->ctx->impl;
+    ctx.set_data(J, Xj, Nj, D, rs, cs);
+    lce::HostData host;
+    host.J = J;
+    host.D = D;
+    host.X.assign(Xj, Xj + J);
+    host.N.assign(Nj, Nj + J);
+    host.row_stride = rs;
+    host.col_stride = cs;
+    if (algo == LC_ALGO_VDP) {
+      if (verbose) std::cout << "Learning VDP..." << std::endl;  // cluster.cpp:647-648
+      m->model.wkind = lch::W_STICKBREAK;
+      m->model.weights.emplace_back(lch::W_STICKBREAK, wprior);  // vecweights(1, weights), :653
+    } else if (algo == LC_ALGO_BGMM) {
+      if (verbose) std::cout << "Learning Bayesian GMM..." << std::endl;  // :678-679
+      m->model.wkind = lch::W_DIRICHLET;
+      m->model.weights.emplace_back(lch::W_DIRICHLET, wprior);  // :684
+    } else {
+      if (verbose) std::cout << "Learning " << (sparse ? "(sparse) " : "") << "GMC..." << std::endl;  // :775-779
+      m->model.wkind = lch::W_GDIRICHLET;
+    }
+    lce::ClusterOptions co;
+    co.clusterprior = clusterprior;
+    co.maxclusters = maxclusters;
+    co.sparse = (algo == LC_ALGO_GMC) && sparse;  // learnVDP/BGMM pass sparse=false, :657/:688
+    co.verbose = verbose != 0;
+    co.nthreads = nthreads;
+    co.trace = &m->rounds;
+    const double f = lce::cluster(ctx, host, m->model, co);
+    if (F) *F = f;
+    *out = m.release();
+  });
+}
+
+int lc_model_free(lc_model* m) {
+  return guarded([&] { delete m; });
+}
+
+int lc_model_dims(lc_model* m, int* J, int* K, int* D) {
+  return guarded([&] {
+    need(m, "model");
+    if (J) *J = (int)m->model.weights.size();
+    if (K) *K = (int)m->model.clusters.size();
+    if (D) *D = m->D;
+  });
+}
+
+int lc_model_rounds(lc_model* m, int* nrounds) {
+  return guarded([&] {
+    need(m, "model");
+    need(nrounds, "nrounds");
+    *nrounds = (int)m->rounds.size();
+  });
+}
+
+int lc_model_round(lc_model* m, int r, int* K, int* niter, double* F, int nF) {
+  return guarded([&] {
+    need(m, "model");
+    if (r < 0 || r >= (int)m->rounds.size()) throw std::invalid_argument("round index out of range");
+    const auto& rd = m->rounds[(size_t)r];
+    if (K) *K = rd.first;
+    if (niter) *niter = (int)rd.second.size();
+    if (F)
+      for (int i = 0; i < nF && i < (int)rd.second.size(); ++i) F[i] = rd.second[(size_t)i];
+  });
+}
+
+int lc_model_get_qz(lc_model* m, int j, double* q, int64_t rs, int64_t cs) {
+  return guarded([&] {
+    need(m, "model");
+    need(q, "q");
+    if (!m->ctx) throw std::invalid_argument("model has no context");
+    m->ctx->impl.qz_get(j, q, rs, cs);
+  });
+}
+
+int lc_model_weights(lc_model* m, int j, double* Elogweight, double* Nk) {
+  return guarded([&] {
+    need(m, "model");
+    if (j < 0 || j >= (int)m->model.weights.size()) throw std::invalid_argument("group index out of range");
+    const lch::WeightState& w = m->model.weights[(size_t)j];
+    if (Elogweight) std::copy(w.Elogpi.begin(), w.Elogpi.end(), Elogweight);
+    if (Nk) std::copy(w.Nk.begin(), w.Nk.end(), Nk);
+  });
+}
+
+int lc_model_cluster(lc_model* m, int k, double* N, double* mean, double* cov, double* nu, double* beta, double* iW,
+                     double* logdW) {
+  return guarded([&] {
+    need(m, "model");
+    if (k < 0 || k >= (int)m->model.clusters.size()) throw std::invalid_argument("cluster index out of range");
+    const lch::GaussWishState& c = m->model.clusters[(size_t)k];
+    if (N) *N = c.N;
+    if (mean) std::copy(c.m.begin(), c.m.end(), mean);
+    if (cov) {
+      const std::vector<double> cv = c.getcov();
+      std::copy(cv.begin(), cv.end(), cov);
+    }
+    if (nu) *nu = c.nu;
+    if (beta) *beta = c.beta;
+    if (iW) std::copy(c.iW.begin(), c.iW.end(), iW);
+    if (logdW) *logdW = c.logdW;
+  });
+}
+
+int lc_model_fenergy(lc_model* m, double* Fw, double* Fc) {
+  return guarded([&] {
+    need(m, "model");
+    if (Fw)
+      for (size_t j = 0; j < m->model.weights.size(); ++j) Fw[j] = m->model.weights[j].fenergy();
+    if (Fc)
+      for (size_t k = 0; k < m->model.clusters.size(); ++k) Fc[k] = m->model.clusters[k].fenergy();
+  });
+}
+
+// ---------------------------------------------------------------------------
+double lc_digamma(double x) { return lch::digamma(x); }
+
+int lc_weights_update(int wkind, double wprior, const double* Nk, int K, double* Elogweight, double* fenergy) {
+  return guarded([&] {
+    need(Nk, "Nk");
+    if (wkind < 0 || wkind > 2) throw std::invalid_argument("unknown weight kind");
+    if (K < 1) throw std::invalid_argument("K must be >= 1");
+    lch::WeightState w(wkind, wprior);
+    w.update(Nk, K);
+    if (Elogweight) std::copy(w.Elogpi.begin(), w.Elogpi.end(), Elogweight);
+    if (fenergy) *fenergy = w.fenergy();
+  });
+}
+
+int lc_gw_mstep(double clustwidth, int D, double Ns, const double* xs, const double* xxs, double* nu, double* beta,
+                double* m, double* iW, double* logdW, double* fenergy, double* A, double* eloglike_const) {
+  return guarded([&] {
+    need(xs, "xs");
+    need(xxs, "xxs");
+    lch::GaussWishState g(clustwidth, D);
+    g.addstats(Ns, xs, xxs);
+    g.update();
+    if (nu) *nu = g.nu;
+    if (beta) *beta = g.beta;
+    if (m) std::copy(g.m.begin(), g.m.end(), m);
+    if (iW) std::copy(g.iW.begin(), g.iW.end(), iW);
+    if (logdW) *logdW = g.logdW;
+    if (fenergy) *fenergy = g.fenergy();
+    if (A) {
+      const std::vector<double> a = g.whitener();
+      std::copy(a.begin(), a.end(), A);
+    }
+    if (eloglike_const) *eloglike_const = g.eloglike_const();
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,465 @@
+#include "lc_ctx.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace lcc {
+
+#define LC_HIP(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess)                                                                              \
+      throw HipFailure(std::string("HIP error: ") + hipGetErrorString(e_) + " in " #expr " (" __FILE__ \
+                                                                            ":" +                      \
+                       std::to_string(__LINE__) + ")");                                                \
+  } while (0)
+
+template <typename T>
+void DevBuf<T>::reserve(size_t n) {
+  if (n <= cap) return;
+  release();
+  void* q = nullptr;
+  hipError_t e = hipMalloc(&q, n * sizeof(T));
+  if (e != hipSuccess)
+    throw HipFailure(std::string("HIP error: hipMalloc of ") + std::to_string(n * sizeof(T)) +
+                     " bytes failed: " + hipGetErrorString(e));
+  p = static_cast<T*>(q);
+  cap = n;
+}
+template struct DevBuf<double>;
+template struct DevBuf<int>;
+template struct DevBuf<int64_t>;
+template struct DevBuf<unsigned char>;
+
+Context::Context(int device, hipStream_t stream) : device_(device), stream_(stream) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    throw HipFailure("libcluster_amd: no HIP device available (the E-step has no CPU fallback): " +
+                     std::string(e != hipSuccess ? hipGetErrorString(e) : "device count is 0"));
+  if (device < 0 || device >= n) throw std::invalid_argument("device index out of range");
+  LC_HIP(hipSetDevice(device_));
+}
+
+Context::~Context() {
+  for (auto& p : pending_) {
+    (void)hipEventDestroy(p.a);
+    (void)hipEventDestroy(p.b);
+  }
+}
+
+void Context::synchronize() const { LC_HIP(hipStreamSynchronize(stream_)); }
+
+void Context::build_layout(int J, const int64_t* Nj, int D) {
+  if (J < 1) throw std::invalid_argument("need at least one group of observations");
+  if (D < 1) throw std::invalid_argument("observations must have at least one dimension");
+  const int DP = lck::padded_dim(D);
+  if (DP < 0) throw std::invalid_argument("D > 128 is not supported by the gfx950 kernels");
+  J_ = J;
+  D_ = D;
+  DP_ = DP;
+  Nj_.assign(Nj, Nj + J);
+  goff_.assign(J + 1, 0);
+  Ntot_ = 0;
+  for (int j = 0; j < J; ++j) {
+    if (Nj[j] < 0) throw std::invalid_argument("negative group size");
+    goff_[j + 1] = goff_[j] + (Nj[j] + lck::RG - 1) / lck::RG * lck::RG;
+    Ntot_ += Nj[j];
+  }
+  NP_ = goff_[J];
+  qz_[0].K = qz_[1].K = 0;
+  LC_HIP(hipSetDevice(device_));
+  X_.reserve((size_t)std::max<int64_t>(NP_, 1) * DP_);
+  goff_d_.reserve(J + 1);
+  LC_HIP(hipMemcpyAsync(goff_d_.p, goff_.data(), (J + 1) * sizeof(int64_t), hipMemcpyHostToDevice, stream_));
+  if (J > 1) {
+    std::vector<int> info((size_t)(NP_ / lck::RG));
+    for (int j = 0; j < J; ++j) {
+      const int64_t g0 = goff_[j] / lck::RG, g1 = goff_[j + 1] / lck::RG;
+      for (int64_t g = g0; g < g1; ++g) {
+        const int64_t rem = Nj[j] - (g - g0) * lck::RG;
+        info[(size_t)g] = lck::rginfo_pack(j, (int)std::min<int64_t>(rem, lck::RG));
+      }
+    }
+    rginfo_.reserve(std::max<size_t>(info.size(), 1));
+    if (!info.empty())
+      LC_HIP(hipMemcpyAsync(rginfo_.p, info.data(), info.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
+    LC_HIP(hipStreamSynchronize(stream_));
+  } else {
+    rginfo_.release();
+  }
+  LC_HIP(hipStreamSynchronize(stream_));
+}
+
+void Context::set_data(int J, const double* const* Xj, const int64_t* Nj, int D, int64_t rs, int64_t cs) {
+  build_layout(J, Nj, D);
+  if (NP_ == 0) return;
+  // stage in row chunks so the host copy stays bounded
+  const int64_t chunk = std::max<int64_t>(lck::RG, ((int64_t)32 << 20) / DP_ / lck::RG * lck::RG);
+  std::vector<double> stage;
+  for (int j = 0; j < J; ++j) {
+    const int64_t np = goff_[j + 1] - goff_[j];
+    for (int64_t r0 = 0; r0 < np; r0 += chunk) {
+      const int64_t nr = std::min(chunk, np - r0);
+      stage.assign((size_t)nr * DP_, 0.0);
+      const int64_t nvalid = std::max<int64_t>(0, std::min(nr, Nj[j] - r0));
+      for (int64_t r = 0; r < nvalid; ++r) {
+        const double* src = Xj[j] + (r0 + r) * rs;
+        double* dst = stage.data() + (size_t)r * DP_;
+        for (int d = 0; d < D; ++d) dst[d] = src[d * cs];
+      }
+      LC_HIP(hipMemcpyAsync(X_.p + (size_t)(goff_[j] + r0) * DP_, stage.data(), stage.size() * sizeof(double),
+                            hipMemcpyHostToDevice, stream_));
+      LC_HIP(hipStreamSynchronize(stream_));
+    }
+  }
+}
+
+void Context::synth(int64_t N, int D, int K, const double* mu, const double* L, uint64_t seed, int64_t row_offset,
+                    double hard) {
+  if (K < 1) throw std::invalid_argument("K must be >= 1");
+  build_layout(1, &N, D);
+  DevBuf<double> dmu, dL;
+  dmu.reserve((size_t)K * D);
+  dL.reserve((size_t)K * D * D);
+  LC_HIP(hipMemcpyAsync(dmu.p, mu, (size_t)K * D * sizeof(double), hipMemcpyHostToDevice, stream_));
+  LC_HIP(hipMemcpyAsync(dL.p, L, (size_t)K * D * D * sizeof(double), hipMemcpyHostToDevice, stream_));
+  ensure_qz(qz_[cur_], K, false);
+  qz_[cur_].K = K;
+  lck::SynthLaunch a;
+  a.DP = DP_;
+  a.D = D;
+  a.K = K;
+  a.X = X_.p;
+  a.qZ = qz_[cur_].buf.p;
+  a.ldq = NP_;
+  a.nrows = N;
+  a.NP = NP_;
+  a.row_offset = row_offset;
+  a.seed = seed;
+  a.mu = dmu.p;
+  a.L = dL.p;
+  a.hard = hard;
+  LC_HIP(lck::launch_synth(a, stream_));
+  LC_HIP(hipStreamSynchronize(stream_));
+}
+
+void Context::get_rows(int j, int64_t row0, int64_t n, double* out) const {
+  if (j < 0 || j >= J_ || row0 < 0 || n < 0 || row0 + n > Nj_[j]) throw std::invalid_argument("row range out of bounds");
+  if (n == 0) return;
+  std::vector<double> tmp((size_t)n * DP_);
+  LC_HIP(hipMemcpyAsync(tmp.data(), X_.p + (size_t)(goff_[j] + row0) * DP_, tmp.size() * sizeof(double),
+                        hipMemcpyDeviceToHost, stream_));
+  LC_HIP(hipStreamSynchronize(stream_));
+  for (int64_t r = 0; r < n; ++r) std::memcpy(out + r * D_, tmp.data() + (size_t)r * DP_, D_ * sizeof(double));
+}
+
+// ---------------------------------------------------------------------------
+// qZ
+// ---------------------------------------------------------------------------
+void Context::ensure_qz(QZ& q, int K, bool preserve) {
+  if (K <= q.cap && q.buf.p) return;
+  int newcap = std::max(K, q.cap > 0 ? q.cap + std::max(4, q.cap / 2) : K);
+  DevBuf<double> nb;
+  nb.reserve((size_t)std::max<int64_t>(NP_, 1) * newcap);
+  LC_HIP(hipMemsetAsync(nb.p, 0, (size_t)std::max<int64_t>(NP_, 1) * newcap * sizeof(double), stream_));
+  if (preserve && q.buf.p && q.K > 0)
+    LC_HIP(hipMemcpyAsync(nb.p, q.buf.p, (size_t)NP_ * q.K * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+  LC_HIP(hipStreamSynchronize(stream_));
+  std::swap(q.buf.p, nb.p);
+  std::swap(q.buf.cap, nb.cap);
+  q.cap = newcap;
+}
+
+void Context::qz_fill(int K, double value) {
+  if (K < 1) throw std::invalid_argument("K must be >= 1");
+  ensure_qz(qz_[cur_], K, false);
+  qz_[cur_].K = K;
+  LC_HIP(lck::launch_fill_qz(qz_[cur_].buf.p, NP_, K, rginfo_.p, Nj_[0], NP_ / lck::RG, value, stream_));
+}
+
+void Context::qz_set(int j, const double* q, int K, int64_t rs, int64_t cs) {
+  if (j < 0 || j >= J_) throw std::invalid_argument("group index out of range");
+  if (K < 1) throw std::invalid_argument("K must be >= 1");
+  if (K != qz_[cur_].K) {
+    ensure_qz(qz_[cur_], K, false);
+    // a new K invalidates every group: start from zeros
+    LC_HIP(hipMemsetAsync(qz_[cur_].buf.p, 0, (size_t)NP_ * K * sizeof(double), stream_));
+    qz_[cur_].K = K;
+  }
+  const int64_t n = Nj_[j];
+  if (n == 0) return;
+  std::vector<double> col((size_t)n);
+  for (int k = 0; k < K; ++k) {
+    for (int64_t r = 0; r < n; ++r) col[(size_t)r] = q[r * rs + k * cs];
+    LC_HIP(hipMemcpyAsync(qz_[cur_].buf.p + (size_t)k * NP_ + goff_[j], col.data(), n * sizeof(double),
+                          hipMemcpyHostToDevice, stream_));
+    LC_HIP(hipStreamSynchronize(stream_));
+  }
+}
+
+void Context::qz_get_column(int j, int k, double* out) const {
+  if (j < 0 || j >= J_ || k < 0 || k >= qz_[cur_].K) throw std::invalid_argument("qZ column out of range");
+  if (Nj_[j] == 0) return;
+  LC_HIP(hipMemcpyAsync(out, qz_[cur_].buf.p + (size_t)k * NP_ + goff_[j], Nj_[j] * sizeof(double),
+                        hipMemcpyDeviceToHost, stream_));
+  LC_HIP(hipStreamSynchronize(stream_));
+}
+
+void Context::qz_get(int j, double* q, int64_t rs, int64_t cs) const {
+  if (j < 0 || j >= J_) throw std::invalid_argument("group index out of range");
+  const int64_t n = Nj_[j];
+  std::vector<double> col((size_t)n);
+  for (int k = 0; k < qz_[cur_].K; ++k) {
+    qz_get_column(j, k, col.data());
+    for (int64_t r = 0; r < n; ++r) q[r * rs + k * cs] = col[(size_t)r];
+  }
+}
+
+void Context::qz_keep_columns(const std::vector<int>& keep) {
+  QZ& q = qz_[cur_];
+  for (size_t i = 0; i < keep.size(); ++i) {
+    const int src = keep[i];
+    if (src < (int)i || src >= q.K) throw std::invalid_argument("bad column list");
+    if (src != (int)i)
+      LC_HIP(hipMemcpyAsync(q.buf.p + i * (size_t)NP_, q.buf.p + (size_t)src * NP_, NP_ * sizeof(double),
+                            hipMemcpyDeviceToDevice, stream_));
+  }
+  q.K = (int)keep.size();
+}
+
+void Context::qz_clone_to_alt() {
+  QZ& a = qz_[cur_ ^ 1];
+  const int Ksave = qz_[cur_].K;
+  ensure_qz(a, Ksave + 1, false);
+  a.K = Ksave;
+  LC_HIP(hipMemcpyAsync(a.buf.p, qz_[cur_].buf.p, (size_t)NP_ * Ksave * sizeof(double), hipMemcpyDeviceToDevice,
+                        stream_));
+  LC_HIP(hipMemsetAsync(a.buf.p + (size_t)NP_ * Ksave, 0, (size_t)NP_ * sizeof(double), stream_));
+}
+
+void Context::qz_swap_alt() { cur_ ^= 1; }
+
+void Context::qz_split_column(int k, const std::vector<int64_t>& rows) {
+  QZ& q = qz_[cur_];
+  if (k < 0 || k >= q.K) throw std::invalid_argument("split column out of range");
+  if (q.K + 1 > q.cap) ensure_qz(q, q.K + 1, true);
+  LC_HIP(hipMemsetAsync(q.buf.p + (size_t)NP_ * q.K, 0, (size_t)NP_ * sizeof(double), stream_));
+  if (!rows.empty()) {
+    idx_.reserve(rows.size());
+    LC_HIP(hipMemcpyAsync(idx_.p, rows.data(), rows.size() * sizeof(int64_t), hipMemcpyHostToDevice, stream_));
+    LC_HIP(lck::launch_move_rows(q.buf.p, NP_, k, q.K, idx_.p, (int64_t)rows.size(), stream_));
+    LC_HIP(hipStreamSynchronize(stream_));  // rows' storage may go away
+  }
+  q.K += 1;
+}
+
+// ---------------------------------------------------------------------------
+// hot path
+// ---------------------------------------------------------------------------
+void Context::allreduce(double* dbuf, int64_t count) {
+  if (!ar_fn_) return;
+  const int rc = ar_fn_(ar_user_, dbuf, count, (void*)stream_);
+  if (rc != 0) throw std::runtime_error("all-reduce hook failed with status " + std::to_string(rc));
+}
+
+void Context::estep(int K, const double* A, const double* m, const double* c, double* Fz, double* LLk) {
+  if (K < 1) throw std::invalid_argument("K must be >= 1");
+  if (NP_ == 0 && !ar_fn_) {
+    if (Fz) *Fz = -0.0;
+    if (LLk) std::fill(LLk, LLk + K, 0.0);
+    qz_[cur_].K = K;
+    return;
+  }
+  LC_HIP(hipSetDevice(device_));
+  const int D = D_, DP = DP_, NT = DP / 4;
+  const int PS = lck::pstride(DP), NTILES = lck::ntiles(DP);
+  // ---- pack: tiles of A_k in consumption order, then b_k = A_k m_k --------
+  hpack_.assign((size_t)K * PS + (size_t)J_ * K, 0.0);
+  for (int k = 0; k < K; ++k) {
+    const double* Ak = A + (size_t)k * D * D;
+    const double* mk = m + (size_t)k * D;
+    double* P = hpack_.data() + (size_t)k * PS;
+    for (int it = 0; it < NT; ++it)
+      for (int jt = 0; jt <= it; ++jt) {
+        double* T = P + (size_t)(it * (it + 1) / 2 + jt) * 16;
+        for (int hi = 0; hi < 4; ++hi)
+          for (int lo = 0; lo < 4; ++lo) {
+            const int i = 4 * it + lo, j = 4 * jt + hi;
+            T[lo + 4 * hi] = (i < D && j <= i) ? Ak[(size_t)i * D + j] : 0.0;
+          }
+      }
+    double* b = P + (size_t)NTILES * 16;
+    for (int i = 0; i < D; ++i) {
+      double s = 0.0;
+      for (int j = 0; j <= i; ++j) s += Ak[(size_t)i * D + j] * mk[j];
+      b[i] = s;
+    }
+  }
+  std::memcpy(hpack_.data() + (size_t)K * PS, c, (size_t)J_ * K * sizeof(double));
+  params_.reserve(hpack_.size());
+  LC_HIP(hipMemcpyAsync(params_.p, hpack_.data(), hpack_.size() * sizeof(double), hipMemcpyHostToDevice, stream_));
+
+  ensure_qz(qz_[cur_], K, false);  // E-step overwrites every column
+  qz_[cur_].K = K;
+  const int64_t nrg = NP_ / lck::RG;
+  const int64_t grid = lck::estep_grid(DP, nrg);
+  fzpart_.reserve((size_t)std::max<int64_t>(grid, 1));
+  llpart_.reserve((size_t)std::max<int64_t>(grid, 1) * K);
+  red_.reserve((size_t)1 + K);
+
+  lck::EstepLaunch a;
+  a.DP = DP;
+  a.X = X_.p;
+  a.nrg = nrg;
+  a.rginfo = J_ > 1 ? rginfo_.p : nullptr;
+  a.nrows = Nj_[0];
+  a.params = params_.p;
+  a.ctab = params_.p + (size_t)K * PS;
+  a.K = K;
+  a.qZ = qz_[cur_].buf.p;
+  a.ldq = NP_;
+  a.fz_part = fzpart_.p;
+  a.ll_part = llpart_.p;
+  EvPair ev{};
+  if (timing_) {
+    LC_HIP(hipEventCreate(&ev.a));
+    LC_HIP(hipEventCreate(&ev.b));
+    ev.kind = 0;
+    LC_HIP(hipEventRecord(ev.a, stream_));
+  }
+  LC_HIP(lck::launch_estep(a, stream_));
+  if (timing_) {
+    LC_HIP(hipEventRecord(ev.b, stream_));
+    pending_.push_back(ev);
+  }
+  if (grid > 0) {
+    LC_HIP(lck::launch_reduce_partials(fzpart_.p, (int)grid, 1, red_.p, stream_));
+    LC_HIP(lck::launch_reduce_partials(llpart_.p, (int)grid, K, red_.p + 1, stream_));
+  } else {
+    LC_HIP(hipMemsetAsync(red_.p, 0, (size_t)(1 + K) * sizeof(double), stream_));
+  }
+  allreduce(red_.p, 1 + K);
+  hred_.resize((size_t)1 + K);
+  LC_HIP(hipMemcpyAsync(hred_.data(), red_.p, (size_t)(1 + K) * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  LC_HIP(hipStreamSynchronize(stream_));
+  if (Fz) *Fz = hred_[0];
+  if (LLk) std::copy(hred_.begin() + 1, hred_.end(), LLk);
+}
+
+void Context::suffstat(const unsigned char* smask, double* Nk, double* xs, double* xxs, double* Njk) {
+  const int K = qz_[cur_].K, D = D_, DP = DP_;
+  if (K < 1) throw std::invalid_argument("qZ has not been set");
+  LC_HIP(hipSetDevice(device_));
+  const int64_t SS = lck::stat_stride(DP);
+  const size_t nout = (size_t)K * SS + (size_t)J_ * K;
+  ssout_.reserve(nout);
+  double* njk_d = ssout_.p + (size_t)K * SS;
+  if (NP_ > 0) {
+    int64_t chunk_rows = 0;
+    const int nchunks = lck::suffstat_plan(DP, NP_, K, &chunk_rows);
+    sspart_.reserve((size_t)nchunks * K * SS);
+    lck::SuffstatLaunch a;
+    a.DP = DP;
+    a.X = X_.p;
+    a.NP = NP_;
+    a.qZ = qz_[cur_].buf.p;
+    a.ldq = NP_;
+    a.K = K;
+    a.rginfo = nullptr;
+    a.smask = nullptr;
+    if (smask && J_ > 1) {
+      smask_.reserve((size_t)J_ * K);
+      LC_HIP(hipMemcpyAsync(smask_.p, smask, (size_t)J_ * K, hipMemcpyHostToDevice, stream_));
+      a.rginfo = rginfo_.p;
+      a.smask = smask_.p;
+    } else if (smask) {
+      // single group: a masked cluster simply receives nothing (handled on the host below)
+    }
+    a.partial = sspart_.p;
+    a.nchunks = nchunks;
+    a.chunk_rows = chunk_rows;
+    EvPair ev{};
+    if (timing_) {
+      LC_HIP(hipEventCreate(&ev.a));
+      LC_HIP(hipEventCreate(&ev.b));
+      ev.kind = 1;
+      LC_HIP(hipEventRecord(ev.a, stream_));
+    }
+    LC_HIP(lck::launch_suffstat(a, stream_));
+    if (timing_) {
+      LC_HIP(hipEventRecord(ev.b, stream_));
+      pending_.push_back(ev);
+    }
+    LC_HIP(lck::launch_reduce_partials(sspart_.p, nchunks, (int64_t)K * SS, ssout_.p, stream_));
+    LC_HIP(lck::launch_group_colsum(qz_[cur_].buf.p, NP_, K, goff_d_.p, J_, njk_d, stream_));
+  } else {
+    LC_HIP(hipMemsetAsync(ssout_.p, 0, nout * sizeof(double), stream_));
+  }
+  allreduce(ssout_.p, (int64_t)nout);
+  hss_.resize(nout);
+  LC_HIP(hipMemcpyAsync(hss_.data(), ssout_.p, nout * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  LC_HIP(hipStreamSynchronize(stream_));
+  for (int k = 0; k < K; ++k) {
+    const double* rec = hss_.data() + (size_t)k * SS;
+    const bool off = smask && J_ == 1 && !smask[k];
+    if (Nk) Nk[k] = off ? 0.0 : rec[0];
+    if (xs)
+      for (int d = 0; d < D; ++d) xs[(size_t)k * D + d] = off ? 0.0 : rec[1 + d];
+    if (xxs) {
+      const double* S = rec + 1 + DP;
+      double* o = xxs + (size_t)k * D * D;
+      // lower triangle is authoritative; mirror it so the result is exactly symmetric
+      for (int i = 0; i < D; ++i)
+        for (int j = 0; j <= i; ++j) {
+          const double v = off ? 0.0 : S[(size_t)i * DP + j];
+          o[(size_t)i * D + j] = v;
+          o[(size_t)j * D + i] = v;
+        }
+    }
+  }
+  if (Njk) std::copy(hss_.begin() + (size_t)K * SS, hss_.end(), Njk);
+}
+
+void Context::colsums(double* Njk) {
+  const int K = qz_[cur_].K;
+  if (K < 1) throw std::invalid_argument("qZ has not been set");
+  red_.reserve((size_t)std::max(1 + K, J_ * K));
+  if (NP_ > 0)
+    LC_HIP(lck::launch_group_colsum(qz_[cur_].buf.p, NP_, K, goff_d_.p, J_, red_.p, stream_));
+  else
+    LC_HIP(hipMemsetAsync(red_.p, 0, (size_t)J_ * K * sizeof(double), stream_));
+  allreduce(red_.p, (int64_t)J_ * K);
+  LC_HIP(hipMemcpyAsync(Njk, red_.p, (size_t)J_ * K * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  LC_HIP(hipStreamSynchronize(stream_));
+}
+
+// ---------------------------------------------------------------------------
+// timing
+// ---------------------------------------------------------------------------
+KernelTimes Context::timing_get() {
+  if (!pending_.empty()) LC_HIP(hipStreamSynchronize(stream_));
+  for (auto& p : pending_) {
+    float ms = 0.f;
+    LC_HIP(hipEventElapsedTime(&ms, p.a, p.b));
+    if (p.kind == 0) {
+      times_.estep_ms += ms;
+      times_.estep_calls += 1;
+    } else {
+      times_.suffstat_ms += ms;
+      times_.suffstat_calls += 1;
+    }
+    (void)hipEventDestroy(p.a);
+    (void)hipEventDestroy(p.b);
+  }
+  pending_.clear();
+  return times_;
+}
+
+void Context::timing_reset() {
+  (void)timing_get();
+  times_ = KernelTimes();
+}
+
+}  // namespace lcc

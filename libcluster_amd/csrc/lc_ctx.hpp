@@ -1,0 +1,143 @@
+// Device context: owns the device-resident copy of one data set (all groups,
+// padded), the responsibility matrix qZ and every workspace of the hot path,
+// and drives the kernels of lc_kernels.hip.  One context per learn*() call
+// (and one per split sub-problem); contexts are independent.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "lc_kernels.h"
+
+namespace lcc {
+
+struct HipFailure : std::runtime_error {
+  explicit HipFailure(const std::string& s) : std::runtime_error(s) {}
+};
+
+// all-reduce hook: sum `count` doubles in place across ranks (device buffer),
+// enqueued on / ordered with `stream`.  Returns 0 on success.
+typedef int (*allreduce_fn)(void* user, void* device_buf, int64_t count, void* stream);
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t cap = 0;  // elements
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  // grow (contents NOT preserved)
+  void reserve(size_t n);
+};
+
+struct KernelTimes {
+  double estep_ms = 0, suffstat_ms = 0;
+  int64_t estep_calls = 0, suffstat_calls = 0;
+};
+
+class Context {
+ public:
+  Context(int device, hipStream_t stream);
+  ~Context();
+  Context(const Context&) = delete;
+  Context& operator=(const Context&) = delete;
+
+  // ---- data ---------------------------------------------------------------
+  // Host groups -> device (row-major, padded).  Element (n,d) of group j is at
+  // Xj[j][n*row_stride + d*col_stride].
+  void set_data(int J, const double* const* Xj, const int64_t* Nj, int D, int64_t row_stride, int64_t col_stride);
+  // Single-group synthetic mixture generated on the device (+ initial qZ, K columns)
+  void synth(int64_t N, int D, int K, const double* mu, const double* L, uint64_t seed, int64_t row_offset,
+             double hard);
+  // rows [row0, row0+n) of group j -> row-major n x D host buffer
+  void get_rows(int j, int64_t row0, int64_t n, double* out) const;
+
+  int J() const { return J_; }
+  int D() const { return D_; }
+  int DP() const { return DP_; }
+  int K() const { return qz_[cur_].K; }
+  int64_t N(int j) const { return Nj_[j]; }
+  int64_t Ntotal() const { return Ntot_; }
+  int64_t NP() const { return NP_; }
+  int device() const { return device_; }
+  hipStream_t stream() const { return stream_; }
+  void set_stream(hipStream_t s) { stream_ = s; }
+  void synchronize() const;
+  void set_allreduce(allreduce_fn f, void* user) {
+    ar_fn_ = f;
+    ar_user_ = user;
+  }
+  bool distributed() const { return ar_fn_ != nullptr; }
+
+  // ---- qZ -----------------------------------------------------------------
+  void qz_fill(int K, double value);  // K columns = value on valid rows
+  void qz_set(int j, const double* q, int K, int64_t row_stride, int64_t col_stride);
+  void qz_get(int j, double* q, int64_t row_stride, int64_t col_stride) const;
+  void qz_get_column(int j, int k, double* out) const;  // N(j) doubles
+  void qz_keep_columns(const std::vector<int>& keep);    // prune_clusters
+  void qz_clone_to_alt();                                // alt <- copy of current (capacity K+1)
+  void qz_swap_alt();                                    // current <-> alt
+  // auglabels on the current buffer: rows (global padded indices) move column k -> new column K
+  void qz_split_column(int k, const std::vector<int64_t>& rows);
+  int64_t padded_row(int j, int64_t n) const { return goff_[j] + n; }
+
+  // ---- hot path -------------------------------------------------------------
+  // A: K x D x D row-major lower-triangular whiteners, m: K x D, c: J x K.
+  // Writes new responsibilities into qZ (K columns).  Fz = -sum logZ; LLk[k] =
+  // sum_n q_nk (log q~_nk - c_jk)  (the data term of cluster.cpp:409-410).
+  void estep(int K, const double* A, const double* m, const double* c, double* Fz, double* LLk);
+  // Sufficient statistics of the current qZ.  smask: J x K (1 = accumulate) or null.
+  // Nk[K], xs[K*D], xxs[K*D*D] (row-major, symmetric), Njk[J*K].
+  void suffstat(const unsigned char* smask, double* Nk, double* xs, double* xxs, double* Njk);
+  void colsums(double* Njk);  // J x K column sums of the current qZ
+
+  // ---- timing ---------------------------------------------------------------
+  void timing_enable(bool on) { timing_ = on; }
+  KernelTimes timing_get();  // resolves pending events (synchronises the stream)
+  void timing_reset();
+
+ private:
+  struct QZ {
+    DevBuf<double> buf;
+    int cap = 0;  // columns allocated
+    int K = 0;    // columns in use
+  };
+  void ensure_qz(QZ& q, int K, bool preserve);
+  void build_layout(int J, const int64_t* Nj, int D);
+  void allreduce(double* dbuf, int64_t count);
+
+  int device_;
+  hipStream_t stream_;
+  allreduce_fn ar_fn_ = nullptr;
+  void* ar_user_ = nullptr;
+
+  int J_ = 0, D_ = 0, DP_ = 0;
+  std::vector<int64_t> Nj_, goff_;  // goff_: padded row offsets, size J+1
+  int64_t Ntot_ = 0, NP_ = 0;
+  DevBuf<double> X_;
+  DevBuf<int> rginfo_;      // only when J > 1
+  DevBuf<int64_t> goff_d_;  // J+1
+  QZ qz_[2];
+  int cur_ = 0;
+
+  DevBuf<double> params_, ctab_, fzpart_, llpart_, red_, sspart_, ssout_;
+  DevBuf<unsigned char> smask_;
+  DevBuf<int64_t> idx_;
+  std::vector<double> hpack_, hred_, hss_;
+
+  bool timing_ = false;
+  struct EvPair {
+    hipEvent_t a, b;
+    int kind;
+  };
+  std::vector<EvPair> pending_;
+  KernelTimes times_;
+};
+
+}  // namespace lcc

@@ -1,0 +1,335 @@
+#include "lc_engine.hpp"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <exception>
+#include <iostream>
+#include <limits>
+#include <thread>
+
+namespace lce {
+
+using lch::GaussWishState;
+using lch::WeightState;
+
+namespace {
+
+// Run fn(k) for k in [0,n) on up to nthreads host threads (the reference's
+// "omp parallel for" over clusters, cluster.cpp:215-217).  Exceptions are
+// collected and the first one re-thrown on the calling thread.
+template <typename F>
+void parallel_for(int n, unsigned nthreads, double work_per_item, F fn) {
+  unsigned nt = std::min<unsigned>(nthreads, (unsigned)std::max(n, 1));
+  if (nt <= 1 || work_per_item * n < 2e6) {
+    for (int k = 0; k < n; ++k) fn(k);
+    return;
+  }
+  std::vector<std::exception_ptr> errs(nt);
+  std::vector<std::thread> th;
+  th.reserve(nt);
+  for (unsigned t = 0; t < nt; ++t)
+    th.emplace_back([&, t] {
+      try {
+        for (int k = (int)t; k < n; k += (int)nt) fn(k);
+      } catch (...) {
+        errs[t] = std::current_exception();
+      }
+    });
+  for (auto& x : th) x.join();
+  for (auto& e : errs)
+    if (e) std::rethrow_exception(e);
+}
+
+bool anyempty(const std::vector<GaussWishState>& c) {  // src/comutils.h:114-123
+  for (const auto& x : c)
+    if (x.N <= 1) return true;
+  return false;
+}
+
+struct GreedOrder {  // src/comutils.h:44-49
+  int k;
+  int tally;
+  double Fk;
+};
+bool greedcomp(const GreedOrder& i, const GreedOrder& j) {  // src/comutils.h:60-68
+  if (i.tally == j.tally) return i.Fk > j.Fk;
+  return i.tally < j.tally;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// cluster.cpp:177-239
+// ---------------------------------------------------------------------------
+double vbem(lcc::Context& ctx, Model& model, const VbemOptions& opt) {
+  const int J = ctx.J(), K = ctx.K(), D = ctx.D();
+  if (K < 1) throw std::invalid_argument("qZ must have at least one column");
+
+  // weights.resize(J, W()); clusters.resize(K, C(clusterprior, D))  (:192-193)
+  if ((int)model.weights.size() > J) model.weights.resize(J);
+  while ((int)model.weights.size() < J) model.weights.emplace_back(model.wkind, lch::ALPHA1PRIOR);
+  if ((int)model.clusters.size() > K) model.clusters.resize(K);
+  while ((int)model.clusters.size() < K) model.clusters.emplace_back(opt.clusterprior, D);
+  for (const auto& c : model.clusters)
+    if (c.D != D) throw std::invalid_argument("Mismatched dims. of cluster params and obs.!");
+
+  std::vector<double> Nk(K), xs((size_t)K * D), xxs((size_t)K * D * D), Njk((size_t)J * K);
+  std::vector<double> A((size_t)K * D * D), m((size_t)K * D), c((size_t)J * K), cst(K);
+  std::vector<unsigned char> mask;
+  model.LLk.assign(K, 0.0);
+
+  double F = std::numeric_limits<double>::max(), Fold;
+  int i = 0, done = 0;
+  bool again;
+  do {
+    Fold = F;
+    for (auto& cl : model.clusters) cl.clearobs();  // :203-204
+
+    // updateSS (:53-82) for all groups + weights update (:207-212)
+    const unsigned char* maskp = nullptr;
+    if (opt.sparse) {
+      ctx.colsums(Njk.data());
+      mask.resize((size_t)J * K);
+      for (size_t t = 0; t < mask.size(); ++t) mask[t] = Njk[t] >= lch::ZEROCUTOFF ? 1 : 0;
+      maskp = mask.data();
+    }
+    ctx.suffstat(maskp, Nk.data(), xs.data(), xxs.data(), Njk.data());
+    for (int j = 0; j < J; ++j) model.weights[j].update(Njk.data() + (size_t)j * K, K);
+
+    // VBM for clusters (:215-217) + the per-cluster constants of the E-step
+    parallel_for(K, opt.nthreads, 2.0 * D * D * D, [&](int k) {
+      GaussWishState& cl = model.clusters[k];
+      cl.addstats(Nk[k], xs.data() + (size_t)k * D, xxs.data() + (size_t)k * D * D);
+      cl.update();
+      const std::vector<double> Ak = cl.whitener();
+      std::copy(Ak.begin(), Ak.end(), A.begin() + (size_t)k * D * D);
+      std::copy(cl.m.begin(), cl.m.end(), m.begin() + (size_t)k * D);
+      cst[k] = cl.eloglike_const();
+    });
+
+    // VBE (:220-223): c_jk = E_logZ_j(k) + const_k ; sparse-inactive clusters get -inf (:109-112, 134-135)
+    for (int j = 0; j < J; ++j) {
+      const WeightState& w = model.weights[j];
+      for (int k = 0; k < K; ++k) {
+        double v = w.Elogpi[k] + cst[k];
+        if (opt.sparse && !(w.Nk[k] >= lch::ZEROCUTOFF)) v = -std::numeric_limits<double>::infinity();
+        c[(size_t)j * K + k] = v;
+      }
+    }
+    double Fz = 0.0;
+    ctx.estep(K, A.data(), m.data(), c.data(), &Fz, model.LLk.data());
+
+    // fenergy (:145-165)
+    double Fw = 0.0, Fc = 0.0;
+    for (const auto& w : model.weights) Fw += w.fenergy();
+    std::vector<double> fck(K);
+    parallel_for(K, opt.nthreads, 1.0 * D * D, [&](int k) { fck[k] = model.clusters[k].fenergy(); });
+    for (int k = 0; k < K; ++k) Fc += fck[k];
+    F = Fc + Fw + Fz;
+    if (opt.trace) opt.trace->push_back(F);
+    ++done;
+
+    if (opt.fixed_iters >= 0) {
+      again = done < opt.fixed_iters;
+    } else {
+      if ((F - Fold) / std::abs(Fold) > lch::FENGYDEL) throw std::runtime_error("Free energy increase!");  // :229-230
+      if (opt.verbose) std::cout << '-' << std::flush;
+      again = (std::abs((Fold - F) / Fold) > lch::CONVERGE) && ((i++ < opt.maxit) || (opt.maxit < 0));  // :235-236
+    }
+  } while (again);
+  return F;
+}
+
+// ---------------------------------------------------------------------------
+// cluster.cpp:505-552
+// ---------------------------------------------------------------------------
+static bool prune_clusters(lcc::Context& ctx, Model& model, bool verbose) {
+  const int K = (int)model.clusters.size(), J = ctx.J();
+  std::vector<int> keep;
+  for (int k = 0; k < K; ++k)
+    if (!(model.clusters[k].N < lch::ZEROCUTOFF)) keep.push_back(k);
+  if ((int)keep.size() == K) return false;
+  if (verbose) std::cout << '*' << std::flush;
+  if (keep.empty()) throw std::runtime_error("all clusters are empty");
+  std::vector<GaussWishState> nc;
+  std::vector<double> nll;
+  for (int k : keep) {
+    nc.push_back(std::move(model.clusters[k]));
+    nll.push_back(k < (int)model.LLk.size() ? model.LLk[k] : 0.0);
+  }
+  model.clusters.swap(nc);
+  model.LLk.swap(nll);
+  ctx.qz_keep_columns(keep);
+  const int nK = (int)keep.size();
+  std::vector<double> Njk((size_t)J * nK);
+  ctx.colsums(Njk.data());
+  for (int j = 0; j < J; ++j) model.weights[j].update(Njk.data() + (size_t)j * nK, nK);  // :546
+  return true;
+}
+
+// ---------------------------------------------------------------------------
+// cluster.cpp:366-495
+// ---------------------------------------------------------------------------
+static bool split_gr(lcc::Context& ctx, const HostData& host, Model& model, std::vector<int>& tally, double F,
+                     const ClusterOptions& opt) {
+  const int J = ctx.J(), K = (int)model.clusters.size(), D = ctx.D();
+  if (K >= opt.maxclusters && opt.maxclusters >= 0) return false;
+  if (ctx.distributed()) throw std::runtime_error("the split search is single-process in this build");
+  tally.resize(K, 0);
+
+  // cluster free energies and data likelihoods (:391-415).  The data term
+  // sum_n q_nk Eloglike_k(x_n) = const_k * sum_n q_nk + LLk (from the last E-step).
+  std::vector<double> Njk((size_t)J * K);
+  ctx.colsums(Njk.data());
+  std::vector<GreedOrder> ord(K);
+  for (int k = 0; k < K; ++k) {
+    ord[k].k = k;
+    ord[k].tally = tally[k];
+    ord[k].Fk = model.clusters[k].fenergy();
+    const double cst = model.clusters[k].eloglike_const();
+    for (int j = 0; j < J; ++j) ord[k].Fk -= (model.weights[j].Elogpi[k] + cst) * Njk[(size_t)j * K + k];
+    ord[k].Fk -= model.LLk[k];
+  }
+  std::sort(ord.begin(), ord.end(), greedcomp);  // :418
+
+  std::vector<std::vector<int64_t>> mapidx(J);
+  std::vector<std::vector<double>> Xk(J), qZref(J);
+  std::vector<double> col;
+  std::vector<unsigned char> splitk;
+  const double prior = model.clusters[0].prior;
+
+  for (const GreedOrder& o : ord) {
+    const int k = o.k;
+    ++tally[k];
+    if (model.clusters[k].N < 4) continue;  // :432
+
+    // partobs + splitobs per group (:438-453)
+    int64_t scount = 0, Mtot = 0;
+    for (int j = 0; j < J; ++j) {
+      const int64_t n = ctx.N(j);
+      col.resize((size_t)n);
+      ctx.qz_get_column(j, k, col.data());
+      mapidx[j].clear();
+      for (int64_t r = 0; r < n; ++r)
+        if (col[(size_t)r] > 0.5) mapidx[j].push_back(r);
+      const int64_t M = (int64_t)mapidx[j].size();
+      Xk[j].resize((size_t)M * D);
+      for (int64_t t = 0; t < M; ++t) {
+        const double* src = host.X[j] + mapidx[j][(size_t)t] * host.row_stride;
+        for (int d = 0; d < D; ++d) Xk[j][(size_t)t * D + d] = src[d * host.col_stride];
+      }
+      Mtot += M;
+      model.clusters[k].splitobs(Xk[j].data(), M, D, splitk);
+      qZref[j].assign((size_t)M * 2, 0.0);
+      for (int64_t t = 0; t < M; ++t) {
+        qZref[j][(size_t)t * 2 + 0] = splitk[(size_t)t] ? 1.0 : 0.0;
+        qZref[j][(size_t)t * 2 + 1] = splitk[(size_t)t] ? 0.0 : 1.0;
+        scount += splitk[(size_t)t] ? 1 : 0;
+      }
+    }
+    if (scount < 2 || scount > Mtot - 2) continue;  // :456
+
+    // refine the split on the selected observations (:459-462)
+    Model ms;
+    ms.wkind = model.wkind;
+    {
+      lcc::Context sub(ctx.device(), ctx.stream());
+      std::vector<const double*> xp(J);
+      std::vector<int64_t> mj(J);
+      for (int j = 0; j < J; ++j) {
+        xp[j] = Xk[j].data();
+        mj[j] = (int64_t)mapidx[j].size();
+      }
+      sub.set_data(J, xp.data(), mj.data(), D, D, 1);
+      // every group must be written so that K is consistent, including empty ones
+      bool first = true;
+      for (int j = 0; j < J; ++j) {
+        if (mj[j] == 0 && !first) continue;
+        sub.qz_set(j, qZref[j].data(), 2, 2, 1);
+        first = false;
+      }
+      VbemOptions vo;
+      vo.clusterprior = prior;
+      vo.maxit = (int)lch::SPLITITER;
+      vo.sparse = opt.sparse;
+      vo.nthreads = opt.nthreads;
+      vbem(sub, ms, vo);
+      if (anyempty(ms.clusters)) continue;  // :464
+      for (int j = 0; j < J; ++j) {
+        col.resize((size_t)mj[j]);
+        sub.qz_get_column(j, 1, col.data());
+        for (int64_t t = 0; t < mj[j]; ++t) qZref[j][(size_t)t * 2 + 1] = col[(size_t)t];
+      }
+    }
+
+    // auglabels (:468-470, comutils.cpp:75-104) on a copy of qZ
+    std::vector<int64_t> rows;
+    for (int j = 0; j < J; ++j)
+      for (size_t t = 0; t < mapidx[j].size(); ++t)
+        if (qZref[j][t * 2 + 1] > 0.5) rows.push_back(ctx.padded_row(j, mapidx[j][t]));
+    ctx.qz_clone_to_alt();
+    ctx.qz_swap_alt();
+    ctx.qz_split_column(k, rows);
+
+    // free energy of the split with all data (:473)
+    VbemOptions vo;
+    vo.clusterprior = prior;
+    vo.maxit = 1;
+    vo.sparse = opt.sparse;
+    vo.nthreads = opt.nthreads;
+    double Fsplit;
+    try {
+      Fsplit = vbem(ctx, ms, vo);
+    } catch (...) {
+      ctx.qz_swap_alt();
+      throw;
+    }
+    if (anyempty(ms.clusters)) {  // :476
+      ctx.qz_swap_alt();
+      continue;
+    }
+    if (opt.verbose) std::cout << '=' << std::flush;
+    if ((Fsplit < F) && (std::abs((F - Fsplit) / F) > lch::CONVERGE)) {  // :484-489
+      tally[k] = 0;
+      return true;  // the augmented qZ is now the current one
+    }
+    ctx.qz_swap_alt();
+  }
+  return false;
+}
+
+// ---------------------------------------------------------------------------
+// cluster.cpp:564-629
+// ---------------------------------------------------------------------------
+double cluster(lcc::Context& ctx, const HostData& host, Model& model, const ClusterOptions& opt) {
+  if (opt.nthreads < 1) throw std::invalid_argument("Must specify at least one thread for execution!");
+  ctx.qz_fill(1, 1.0);  // :583-585
+  std::vector<int> tally;
+  bool issplit = true;
+  double F = 0.0;
+  while (issplit) {
+    std::vector<double> tr;
+    VbemOptions vo;
+    vo.clusterprior = opt.clusterprior;
+    vo.maxit = -1;
+    vo.sparse = opt.sparse;
+    vo.verbose = opt.verbose;
+    vo.nthreads = opt.nthreads;
+    vo.trace = &tr;
+    F = vbem(ctx, model, vo);
+    if (opt.trace) opt.trace->emplace_back((int)model.clusters.size(), tr);
+    prune_clusters(ctx, model, opt.verbose);
+    if (opt.verbose) std::cout << '<' << std::flush;
+    issplit = split_gr(ctx, host, model, tally, F, opt);
+    if (opt.verbose) std::cout << '>' << std::endl;
+  }
+  if (opt.verbose) {
+    std::cout << "Finished!" << std::endl;
+    std::cout << "Number of clusters = " << model.clusters.size() << std::endl;
+    std::cout << "Free energy = " << F << std::endl;
+  }
+  return F;
+}
+
+}  // namespace lce

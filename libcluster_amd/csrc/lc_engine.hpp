@@ -1,0 +1,59 @@
+// Host driver of the variational Bayes loops, re-written around the device
+// context: the M-step, free energy, pruning and the split heuristic stay on
+// the host; every pass over the data goes through lcc::Context (HIP kernels).
+//
+// Restates src/cluster.cpp: vbem (177-239), prune_clusters (505-552),
+// split_gr (366-495), cluster (564-629), learnVDP/BGMM/GMC (636-695, 763-784).
+#pragma once
+#include <cstdint>
+#include <memory>
+#include <vector>
+
+#include "lc_ctx.hpp"
+#include "lc_host.hpp"
+
+namespace lce {
+
+// borrowed view of the caller's host observations (needed by the split
+// heuristic's partobs gather, src/comutils.cpp:56-72)
+struct HostData {
+  int J = 0, D = 0;
+  std::vector<const double*> X;
+  std::vector<int64_t> N;
+  int64_t row_stride = 0, col_stride = 0;
+};
+
+struct Model {
+  int wkind = lch::W_DIRICHLET;
+  std::vector<lch::WeightState> weights;      // J
+  std::vector<lch::GaussWishState> clusters;  // K
+  std::vector<double> LLk;                    // data term of the last E-step, per cluster
+};
+
+struct VbemOptions {
+  double clusterprior = lch::PRIORVAL;
+  int maxit = -1;
+  bool sparse = false;
+  bool verbose = false;
+  int fixed_iters = -1;            // >= 0: run exactly this many iterations, no convergence / increase test
+  std::vector<double>* trace = nullptr;  // F after every iteration
+  unsigned nthreads = 1;
+};
+
+// cluster.cpp:177-239 on the context's current qZ.  Returns F.
+double vbem(lcc::Context& ctx, Model& model, const VbemOptions& opt);
+
+struct ClusterOptions {
+  double clusterprior = lch::PRIORVAL;
+  int maxclusters = -1;
+  bool sparse = false;
+  bool verbose = false;
+  unsigned nthreads = 1;
+  std::vector<std::pair<int, std::vector<double>>>* trace = nullptr;  // (K, F per iteration) per round
+};
+
+// cluster.cpp:564-629.  ctx must hold the data; model.weights may be pre-seeded
+// (learnVDP/learnBGMM pass the caller's weight prior in element 0).
+double cluster(lcc::Context& ctx, const HostData& host, Model& model, const ClusterOptions& opt);
+
+}  // namespace lce

@@ -1,0 +1,91 @@
+// Internal launcher interface between the C-ABI layer and the gfx950 kernels.
+// Everything here is plain pointers + sizes; all pointers are DEVICE pointers
+// unless a name ends in _h.  Launchers enqueue on `stream` and do not sync.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace lck {
+
+// ---- data layout constants -------------------------------------------------
+// X on device: row-major [NP x DP] doubles, DP = D rounded up to {16,32,64,128},
+// pad columns zero.  Groups are padded to multiples of 16 rows (a "row-group"),
+// pad rows zero.  qZ on device: column-major, qZ[k*ldq + row], ldq = NP.
+constexpr int RG = 16;  // rows per row-group (one MFMA column block)
+
+inline int padded_dim(int D) { return D <= 16 ? 16 : D <= 32 ? 32 : D <= 64 ? 64 : D <= 128 ? 128 : -1; }
+inline int ntiles(int DP) { int nt = DP / 4; return nt * (nt + 1) / 2; }
+// doubles per cluster in the packed E-step parameter stream
+inline int pstride(int DP) { return ntiles(DP) * 16 + DP; }
+// doubles per cluster in a stats record: [N_k, s_k[DP], S_k[DP*DP]]
+inline int64_t stat_stride(int DP) { return 1 + (int64_t)DP + (int64_t)DP * DP; }
+
+// rginfo word per row-group: (group << 5) | nvalid   (nvalid in 0..16)
+inline int rginfo_pack(int group, int nvalid) { return (group << 5) | nvalid; }
+
+struct EstepLaunch {
+  int DP;
+  const double* X;       // [NP x DP]
+  int64_t nrg;           // number of row-groups (NP / 16)
+  const int* rginfo;     // [nrg] or nullptr (single group; nvalid from nrows)
+  int64_t nrows;         // valid rows when rginfo == nullptr
+  const double* params;  // [K x pstride(DP)] packed tiles + b
+  const double* ctab;    // [J x K] c_jk (may hold -inf for sparse-inactive)
+  int K;
+  double* qZ;            // [K x ldq]
+  int64_t ldq;
+  double* fz_part;       // [estep_grid(...)]
+  double* ll_part;       // [estep_grid(...) x K]
+};
+int estep_rows_per_block(int DP);
+int64_t estep_grid(int DP, int64_t nrg);
+hipError_t launch_estep(const EstepLaunch& a, hipStream_t stream);
+
+struct SuffstatLaunch {
+  int DP;
+  const double* X;
+  int64_t NP;               // padded rows (multiple of 16)
+  const double* qZ;
+  int64_t ldq;
+  int K;
+  const int* rginfo;        // needed only with smask
+  const unsigned char* smask;  // [J x K] 1 = accumulate (sparse), or nullptr
+  double* partial;          // [nchunks x K x stat_stride(DP)]
+  int nchunks;
+  int64_t chunk_rows;       // multiple of 4
+};
+// choose a chunking for (NP, K); returns nchunks and sets chunk_rows
+int suffstat_plan(int DP, int64_t NP, int K, int64_t* chunk_rows);
+hipError_t launch_suffstat(const SuffstatLaunch& a, hipStream_t stream);
+
+// out[e] = sum_c partial[c*n + e]  (fixed order => deterministic)
+hipError_t launch_reduce_partials(const double* partial, int nparts, int64_t n, double* out, hipStream_t stream);
+// out[j*K+k] = sum over rows of group j of qZ[k*ldq + row]; goff = padded row offsets [J+1]
+hipError_t launch_group_colsum(const double* qZ, int64_t ldq, int K, const int64_t* goff, int J, double* out,
+                               hipStream_t stream);
+// qZ[:, 0..K) = value on valid rows, 0 on pad rows
+hipError_t launch_fill_qz(double* qZ, int64_t ldq, int K, const int* rginfo, int64_t nrows, int64_t nrg, double value,
+                          hipStream_t stream);
+// auglabels (src/comutils.cpp:75-104): for i<n: r=idx[i]; qZ[K][r]=qZ[k][r]; qZ[k][r]=0
+hipError_t launch_move_rows(double* qZ, int64_t ldq, int k, int K, const int64_t* idx, int64_t n, hipStream_t stream);
+// splitobs projection (src/distributions.cpp:373-385): out[row] = sum_d (x[row][d]-m[d])*v[d] >= 0
+hipError_t launch_project(const double* X, int DP, int64_t NP, const double* mv /*[2*DP]: m then v*/,
+                          unsigned char* out, hipStream_t stream);
+
+// synthetic mixture generator (bench): Philox4x32-10, counter = global row.
+struct SynthLaunch {
+  int DP, D, K;
+  double* X;               // [NP x DP]
+  double* qZ;              // [K x ldq] initial responsibilities, or nullptr
+  int64_t ldq;
+  int64_t nrows;           // valid rows
+  int64_t NP;
+  int64_t row_offset;      // global index of row 0 (rank sharding)
+  uint64_t seed;
+  const double* mu;        // [K x D]
+  const double* L;         // [K x D x D] lower Cholesky factors, row-major
+  double hard;             // q on the true label (0.9); rest (1-hard)/(K-1)
+};
+hipError_t launch_synth(const SynthLaunch& a, hipStream_t stream);
+
+}  // namespace lck

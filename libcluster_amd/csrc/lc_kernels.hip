@@ -1,0 +1,710 @@
+// gfx950 (MI355X / CDNA4) kernels for the libcluster variational E-step and
+// sufficient-statistic accumulation.  fp64 throughout.
+//
+// What they replace in the reference (dsteinberg/libcluster):
+//   estep_kernel     vbexpectation            src/cluster.cpp:91-138
+//                    -> GaussWish::Eloglike   src/distributions.cpp:356-370
+//                    -> probutils::mahaldist  src/probutils.cpp:113-138
+//                    -> probutils::logsumexp  src/probutils.cpp:141-150
+//   suffstat_kernel  updateSS                 src/cluster.cpp:53-82
+//                    -> GaussWish::addobs     src/distributions.cpp:301-313
+//
+// Matrix instruction: v_mfma_f64_4x4x4_4b_f64 (four independent 4x4x4 blocks,
+// 512 flop, 16 cycles/SIMD = 32 flop/clk/SIMD; measured 73-74 TFLOP/s on
+// MI355X, vs 47-49 for v_mfma_f64_16x16x4_f64 -- profiles/r01_mfma_f64_probe.log).
+// Lane layout (probed, tools/mfma_f64_4x4_layout.hip), lane = lo2 + 4*blk + 16*hi:
+//   A[i][k] of block blk : i = lo2, k = hi
+//   B[k][j] of block blk : j = lo2, k = hi
+//   D[i][j] of block blk : j = lo2, i = hi
+#include "lc_kernels.h"
+
+#include <cmath>
+
+namespace lck {
+
+__device__ __forceinline__ double mfma4(double a, double b, double c) {
+  return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
+}
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = dpp_i32<CTRL>(lo);
+  hi = dpp_i32<CTRL>(hi);
+  return __hiloint2double(hi, lo);
+}
+constexpr int DPP_ROW_ROR4 = 0x124, DPP_ROW_ROR8 = 0x128, DPP_ROW_ROR12 = 0x12C;
+
+// sum over the 4 lanes {l, l^16, l^32, l^48}
+__device__ __forceinline__ double sum_over_hi(double v) {
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+// sum over the 16 lanes of a DPP row (same hi)
+__device__ __forceinline__ double sum_over_lo4(double v) {
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 8);
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+  v = sum_over_lo4(v);
+  return sum_over_hi(v);
+}
+
+// ===========================================================================
+// E-step
+// ===========================================================================
+// One wave owns R row-groups of 16 rows and keeps their X fragments in
+// registers for the whole cluster loop (X is read from HBM exactly once).
+// Per cluster k the host supplies A_k = sqrt(nu_k) * chol(iW_k)^-1 (lower
+// triangular), b_k = A_k m_k and c_jk, so that
+//     log q~[n,k] = c_jk - 0.5 * || A_k x_n - b_k ||^2
+// which equals E_logZ(k) + Eloglike_k(x_n) of cluster.cpp:120-121.
+// A_k arrives as 4x4 tiles in consumption order (only tiles on or below the
+// diagonal), staged through LDS with register double-buffering; one tile read
+// feeds R MFMAs.  MFMA block b <-> rows 4b..4b+3 of the row-group, so
+//   A operand = tile A_k[4it+lo2][4jt+hi]   (same for all 4 blocks)
+//   B operand = x[row = lane&15][4jt + hi]
+//   D         = y[4it+hi][row = lane&15]
+// log q~ is written to the qZ buffer as scratch, then normalised in place in
+// the same arithmetic order as the reference: max, sum exp(x-max), log+max,
+// exp(x - logZ).
+template <int DP, int R, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64, 2) estep_kernel(EstepLaunch a) {
+  constexpr int NT = DP / 4;
+  constexpr int NTILES = NT * (NT + 1) / 2;
+  constexpr int PS = NTILES * 16 + DP;
+  constexpr int NTHR = WAVES * 64;
+  constexpr int NV2 = PS / 2;
+  constexpr int NPRE = (NV2 + NTHR - 1) / NTHR;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* pbuf = lds;              // [2][PS]
+  double* llw = lds + 2 * PS;      // [WAVES][K]
+  double* fzw = llw + WAVES * a.K; // [WAVES]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lo4 = lane & 15, hi = lane >> 4;
+  const int K = a.K;
+  const int64_t rg0 = ((int64_t)blockIdx.x * WAVES + wave) * R;
+
+  double xf[R][NT];
+  int grp[R];
+  bool rowok[R], rgok[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int64_t rg = rg0 + r;
+    rgok[r] = rg < a.nrg;
+    int info = 0;
+    if (rgok[r]) {
+      if (a.rginfo) {
+        info = a.rginfo[rg];
+      } else {
+        const int64_t rem = a.nrows - rg * RG;
+        info = rem >= RG ? RG : (rem > 0 ? (int)rem : 0);
+      }
+    }
+    grp[r] = info >> 5;
+    rowok[r] = lo4 < (info & 31);
+    const double* xr = a.X + ((rgok[r] ? rg : 0) * RG + lo4) * DP + hi;
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) xf[r][jt] = xr[4 * jt];
+  }
+
+  // register double-buffer for the next cluster's parameter record
+  double pre[NPRE][2];
+#define LC_GLOAD(kk)                                                                          \
+  {                                                                                           \
+    const double2* src_ = reinterpret_cast<const double2*>(a.params + (int64_t)(kk) * PS);   \
+    _Pragma("unroll") for (int i_ = 0; i_ < NPRE; ++i_) {                                     \
+      const int idx_ = tid + i_ * NTHR;                                                       \
+      const double2 v_ = src_[idx_ < NV2 ? idx_ : NV2 - 1];                                   \
+      pre[i_][0] = v_.x;                                                                      \
+      pre[i_][1] = v_.y;                                                                      \
+    }                                                                                         \
+  }
+#define LC_LSTORE(bb)                                                                         \
+  {                                                                                           \
+    double2* dst_ = reinterpret_cast<double2*>(pbuf + (bb) * PS);                             \
+    _Pragma("unroll") for (int i_ = 0; i_ < NPRE; ++i_) {                                     \
+      const int idx_ = tid + i_ * NTHR;                                                       \
+      if (idx_ < NV2) dst_[idx_] = make_double2(pre[i_][0], pre[i_][1]);                      \
+    }                                                                                         \
+  }
+
+  LC_GLOAD(0);
+  LC_LSTORE(0);
+  __syncthreads();
+
+  double mx[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) mx[r] = -INFINITY;
+
+  for (int k = 0; k < K; ++k) {
+    const int buf = k & 1;
+    if (k + 1 < K) LC_GLOAD(k + 1);
+    const double* P = pbuf + buf * PS;
+    const double* Pt = P + (lane & 3) + 4 * hi;
+    double d2[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) d2[r] = 0.0;
+#pragma unroll
+    for (int it = 0; it < NT; ++it) {
+      const double binit = -P[NTILES * 16 + 4 * it + hi];
+      double acc[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc[r] = binit;
+#pragma unroll
+      for (int jt = 0; jt <= it; ++jt) {
+        const double at = Pt[(it * (it + 1) / 2 + jt) * 16];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = mfma4(at, xf[r][jt], acc[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) d2[r] = fma(acc[r], acc[r], d2[r]);
+      // keep the scheduler from hoisting later tile rows' LDS reads (and their
+      // registers) above this row's MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const double dd = sum_over_hi(d2[r]);
+      const double lq = a.ctab[(int64_t)grp[r] * K + k] - 0.5 * dd;
+      mx[r] = fmax(mx[r], lq);
+      if (rgok[r] && hi == (k & 3)) a.qZ[(int64_t)k * a.ldq + (rg0 + r) * RG + lo4] = lq;
+    }
+    if (k + 1 < K) LC_LSTORE(buf ^ 1);
+    __syncthreads();
+  }
+
+#undef LC_GLOAD
+#undef LC_LSTORE
+
+  // ---- normalise (probutils.cpp:141-150, cluster.cpp:124-131) -------------
+  double logZ[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    double s = 0.0;
+    if (rgok[r]) {
+      const double* qp = a.qZ + (rg0 + r) * RG + lo4;
+      for (int k = hi; k < K; k += 4) s += exp(qp[(int64_t)k * a.ldq] - mx[r]);
+    }
+    s = sum_over_hi(s);
+    logZ[r] = log(s) + mx[r];
+  }
+  for (int kb = 0; kb < K; kb += 4) {
+    const int k = kb + hi;
+    double ll = 0.0;
+    if (k < K) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (rgok[r]) {
+          double* qp = a.qZ + (int64_t)k * a.ldq + (rg0 + r) * RG + lo4;
+          const double lq = *qp;
+          double q = exp(lq - logZ[r]);
+          if (!rowok[r]) q = 0.0;
+          *qp = q;
+          if (q > 0.0) ll += q * (lq - a.ctab[(int64_t)grp[r] * K + k]);
+        }
+      }
+    }
+    ll = sum_over_lo4(ll);
+    if (k < K && lo4 == 0) llw[wave * K + k] = ll;
+  }
+  double fz = 0.0;
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    if (rgok[r] && rowok[r] && hi == 0) fz += logZ[r];
+  fz = wave_sum(fz);
+  if (lane == 0) fzw[wave] = fz;
+  __syncthreads();
+  for (int k = tid; k < K; k += NTHR) {
+    double s = 0.0;
+    for (int w = 0; w < WAVES; ++w) s += llw[w * K + k];
+    a.ll_part[(int64_t)blockIdx.x * K + k] = s;
+  }
+  if (tid == 0) {
+    double s = 0.0;
+    for (int w = 0; w < WAVES; ++w) s += fzw[w];
+    a.fz_part[blockIdx.x] = -s;  // cluster.cpp:137 returns -sum(logZ)
+  }
+}
+
+template <int DP>
+struct EstepCfg;
+template <>
+struct EstepCfg<16> { static constexpr int R = 4, WAVES = 4; };
+template <>
+struct EstepCfg<32> { static constexpr int R = 4, WAVES = 4; };
+template <>
+struct EstepCfg<64> { static constexpr int R = 4, WAVES = 4; };
+template <>
+struct EstepCfg<128> { static constexpr int R = 2, WAVES = 8; };
+
+template <int DP>
+static int rows_per_block_t() { return EstepCfg<DP>::R * EstepCfg<DP>::WAVES * RG; }
+
+int estep_rows_per_block(int DP) {
+  switch (DP) {
+    case 16: return rows_per_block_t<16>();
+    case 32: return rows_per_block_t<32>();
+    case 64: return rows_per_block_t<64>();
+    case 128: return rows_per_block_t<128>();
+  }
+  return -1;
+}
+
+int64_t estep_grid(int DP, int64_t nrg) {
+  const int64_t rgpb = estep_rows_per_block(DP) / RG;
+  return (nrg + rgpb - 1) / rgpb;
+}
+
+template <int DP>
+static hipError_t launch_estep_t(const EstepLaunch& a, hipStream_t stream) {
+  constexpr int R = EstepCfg<DP>::R, WAVES = EstepCfg<DP>::WAVES;
+  const size_t shmem = (size_t)(2 * pstride(DP) + WAVES * a.K + WAVES) * sizeof(double);
+  auto kern = estep_kernel<DP, R, WAVES>;
+  static size_t attr_set = 0;  // largest dynamic-LDS size already granted
+  if (shmem > 64 * 1024 && shmem > attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e != hipSuccess) return e;
+    attr_set = shmem;
+  }
+  const int64_t grid = estep_grid(DP, a.nrg);
+  if (grid <= 0) return hipSuccess;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVES * 64), shmem, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_estep(const EstepLaunch& a, hipStream_t stream) {
+  switch (a.DP) {
+    case 16: return launch_estep_t<16>(a, stream);
+    case 32: return launch_estep_t<32>(a, stream);
+    case 64: return launch_estep_t<64>(a, stream);
+    case 128: return launch_estep_t<128>(a, stream);
+  }
+  return hipErrorInvalidValue;
+}
+
+// ===========================================================================
+// Sufficient statistics
+// ===========================================================================
+// S_k = sum_n q_nk x_n x_n^T is a GEMM whose reduction dimension is the data
+// rows.  One wave owns CPW clusters and streams over a chunk of rows, four
+// rows per step, with the (symmetric, lower-triangular 16x16-blocked)
+// accumulators in registers for the whole chunk.  Per step the wave loads
+// NB = DP/16 natural-layout fragments xf[JB] (row = hi, feature = 16*JB +
+// lane&15: 128-byte coalesced segments), forms qx = q_k * xf once per cluster,
+// and issues for every needed pair of 16-wide feature blocks (JBp >= JB)
+//   D += A(xrot[JBp][s]) * B(qx[JB]),  s = rotation of the four 4-wide
+// sub-blocks inside JBp (DPP row_ror, no memory traffic), so that MFMA block
+// blk computes the 4x4 tile (i-tile = src(blk,s), j-tile = blk).
+// Off-diagonal 16x16 blocks need s=0..3, diagonal ones s=0..2 (symmetry).
+// s_k and N_k ride along on the VALU.  Each (chunk, cluster) writes one
+// partial record; launch_reduce_partials sums chunks in fixed order.
+template <int NB>
+struct SSAcc { static constexpr int N = NB * 3 + NB * (NB - 1) / 2 * 4; };
+
+template <int DP, int CPW>
+__global__ void __launch_bounds__(256) suffstat_kernel(SuffstatLaunch a) {
+  constexpr int NB = DP / 16;
+  constexpr int NACC = SSAcc<NB>::N;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lo4 = lane & 15, hi = lane >> 4, blk = (lane >> 2) & 3, lo2 = lane & 3;
+  const int K = a.K;
+  const int kbase = ((int)blockIdx.y * (int)(blockDim.x >> 6) + wave) * CPW;
+  if (kbase >= K) return;
+  const int nk = (K - kbase) < CPW ? (K - kbase) : CPW;
+  const int64_t r0 = (int64_t)blockIdx.x * a.chunk_rows;
+  const int64_t r1 = (r0 + a.chunk_rows) < a.NP ? (r0 + a.chunk_rows) : a.NP;
+
+  double acc[CPW][NACC];
+  double sacc[CPW][NB];
+  double nacc[CPW];
+#pragma unroll
+  for (int c = 0; c < CPW; ++c) {
+    nacc[c] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[c][i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) sacc[c][i] = 0.0;
+  }
+
+  double xn[NB], qn[CPW];
+  auto load = [&](int64_t n0) {
+    const int64_t row = n0 + hi;
+    const double* xr = a.X + row * DP + lo4;
+#pragma unroll
+    for (int jb = 0; jb < NB; ++jb) xn[jb] = xr[16 * jb];
+    int g = 0;
+    if (a.smask) g = a.rginfo[row >> 4] >> 5;
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+      double q = 0.0;
+      if (c < nk) {
+        q = a.qZ[(int64_t)(kbase + c) * a.ldq + row];
+        if (a.smask && !a.smask[(int64_t)g * K + kbase + c]) q = 0.0;
+      }
+      qn[c] = q;
+    }
+  };
+
+  if (r0 < r1) load(r0);
+  for (int64_t n0 = r0; n0 < r1; n0 += 4) {
+    double xf[NB], q[CPW];
+#pragma unroll
+    for (int jb = 0; jb < NB; ++jb) xf[jb] = xn[jb];
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) q[c] = qn[c];
+    if (n0 + 4 < r1) load(n0 + 4);
+    double xrot[NB][3];
+#pragma unroll
+    for (int jb = 0; jb < NB; ++jb) {
+      xrot[jb][0] = dpp_f64<DPP_ROW_ROR4>(xf[jb]);
+      xrot[jb][1] = dpp_f64<DPP_ROW_ROR8>(xf[jb]);
+      xrot[jb][2] = dpp_f64<DPP_ROW_ROR12>(xf[jb]);
+    }
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+      if (c < nk) {
+        double qx[NB];
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb) {
+          qx[jb] = q[c] * xf[jb];
+          sacc[c][jb] += qx[jb];
+        }
+        nacc[c] += q[c];
+        int idx = 0;
+#pragma unroll
+        for (int jbp = 0; jbp < NB; ++jbp) {
+#pragma unroll
+          for (int jb = 0; jb <= jbp; ++jb) {
+            acc[c][idx] = mfma4(xf[jbp], qx[jb], acc[c][idx]);
+            ++idx;
+            acc[c][idx] = mfma4(xrot[jbp][0], qx[jb], acc[c][idx]);
+            ++idx;
+            acc[c][idx] = mfma4(xrot[jbp][1], qx[jb], acc[c][idx]);
+            ++idx;
+            if (jb < jbp) {
+              acc[c][idx] = mfma4(xrot[jbp][2], qx[jb], acc[c][idx]);
+              ++idx;
+            }
+          }
+        }
+      }
+    }
+  }
+
+  // which sub-block each rotation brought into this lane's block
+  int src[4];
+  src[0] = blk;
+  src[1] = dpp_i32<DPP_ROW_ROR4>(blk);
+  src[2] = dpp_i32<DPP_ROW_ROR8>(blk);
+  src[3] = dpp_i32<DPP_ROW_ROR12>(blk);
+
+  const int64_t SS = 1 + (int64_t)DP + (int64_t)DP * DP;
+#pragma unroll
+  for (int c = 0; c < CPW; ++c) {
+    if (c < nk) {
+      double* out = a.partial + ((int64_t)blockIdx.x * K + kbase + c) * SS;
+      const double nsum = sum_over_hi(nacc[c]);
+      if (lane == 0) out[0] = nsum;
+#pragma unroll
+      for (int jb = 0; jb < NB; ++jb) {
+        const double s = sum_over_hi(sacc[c][jb]);
+        if (hi == 0) out[1 + 16 * jb + lo4] = s;
+      }
+      double* S = out + 1 + DP;
+      int idx = 0;
+#pragma unroll
+      for (int jbp = 0; jbp < NB; ++jbp) {
+#pragma unroll
+        for (int jb = 0; jb <= jbp; ++jb) {
+          const int ns = jb < jbp ? 4 : 3;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            if (s < ns) {
+              const int ti = src[s], tj = blk;
+              const int gi = 16 * jbp + 4 * ti + hi, gj = 16 * jb + 4 * tj + lo2;
+              const bool diag = jb == jbp;
+              const bool wr = !diag || ti == tj || s == 1 || ti > tj;
+              const double v = acc[c][idx];
+              if (wr) {
+                S[(int64_t)gi * DP + gj] = v;
+                if (!diag || ti != tj) S[(int64_t)gj * DP + gi] = v;
+              }
+              ++idx;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int DP>
+struct SSCfg;
+template <>
+struct SSCfg<16> { static constexpr int CPW = 4; };
+template <>
+struct SSCfg<32> { static constexpr int CPW = 4; };
+template <>
+struct SSCfg<64> { static constexpr int CPW = 2; };
+template <>
+struct SSCfg<128> { static constexpr int CPW = 1; };
+
+static int ss_cpw(int DP, int K) {
+  int cpw = DP == 16 ? SSCfg<16>::CPW : DP == 32 ? SSCfg<32>::CPW : DP == 64 ? SSCfg<64>::CPW : SSCfg<128>::CPW;
+  // few clusters: spread them over more waves instead of stacking them in one
+  while (cpw > 1 && (K + cpw - 1) / cpw < 4 && (K + cpw / 2 - 1) / (cpw / 2) <= 4) cpw /= 2;
+  return cpw;
+}
+
+int suffstat_plan(int DP, int64_t NP, int K, int64_t* chunk_rows) {
+  const int cpw = ss_cpw(DP, K);
+  const int kwaves = (K + cpw - 1) / cpw;  // waves needed to cover the clusters
+  // aim for ~8 waves per CU on 256 CUs, at least 256 rows per chunk
+  int64_t want = (256 * 8 + kwaves - 1) / kwaves;
+  int64_t maxchunks = (NP + 255) / 256;
+  if (want > maxchunks) want = maxchunks;
+  if (want < 1) want = 1;
+  int64_t rows = (NP + want - 1) / want;
+  rows = (rows + 3) / 4 * 4;
+  if (rows < 4) rows = 4;
+  *chunk_rows = rows;
+  return (int)((NP + rows - 1) / rows);
+}
+
+template <int DP, int CPW>
+static hipError_t launch_ss_t(const SuffstatLaunch& a, hipStream_t stream) {
+  const int kwaves = (a.K + CPW - 1) / CPW;
+  const int wpb = kwaves < 4 ? kwaves : 4;
+  const int nslice = (kwaves + wpb - 1) / wpb;
+  hipLaunchKernelGGL((suffstat_kernel<DP, CPW>), dim3((unsigned)a.nchunks, (unsigned)nslice), dim3(wpb * 64), 0,
+                     stream, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_suffstat(const SuffstatLaunch& a, hipStream_t stream) {
+  if (a.K <= 0 || a.nchunks <= 0) return hipSuccess;
+  const int cpw = ss_cpw(a.DP, a.K);
+  switch (a.DP) {
+    case 16:
+      return cpw == 4 ? launch_ss_t<16, 4>(a, stream) : cpw == 2 ? launch_ss_t<16, 2>(a, stream)
+                                                                : launch_ss_t<16, 1>(a, stream);
+    case 32:
+      return cpw == 4 ? launch_ss_t<32, 4>(a, stream) : cpw == 2 ? launch_ss_t<32, 2>(a, stream)
+                                                                : launch_ss_t<32, 1>(a, stream);
+    case 64:
+      return cpw == 2 ? launch_ss_t<64, 2>(a, stream) : launch_ss_t<64, 1>(a, stream);
+    case 128:
+      return launch_ss_t<128, 1>(a, stream);
+  }
+  return hipErrorInvalidValue;
+}
+
+// ===========================================================================
+// small helpers
+// ===========================================================================
+__global__ void __launch_bounds__(256) reduce_partials_kernel(const double* partial, int nparts, int64_t n,
+                                                              double* out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  double s = 0.0;
+  for (int c = 0; c < nparts; ++c) s += partial[(int64_t)c * n + e];
+  out[e] = s;
+}
+
+// few elements, many parts: one block per element, fixed-shape strided sum + tree
+__global__ void __launch_bounds__(256) reduce_cols_kernel(const double* partial, int nparts, int64_t n, double* out) {
+  __shared__ double sh[256];
+  const int64_t e = blockIdx.x;
+  double s = 0.0;
+  for (int c = threadIdx.x; c < nparts; c += 256) s += partial[(int64_t)c * n + e];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[e] = sh[0];
+}
+
+hipError_t launch_reduce_partials(const double* partial, int nparts, int64_t n, double* out, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  if (nparts > 512 && n <= 4096)
+    hipLaunchKernelGGL(reduce_cols_kernel, dim3((unsigned)n), dim3(256), 0, stream, partial, nparts, n, out);
+  else
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, partial,
+                       nparts, n, out);
+  return hipGetLastError();
+}
+
+// one block per (k, j): fixed-shape tree => deterministic
+__global__ void __launch_bounds__(256) group_colsum_kernel(const double* qZ, int64_t ldq, int K, const int64_t* goff,
+                                                           double* out) {
+  __shared__ double sh[256];
+  const int k = blockIdx.x, j = blockIdx.y;
+  const int64_t b = goff[j], e = goff[j + 1];
+  double s = 0.0;
+  for (int64_t r = b + threadIdx.x; r < e; r += 256) s += qZ[(int64_t)k * ldq + r];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[(int64_t)j * K + k] = sh[0];
+}
+
+hipError_t launch_group_colsum(const double* qZ, int64_t ldq, int K, const int64_t* goff, int J, double* out,
+                               hipStream_t stream) {
+  if (K <= 0 || J <= 0) return hipSuccess;
+  hipLaunchKernelGGL(group_colsum_kernel, dim3((unsigned)K, (unsigned)J), dim3(256), 0, stream, qZ, ldq, K, goff, out);
+  return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) fill_qz_kernel(double* qZ, int64_t ldq, int K, const int* rginfo,
+                                                      int64_t nrows, int64_t NP, double value) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= NP) return;
+  bool ok;
+  if (rginfo)
+    ok = (row & 15) < (rginfo[row >> 4] & 31);
+  else
+    ok = row < nrows;
+  const double v = ok ? value : 0.0;
+  for (int k = 0; k < K; ++k) qZ[(int64_t)k * ldq + row] = v;
+}
+
+hipError_t launch_fill_qz(double* qZ, int64_t ldq, int K, const int* rginfo, int64_t nrows, int64_t nrg, double value,
+                          hipStream_t stream) {
+  const int64_t NP = nrg * RG;
+  if (NP <= 0 || K <= 0) return hipSuccess;
+  hipLaunchKernelGGL(fill_qz_kernel, dim3((unsigned)((NP + 255) / 256)), dim3(256), 0, stream, qZ, ldq, K, rginfo,
+                     nrows, NP, value);
+  return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) move_rows_kernel(double* qZ, int64_t ldq, int k, int K, const int64_t* idx,
+                                                        int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t r = idx[i];
+  qZ[(int64_t)K * ldq + r] = qZ[(int64_t)k * ldq + r];
+  qZ[(int64_t)k * ldq + r] = 0.0;
+}
+
+hipError_t launch_move_rows(double* qZ, int64_t ldq, int k, int K, const int64_t* idx, int64_t n,
+                            hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(move_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, qZ, ldq, k, K, idx, n);
+  return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) project_kernel(const double* X, int DP, int64_t NP, const double* mv,
+                                                      unsigned char* out) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= NP) return;
+  double s = 0.0;
+  for (int d = 0; d < DP; ++d) s += (X[row * DP + d] - mv[d]) * mv[DP + d];
+  out[row] = s >= 0.0 ? 1 : 0;
+}
+
+hipError_t launch_project(const double* X, int DP, int64_t NP, const double* mv, unsigned char* out,
+                          hipStream_t stream) {
+  if (NP <= 0) return hipSuccess;
+  hipLaunchKernelGGL(project_kernel, dim3((unsigned)((NP + 255) / 256)), dim3(256), 0, stream, X, DP, NP, mv, out);
+  return hipGetLastError();
+}
+
+// ===========================================================================
+// synthetic mixture (bench workload)
+// ===========================================================================
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t out[4]) {
+  constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+    const uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += W0; k1 += W1;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ double u01(uint32_t a, uint32_t b) {
+  // 53-bit uniform in (0,1)
+  const uint64_t v = (((uint64_t)a << 32) | b) >> 11;
+  return ((double)v + 0.5) * (1.0 / 9007199254740992.0);
+}
+
+// 16 rows per 256-thread block; eps staged in LDS
+__global__ void __launch_bounds__(256) synth_kernel(SynthLaunch a) {
+  extern __shared__ double eps[];  // [16][DP]
+  __shared__ int zlab[16];
+  const int DP = a.DP, D = a.D, K = a.K;
+  const int64_t row0 = (int64_t)blockIdx.x * 16;
+  const uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32);
+  const int npair = (D + 1) / 2;
+  for (int t = threadIdx.x; t < 16 * npair; t += 256) {
+    const int r = t / npair, p = t % npair;
+    const uint64_t g = (uint64_t)(a.row_offset + row0 + r);
+    uint32_t o[4];
+    philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)p, 1u, k0, k1, o);
+    const double u1 = u01(o[0], o[1]), u2 = u01(o[2], o[3]);
+    const double rad = sqrt(-2.0 * log(u1));
+    double s, c;
+    sincos(6.283185307179586476925 * u2, &s, &c);
+    eps[r * DP + 2 * p] = rad * c;
+    if (2 * p + 1 < D) eps[r * DP + 2 * p + 1] = rad * s;
+  }
+  if (threadIdx.x < 16) {
+    const uint64_t g = (uint64_t)(a.row_offset + row0 + threadIdx.x);
+    uint32_t o[4];
+    philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), 0u, 2u, k0, k1, o);
+    zlab[threadIdx.x] = (int)(o[0] % (uint32_t)K);
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < 16 * DP; t += 256) {
+    const int r = t / DP, i = t % DP;
+    const int64_t row = row0 + r;
+    if (row >= a.NP) continue;
+    double v = 0.0;
+    if (row < a.nrows && i < D) {
+      const int z = zlab[r];
+      const double* Lz = a.L + ((int64_t)z * D + i) * D;
+      v = a.mu[(int64_t)z * D + i];
+      for (int j = 0; j <= i; ++j) v += Lz[j] * eps[r * DP + j];
+    }
+    a.X[row * DP + i] = v;
+  }
+  if (a.qZ) {
+    for (int t = threadIdx.x; t < 16 * K; t += 256) {
+      const int k = t / 16, r = t % 16;
+      const int64_t row = row0 + r;
+      if (row >= a.NP) continue;
+      double q = 0.0;
+      if (row < a.nrows) q = K == 1 ? 1.0 : (k == zlab[r] ? a.hard : (1.0 - a.hard) / (K - 1));
+      a.qZ[(int64_t)k * a.ldq + row] = q;
+    }
+  }
+}
+
+hipError_t launch_synth(const SynthLaunch& a, hipStream_t stream) {
+  if (a.NP <= 0) return hipSuccess;
+  const size_t shmem = (size_t)16 * a.DP * sizeof(double);
+  hipLaunchKernelGGL(synth_kernel, dim3((unsigned)((a.NP + 15) / 16)), dim3(256), shmem, stream, a);
+  return hipGetLastError();
+}
+
+}  // namespace lck

@@ -1,0 +1,93 @@
+"""Host-side pieces of the product (no GPU): the C-ABI library loads, exports
+every declared symbol, and its M-step arithmetic equals the oracle's."""
+import ctypes as C
+
+import numpy as np
+import pytest
+from scipy.special import digamma
+
+import lc_oracle as o
+from libcluster_amd import capi
+
+
+def test_library_exports_every_declared_symbol(lib):
+    names = capi.declared_symbols()
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/libcluster_hip.h but not exported"
+
+
+def test_constants(lib):
+    assert lib.lc_const_converge() == o.CONVERGE
+    assert lib.lc_const_fengydel() == o.FENGYDEL
+    assert lib.lc_const_zerocutoff() == o.ZEROCUTOFF
+    assert lib.lc_const_splititer() == o.SPLITITER
+
+
+def test_digamma_matches_scipy(lib):
+    x = np.concatenate([np.linspace(1e-3, 12, 2000), np.logspace(1, 8, 200), [0.5, 1.0, 1.4616321449683623, 60.5]])
+    got = np.array([lib.lc_digamma(float(v)) for v in x])
+    ref = digamma(x)
+    assert np.max(np.abs(got - ref) / np.maximum(1.0, np.abs(ref))) < 5e-15
+
+
+@pytest.mark.parametrize("kind,cls", [(capi.W_DIRICHLET, o.Dirichlet), (capi.W_STICKBREAK, o.StickBreak),
+                                      (capi.W_GDIRICHLET, o.GDirichlet)])
+def test_weights_update_matches_oracle(lib, kind, cls):
+    rng = np.random.default_rng(3)
+    for K in (1, 2, 5, 17):
+        Nk = rng.uniform(0, 50, K)
+        w = cls()
+        w.update(Nk)
+        e, f = capi.weights_update(kind, Nk)
+        np.testing.assert_allclose(e, w.Elogweight(), rtol=1e-13, atol=1e-13)
+        assert abs(f - w.fenergy()) <= 1e-12 * max(1.0, abs(w.fenergy()))
+    if kind != capi.W_GDIRICHLET:
+        w = cls(2.5)
+        w.update(np.array([3.0, 9.0, 1.0]))
+        e, f = capi.weights_update(kind, np.array([3.0, 9.0, 1.0]), 2.5)
+        np.testing.assert_allclose(e, w.Elogweight(), rtol=1e-13)
+        assert abs(f - w.fenergy()) < 1e-11
+
+
+def test_gw_mstep_matches_golden(lib, estep_cases):
+    for c in estep_cases:
+        D, K = c["D"], c["K"]
+        for k in range(K):
+            r = capi.gw_mstep(c["prior"], c["stats"]["Nk"][k], np.array(c["stats"]["xs"][k]),
+                              np.array(c["stats"]["xxs"][k]))
+            p = c["post"]
+            assert abs(r["nu"] - p["nu"][k]) < 1e-12 * p["nu"][k]
+            assert abs(r["beta"] - p["beta"][k]) < 1e-12 * p["beta"][k]
+            np.testing.assert_allclose(r["m"], p["m"][k], rtol=1e-12, atol=1e-13)
+            np.testing.assert_allclose(r["iW"], np.array(p["iW"][k]), rtol=1e-11, atol=1e-10)
+            assert abs(r["logdW"] - p["logdW"][k]) < 1e-10 * max(1, abs(p["logdW"][k]))
+            assert abs(r["fenergy"] - p["Fc"][k]) < 1e-9 * max(1, abs(p["Fc"][k]))
+            # whitener: nu * maha(x) == ||A (x - m)||^2
+            x = np.array(c["X"][0][0])
+            g = o.GaussWish(c["prior"], D)
+            g.addstats(c["stats"]["Nk"][k], c["stats"]["xs"][k], c["stats"]["xxs"][k])
+            g.update()
+            lhs = g.nu * o.mahaldist(x[None, :], g.m, g.iW)[0]
+            rhs = np.sum((r["A"] @ (x - r["m"])) ** 2)
+            assert abs(lhs - rhs) < 1e-9 * max(1.0, lhs)
+            assert abs((r["eloglike_const"] - 0.5 * rhs) - g.Eloglike(x[None, :])[0]) < 1e-9 * max(1.0, abs(lhs))
+
+
+def test_error_mapping(lib):
+    with pytest.raises(ValueError):
+        capi.weights_update(capi.W_DIRICHLET, np.array([1.0]), wprior=0.0)  # "Alpha prior must be > 0!"
+    with pytest.raises(ValueError):
+        capi.gw_mstep(0.0, 1.0, np.zeros(2), np.eye(2))  # "clustwidth must be > 0!"
+    with pytest.raises(RuntimeError):  # non-PD iW in update -> runtime_error (distributions.cpp:333-336)
+        capi.gw_mstep(1.0, 5.0, np.zeros(2), -100 * np.eye(2))
+
+
+def test_no_cpu_fallback(lib):
+    """Without a GPU every data-path entry point must fail loudly."""
+    if lib.lc_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(capi.HipError):
+        capi.Context(0)
+    with pytest.raises(capi.HipError):
+        capi.learn(capi.ALGO_BGMM, np.zeros((4, 2)))
