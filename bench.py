@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""Benchmark of the libcluster E-step hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 10 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one full VBEM iteration of the reference loop (cluster.cpp:198-234)
+at fixed K on a synthetic full-covariance Gaussian mixture resident in HBM:
+suff-stat kernel (updateSS/addobs) -> [N>1: RCCL all-reduce] -> host M-step ->
+E-step kernel (vbexpectation) -> [N>1: all-reduce of Fz] -> free energy.
+Nothing is skipped inside the timed region.  value = rows processed by all
+ranks per second (weak scaling: every GPU holds `N` rows).
+
+Default workload: the configuration BASELINE.json's north_star quotes the
+metric on -- BGMM, N=10M rows per GPU, D=64, K=32 (configs[3] is the same
+shape at 8 GPUs).  --config 2 / 3 select BASELINE.json configs[1] / configs[2].
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+FP64_PEAK_TFLOPS = 78.6  # MI355X fp64 vector = matrix spec; v_mfma_f64_4x4x4 measured 73.9 (profiles/)
+
+CONFIGS = {
+    # name: (N per GPU, D, K, weight kind, seed)
+    "northstar": dict(N=10_000_000, D=64, K=32, w="Dirichlet", seed=1004,
+                      label="BGMM N=10M/GPU D=64 K=32 (north_star target; BASELINE configs[3] = 8 of these)"),
+    "2": dict(N=1_000_000, D=16, K=8, w="Dirichlet", seed=1002, label="BASELINE configs[1]: BGMM N=1M D=16 K=8"),
+    "3": dict(N=10_000_000, D=64, K=32, w="StickBreak", seed=1003,
+              label="BASELINE configs[2]: VDP N=10M D=64 K=32"),
+    "5": dict(N=4_000_000, D=128, K=64, w="Dirichlet", seed=1005,
+              label="BASELINE configs[4] shape per GPU (single group): N=4M D=128 K=64"),
+    "tiny": dict(N=200_000, D=16, K=4, w="Dirichlet", seed=7, label="smoke: N=200k D=16 K=4"),
+}
+
+
+def mixture(D, K, seed):
+    """mu_k ~ N(0, 9 I), Sigma_k = B B^T / D + 0.5 I."""
+    rng = np.random.default_rng(seed)
+    mu = rng.normal(0.0, 3.0, (K, D))
+    L = np.empty((K, D, D))
+    for k in range(K):
+        B = rng.normal(size=(D, D))
+        L[k] = np.linalg.cholesky(B @ B.T / D + 0.5 * np.eye(D))
+    return mu, L
+
+
+def alg_flops(N, D, K):
+    """Algorithmic (minimal, structure-exploiting) flops per launch, SURVEY 8(d)."""
+    return {"estep": N * K * (D * D + 4 * D), "suffstat": N * K * (D * D + 3 * D + 1)}
+
+
+def cpu_baseline(ctx, model, cfg, wkind_name, sample_rows):
+    """Time the C port of the reference arithmetic (oracle/lc_oracle_c.c) on the
+    first `sample_rows` rows of the same workload, on this host's cores."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import lc_oracle_c as oc
+
+    D, K = cfg["D"], cfg["K"]
+    n = min(sample_rows, cfg["N"])
+    X = ctx.get_rows(0, 0, n)
+    cl = [model.cluster(k) for k in range(K)]
+    el, _ = model.weights(0)
+    post = ([c["nu"] for c in cl], [c["beta"] for c in cl], np.stack([c["m"] if "m" in c else c["mean"] for c in cl]),
+            np.stack([c["iW"] for c in cl]), [c["logdW"] for c in cl], el)
+    cores = oc.physical_cores()
+    out = {}
+    for label, nt, rows in (("all_cores", cores, n), ("one_thread", 1, max(1000, n // 32))):
+        Xs = X[:rows]
+        q, _ = oc.estep(Xs, *post, nthreads=nt)  # warm-up (also produces the q the suff-stat pass consumes)
+        oc.suffstat(Xs, q, nt)
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            q, _ = oc.estep(Xs, *post, nthreads=nt)
+            oc.suffstat(Xs, q, nt)
+            ts.append(time.perf_counter() - t0)
+        out[label] = {"pts_per_s": rows / float(np.median(ts)), "rows": rows, "threads": nt}
+    return {
+        "value": out["all_cores"]["pts_per_s"], "unit": "points/s", "cores": cores, "kind": "port",
+        "sample": f"first {n} rows of the same synthetic stream, E-step + suff-stats per cluster pass "
+                  f"(oracle/lc_oracle_c.c, gcc -O3 -march=native -fopenmp, rows chunked over {cores} threads), "
+                  f"median of 3",
+        "one_thread_value": out["one_thread"]["pts_per_s"],
+        "one_thread_sample_rows": out["one_thread"]["rows"],
+    }
+
+
+def parity(capi, cfg, wkind, mu, L, device, rows=20000, iters=3):
+    """Free-energy / qZ delta of the GPU path vs the numpy oracle on identical inputs
+    (the first `rows` rows of the Philox stream, same initial qZ)."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import lc_oracle as o
+
+    D, K = cfg["D"], cfg["K"]
+    with capi.Context(device) as c2:
+        c2.synth(rows, D, K, mu, L, cfg["seed"], 0, 0.9)
+        X = c2.get_rows(0, 0, rows)
+        q0 = c2.get_qz([rows])[0]
+        F, tr, m = c2.vbem(wkind, fixed_iters=iters, nthreads=8)
+        q = c2.get_qz([rows])[0]
+        m.close()
+    wf = {"Dirichlet": o.Dirichlet, "StickBreak": o.StickBreak}[cfg["w"]]
+    Ftr, _, qT, _, _ = o.vbem_fixed([X], [q0], wf, 1.0, iters)
+    big = qT[0] > 1e-12
+    return {
+        "rows": rows, "iters": iters, "F_gpu": float(tr[-1]), "F_cpu": float(Ftr[-1]),
+        "rel_dF": float(abs(tr[-1] - Ftr[-1]) / abs(Ftr[-1])),
+        "max_rel_dqZ": float(np.max(np.abs(q[big] - qT[0][big]) / qT[0][big])),
+        "max_abs_dqZ": float(np.max(np.abs(q - qT[0]))),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="northstar", choices=sorted(CONFIGS))
+    ap.add_argument("--rows", type=int, default=0, help="override rows per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    import torch
+
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from libcluster_amd import build, capi
+    from libcluster_amd import dist as lcd
+
+    if not capi.LIB_PATH.exists():
+        build.build()
+    cfg = dict(CONFIGS[args.config])
+    if args.rows:
+        cfg["N"] = args.rows
+    N, D, K = cfg["N"], cfg["D"], cfg["K"]
+    wkind = {"Dirichlet": capi.W_DIRICHLET, "StickBreak": capi.W_STICKBREAK}[cfg["w"]]
+    mu, L = mixture(D, K, cfg["seed"])
+    nthreads = max(1, min(32, (os.cpu_count() or 2) // max(1, world)))
+
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = capi.Context(local_rank, stream)
+    ctx.synth(N, D, K, mu, L, cfg["seed"], rank * N, 0.9)
+    if world > 1:
+        ctx.set_allreduce(lcd.make_device_hook(local_rank))
+
+    model = None
+    if args.warmup > 0:
+        _, _, model = ctx.vbem(wkind, fixed_iters=args.warmup, nthreads=nthreads)
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    F, tr, model = ctx.vbem(wkind, fixed_iters=args.steps, nthreads=nthreads, model=model)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    kt = ctx.timing_get()
+    ctx.timing_enable(False)
+
+    if rank == 0:
+        steps = args.steps
+        fl = alg_flops(N, D, K)
+        est = kt["estep_ms"] / max(1, kt["estep_calls"])
+        sst = kt["suffstat_ms"] / max(1, kt["suffstat_calls"])
+        dom = "estep_kernel" if est >= sst else "suffstat_kernel"
+        dom_ms = max(est, sst)
+        dom_fl = fl["estep"] if est >= sst else fl["suffstat"]
+        achieved = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        both = (fl["estep"] + fl["suffstat"]) / ((est + sst) * 1e-3) / 1e12 if est + sst > 0 else 0.0
+        line = {
+            "metric": "E-step data-points/sec (full VBEM iteration: suff-stats + M-step + E-step)",
+            "value": world * N * steps / dt,
+            "unit": "points/s",
+            "n_gpus": world,
+            "steps": steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": cfg["label"], "rows_per_gpu": N, "D": D, "K": K, "weights": cfg["w"],
+                       "seed": cfg["seed"], "parallelism": f"rows sharded x{world}, all-reduce of suff-stats"},
+            "free_energy": float(F),
+            "kernels": {"estep_ms": est, "suffstat_ms": sst, "estep_calls": kt["estep_calls"],
+                        "suffstat_calls": kt["suffstat_calls"],
+                        "estep_kernel_points_per_s": N / (est * 1e-3) if est > 0 else None,
+                        "both_kernels_alg_tflops": both},
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+                         "alg_flops_per_launch": dom_fl, "avg_launch_ms": dom_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(ctx, model, cfg, cfg["w"], args.cpu_sample_rows)
+        if world == 1 and not args.no_parity:
+            line["parity"] = parity(capi, cfg, wkind, mu, L, local_rank)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
