@@ -275,7 +275,7 @@ void Context::estep(int K, const double* A, const double* m, const double* c, do
   LC_HIP(hipSetDevice(device_));
   const int D = D_, DP = DP_, NT = DP / 4;
   const int PS = lck::pstride(DP), NTILES = lck::ntiles(DP);
-  // ---- pack: tiles of A_k in consumption order, then b_k = A_k m_k --------
+  // ---- pack: tiles of A_k in consumption order, then -b_k = -A_k m_k ------
   hpack_.assign((size_t)K * PS + (size_t)J_ * K, 0.0);
   for (int k = 0; k < K; ++k) {
     const double* Ak = A + (size_t)k * D * D;
@@ -294,7 +294,7 @@ void Context::estep(int K, const double* A, const double* m, const double* c, do
     for (int i = 0; i < D; ++i) {
       double s = 0.0;
       for (int j = 0; j <= i; ++j) s += Ak[(size_t)i * D + j] * mk[j];
-      b[i] = s;
+      b[i] = -s;  // the kernel's accumulators start at -b so that y = A x - b
     }
   }
   std::memcpy(hpack_.data() + (size_t)K * PS, c, (size_t)J_ * K * sizeof(double));
@@ -393,7 +393,9 @@ void Context::suffstat(const unsigned char* smask, double* Nk, double* xs, doubl
       pending_.push_back(ev);
     }
     LC_HIP(lck::launch_reduce_partials(sspart_.p, nchunks, (int64_t)K * SS, ssout_.p, stream_));
-    LC_HIP(lck::launch_group_colsum(qz_[cur_].buf.p, NP_, K, goff_d_.p, J_, njk_d, stream_));
+    // per-group counts N_jk: with one group they are the N_k just reduced (filled in on the host below)
+    if (J_ > 1) LC_HIP(lck::launch_group_colsum(qz_[cur_].buf.p, NP_, K, goff_d_.p, J_, njk_d, stream_));
+    else LC_HIP(hipMemsetAsync(njk_d, 0, (size_t)K * sizeof(double), stream_));
   } else {
     LC_HIP(hipMemsetAsync(ssout_.p, 0, nout * sizeof(double), stream_));
   }
@@ -419,7 +421,12 @@ void Context::suffstat(const unsigned char* smask, double* Nk, double* xs, doubl
         }
     }
   }
-  if (Njk) std::copy(hss_.begin() + (size_t)K * SS, hss_.end(), Njk);
+  if (Njk) {
+    if (J_ == 1)  // qZ.colwise().sum() of the only group == the (unmasked) N_k record
+      for (int k = 0; k < K; ++k) Njk[k] = hss_[(size_t)k * SS];
+    else
+      std::copy(hss_.begin() + (size_t)K * SS, hss_.end(), Njk);
+  }
 }
 
 void Context::colsums(double* Njk) {

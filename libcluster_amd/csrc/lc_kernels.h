@@ -53,6 +53,7 @@ struct SuffstatLaunch {
   double* partial;          // [nchunks x K x stat_stride(DP)]
   int nchunks;
   int64_t chunk_rows;       // multiple of 4
+  int nslice = 1;           // filled in by launch_suffstat
 };
 // choose a chunking for (NP, K); returns nchunks and sets chunk_rows
 int suffstat_plan(int DP, int64_t NP, int K, int64_t* chunk_rows);

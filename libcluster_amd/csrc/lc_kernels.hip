@@ -19,6 +19,8 @@
 #include "lc_kernels.h"
 
 #include <cmath>
+#include <type_traits>
+#include <utility>
 
 namespace lck {
 
@@ -76,10 +78,35 @@ __device__ __forceinline__ double wave_sum(double v) {
 // log q~ is written to the qZ buffer as scratch, then normalised in place in
 // the same arithmetic order as the reference: max, sum exp(x-max), log+max,
 // exp(x - logZ).
+// n-th read of a cluster's parameter stream (for it: -b[it], tile(it,0), ..., tile(it,it)):
+// .jt < 0: element of the -b vector (offset in doubles from Pb), else of tile (it,jt) (from Pt)
+struct RdInfo {
+  int it, jt, off;
+};
+__host__ __device__ constexpr RdInfo rd_info(int n) {
+  int it = 0;
+  while (n >= it + 2) {
+    n -= it + 2;
+    ++it;
+  }
+  return n == 0 ? RdInfo{it, -1, 4 * it} : RdInfo{it, n - 1, (it * (it + 1) / 2 + (n - 1)) * 16};
+}
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(<N-1>)
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
 template <int DP, int R, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64, 2) estep_kernel(EstepLaunch a) {
   constexpr int NT = DP / 4;
   constexpr int NTILES = NT * (NT + 1) / 2;
+  constexpr int NREAD = NTILES + NT;  // LDS reads per cluster
+  constexpr int PF = 6;               // reads in flight ahead of their use
   constexpr int PS = NTILES * 16 + DP;
   constexpr int NTHR = WAVES * 64;
   constexpr int NV2 = PS / 2;
@@ -150,28 +177,44 @@ __global__ void __launch_bounds__(WAVES * 64, 2) estep_kernel(EstepLaunch a) {
     const int buf = k & 1;
     if (k + 1 < K) LC_GLOAD(k + 1);
     const double* P = pbuf + buf * PS;
-    const double* Pt = P + (lane & 3) + 4 * hi;
-    double d2[R];
+    const double* Pt = P + (lane & 3) + 4 * hi;  // this lane's element of every 4x4 tile
+    const double* Pb = P + NTILES * 16 + hi;     // this lane's element of every 4-vector of -b
+    // The cluster's parameters are consumed as one linear stream of LDS reads
+    // (for it: -b[it], tile(it,0..it)), software-pipelined PF reads ahead so no
+    // MFMA ever waits on the read issued just before it.
+    double ring[PF];
+    static_for<PF>([&](auto ic) {
+      constexpr RdInfo ri = rd_info(ic);
+      ring[ic] = ri.jt < 0 ? Pb[ri.off] : Pt[ri.off];
+    });
+    double d2[R], acc[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) d2[r] = 0.0;
-#pragma unroll
-    for (int it = 0; it < NT; ++it) {
-      const double binit = -P[NTILES * 16 + 4 * it + hi];
-      double acc[R];
-#pragma unroll
-      for (int r = 0; r < R; ++r) acc[r] = binit;
-#pragma unroll
-      for (int jt = 0; jt <= it; ++jt) {
-        const double at = Pt[(it * (it + 1) / 2 + jt) * 16];
-#pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = mfma4(at, xf[r][jt], acc[r]);
+    static_for<NREAD>([&](auto nc) {
+      constexpr int n = nc;
+      constexpr RdInfo ri = rd_info(n);
+      const double v = ring[n % PF];
+      if constexpr (n + PF < NREAD) {
+        constexpr RdInfo rn = rd_info(n + PF);
+        ring[n % PF] = rn.jt < 0 ? Pb[rn.off] : Pt[rn.off];
       }
+      if constexpr (ri.jt < 0) {
 #pragma unroll
-      for (int r = 0; r < R; ++r) d2[r] = fma(acc[r], acc[r], d2[r]);
-      // keep the scheduler from hoisting later tile rows' LDS reads (and their
-      // registers) above this row's MFMAs
-      __builtin_amdgcn_sched_barrier(0);
-    }
+        for (int r = 0; r < R; ++r) acc[r] = v;
+      } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = mfma4(v, xf[r][ri.jt], acc[r]);
+        if constexpr (ri.jt == ri.it) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            d2[r] = fma(acc[r], acc[r], d2[r]);
+            // pin the running sum here: otherwise LLVM sinks the whole fma chain below the
+            // MFMA stream and keeps every row's accumulator alive (96 extra VGPRs, spills)
+            asm volatile("" : "+v"(d2[r]));
+          }
+        }
+      }
+    });
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const double dd = sum_over_hi(d2[r]);
@@ -193,6 +236,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) estep_kernel(EstepLaunch a) {
     double s = 0.0;
     if (rgok[r]) {
       const double* qp = a.qZ + (rg0 + r) * RG + lo4;
+#pragma unroll 8
       for (int k = hi; k < K; k += 4) s += exp(qp[(int64_t)k * a.ldq] - mx[r]);
     }
     s = sum_over_hi(s);
@@ -319,10 +363,29 @@ __global__ void __launch_bounds__(256) suffstat_kernel(SuffstatLaunch a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lo4 = lane & 15, hi = lane >> 4, blk = (lane >> 2) & 3, lo2 = lane & 3;
   const int K = a.K;
-  const int kbase = ((int)blockIdx.y * (int)(blockDim.x >> 6) + wave) * CPW;
+  // Workgroup -> (row chunk, cluster slice).  Every slice of a chunk re-reads the
+  // same X rows, so the slices of one chunk are placed back-to-back on ONE XCD
+  // (block b runs on XCD b % 8, each XCD has its own L2): seq = b / 8 walks
+  // (chunk-in-XCD, slice) with the slice fastest.  Pure speed; any placement is correct.
+  int chunk, slice;
+  {
+    const int nslice = a.nslice, nchunks = a.nchunks;
+    const int b = blockIdx.x;
+    const int full = (nchunks / 8) * 8;          // chunks that fill all 8 XCDs evenly
+    if (b < full * nslice) {
+      const int xcd = b & 7, seq = b >> 3;
+      chunk = (seq / nslice) * 8 + xcd;
+      slice = seq % nslice;
+    } else {                                     // remainder: plain order
+      const int t = b - full * nslice;
+      chunk = full + t / nslice;
+      slice = t % nslice;
+    }
+  }
+  const int kbase = (slice * (int)(blockDim.x >> 6) + wave) * CPW;
   if (kbase >= K) return;
   const int nk = (K - kbase) < CPW ? (K - kbase) : CPW;
-  const int64_t r0 = (int64_t)blockIdx.x * a.chunk_rows;
+  const int64_t r0 = (int64_t)chunk * a.chunk_rows;
   const int64_t r1 = (r0 + a.chunk_rows) < a.NP ? (r0 + a.chunk_rows) : a.NP;
 
   double acc[CPW][NACC];
@@ -413,7 +476,7 @@ __global__ void __launch_bounds__(256) suffstat_kernel(SuffstatLaunch a) {
 #pragma unroll
   for (int c = 0; c < CPW; ++c) {
     if (c < nk) {
-      double* out = a.partial + ((int64_t)blockIdx.x * K + kbase + c) * SS;
+      double* out = a.partial + ((int64_t)chunk * K + kbase + c) * SS;
       const double nsum = sum_over_hi(nacc[c]);
       if (lane == 0) out[0] = nsum;
 #pragma unroll
@@ -487,8 +550,9 @@ static hipError_t launch_ss_t(const SuffstatLaunch& a, hipStream_t stream) {
   const int kwaves = (a.K + CPW - 1) / CPW;
   const int wpb = kwaves < 4 ? kwaves : 4;
   const int nslice = (kwaves + wpb - 1) / wpb;
-  hipLaunchKernelGGL((suffstat_kernel<DP, CPW>), dim3((unsigned)a.nchunks, (unsigned)nslice), dim3(wpb * 64), 0,
-                     stream, a);
+  SuffstatLaunch b = a;
+  b.nslice = nslice;
+  hipLaunchKernelGGL((suffstat_kernel<DP, CPW>), dim3((unsigned)(a.nchunks * nslice)), dim3(wpb * 64), 0, stream, b);
   return hipGetLastError();
 }
 
