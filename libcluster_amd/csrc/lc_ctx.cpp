@@ -321,7 +321,7 @@ void Context::estep(int K, const double* A, const double* m, const double* c, do
   a.qZ = qz_[cur_].buf.p;
   a.ldq = NP_;
   a.fz_part = fzpart_.p;
-  a.ll_part = llpart_.p;
+  a.ll_part = LLk ? llpart_.p : nullptr;
   EvPair ev{};
   if (timing_) {
     LC_HIP(hipEventCreate(&ev.a));
@@ -336,7 +336,8 @@ void Context::estep(int K, const double* A, const double* m, const double* c, do
   }
   if (grid > 0) {
     LC_HIP(lck::launch_reduce_partials(fzpart_.p, (int)grid, 1, red_.p, stream_));
-    LC_HIP(lck::launch_reduce_partials(llpart_.p, (int)grid, K, red_.p + 1, stream_));
+    if (LLk) LC_HIP(lck::launch_reduce_partials(llpart_.p, (int)grid, K, red_.p + 1, stream_));
+    else LC_HIP(hipMemsetAsync(red_.p + 1, 0, (size_t)K * sizeof(double), stream_));
   } else {
     LC_HIP(hipMemsetAsync(red_.p, 0, (size_t)(1 + K) * sizeof(double), stream_));
   }

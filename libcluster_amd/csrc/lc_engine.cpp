@@ -75,7 +75,13 @@ double vbem(lcc::Context& ctx, Model& model, const VbemOptions& opt) {
     if (c.D != D) throw std::invalid_argument("Mismatched dims. of cluster params and obs.!");
 
   std::vector<double> Nk(K), xs((size_t)K * D), xxs((size_t)K * D * D), Njk((size_t)J * K);
-  std::vector<double> A((size_t)K * D * D), m((size_t)K * D), c((size_t)J * K), cst(K);
+  // the packed E-step parameters of the last iteration stay in the model (the split search
+  // re-runs that E-step once to get its data term, see data_loglik)
+  std::vector<double>&A = model.lastA, &m = model.lastm, &c = model.lastc;
+  A.assign((size_t)K * D * D, 0.0);
+  m.assign((size_t)K * D, 0.0);
+  c.assign((size_t)J * K, 0.0);
+  std::vector<double> cst(K);
   std::vector<unsigned char> mask;
   model.LLk.assign(K, 0.0);
 
@@ -118,7 +124,7 @@ double vbem(lcc::Context& ctx, Model& model, const VbemOptions& opt) {
       }
     }
     double Fz = 0.0;
-    ctx.estep(K, A.data(), m.data(), c.data(), &Fz, model.LLk.data());
+    ctx.estep(K, A.data(), m.data(), c.data(), &Fz, nullptr);
 
     // fenergy (:145-165)
     double Fw = 0.0, Fc = 0.0;
@@ -139,6 +145,16 @@ double vbem(lcc::Context& ctx, Model& model, const VbemOptions& opt) {
     }
   } while (again);
   return F;
+}
+
+// Data term of the split ordering (cluster.cpp:407-410): LLk[k] = sum_n q_nk (log q~_nk - c_jk).
+// vbem's iterations skip it; it is produced here by repeating the last E-step (same parameters,
+// so qZ is rewritten with identical values) with the per-cluster reduction switched on.
+static void data_loglik(lcc::Context& ctx, Model& model) {
+  const int K = (int)model.clusters.size();
+  double Fz = 0.0;
+  model.LLk.assign(K, 0.0);
+  ctx.estep(K, model.lastA.data(), model.lastm.data(), model.lastc.data(), &Fz, model.LLk.data());
 }
 
 // ---------------------------------------------------------------------------
@@ -319,6 +335,9 @@ double cluster(lcc::Context& ctx, const HostData& host, Model& model, const Clus
     vo.trace = &tr;
     F = vbem(ctx, model, vo);
     if (opt.trace) opt.trace->emplace_back((int)model.clusters.size(), tr);
+    int nkeep = 0;
+    for (const auto& cl : model.clusters) nkeep += !(cl.N < lch::ZEROCUTOFF);
+    if (!(nkeep >= opt.maxclusters && opt.maxclusters >= 0)) data_loglik(ctx, model);  // split_gr will need it
     prune_clusters(ctx, model, opt.verbose);
     if (opt.verbose) std::cout << '<' << std::flush;
     issplit = split_gr(ctx, host, model, tally, F, opt);

@@ -28,6 +28,7 @@ struct Model {
   std::vector<lch::WeightState> weights;      // J
   std::vector<lch::GaussWishState> clusters;  // K
   std::vector<double> LLk;                    // data term of the last E-step, per cluster
+  std::vector<double> lastA, lastm, lastc;    // packed parameters of the last E-step (K*D*D, K*D, J*K)
 };
 
 struct VbemOptions {

@@ -35,7 +35,7 @@ struct EstepLaunch {
   double* qZ;            // [K x ldq]
   int64_t ldq;
   double* fz_part;       // [estep_grid(...)]
-  double* ll_part;       // [estep_grid(...) x K]
+  double* ll_part;       // [estep_grid(...) x K], or nullptr: skip the split-ordering data term
 };
 int estep_rows_per_block(int DP);
 int64_t estep_grid(int DP, int64_t nrg);

@@ -19,6 +19,7 @@
 #include "lc_kernels.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -30,7 +31,9 @@ __device__ __forceinline__ double mfma4(double a, double b, double c) {
 
 template <int CTRL>
 __device__ __forceinline__ int dpp_i32(int v) {
-  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
+  // row_ror reads a valid lane for every lane, so `old` is never used: bound_ctrl lets the
+  // compiler skip materialising it
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
 }
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
@@ -217,7 +220,9 @@ __global__ void __launch_bounds__(WAVES * 64, 2) estep_kernel(EstepLaunch a) {
     });
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const double dd = sum_over_hi(d2[r]);
+      // sum over the four hi lanes on the matrix pipe: D[i][j] = sum_k 1 * B[k][j] leaves the
+      // total in every lane (B[k=hi][j=row] is exactly where the partial sums live)
+      const double dd = mfma4(1.0, d2[r], 0.0);
       const double lq = a.ctab[(int64_t)grp[r] * K + k] - 0.5 * dd;
       mx[r] = fmax(mx[r], lq);
       if (rgok[r] && hi == (k & 3)) a.qZ[(int64_t)k * a.ldq + (rg0 + r) * RG + lo4] = lq;
@@ -254,12 +259,14 @@ __global__ void __launch_bounds__(WAVES * 64, 2) estep_kernel(EstepLaunch a) {
           double q = exp(lq - logZ[r]);
           if (!rowok[r]) q = 0.0;
           *qp = q;
-          if (q > 0.0) ll += q * (lq - a.ctab[(int64_t)grp[r] * K + k]);
+          if (a.ll_part && q > 0.0) ll += q * (lq - a.ctab[(int64_t)grp[r] * K + k]);
         }
       }
     }
-    ll = sum_over_lo4(ll);
-    if (k < K && lo4 == 0) llw[wave * K + k] = ll;
+    if (a.ll_part) {  // wave-uniform
+      ll = sum_over_lo4(ll);
+      if (k < K && lo4 == 0) llw[wave * K + k] = ll;
+    }
   }
   double fz = 0.0;
 #pragma unroll
@@ -268,11 +275,12 @@ __global__ void __launch_bounds__(WAVES * 64, 2) estep_kernel(EstepLaunch a) {
   fz = wave_sum(fz);
   if (lane == 0) fzw[wave] = fz;
   __syncthreads();
-  for (int k = tid; k < K; k += NTHR) {
-    double s = 0.0;
-    for (int w = 0; w < WAVES; ++w) s += llw[w * K + k];
-    a.ll_part[(int64_t)blockIdx.x * K + k] = s;
-  }
+  if (a.ll_part)
+    for (int k = tid; k < K; k += NTHR) {
+      double s = 0.0;
+      for (int w = 0; w < WAVES; ++w) s += llw[w * K + k];
+      a.ll_part[(int64_t)blockIdx.x * K + k] = s;
+    }
   if (tid == 0) {
     double s = 0.0;
     for (int w = 0; w < WAVES; ++w) s += fzw[w];
@@ -343,24 +351,43 @@ hipError_t launch_estep(const EstepLaunch& a, hipStream_t stream) {
 // S_k = sum_n q_nk x_n x_n^T is a GEMM whose reduction dimension is the data
 // rows.  One wave owns CPW clusters and streams over a chunk of rows, four
 // rows per step, with the (symmetric, lower-triangular 16x16-blocked)
-// accumulators in registers for the whole chunk.  Per step the wave loads
-// NB = DP/16 natural-layout fragments xf[JB] (row = hi, feature = 16*JB +
-// lane&15: 128-byte coalesced segments), forms qx = q_k * xf once per cluster,
-// and issues for every needed pair of 16-wide feature blocks (JBp >= JB)
-//   D += A(xrot[JBp][s]) * B(qx[JB]),  s = rotation of the four 4-wide
-// sub-blocks inside JBp (DPP row_ror, no memory traffic), so that MFMA block
-// blk computes the 4x4 tile (i-tile = src(blk,s), j-tile = blk).
+// accumulators in registers for the whole chunk.  For every needed pair of
+// 16-wide feature blocks (JBp >= JB) and every rotation s of the four 4-wide
+// sub-blocks inside JBp the wave issues
+//     D += A(x[., 16*JBp + 4*((blk+s)&3) + lo2]) * B(q_k * x[., 16*JB + 4*blk + lo2])
+// so that MFMA block blk computes the 4x4 tile (i-tile (blk+s)&3, j-tile blk).
 // Off-diagonal 16x16 blocks need s=0..3, diagonal ones s=0..2 (symmetry).
-// s_k and N_k ride along on the VALU.  Each (chunk, cluster) writes one
-// partial record; launch_reduce_partials sums chunks in fixed order.
+//
+// fp64 VALU and fp64 MFMA share the issue pipe on gfx950 (a VALU block between
+// MFMA streams is not hidden by the other resident wave:
+// tools/mfma_issue_probe.hip, 97% -> 81% of peak), so the rotated operands are
+// NOT formed with DPP moves: the workgroup stages BR rows of X in LDS (every
+// wave of the group needs the same rows) and each wave reads all four
+// rotations of a fragment straight from LDS with rotated addresses (LGKM
+// path).  Row stride DP+16 doubles keeps the two rows a ds_read_b64 half-wave
+// touches on disjoint banks.  q columns are staged per wave the same way.
+// What remains on the VALU per cluster and step: NB multiplies (q*x), NB adds
+// (s_k) and one add (N_k) against NACC MFMAs.
+// Each (chunk, cluster) writes one partial record; launch_reduce_partials sums
+// chunks in fixed order.
 template <int NB>
 struct SSAcc { static constexpr int N = NB * 3 + NB * (NB - 1) / 2 * 4; };
 
+constexpr int SS_BR = 32;  // rows staged per batch
+
 template <int DP, int CPW>
-__global__ void __launch_bounds__(256) suffstat_kernel(SuffstatLaunch a) {
+__global__ void __launch_bounds__(256, (DP <= 64 ? 2 : 1)) suffstat_kernel(SuffstatLaunch a) {
   constexpr int NB = DP / 16;
   constexpr int NACC = SSAcc<NB>::N;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int BR = SS_BR;
+  constexpr int LD = DP + 16;            // padded LDS row stride (doubles)
+  constexpr int XBUF = BR * LD;          // doubles per X buffer
+  constexpr int NV2 = BR * DP / 2;       // double2 elements per staged batch
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  constexpr int nwaves = 4, nthr = 256;  // always launched with 4 waves; surplus waves only help staging
+  double* xbuf = lds;                              // [2][BR][LD]
+  double* qbuf = lds + 2 * XBUF;                   // [2][nwaves][CPW][BR]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lo4 = lane & 15, hi = lane >> 4, blk = (lane >> 2) & 3, lo2 = lane & 3;
   const int K = a.K;
   // Workgroup -> (row chunk, cluster slice).  Every slice of a chunk re-reads the
@@ -371,20 +398,19 @@ __global__ void __launch_bounds__(256) suffstat_kernel(SuffstatLaunch a) {
   {
     const int nslice = a.nslice, nchunks = a.nchunks;
     const int b = blockIdx.x;
-    const int full = (nchunks / 8) * 8;          // chunks that fill all 8 XCDs evenly
+    const int full = (nchunks / 8) * 8;
     if (b < full * nslice) {
       const int xcd = b & 7, seq = b >> 3;
       chunk = (seq / nslice) * 8 + xcd;
       slice = seq % nslice;
-    } else {                                     // remainder: plain order
+    } else {
       const int t = b - full * nslice;
       chunk = full + t / nslice;
       slice = t % nslice;
     }
   }
-  const int kbase = (slice * (int)(blockDim.x >> 6) + wave) * CPW;
-  if (kbase >= K) return;
-  const int nk = (K - kbase) < CPW ? (K - kbase) : CPW;
+  const int kbase = (slice * nwaves + wave) * CPW;   // may be >= K: the wave still helps staging
+  const int nk = kbase >= K ? 0 : ((K - kbase) < CPW ? (K - kbase) : CPW);
   const int64_t r0 = (int64_t)chunk * a.chunk_rows;
   const int64_t r1 = (r0 + a.chunk_rows) < a.NP ? (r0 + a.chunk_rows) : a.NP;
 
@@ -400,77 +426,105 @@ __global__ void __launch_bounds__(256) suffstat_kernel(SuffstatLaunch a) {
     for (int i = 0; i < NB; ++i) sacc[c][i] = 0.0;
   }
 
-  double xn[NB], qn[CPW];
-  auto load = [&](int64_t n0) {
-    const int64_t row = n0 + hi;
-    const double* xr = a.X + row * DP + lo4;
+  // ---- staging: registers hold the next batch while the current one is consumed
+  constexpr int NPRE_MAX = (NV2 + nthr - 1) / nthr, npre = NPRE_MAX;
+  double pre[NPRE_MAX][2];
+  double qpre[CPW];
+  auto gload = [&](int64_t b0) {
 #pragma unroll
-    for (int jb = 0; jb < NB; ++jb) xn[jb] = xr[16 * jb];
+    for (int i = 0; i < NPRE_MAX; ++i) {
+      if (i < npre) {
+        const int idx = tid + i * nthr;          // double2 index inside the batch: row-major [BR][DP/2]
+        const int row = idx / (DP / 2), c2 = idx % (DP / 2);
+        double2 v = make_double2(0.0, 0.0);
+        if (idx < NV2 && b0 + row < r1) v = *reinterpret_cast<const double2*>(a.X + (b0 + row) * DP + 2 * c2);
+        pre[i][0] = v.x;
+        pre[i][1] = v.y;
+      }
+    }
+    // q: lanes 0..BR-1 of each wave fetch that wave's CPW columns (coalesced)
     int g = 0;
-    if (a.smask) g = a.rginfo[row >> 4] >> 5;
+    const int64_t qrow = b0 + lane;
+    const bool qok = lane < BR && qrow < r1;
+    if (a.smask && qok) g = a.rginfo[qrow >> 4] >> 5;
 #pragma unroll
     for (int c = 0; c < CPW; ++c) {
       double q = 0.0;
-      if (c < nk) {
-        q = a.qZ[(int64_t)(kbase + c) * a.ldq + row];
+      if (c < nk && qok) {
+        q = a.qZ[(int64_t)(kbase + c) * a.ldq + qrow];
         if (a.smask && !a.smask[(int64_t)g * K + kbase + c]) q = 0.0;
       }
-      qn[c] = q;
+      qpre[c] = q;
+    }
+  };
+  auto lstore = [&](int buf) {
+    double* xb = xbuf + buf * XBUF;
+#pragma unroll
+    for (int i = 0; i < NPRE_MAX; ++i) {
+      if (i < npre) {
+        const int idx = tid + i * nthr;
+        const int row = idx / (DP / 2), c2 = idx % (DP / 2);
+        if (idx < NV2) *reinterpret_cast<double2*>(xb + row * LD + 2 * c2) = make_double2(pre[i][0], pre[i][1]);
+      }
+    }
+    if (lane < BR) {
+      double* qb = qbuf + ((buf * nwaves + wave) * CPW) * BR;
+#pragma unroll
+      for (int c = 0; c < CPW; ++c) qb[c * BR + lane] = qpre[c];
     }
   };
 
-  if (r0 < r1) load(r0);
-  for (int64_t n0 = r0; n0 < r1; n0 += 4) {
-    double xf[NB], q[CPW];
+  if (r0 < r1) {
+    gload(r0);
+    lstore(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int64_t b0 = r0; b0 < r1; b0 += BR, buf ^= 1) {
+    const bool more = b0 + BR < r1;
+    if (more) gload(b0 + BR);
+    if (nk > 0) {
+      const double* xb = xbuf + buf * XBUF + hi * LD + lo2;
+      const double* qb = qbuf + ((buf * nwaves + wave) * CPW) * BR + hi;
+      const int nstep = (int)(((r1 - b0) < BR ? (r1 - b0) : BR) / 4);
+      for (int st = 0; st < nstep; ++st) {
+        // fragments: xr[jb][s] = x[row 4*st+hi][16*jb + 4*((blk+s)&3) + lo2]
+        double xr[NB][4];
 #pragma unroll
-    for (int jb = 0; jb < NB; ++jb) xf[jb] = xn[jb];
+        for (int jb = 0; jb < NB; ++jb)
 #pragma unroll
-    for (int c = 0; c < CPW; ++c) q[c] = qn[c];
-    if (n0 + 4 < r1) load(n0 + 4);
-    double xrot[NB][3];
+          for (int s = 0; s < 4; ++s) xr[jb][s] = xb[st * 4 * LD + 16 * jb + 4 * ((blk + s) & 3)];
 #pragma unroll
-    for (int jb = 0; jb < NB; ++jb) {
-      xrot[jb][0] = dpp_f64<DPP_ROW_ROR4>(xf[jb]);
-      xrot[jb][1] = dpp_f64<DPP_ROW_ROR8>(xf[jb]);
-      xrot[jb][2] = dpp_f64<DPP_ROW_ROR12>(xf[jb]);
-    }
+        for (int c = 0; c < CPW; ++c) {
+          const double q = qb[c * BR + st * 4];
+          double qx[NB];
 #pragma unroll
-    for (int c = 0; c < CPW; ++c) {
-      if (c < nk) {
-        double qx[NB];
+          for (int jb = 0; jb < NB; ++jb) {
+            qx[jb] = q * xr[jb][0];
+            sacc[c][jb] += qx[jb];
+          }
+          nacc[c] += q;
+          int idx = 0;
 #pragma unroll
-        for (int jb = 0; jb < NB; ++jb) {
-          qx[jb] = q[c] * xf[jb];
-          sacc[c][jb] += qx[jb];
-        }
-        nacc[c] += q[c];
-        int idx = 0;
+          for (int jbp = 0; jbp < NB; ++jbp) {
 #pragma unroll
-        for (int jbp = 0; jbp < NB; ++jbp) {
+            for (int jb = 0; jb <= jbp; ++jb) {
 #pragma unroll
-          for (int jb = 0; jb <= jbp; ++jb) {
-            acc[c][idx] = mfma4(xf[jbp], qx[jb], acc[c][idx]);
-            ++idx;
-            acc[c][idx] = mfma4(xrot[jbp][0], qx[jb], acc[c][idx]);
-            ++idx;
-            acc[c][idx] = mfma4(xrot[jbp][1], qx[jb], acc[c][idx]);
-            ++idx;
-            if (jb < jbp) {
-              acc[c][idx] = mfma4(xrot[jbp][2], qx[jb], acc[c][idx]);
-              ++idx;
+              for (int s = 0; s < 4; ++s) {
+                if (s < 3 || jb < jbp) {
+                  acc[c][idx] = mfma4(xr[jbp][s], qx[jb], acc[c][idx]);
+                  ++idx;
+                }
+              }
             }
           }
         }
       }
     }
+    if (more) lstore(buf ^ 1);
+    __syncthreads();
   }
-
-  // which sub-block each rotation brought into this lane's block
-  int src[4];
-  src[0] = blk;
-  src[1] = dpp_i32<DPP_ROW_ROR4>(blk);
-  src[2] = dpp_i32<DPP_ROW_ROR8>(blk);
-  src[3] = dpp_i32<DPP_ROW_ROR12>(blk);
+  if (nk == 0) return;
 
   const int64_t SS = 1 + (int64_t)DP + (int64_t)DP * DP;
 #pragma unroll
@@ -494,9 +548,11 @@ __global__ void __launch_bounds__(256) suffstat_kernel(SuffstatLaunch a) {
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             if (s < ns) {
-              const int ti = src[s], tj = blk;
+              const int ti = (blk + s) & 3, tj = blk;
               const int gi = 16 * jbp + 4 * ti + hi, gj = 16 * jb + 4 * tj + lo2;
               const bool diag = jb == jbp;
+              // diagonal 16x16 blocks: s=0 gives the diagonal tiles, s=1 every pair {t,t+1 mod 4}
+              // once, s=2 the pairs {0,2},{1,3} twice (keep the lower copy); s=3 is never issued
               const bool wr = !diag || ti == tj || s == 1 || ti > tj;
               const double v = acc[c][idx];
               if (wr) {
@@ -524,6 +580,10 @@ template <>
 struct SSCfg<128> { static constexpr int CPW = 1; };
 
 static int ss_cpw(int DP, int K) {
+  if (const char* e = getenv("LC_SS_CPW")) {  // tuning knob
+    const int v = atoi(e);
+    if (v == 1 || (v == 2 && DP <= 64) || (v == 4 && DP <= 32)) return v;
+  }
   int cpw = DP == 16 ? SSCfg<16>::CPW : DP == 32 ? SSCfg<32>::CPW : DP == 64 ? SSCfg<64>::CPW : SSCfg<128>::CPW;
   // few clusters: spread them over more waves instead of stacking them in one
   while (cpw > 1 && (K + cpw - 1) / cpw < 4 && (K + cpw / 2 - 1) / (cpw / 2) <= 4) cpw /= 2;
@@ -539,8 +599,7 @@ int suffstat_plan(int DP, int64_t NP, int K, int64_t* chunk_rows) {
   if (want > maxchunks) want = maxchunks;
   if (want < 1) want = 1;
   int64_t rows = (NP + want - 1) / want;
-  rows = (rows + 3) / 4 * 4;
-  if (rows < 4) rows = 4;
+  rows = (rows + SS_BR - 1) / SS_BR * SS_BR;  // whole staging batches
   *chunk_rows = rows;
   return (int)((NP + rows - 1) / rows);
 }
@@ -548,11 +607,20 @@ int suffstat_plan(int DP, int64_t NP, int K, int64_t* chunk_rows) {
 template <int DP, int CPW>
 static hipError_t launch_ss_t(const SuffstatLaunch& a, hipStream_t stream) {
   const int kwaves = (a.K + CPW - 1) / CPW;
-  const int wpb = kwaves < 4 ? kwaves : 4;
+  const int wpb = 4;
   const int nslice = (kwaves + wpb - 1) / wpb;
   SuffstatLaunch b = a;
   b.nslice = nslice;
-  hipLaunchKernelGGL((suffstat_kernel<DP, CPW>), dim3((unsigned)(a.nchunks * nslice)), dim3(wpb * 64), 0, stream, b);
+  const size_t shmem = (size_t)(2 * SS_BR * (DP + 16) + 2 * wpb * CPW * SS_BR) * sizeof(double);
+  auto kern = suffstat_kernel<DP, CPW>;
+  static bool attr_set = false;
+  if (shmem > 64 * 1024 && !attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(96 * 1024));
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.nchunks * nslice)), dim3(wpb * 64), shmem, stream, b);
   return hipGetLastError();
 }
 
