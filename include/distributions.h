@@ -1,0 +1,258 @@
+/* distributions.h -- the weight / cluster distribution classes of libcluster
+ * (reference: include/distributions.h:60-337), restricted to the families on
+ * the accelerated path: Dirichlet, StickBreak, GDirichlet and GaussWish.
+ * Same class names, method names, argument meaning and exceptions.  The
+ * arithmetic lives behind the C ABI (include/libcluster_hip.h): host M-step
+ * pieces in lc_weights_update / lc_gw_mstep, the per-observation passes
+ * (addobs, Eloglike) in the gfx950 kernels.  NormGamma / ExpGamma are not part
+ * of this build ("next").
+ */
+#ifndef DISTRIBUTIONS_H
+#define DISTRIBUTIONS_H
+
+#include <cmath>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "lc_matrix.h"
+#include "libcluster_hip.h"
+
+namespace distributions {
+
+const double BETAPRIOR = 1.0;   /* distributions.h:39-43 */
+const double NUPRIOR = 1.0;
+const double ALPHA1PRIOR = 1.0;
+const double ALPHA2PRIOR = 1.0;
+const double APRIOR = 1.0;
+
+typedef lcmat::ArrayXb ArrayXb;
+
+namespace detail {
+/* lc_status -> the exception classes the reference throws (libcluster.h:171-175) */
+inline void check(int rc) {
+  if (rc == LC_OK) return;
+  const std::string msg = lc_last_error();
+  if (rc == LC_EINVAL) throw std::invalid_argument(msg);
+  if (rc == LC_EDOMAIN) throw std::domain_error(msg);
+  throw std::runtime_error(msg);
+}
+struct CtxGuard {
+  lc_ctx* c;
+  CtxGuard() : c(0) { check(lc_ctx_create(0, 0, &c)); }
+  ~CtxGuard() { lc_ctx_destroy(c); }
+};
+}  // namespace detail
+
+/* ---- weights: reference distributions.h:60-189 --------------------------- */
+class WeightDist {
+ public:
+  virtual void update(const lcmat::ArrayXd& Nk) = 0;
+  virtual const lcmat::ArrayXd& Elogweight() const = 0;
+  const lcmat::ArrayXd& getNk() const { return this->Nk; }
+  virtual double fenergy() const = 0;
+  virtual ~WeightDist() {}
+ protected:
+  WeightDist() : Nk(1, 0.0) {}
+  lcmat::ArrayXd Nk;
+};
+
+namespace detail {
+/* shared implementation: every update goes through lc_weights_update */
+class WeightImpl : public WeightDist {
+ public:
+  void update(const lcmat::ArrayXd& Nk_) {
+    const int K = (int)Nk_.size();
+    lcmat::ArrayXd e(K);
+    double f = 0.0;
+    check(lc_weights_update(kind_, prior_, Nk_.data(), K, e.data(), &f));
+    this->Nk = Nk_;
+    E_logpi = e;
+    F_ = f;
+  }
+  const lcmat::ArrayXd& Elogweight() const { return E_logpi; }
+  double fenergy() const { return F_; }
+  double prior() const { return prior_; } /* additive: the concentration/alpha given at construction */
+ protected:
+  WeightImpl(int kind, double prior, const char* msg) : kind_(kind), prior_(prior), E_logpi(1, 0.0), F_(0.0) {
+    if (!(prior > 0)) throw std::invalid_argument(msg);
+  }
+  int kind_;
+  double prior_;
+  lcmat::ArrayXd E_logpi;
+  double F_;
+};
+}  // namespace detail
+
+class StickBreak : public detail::WeightImpl { /* distributions.h:103-140 */
+ public:
+  StickBreak() : WeightImpl(LC_W_STICKBREAK, ALPHA1PRIOR, "") {}
+  StickBreak(const double concentration)
+      : WeightImpl(LC_W_STICKBREAK, concentration, "Concentration parameter has to be > 0!") {}
+  virtual ~StickBreak() {}
+ protected:
+  StickBreak(int kind) : WeightImpl(kind, ALPHA1PRIOR, "") {}
+};
+
+class GDirichlet : public StickBreak { /* distributions.h:147-157 */
+ public:
+  GDirichlet() : StickBreak(LC_W_GDIRICHLET) {}
+  virtual ~GDirichlet() {}
+};
+
+class Dirichlet : public detail::WeightImpl { /* distributions.h:163-189 */
+ public:
+  Dirichlet() : WeightImpl(LC_W_DIRICHLET, ALPHA1PRIOR, "") {}
+  Dirichlet(const double alpha) : WeightImpl(LC_W_DIRICHLET, alpha, "Alpha prior must be > 0!") {}
+  virtual ~Dirichlet() {}
+};
+
+/* ---- clusters: reference distributions.h:200-337 ------------------------- */
+class ClusterDist {
+ public:
+  virtual void addobs(const lcmat::VectorXd& qZk, const lcmat::MatrixXd& X) = 0;
+  virtual void update() = 0;
+  virtual void clearobs() = 0;
+  virtual lcmat::VectorXd Eloglike(const lcmat::MatrixXd& X) const = 0;
+  virtual double fenergy() const = 0;
+  virtual ArrayXb splitobs(const lcmat::MatrixXd& X) const = 0;
+  double getN() const { return this->N; }
+  double getprior() const { return this->prior; }
+  virtual ~ClusterDist() {}
+ protected:
+  ClusterDist(const double prior, const unsigned int D) : D(D), prior(prior), N(0) {}
+  unsigned int D;
+  double prior;
+  double N;
+};
+
+class GaussWish : public ClusterDist {
+ public:
+  GaussWish(const double clustwidth, const unsigned int D) : ClusterDist(clustwidth, D), F_(0.0) {
+    /* the prior is the posterior of "no observations": distributions.cpp:273-298 */
+    if (!(clustwidth > 0)) throw std::invalid_argument("clustwidth must be > 0!");
+    clearobs();
+  }
+
+  /* distributions.cpp:301-313, accumulated on the GPU (suff-stat kernel) */
+  void addobs(const lcmat::VectorXd& qZk, const lcmat::MatrixXd& X) {
+    if ((unsigned)X.cols() != D) throw std::invalid_argument("Mismatched dims. of cluster params and obs.!");
+    if (qZk.rows() != X.rows()) throw std::invalid_argument("qZk and X ar not the same length!");
+    detail::CtxGuard g;
+    upload(g.c, X);
+    detail::check(lc_ctx_set_qz(g.c, 0, qZk.data(), 1, 1, (int64_t)qZk.size()));
+    double n = 0.0;
+    std::vector<double> xs(D), xxs((size_t)D * D);
+    detail::check(lc_suffstat(g.c, 0, &n, xs.data(), xxs.data(), 0));
+    N_s += n;
+    for (unsigned d = 0; d < D; ++d) x_s[d] += xs[d];
+    for (size_t i = 0; i < xxs.size(); ++i) xx_s[i] += xxs[i];
+  }
+
+  /* distributions.cpp:316-337 */
+  void update() {
+    detail::check(lc_gw_mstep(prior, (int)D, N_s, x_s.data(), xx_s.data(), &nu, &beta, m_.data(), iW_.data(), &logdW,
+                              &F_, 0, 0));
+    N = N_s;
+  }
+
+  /* distributions.cpp:340-353 */
+  void clearobs() {
+    N_s = 0.0;
+    x_s.assign(D, 0.0);
+    xx_s.assign((size_t)D * D, 0.0);
+    m_.assign(D, 0.0);
+    iW_.assign((size_t)D * D, 0.0);
+    /* posterior := prior (lc_gw_mstep with empty statistics) */
+    detail::check(lc_gw_mstep(prior, (int)D, 0.0, x_s.data(), xx_s.data(), &nu, &beta, m_.data(), iW_.data(), &logdW,
+                              &F_, 0, 0));
+  }
+
+  /* distributions.cpp:356-370, evaluated by the E-step kernel (no weights, no normalisation) */
+  lcmat::VectorXd Eloglike(const lcmat::MatrixXd& X) const {
+    if ((unsigned)X.cols() != D) throw std::invalid_argument("Arguments do not have the same dimensionality");
+    detail::CtxGuard g;
+    upload(g.c, X);
+    detail::check(lc_eloglike(g.c, 1, &nu, &beta, m_.data(), iW_.data(), &logdW));
+    lcmat::VectorXd out(X.rows());
+    detail::check(lc_ctx_get_qz(g.c, 0, out.data(), 1, (int64_t)X.rows()));
+    return out;
+  }
+
+  /* distributions.cpp:373-385 (host: power method + projection, via the learner's own code path) */
+  ArrayXb splitobs(const lcmat::MatrixXd& X) const {
+    std::vector<double> v(D, 0.0);
+    {
+      /* probutils.cpp:153-186 */
+      if (D == 1) v[0] = 1.0;
+      else {
+        std::vector<double> o(D), t(D);
+        double nrm = 0.0;
+        for (unsigned i = 0; i < D; ++i) { t[i] = -1.0 + 2.0 * i / (D - 1); nrm += t[i] * t[i]; }
+        nrm = std::sqrt(nrm);
+        for (unsigned i = 0; i < D; ++i) v[i] = t[i] / nrm;
+        const double thresh = 1.0e-8f;
+        double dist = 1e300;
+        for (int it = 0; dist > thresh && it < 100; ++it) {
+          o = v;
+          nrm = 0.0;
+          for (unsigned i = 0; i < D; ++i) {
+            double s = 0.0;
+            for (unsigned j = 0; j < D; ++j) s += iW_[(size_t)i * D + j] * o[j];
+            t[i] = s; nrm += s * s;
+          }
+          nrm = std::sqrt(nrm);
+          dist = 0.0;
+          for (unsigned i = 0; i < D; ++i) { v[i] = t[i] / nrm; dist += (v[i] - o[i]) * (v[i] - o[i]); }
+          dist = std::sqrt(dist);
+        }
+      }
+    }
+    ArrayXb out(X.rows());
+    for (std::ptrdiff_t r = 0; r < X.rows(); ++r) {
+      double s = 0.0;
+      for (unsigned d = 0; d < D; ++d) s += (X(r, d) - m_[d]) * v[d];
+      out(r) = s >= 0.0;
+    }
+    return out;
+  }
+
+  double fenergy() const { return F_; } /* distributions.cpp:388-399, evaluated at update() */
+
+  lcmat::RowVectorXd getmean() const { /* distributions.h:306 */
+    lcmat::RowVectorXd r(D);
+    for (unsigned d = 0; d < D; ++d) r(d) = m_[d];
+    return r;
+  }
+  lcmat::MatrixXd getcov() const { /* distributions.h:311: iW / nu */
+    lcmat::MatrixXd c(D, D);
+    for (unsigned i = 0; i < D; ++i)
+      for (unsigned j = 0; j < D; ++j) c(i, j) = iW_[(size_t)i * D + j] / nu;
+    return c;
+  }
+  virtual ~GaussWish() {}
+
+  /* additive (not in the reference): load a posterior computed by the learners */
+  void set_posterior_(double N_, double nu_, double beta_, const double* m, const double* iW, double logdW_,
+                      double F) {
+    N = N_; nu = nu_; beta = beta_; logdW = logdW_; F_ = F;
+    m_.assign(m, m + D);
+    iW_.assign(iW, iW + (size_t)D * D);
+  }
+
+ private:
+  static void upload(lc_ctx* c, const lcmat::MatrixXd& X) {
+    int64_t rs, cs;
+    lcmat::strides(X, rs, cs);
+    const double* p = X.data();
+    const int64_t n = (int64_t)X.rows();
+    detail::check(lc_ctx_set_data(c, 1, &p, &n, (int)X.cols(), rs, cs));
+  }
+  double nu, beta, logdW, F_;
+  std::vector<double> m_, iW_; /* row-major D x D */
+  double N_s;
+  std::vector<double> x_s, xx_s;
+};
+
+}  // namespace distributions
+#endif /* DISTRIBUTIONS_H */

@@ -94,6 +94,11 @@ int lc_estep_posterior(lc_ctx* ctx, int K, const double* nu, const double* beta,
  * 0.5*(sum psi + logdW - D/beta - D ln pi).  LLk here excludes the constant:
  * LLk = sum_n q_nk (log q~_nk - c_jk). */
 int lc_estep(lc_ctx* ctx, int K, const double* A, const double* m, const double* c, double* Fz, double* LLk);
+/* K x GaussWish::Eloglike(X) (distributions.cpp:356-370) for ALL groups: column k of the
+ * context's qZ receives the expected log-likelihood of every observation under cluster k
+ * (no weights, no normalisation); fetch it with lc_ctx_get_qz. */
+int lc_eloglike(lc_ctx* ctx, int K, const double* nu, const double* beta, const double* m, const double* iW,
+                const double* logdW);
 /* updateSS (cluster.cpp:53-82) + K x GaussWish::addobs (distributions.cpp:301-313)
  * for ALL groups on the current qZ: Nk[K], xs[K*D], xxs[K*D*D] (row-major),
  * Njk[J*K] (the returned `Njk` of every group).  smask[J*K]: sparse updates,

@@ -73,6 +73,7 @@ def lib() -> C.CDLL:
     L.lc_estep.argtypes = [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]
     L.lc_estep_posterior.argtypes = [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
                                      c_double_p, c_ubyte_p, c_double_p, c_double_p]
+    L.lc_eloglike.argtypes = [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]
     L.lc_suffstat.argtypes = [C.c_void_p, c_ubyte_p, c_double_p, c_double_p, c_double_p, c_double_p]
     L.lc_colsums.argtypes = [C.c_void_p, c_double_p]
     L.lc_ctx_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p]
@@ -230,6 +231,13 @@ class Context:
         check(lib().lc_estep_posterior(self._h, K, dptr(nu), dptr(beta), dptr(m), dptr(iW), dptr(logdW),
                                        dptr(Elogpi), act, C.byref(Fz), dptr(ll)))
         return Fz.value, ll
+
+    def eloglike(self, nu, beta, m, iW, logdW, rows_per_group):
+        """K x GaussWish::Eloglike for every group -> list of (N_j, K) arrays."""
+        K = len(nu)
+        nu, beta, m, iW, logdW = (np.ascontiguousarray(a, dtype=np.float64) for a in (nu, beta, m, iW, logdW))
+        check(lib().lc_eloglike(self._h, K, dptr(nu), dptr(beta), dptr(m), dptr(iW), dptr(logdW)))
+        return self.get_qz(rows_per_group)
 
     def estep(self, A, m, c):
         A, m, c = (np.ascontiguousarray(a, dtype=np.float64) for a in (A, m, c))

@@ -217,6 +217,33 @@ int lc_estep_posterior(lc_ctx* ctx, int K, const double* nu, const double* beta,
   });
 }
 
+int lc_eloglike(lc_ctx* ctx, int K, const double* nu, const double* beta, const double* m, const double* iW,
+                const double* logdW) {
+  return guarded([&] {
+    need(ctx, "ctx");
+    need(nu, "nu");
+    need(beta, "beta");
+    need(m, "m");
+    need(iW, "iW");
+    need(logdW, "logdW");
+    if (K < 1) throw std::invalid_argument("K must be >= 1");
+    const int D = ctx->impl.D(), J = ctx->impl.J();
+    std::vector<double> A((size_t)K * D * D), c((size_t)J * K);
+    for (int k = 0; k < K; ++k) {
+      std::vector<double> L(iW + (size_t)k * D * D, iW + (size_t)(k + 1) * D * D);
+      if (!lch::cholesky(L, D)) throw std::invalid_argument("Matrix A is not positive definite");
+      std::vector<double> Li = lch::tril_inverse(L, D);
+      const double s = std::sqrt(nu[k]);
+      for (size_t t = 0; t < Li.size(); ++t) A[(size_t)k * D * D + t] = s * Li[t];
+      double sumpsi = 0.0;
+      for (int d = 1; d <= D; ++d) sumpsi += lch::digamma((nu[k] + 1 - d) / 2);
+      const double cst = 0.5 * (sumpsi + logdW[k] - D * (1.0 / beta[k] + std::log(lch::PI)));
+      for (int j = 0; j < J; ++j) c[(size_t)j * K + k] = cst;
+    }
+    ctx->impl.estep(K, A.data(), m, c.data(), nullptr, nullptr, /*raw=*/true);
+  });
+}
+
 int lc_suffstat(lc_ctx* ctx, const unsigned char* smask, double* Nk, double* xs, double* xxs, double* Njk) {
   return guarded([&] {
     need(ctx, "ctx");

@@ -264,7 +264,7 @@ void Context::allreduce(double* dbuf, int64_t count) {
   if (rc != 0) throw std::runtime_error("all-reduce hook failed with status " + std::to_string(rc));
 }
 
-void Context::estep(int K, const double* A, const double* m, const double* c, double* Fz, double* LLk) {
+void Context::estep(int K, const double* A, const double* m, const double* c, double* Fz, double* LLk, bool raw) {
   if (K < 1) throw std::invalid_argument("K must be >= 1");
   if (NP_ == 0 && !ar_fn_) {
     if (Fz) *Fz = -0.0;
@@ -322,6 +322,7 @@ void Context::estep(int K, const double* A, const double* m, const double* c, do
   a.ldq = NP_;
   a.fz_part = fzpart_.p;
   a.ll_part = LLk ? llpart_.p : nullptr;
+  a.raw = raw ? 1 : 0;
   EvPair ev{};
   if (timing_) {
     LC_HIP(hipEventCreate(&ev.a));
@@ -333,6 +334,10 @@ void Context::estep(int K, const double* A, const double* m, const double* c, do
   if (timing_) {
     LC_HIP(hipEventRecord(ev.b, stream_));
     pending_.push_back(ev);
+  }
+  if (raw) {
+    LC_HIP(hipStreamSynchronize(stream_));
+    return;
   }
   if (grid > 0) {
     LC_HIP(lck::launch_reduce_partials(fzpart_.p, (int)grid, 1, red_.p, stream_));

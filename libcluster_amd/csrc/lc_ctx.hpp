@@ -91,7 +91,8 @@ class Context {
   // A: K x D x D row-major lower-triangular whiteners, m: K x D, c: J x K.
   // Writes new responsibilities into qZ (K columns).  Fz = -sum logZ; LLk[k] =
   // sum_n q_nk (log q~_nk - c_jk)  (the data term of cluster.cpp:409-410).
-  void estep(int K, const double* A, const double* m, const double* c, double* Fz, double* LLk);
+  // raw = true stops after log q~ (c_jk - 0.5 d^2) has been written to qZ: GaussWish::Eloglike.
+  void estep(int K, const double* A, const double* m, const double* c, double* Fz, double* LLk, bool raw = false);
   // Sufficient statistics of the current qZ.  smask: J x K (1 = accumulate) or null.
   // Nk[K], xs[K*D], xxs[K*D*D] (row-major, symmetric), Njk[J*K].
   void suffstat(const unsigned char* smask, double* Nk, double* xs, double* xxs, double* Njk);

@@ -36,6 +36,7 @@ struct EstepLaunch {
   int64_t ldq;
   double* fz_part;       // [estep_grid(...)]
   double* ll_part;       // [estep_grid(...) x K], or nullptr: skip the split-ordering data term
+  int raw = 0;           // 1: stop after writing log q~ (no log-sum-exp, fz/ll untouched)
 };
 int estep_rows_per_block(int DP);
 int64_t estep_grid(int DP, int64_t nrg);

@@ -234,6 +234,8 @@ __global__ void __launch_bounds__(WAVES * 64, 2) estep_kernel(EstepLaunch a) {
 #undef LC_GLOAD
 #undef LC_LSTORE
 
+  if (a.raw) return;  // GaussWish::Eloglike: leave c_k - 0.5 d^2 in qZ, no normalisation
+
   // ---- normalise (probutils.cpp:141-150, cluster.cpp:124-131) -------------
   double logZ[R];
 #pragma unroll

@@ -213,3 +213,21 @@ def test_learn_argument_errors(xcat):
         lc.learnBGMM(xcat["Xcat"], prior=-1.0)  # distributions.cpp:282-283
     with pytest.raises(ValueError):
         lc.learnVDP(xcat["Xcat"], concentration=0.0)  # distributions.cpp:107-108
+
+
+def test_eloglike_matches_oracle():
+    """GaussWish::Eloglike (distributions.cpp:356-370) through lc_eloglike."""
+    rng = np.random.default_rng(11)
+    N, D, K = 333, 7, 3
+    X = rng.normal(size=(N, D)) * 2 + 1
+    q = rng.dirichlet(np.ones(K), N)
+    cl = [o.GaussWish(0.7, D) for _ in range(K)]
+    o.updateSS(X, q, cl)
+    for c in cl:
+        c.update()
+    ref = np.stack([c.Eloglike(X) for c in cl], axis=1)
+    with capi.Context(0) as ctx:
+        ctx.set_data(X)
+        got = ctx.eloglike([c.nu for c in cl], [c.beta for c in cl], np.stack([c.m for c in cl]),
+                           np.stack([c.iW for c in cl]), [c.logdW for c in cl], [N])[0]
+    np.testing.assert_allclose(got, ref, rtol=1e-10, atol=1e-10)
