@@ -199,6 +199,10 @@ def main():
         dom_fl = fl["estep"] if est >= sst else fl["suffstat"]
         achieved = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         both = (fl["estep"] + fl["suffstat"]) / ((est + sst) * 1e-3) / 1e12 if est + sst > 0 else 0.0
+        traffic = None  # HBM bytes per launch of the dominant kernel, from the committed PMC passes (not live)
+        tf = ROOT / "profiles" / "r01_pmc_traffic.json"
+        if tf.exists() and not args.rows:
+            traffic = json.loads(tf.read_text()).get(args.config, {}).get(dom)
         line = {
             "metric": "E-step data-points/sec (full VBEM iteration: suff-stats + M-step + E-step)",
             "value": world * N * steps / dt,
@@ -220,7 +224,7 @@ def main():
                         "estep_kernel_points_per_s": N / (est * 1e-3) if est > 0 else None,
                         "both_kernels_alg_tflops": both},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
                          "alg_flops_per_launch": dom_fl, "avg_launch_ms": dom_ms},
         }
         if world == 1 and not args.no_cpu_baseline:

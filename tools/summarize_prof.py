@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 run directory (kernel stats + separate PMC passes) into
+the text committed under profiles/.  Usage: tools/summarize_prof.py gpurun_out/prof_r01b > profiles/...txt"""
+import collections
+import csv
+import sys
+from pathlib import Path
+
+root = Path(sys.argv[1])
+out = []
+ks = root / "kt" / "kt_kernel_stats.csv"
+if ks.exists():
+    out.append("== rocprofv3 --kernel-trace --stats (kernel_stats.csv) ==")
+    rows = list(csv.DictReader(open(ks)))
+    out.append("%-78s %6s %12s %12s %8s" % ("kernel", "calls", "total_ms", "avg_ms", "pct"))
+    for r in rows:
+        out.append("%-78s %6s %12.3f %12.4f %8s" % (r["Name"][:78], r["Calls"], float(r["TotalDurationNs"]) / 1e6,
+                                                    float(r["AverageNs"]) / 1e6, r["Percentage"]))
+log = root / "kt.log"
+if log.exists():
+    for line in open(log):
+        if line.startswith("{"):
+            out.append("\n== bench.py line of the profiled run ==\n" + line.strip())
+
+
+def short(n):
+    return "estep_kernel" if "estep_kernel" in n else "suffstat_kernel" if "suffstat_kernel" in n else None
+
+
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for tag in ("p1", "p2", "p3"):
+    cc = root / tag / f"{tag}_counter_collection.csv"
+    if not cc.exists():
+        continue
+    kt = {r["Dispatch_Id"]: r for r in csv.DictReader(open(root / tag / f"{tag}_kernel_trace.csv"))}
+    seen = set()
+    for r in csv.DictReader(open(cc)):
+        s = short(r["Kernel_Name"])
+        if not s:
+            continue
+        agg[s][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        k = kt.get(r["Dispatch_Id"])
+        if k and (tag, r["Dispatch_Id"]) not in seen:
+            seen.add((tag, r["Dispatch_Id"]))
+            agg[s]["dur_ns_" + tag].append(float(k["End_Timestamp"]) - float(k["Start_Timestamp"]))
+out.append("\n== PMC (separate --pmc passes; per-dispatch means) ==")
+for s, d in agg.items():
+    m = {k: sum(v) / len(v) for k, v in d.items()}
+    out.append(f"[{s}]")
+    for k in sorted(m):
+        out.append(f"  {k:34s} {m[k]:.6g}")
+    if "GRBM_GUI_ACTIVE" in m and "dur_ns_p1" in m:
+        cyc = m["GRBM_GUI_ACTIVE"] / 8  # summed over the 8 XCDs
+        out.append(f"  -> effective clock               {cyc / m['dur_ns_p1']:.3f} GHz")
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in m:
+            out.append(f"  -> MFMA pipe busy                {m['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / cyc * 100:.1f} % "
+                       f"(SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / GRBM cycles per XCD)")
+        if "SQ_INSTS_VALU_MFMA_MOPS_F64" in m:
+            out.append(f"  -> executed MFMA flops           {m['SQ_INSTS_VALU_MFMA_MOPS_F64'] * 512 / m['dur_ns_p1'] / 1e3:.2f} TFLOP/s "
+                       f"(v_mfma_f64_4x4x4_4b = 512 flop)")
+    if "FETCH_SIZE" in m:
+        # FETCH_SIZE is in KiB and reads 1/2 of a wide coalesced stream on gfx950 (MI355X_MICROARCH.md, HBM): x2
+        out.append(f"  -> HBM read  (FETCH_SIZE*1024*2)  {m['FETCH_SIZE'] * 1024 * 2 / 1e9:.3f} GB per launch")
+    if "WRITE_SIZE" in m:
+        out.append(f"  -> HBM write (WRITE_SIZE*1024)    {m['WRITE_SIZE'] * 1024 / 1e9:.3f} GB per launch (uncalibrated)")
+print("\n".join(out))
