@@ -52,6 +52,14 @@ def lib() -> C.CDLL:
             f"{LIB_PATH} is missing: build it with `python -m libcluster_amd.build` "
             "(hipcc, --offload-arch=gfx950).  There is no Python/CPU fallback for the E-step."
         )
+    # One HIP runtime per process: PyTorch wheels bundle their own libamdhip64 / libhsa-runtime64, and
+    # a process that initialises both that copy and the system ROCm copy loses the GPU in the second
+    # one ("no ROCm-capable device").  Loading torch first makes the C-ABI library bind to the runtime
+    # torch uses (same SONAME), which is also what lets torch streams and RCCL see our buffers.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(str(LIB_PATH))
     L.lc_last_error.restype = C.c_char_p
     for f in ("lc_const_converge", "lc_const_fengydel", "lc_const_zerocutoff"):

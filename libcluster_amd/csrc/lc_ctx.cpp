@@ -71,14 +71,6 @@ void Context::build_layout(int J, const int64_t* Nj, int D) {
   qz_[0].K = qz_[1].K = 0;
   LC_HIP(hipSetDevice(device_));
   X_.reserve((size_t)std::max<int64_t>(NP_, 1) * DP_);
-  {
-    ngroups_ = lck::build_feature_table(D_, DP_, nullptr);
-    std::vector<int> ft((size_t)ngroups_ * 16);
-    lck::build_feature_table(D_, DP_, ft.data());
-    feat_.reserve(ft.size());
-    LC_HIP(hipMemcpyAsync(feat_.p, ft.data(), ft.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
-    LC_HIP(hipStreamSynchronize(stream_));
-  }
   goff_d_.reserve(J + 1);
   LC_HIP(hipMemcpyAsync(goff_d_.p, goff_.data(), (J + 1) * sizeof(int64_t), hipMemcpyHostToDevice, stream_));
   if (J > 1) {
@@ -372,13 +364,9 @@ void Context::suffstat(const unsigned char* smask, double* Nk, double* xs, doubl
   double* njk_d = ssout_.p + (size_t)K * SS;
   if (NP_ > 0) {
     int64_t chunk_rows = 0;
-    const int nchunks = lck::suffstat_plan(DP, NP_, K, &chunk_rows, ngroups_);
+    const int nchunks = lck::suffstat_plan(DP, NP_, K, &chunk_rows);
     sspart_.reserve((size_t)nchunks * K * SS);
-    // pad entries of a record (D < DP) are never written by the feature form: keep them zero
-    if (D != DP) LC_HIP(hipMemsetAsync(sspart_.p, 0, (size_t)nchunks * K * SS * sizeof(double), stream_));
     lck::SuffstatLaunch a;
-    a.feat = feat_.p;
-    a.ngroups = ngroups_;
     a.DP = DP;
     a.X = X_.p;
     a.NP = NP_;

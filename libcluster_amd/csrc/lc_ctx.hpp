@@ -123,8 +123,6 @@ class Context {
   int64_t Ntot_ = 0, NP_ = 0;
   DevBuf<double> X_;
   DevBuf<int> rginfo_;      // only when J > 1
-  DevBuf<int> feat_;        // feature table of the feature-GEMM suff-stat kernel
-  int ngroups_ = 0;
   DevBuf<int64_t> goff_d_;  // J+1
   QZ qz_[2];
   int cur_ = 0;

@@ -55,13 +55,9 @@ struct SuffstatLaunch {
   int nchunks;
   int64_t chunk_rows;       // multiple of 4
   int nslice = 1;           // filled in by launch_suffstat
-  const int* feat = nullptr;  // feature table (ca | cb << 16 per feature) for the feature-GEMM form, or null
-  int ngroups = 0;            // 16-wide feature groups in feat
 };
-// host: build the feature table for D (columns: a < D data, DP = constant one, DP + 1 = zero)
-int build_feature_table(int D, int DP, int* out /* may be null: returns the group count */);
 // choose a chunking for (NP, K); returns nchunks and sets chunk_rows
-int suffstat_plan(int DP, int64_t NP, int K, int64_t* chunk_rows, int ngroups = 0);
+int suffstat_plan(int DP, int64_t NP, int K, int64_t* chunk_rows);
 hipError_t launch_suffstat(const SuffstatLaunch& a, hipStream_t stream);
 
 // out[e] = sum_c partial[c*n + e]  (fixed order => deterministic)

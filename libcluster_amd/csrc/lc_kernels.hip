@@ -29,21 +29,6 @@ __device__ __forceinline__ double mfma4(double a, double b, double c) {
   return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
 }
 
-template <int CTRL>
-__device__ __forceinline__ int dpp_i32(int v) {
-  // row_ror reads a valid lane for every lane, so `old` is never used: bound_ctrl lets the
-  // compiler skip materialising it
-  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
-}
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = dpp_i32<CTRL>(lo);
-  hi = dpp_i32<CTRL>(hi);
-  return __hiloint2double(hi, lo);
-}
-constexpr int DPP_ROW_ROR4 = 0x124, DPP_ROW_ROR8 = 0x128, DPP_ROW_ROR12 = 0x12C;
-
 // sum over the 4 lanes {l, l^16, l^32, l^48}
 __device__ __forceinline__ double sum_over_hi(double v) {
   v += __shfl_xor(v, 16);
@@ -570,286 +555,6 @@ __global__ void __launch_bounds__(256, (DP <= 64 ? 2 : 1)) suffstat_kernel(Suffs
   }
 }
 
-// ---------------------------------------------------------------------------
-// Sufficient statistics, "feature GEMM" form (used for 8 <= K <= 64)
-// ---------------------------------------------------------------------------
-// All statistics of all clusters are ONE product  T[k][p] = sum_n q[n][k] * Phi[n][p]  with the
-// exponential-family features of a row, Phi(x) = [x_a x_b (a >= b), x_a, 1]  (P = D(D+1)/2 + D + 1):
-// T holds the lower triangle of S_k, then s_k, then N_k.  Per 4-row step a wave forms each of its
-// 16-wide feature groups ONCE (two LDS gathers + one multiply per lane, shared by every cluster) and
-// issues one MFMA per (feature group, tile of 4 clusters):
-//     A = q[row hi][cluster 4ct+lo2]   B = Phi[row hi][feature 16g + (lane&15)]   D = T[4ct+hi][16g + (lane&15)]
-// Against the per-cluster form above this needs D(D+1)/2+D+1 instead of 36*16*... MFMA columns (6 % fewer
-// MFMAs at D = 64, none wasted on padding when D < DP), and -- what matters on gfx950, where fp64 VALU
-// work is not hidden behind MFMAs -- half the VALU instructions per MFMA at K = 32, a quarter at K = 64,
-// with no separate s_k / N_k accumulation at all.  The "1" feature is column DP of the staged tile,
-// column DP+1 is 0 for padding features, so every feature is the same two-gather product.
-// feat[p] = ca | cb << 16 lists the two tile columns of feature p (built by the host for D).
-template <int DP, int NCT, int GPW, int WPB>
-__global__ void __launch_bounds__(WPB * 64, 2) ssfeat_kernel(SuffstatLaunch a) {
-  constexpr int BR = SS_BR;
-  constexpr int nthr = WPB * 64;
-  constexpr int KP = NCT * 4;       // clusters padded to whole tiles
-  constexpr int QLD = KP + 4;       // q tile row stride (doubles): rows of a half-wave on disjoint banks
-  constexpr int LD = DP + 16;
-  constexpr int XBUF = BR * LD, QBUF = BR * QLD;
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  double* xbuf = lds;               // [2][BR][LD]   (col DP = 1, cols DP+1.. = 0)
-  double* qbuf = lds + 2 * XBUF;    // [2][BR][QLD]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int lo4 = lane & 15, hi = lane >> 4, lo2 = lane & 3;
-  const int K = a.K;
-  // workgroup -> (row chunk, feature slice), slices of a chunk back-to-back on one XCD (see above)
-  int chunk, slice;
-  {
-    const int nslice = a.nslice, nchunks = a.nchunks;
-    const int b = blockIdx.x;
-    const int full = (nchunks / 8) * 8;
-    if (b < full * nslice) {
-      const int xcd = b & 7, seq = b >> 3;
-      chunk = (seq / nslice) * 8 + xcd;
-      slice = seq % nslice;
-    } else {
-      const int t = b - full * nslice;
-      chunk = full + t / nslice;
-      slice = t % nslice;
-    }
-  }
-  // balanced split of the feature groups over all waves of the chunk
-  const int W = a.nslice * WPB, w = slice * WPB + wave;
-  const int base = a.ngroups / W, rem = a.ngroups % W;
-  const int g0 = w * base + (w < rem ? w : rem);
-  const int ng = base + (w < rem ? 1 : 0);  // <= GPW by construction of the launch
-  const int64_t r0 = (int64_t)chunk * a.chunk_rows;
-  const int64_t r1 = (r0 + a.chunk_rows) < a.NP ? (r0 + a.chunk_rows) : a.NP;
-
-  // this lane's two gather offsets (doubles, inside a staged row) for each of its groups
-  int offa[GPW], offb[GPW];
-#pragma unroll
-  for (int g = 0; g < GPW; ++g) {
-    const int f = g < ng ? a.feat[(g0 + g) * 16 + lo4] : ((DP + 1) | ((DP + 1) << 16));
-    offa[g] = hi * LD + (f & 0xffff);
-    offb[g] = hi * LD + (f >> 16);
-  }
-  double acc[GPW][NCT];
-#pragma unroll
-  for (int g = 0; g < GPW; ++g)
-#pragma unroll
-    for (int c = 0; c < NCT; ++c) acc[g][c] = 0.0;
-
-  // ---- staging (registers hold the next batch) -------------------------------------------
-  constexpr int nx2 = BR * DP / 2;                // double2 per X batch
-  constexpr int NPX = (nx2 + nthr - 1) / nthr;
-  constexpr int NPQ = (SS_BR * KP + nthr - 1) / nthr;
-  double prex[NPX][2], preq[NPQ];
-  auto gload = [&](int64_t b0) {
-#pragma unroll
-    for (int i = 0; i < NPX; ++i) {
-      const int idx = tid + i * nthr;
-      double2 v = make_double2(0.0, 0.0);
-      if (idx < nx2) {
-        const int row = idx / (DP / 2), c2 = idx % (DP / 2);
-        if (b0 + row < r1) v = *reinterpret_cast<const double2*>(a.X + (b0 + row) * DP + 2 * c2);
-      }
-      prex[i][0] = v.x;
-      prex[i][1] = v.y;
-    }
-#pragma unroll
-    for (int i = 0; i < NPQ; ++i) {
-      const int idx = tid + i * nthr;  // (cluster, row): row fastest => coalesced column reads
-      const int k = idx / BR, row = idx % BR;
-      double q = 0.0;
-      if (idx < BR * KP && k < K && b0 + row < r1) {
-        q = a.qZ[(int64_t)k * a.ldq + b0 + row];
-        if (a.smask) {
-          const int g = a.rginfo[(b0 + row) >> 4] >> 5;
-          if (!a.smask[(int64_t)g * K + k]) q = 0.0;
-        }
-      }
-      preq[i] = q;
-    }
-  };
-  auto lstore = [&](int buf) {
-    double* xb = xbuf + buf * XBUF;
-#pragma unroll
-    for (int i = 0; i < NPX; ++i) {
-      const int idx = tid + i * nthr;
-      if (idx < nx2) {
-        const int row = idx / (DP / 2), c2 = idx % (DP / 2);
-        *reinterpret_cast<double2*>(xb + row * LD + 2 * c2) = make_double2(prex[i][0], prex[i][1]);
-      }
-    }
-    double* qb = qbuf + buf * QBUF;
-#pragma unroll
-    for (int i = 0; i < NPQ; ++i) {
-      const int idx = tid + i * nthr;
-      const int k = idx / BR, row = idx % BR;
-      if (idx < BR * KP) qb[row * QLD + k] = preq[i];
-    }
-  };
-  // constant columns of both X buffers: [DP] = 1, [DP+1 .. DP+15] = 0
-  for (int i = tid; i < 2 * BR * 16; i += nthr) {
-    const int bufrow = i / 16, c = i % 16;
-    xbuf[(bufrow / BR) * XBUF + (bufrow % BR) * LD + DP + c] = c == 0 ? 1.0 : 0.0;
-  }
-  if (r0 < r1) {
-    gload(r0);
-    lstore(0);
-  }
-  __syncthreads();
-  int buf = 0;
-  for (int64_t b0 = r0; b0 < r1; b0 += BR, buf ^= 1) {
-    const bool more = b0 + BR < r1;
-    if (more) gload(b0 + BR);
-    if (ng > 0) {
-      const double* xb = xbuf + buf * XBUF;
-      const double* qb = qbuf + buf * QBUF + hi * QLD + lo2;
-      // Branch-free (rows past the chunk end were staged as zeros, unused group slots gather the
-      // zero column) and software-pipelined by hand: the two gathers of group g+PF are issued
-      // before the MFMAs of group g (wrapping into the next step), and the q fragments of the next
-      // step are fetched during the current one.  Left to itself the compiler reuses one register
-      // pair for every gather and waits out the full LDS latency per group.
-      constexpr int PF = 3;
-      double ga[PF], gb[PF], qa0[NCT], qa1[NCT];
-#pragma unroll
-      for (int i = 0; i < PF; ++i) {
-        ga[i] = xb[offa[i % GPW]];
-        gb[i] = xb[offb[i % GPW]];
-      }
-#pragma unroll
-      for (int c = 0; c < NCT; ++c) qa0[c] = qb[4 * c];
-      auto step = [&](const double* xs, const double* qn, const double (&qa)[NCT], double (&qnext)[NCT]) {
-#pragma unroll
-        for (int c = 0; c < NCT; ++c) qnext[c] = qn[4 * c];  // next step's q fragments
-        static_for<GPW>([&](auto gc) {
-          constexpr int g = gc;
-          const double phi = ga[g % PF] * gb[g % PF];
-          constexpr int gn = (g + PF) % GPW;
-          constexpr int adv = (g + PF) >= GPW ? 4 * LD : 0;  // wraps into the next step's rows
-          ga[g % PF] = xs[offa[gn] + adv];
-          gb[g % PF] = xs[offb[gn] + adv];
-#pragma unroll
-          for (int c = 0; c < NCT; ++c) acc[g][c] = mfma4(qa[c], phi, acc[g][c]);
-        });
-      };
-      static_assert((BR / 4) % 2 == 0 && GPW >= PF, "step loop is unrolled by two");
-#pragma unroll 1
-      for (int st = 0; st < BR / 4; st += 2) {
-        // (the prefetches of the last step run one step past the batch: inside the LDS allocation,
-        // values unused)
-        step(xb + st * 4 * LD, qb + (st + 1) * 4 * QLD, qa0, qa1);
-        step(xb + (st + 1) * 4 * LD, qb + (st + 2) * 4 * QLD, qa1, qa0);
-      }
-    }
-    if (more) lstore(buf ^ 1);
-    __syncthreads();
-  }
-  if (ng == 0) return;
-
-  // ---- write this wave's slice of every cluster's partial record ---------------------------
-  const int64_t SS = 1 + (int64_t)DP + (int64_t)DP * DP;
-#pragma unroll
-  for (int g = 0; g < GPW; ++g) {
-    if (g < ng) {
-      const int f = a.feat[(g0 + g) * 16 + lo4];
-      const int ca = f & 0xffff, cb = f >> 16;
-#pragma unroll
-      for (int c = 0; c < NCT; ++c) {
-        const int k = 4 * c + hi;
-        if (k < K && ca <= DP) {
-          double* out = a.partial + ((int64_t)chunk * K + k) * SS;
-          const double v = acc[g][c];
-          if (cb < DP) {                      // x_a x_b, a >= b
-            out[1 + DP + (int64_t)ca * DP + cb] = v;
-            out[1 + DP + (int64_t)cb * DP + ca] = v;
-          } else if (ca < DP) {               // x_a * 1
-            out[1 + ca] = v;
-          } else {                            // 1 * 1
-            out[0] = v;
-          }
-        }
-      }
-    }
-  }
-}
-
-struct FeatCfg {
-  int nct, gpw, wpb, nslice;
-};
-// pick the kernel shape: NCT from K, then (waves per group, slices) so that the feature groups split
-// evenly over the waves with at most GPW groups each
-int build_feature_table(int D, int DP, int* out) {
-  const int P = D * (D + 1) / 2 + D + 1, ng = (P + 15) / 16;
-  if (!out) return ng;
-  int p = 0;
-  for (int a = 0; a < D; ++a)
-    for (int b = 0; b <= a; ++b) out[p++] = a | (b << 16);
-  for (int a = 0; a < D; ++a) out[p++] = a | (DP << 16);
-  out[p++] = DP | (DP << 16);
-  while (p < ng * 16) out[p++] = (DP + 1) | ((DP + 1) << 16);
-  return ng;
-}
-
-static FeatCfg feat_cfg(int K, int ngroups) {
-  FeatCfg c;
-  c.nct = K <= 8 ? 2 : K <= 16 ? 4 : K <= 32 ? 8 : 16;
-  c.gpw = c.nct == 2 ? 32 : c.nct == 4 ? 16 : c.nct == 8 ? 8 : 4;  // 64 accumulators, two waves per SIMD
-  // 4 waves per group (one per SIMD); the fewest slices whose waves need at most GPW groups each
-  c.wpb = 4;
-  c.nslice = (ngroups + 4 * c.gpw - 1) / (4 * c.gpw);
-  if (c.nslice < 1) c.nslice = 1;
-  return c;
-}
-
-template <int DP, int NCT, int GPW, int WPB>
-static hipError_t launch_feat_t(const SuffstatLaunch& a, int nslice, hipStream_t stream) {
-  SuffstatLaunch b = a;
-  b.nslice = nslice;
-  const size_t shmem = (size_t)(2 * SS_BR * (a.DP + 16) + 2 * SS_BR * (NCT * 4 + 4)) * sizeof(double);
-  auto kern = ssfeat_kernel<DP, NCT, GPW, WPB>;
-  static bool attr_set = false;
-  if (shmem > 64 * 1024 && !attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(128 * 1024));
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(kern, dim3((unsigned)(a.nchunks * nslice)), dim3(WPB * 64), shmem, stream, b);
-  return hipGetLastError();
-}
-
-static bool use_feat(const SuffstatLaunch& a) {
-  if (!a.feat || a.ngroups <= 0) return false;
-  if (const char* e = getenv("LC_SS_ALGO")) {  // tuning knob: "A" per-cluster form, "B" feature form
-    if (e[0] == 'A') return false;
-    if (e[0] == 'B') return a.K <= 64;
-  }
-  return a.K >= 8 && a.K <= 64;
-}
-
-template <int DP>
-static hipError_t launch_feat_d(const SuffstatLaunch& a, hipStream_t stream) {
-  const FeatCfg c = feat_cfg(a.K, a.ngroups);
-#define LC_FEAT(NCT, GPW)                                                                              \
-  if (c.nct == NCT) return launch_feat_t<DP, NCT, GPW, 4>(a, c.nslice, stream);
-  LC_FEAT(2, 32)
-  LC_FEAT(4, 16)
-  LC_FEAT(8, 8)
-  LC_FEAT(16, 4)
-#undef LC_FEAT
-  return hipErrorInvalidValue;
-}
-
-static hipError_t launch_feat(const SuffstatLaunch& a, hipStream_t stream) {
-  switch (a.DP) {
-    case 16: return launch_feat_d<16>(a, stream);
-    case 32: return launch_feat_d<32>(a, stream);
-    case 64: return launch_feat_d<64>(a, stream);
-    case 128: return launch_feat_d<128>(a, stream);
-  }
-  return hipErrorInvalidValue;
-}
-
 template <int DP>
 struct SSCfg;
 template <>
@@ -872,19 +577,9 @@ static int ss_cpw(int DP, int K) {
   return cpw;
 }
 
-int suffstat_plan(int DP, int64_t NP, int K, int64_t* chunk_rows, int ngroups) {
+int suffstat_plan(int DP, int64_t NP, int K, int64_t* chunk_rows) {
   const int cpw = ss_cpw(DP, K);
-  int kwaves = (K + cpw - 1) / cpw;  // waves needed to cover the clusters
-  {
-    SuffstatLaunch probe;
-    probe.K = K;
-    probe.ngroups = ngroups;
-    probe.feat = ngroups > 0 ? reinterpret_cast<const int*>(1) : nullptr;
-    if (use_feat(probe)) {
-      const FeatCfg c = feat_cfg(K, ngroups);
-      kwaves = c.wpb * c.nslice;
-    }
-  }
+  const int kwaves = (K + cpw - 1) / cpw;  // waves needed to cover the clusters
   // aim for ~8 waves per CU on 256 CUs, at least 256 rows per chunk
   int64_t want = (256 * 8 + kwaves - 1) / kwaves;
   int64_t maxchunks = (NP + 255) / 256;
@@ -918,7 +613,6 @@ static hipError_t launch_ss_t(const SuffstatLaunch& a, hipStream_t stream) {
 
 hipError_t launch_suffstat(const SuffstatLaunch& a, hipStream_t stream) {
   if (a.K <= 0 || a.nchunks <= 0) return hipSuccess;
-  if (use_feat(a)) return launch_feat(a, stream);
   const int cpw = ss_cpw(a.DP, a.K);
   switch (a.DP) {
     case 16:

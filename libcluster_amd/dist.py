@@ -69,9 +69,17 @@ def make_device_hook(device_index: int):
     import torch.distributed as dist
 
     dev = torch.device("cuda", device_index)
+    on_device = dist.get_backend() == "nccl"
 
     def hook(ptr: int, count: int, stream: int) -> None:
         t = torch.as_tensor(_DeviceSpan(ptr, count), device=dev)
-        dist.all_reduce(t)
+        if on_device:
+            dist.all_reduce(t)  # RCCL, in place on the C-ABI's buffer, ordered on the current stream
+        else:
+            # gloo (CPU collectives; used to exercise the multi-rank path where RCCL cannot run,
+            # e.g. several ranks on one GPU): bounce through the host
+            h = t.cpu()
+            dist.all_reduce(h)
+            t.copy_(h)
 
     return hook
