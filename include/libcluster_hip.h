@@ -75,6 +75,8 @@ int lc_ctx_get_rows(lc_ctx* ctx, int j, int64_t row0, int64_t n, double* out);
 /* qZ (the `vMatrixXd& qZ` of cluster.cpp:179): host <-> device, any strides. */
 int lc_ctx_set_qz(lc_ctx* ctx, int j, const double* q, int K, int64_t row_stride, int64_t col_stride);
 int lc_ctx_get_qz(lc_ctx* ctx, int j, double* q, int64_t row_stride, int64_t col_stride);
+/* rows [row0,row0+n) of group j only (qZ[j].block(row0,0,n,K)) */
+int lc_ctx_get_qz_rows(lc_ctx* ctx, int j, int64_t row0, int64_t n, double* q, int64_t row_stride, int64_t col_stride);
 int lc_ctx_fill_qz(lc_ctx* ctx, int K, double value); /* qZ[j].setOnes(N,1): cluster.cpp:583-585 */
 
 /* ---- the hot path ------------------------------------------------------ */

@@ -77,6 +77,7 @@ def lib() -> C.CDLL:
     L.lc_ctx_get_rows.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, c_double_p]
     L.lc_ctx_set_qz.argtypes = [C.c_void_p, C.c_int, c_double_p, C.c_int, C.c_int64, C.c_int64]
     L.lc_ctx_get_qz.argtypes = [C.c_void_p, C.c_int, c_double_p, C.c_int64, C.c_int64]
+    L.lc_ctx_get_qz_rows.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, c_double_p, C.c_int64, C.c_int64]
     L.lc_ctx_fill_qz.argtypes = [C.c_void_p, C.c_int, C.c_double]
     L.lc_estep.argtypes = [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]
     L.lc_estep_posterior.argtypes = [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
@@ -221,6 +222,13 @@ class Context:
                 check(lib().lc_ctx_get_qz(self._h, j, dptr(q), K, 1))
             out.append(q)
         return out
+
+    def get_qz_rows(self, j, row0, n):
+        _, _, _, K = self.dims()
+        q = np.empty((n, K))
+        if n:
+            check(lib().lc_ctx_get_qz_rows(self._h, j, row0, n, dptr(q), K, 1))
+        return q
 
     def fill_qz(self, K, value=1.0):
         check(lib().lc_ctx_fill_qz(self._h, K, value))

@@ -153,6 +153,14 @@ int lc_ctx_get_qz(lc_ctx* ctx, int j, double* q, int64_t rs, int64_t cs) {
   });
 }
 
+int lc_ctx_get_qz_rows(lc_ctx* ctx, int j, int64_t row0, int64_t n, double* q, int64_t rs, int64_t cs) {
+  return guarded([&] {
+    need(ctx, "ctx");
+    need(q, "q");
+    ctx->impl.qz_get_rows(j, row0, n, q, rs, cs);
+  });
+}
+
 int lc_ctx_fill_qz(lc_ctx* ctx, int K, double value) {
   return guarded([&] {
     need(ctx, "ctx");

@@ -207,6 +207,18 @@ void Context::qz_get_column(int j, int k, double* out) const {
   LC_HIP(hipStreamSynchronize(stream_));
 }
 
+void Context::qz_get_rows(int j, int64_t row0, int64_t n, double* q, int64_t rs, int64_t cs) const {
+  if (j < 0 || j >= J_ || row0 < 0 || n < 0 || row0 + n > Nj_[j]) throw std::invalid_argument("row range out of bounds");
+  if (n == 0) return;
+  std::vector<double> col((size_t)n);
+  for (int k = 0; k < qz_[cur_].K; ++k) {
+    LC_HIP(hipMemcpyAsync(col.data(), qz_[cur_].buf.p + (size_t)k * NP_ + goff_[j] + row0, n * sizeof(double),
+                          hipMemcpyDeviceToHost, stream_));
+    LC_HIP(hipStreamSynchronize(stream_));
+    for (int64_t r = 0; r < n; ++r) q[r * rs + k * cs] = col[(size_t)r];
+  }
+}
+
 void Context::qz_get(int j, double* q, int64_t rs, int64_t cs) const {
   if (j < 0 || j >= J_) throw std::invalid_argument("group index out of range");
   const int64_t n = Nj_[j];

@@ -1,0 +1,93 @@
+"""BASELINE.json's full sizes on the GPU, checked through size-independent
+properties (the oracle cannot run 10M x 64 x 32 in seconds):
+  * rows of qZ sum to 1  <=>  sum_k N_k = N, and per sampled row;
+  * the E-step is row-independent given the posterior: the first rows of the
+    full run equal, bit for bit, a separate run on just those rows, which in
+    turn equals the oracle;
+  * suff-stats are exactly symmetric;
+  * statistics and sum_n logZ are additive over row shards (two half-size contexts generated from
+    the same Philox stream reproduce the unsharded values -- the multi-GPU invariant);
+  * the free energy never increases over EM iterations.
+"""
+import numpy as np
+import pytest
+
+import lc_oracle as o
+from libcluster_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def _mixture(D, K, seed):
+    rng = np.random.default_rng(seed)
+    mu = rng.normal(0.0, 3.0, (K, D))
+    L = np.stack([np.linalg.cholesky((lambda B: B @ B.T / D + 0.5 * np.eye(D))(rng.normal(size=(D, D))))
+                  for _ in range(K)])
+    return mu, L
+
+
+@pytest.mark.parametrize("N,D,K,seed", [(1_000_000, 16, 8, 1002), (10_000_000, 64, 32, 1003)])
+def test_full_size_properties(N, D, K, seed):
+    mu, L = _mixture(D, K, seed)
+    P = 4096  # prefix checked against the oracle
+    with capi.Context(0) as ctx:
+        ctx.synth(N, D, K, mu, L, seed, 0, 0.9)
+        Xp = ctx.get_rows(0, 0, P)
+        q0p = ctx.get_qz_rows(0, 0, P)
+        np.testing.assert_allclose(q0p.sum(axis=1), 1.0, rtol=1e-13)
+        Nk, xs, xxs, Njk = ctx.suffstat()
+        assert abs(Nk.sum() - N) <= 1e-9 * N                       # rows of the initial qZ sum to 1
+        assert np.array_equal(xxs, np.transpose(xxs, (0, 2, 1)))   # exactly symmetric
+        np.testing.assert_array_equal(Njk[0], Nk)
+        assert np.all(np.einsum("kii->k", xxs) > 0)
+        # posterior from the full statistics (host M-step through the C-ABI)
+        post = [capi.gw_mstep(1.0, Nk[k], xs[k], xxs[k]) for k in range(K)]
+        elog, _ = capi.weights_update(capi.W_STICKBREAK, Nk)
+        args = ([p["nu"] for p in post], [p["beta"] for p in post], np.stack([p["m"] for p in post]),
+                np.stack([p["iW"] for p in post]), [p["logdW"] for p in post], elog[None, :])
+        Fz, _ = ctx.estep_posterior(*args, want_ll=False)
+        qp = ctx.get_qz_rows(0, 0, P)
+        qmid = ctx.get_qz_rows(0, N // 2 - 7, 1001)
+        colsum = ctx.colsums()[0]
+        F, tr, m = ctx.vbem(capi.W_STICKBREAK, fixed_iters=3, nthreads=16)
+        m.close()
+    assert abs(colsum.sum() - N) <= 1e-9 * N                       # every row of the new qZ sums to 1
+    np.testing.assert_allclose(qp.sum(axis=1), 1.0, rtol=1e-12)
+    np.testing.assert_allclose(qmid.sum(axis=1), 1.0, rtol=1e-12)
+    assert np.all(np.diff(tr) <= 1e-9 * abs(tr[0]))                # F is non-increasing
+
+    # the same posterior on the prefix alone: identical rows, and equal to the oracle
+    with capi.Context(0) as c2:
+        c2.set_data(Xp)
+        Fzp, _ = c2.estep_posterior(*args, want_ll=False)
+        qp2 = c2.get_qz([P])[0]
+    np.testing.assert_array_equal(qp, qp2)
+    cl = []
+    for k in range(K):
+        g = o.GaussWish(1.0, D)
+        g.nu, g.beta, g.m, g.iW, g.logdW = (post[k]["nu"], post[k]["beta"], post[k]["m"], post[k]["iW"],
+                                            post[k]["logdW"])
+        cl.append(g)
+    w = o.StickBreak()
+    w.E_logpi, w.Nk = elog, Nk
+    qref, Fzref = o.vbexpectation(Xp, w, cl)
+    big = qref > 1e-12
+    assert np.max(np.abs(qp[big] - qref[big]) / qref[big]) < 1e-9
+    assert abs(Fzp - Fzref) <= 1e-10 * abs(Fzref)
+    assert np.isfinite(Fz) and Fz > 0
+
+    # row sharding (what the multi-GPU path does): statistics and Fz of two half-shards generated
+    # from the same Philox stream add up to the unsharded values
+    half = N // 2
+    tot_stats, tot_Fz = None, 0.0
+    for r in range(2):
+        with capi.Context(0) as cs:
+            cs.synth(half, D, K, mu, L, seed, r * half, 0.9)
+            st = cs.suffstat()
+            fz, _ = cs.estep_posterior(*args, want_ll=False)
+        tot_Fz += fz
+        tot_stats = st if tot_stats is None else tuple(a + b for a, b in zip(tot_stats, st))
+    np.testing.assert_allclose(tot_stats[0], Nk, rtol=1e-12)
+    np.testing.assert_allclose(tot_stats[1], xs, rtol=1e-9, atol=1e-6)
+    np.testing.assert_allclose(tot_stats[2], xxs, rtol=1e-9, atol=1e-5)
+    assert abs(tot_Fz - Fz) <= 1e-11 * abs(Fz)
