@@ -1,9 +1,9 @@
-/* libcluster.h -- learnVDP / learnBGMM / learnGMC with the reference's
- * signatures (include/libcluster.h:177-186, 218-227, 356-366), running the
+/* libcluster.h -- learnVDP / learnBGMM / learnGMC / learnSGMC with the reference's
+ * signatures (include/libcluster.h:177-186, 218-227, 356-366, 409-419), running the
  * variational E-step and sufficient statistics on an MI355X through the C ABI
  * (include/libcluster_hip.h).  Drop-in for that path: same namespaces, names,
  * argument meaning, constants and exception classes.  The other learners of the
- * reference (DGMM, BEMM, SGMC, DGMC, EGMC, SCM, MCM) are not part of this build.
+ * reference (DGMM, BEMM, DGMC, EGMC, SCM, MCM) are not part of this build.
  */
 #ifndef LIBCLUSTER_H
 #define LIBCLUSTER_H
@@ -138,6 +138,15 @@ inline double learnGMC(const vMatrixXd& X, vMatrixXd& qZ, std::vector<distributi
                        const int maxclusters = -1, const bool sparse = false, const bool verbose = false,
                        const unsigned int nthreads = detail::default_threads()) {
   return detail::run(LC_ALGO_GMC, X, qZ, weights, clusters, 1.0, clusterprior, maxclusters, sparse, verbose,
+                     nthreads);
+}
+
+/* include/libcluster.h:409-419, src/cluster.cpp:787-807 */
+inline double learnSGMC(const vMatrixXd& X, vMatrixXd& qZ, std::vector<distributions::Dirichlet>& weights,
+                        std::vector<distributions::GaussWish>& clusters, const double clusterprior = PRIORVAL,
+                        const int maxclusters = -1, const bool sparse = false, const bool verbose = false,
+                        const unsigned int nthreads = detail::default_threads()) {
+  return detail::run(LC_ALGO_SGMC, X, qZ, weights, clusters, 1.0, clusterprior, maxclusters, sparse, verbose,
                      nthreads);
 }
 

@@ -31,8 +31,8 @@ typedef enum { LC_OK = 0, LC_EINVAL = 1, LC_ERUNTIME = 2, LC_EHIP = 3, LC_EDOMAI
 
 /* weight distribution kinds: include/distributions.h:163 (Dirichlet), :103 (StickBreak), :147 (GDirichlet) */
 typedef enum { LC_W_DIRICHLET = 0, LC_W_STICKBREAK = 1, LC_W_GDIRICHLET = 2 } lc_weight_kind;
-/* learners: include/libcluster.h:177 (learnVDP), :218 (learnBGMM), :356 (learnGMC) */
-typedef enum { LC_ALGO_VDP = 0, LC_ALGO_BGMM = 1, LC_ALGO_GMC = 2 } lc_algo;
+/* learners: include/libcluster.h:177 (learnVDP), :218 (learnBGMM), :356 (learnGMC), :409 (learnSGMC) */
+typedef enum { LC_ALGO_VDP = 0, LC_ALGO_BGMM = 1, LC_ALGO_GMC = 2, LC_ALGO_SGMC = 3 } lc_algo;
 
 typedef struct lc_ctx lc_ctx;     /* device-resident data set + qZ + workspaces */
 typedef struct lc_model lc_model; /* weights + clusters (+ the context that holds qZ) */
@@ -135,14 +135,22 @@ int lc_ctx_timing_get(lc_ctx* ctx, double* estep_ms, int64_t* estep_calls, doubl
 int lc_vbem(lc_ctx* ctx, lc_model** model, int wkind, double wprior, double clusterprior, int maxit, int sparse,
             int fixed_iters, int verbose, unsigned nthreads, double* F, int* niter, double* Ftrace, int ntrace);
 
-/* learnVDP / learnBGMM / learnGMC (cluster.cpp:636-695, 763-784): uploads X,
+/* learnVDP / learnBGMM / learnGMC / learnSGMC (cluster.cpp:636-695, 763-807): uploads X,
  * runs the model-selection loop, returns the model (which owns its context so
  * qZ can be fetched).  wprior: StickBreak concentration / Dirichlet alpha the
  * caller's `weights` argument carried (1.0 = default-constructed); ignored
- * for GMC (default-constructed GDirichlet per group, cluster.cpp:192). */
+ * for GMC / SGMC (default-constructed GDirichlet / Dirichlet per group, cluster.cpp:192). */
 int lc_learn(int algo, int J, const double* const* Xj, const int64_t* Nj, int D, int64_t row_stride,
              int64_t col_stride, double wprior, double clusterprior, int maxclusters, int sparse, int verbose,
              unsigned nthreads, int device, lc_model** out, double* F);
+
+/* The same model-selection loop (cluster(), cluster.cpp:564-629) on observations that already live in
+ * a context (lc_ctx_set_data or lc_ctx_synth): nothing but the M-step statistics crosses PCIe, the
+ * split search (partobs / splitobs / auglabels, cluster.cpp:438-470) runs on the device too.
+ * wkind / wprior as in lc_vbem (GDirichlet and per-group Dirichlet ignore wprior for new groups).
+ * The returned model borrows ctx (keep it alive while reading qZ through the model). */
+int lc_cluster(lc_ctx* ctx, int wkind, double wprior, double clusterprior, int maxclusters, int sparse, int verbose,
+               unsigned nthreads, lc_model** out, double* F);
 
 /* ---- model accessors ----------------------------------------------------- */
 int lc_model_free(lc_model* m);

@@ -9,4 +9,4 @@ learnGMC with the reference Python binding's return shape) and `dist`
 a CPU implementation of the data path.
 """
 from . import capi  # noqa: F401
-from .api import learnBGMM, learnGMC, learnVDP  # noqa: F401
+from .api import learnBGMM, learnGMC, learnSGMC, learnVDP  # noqa: F401

@@ -43,3 +43,10 @@ def learnGMC(X, prior=1.0, maxclusters=-1, sparse=False, verbose=False, nthreads
     F, m, rows = capi.learn(capi.ALGO_GMC, [np.asarray(x, dtype=np.float64) for x in X], 1.0, prior, maxclusters,
                             sparse, verbose, nthreads, device)
     return _result(F, m, rows, True)
+
+
+def learnSGMC(X, prior=1.0, maxclusters=-1, sparse=False, verbose=False, nthreads=1, device=0):
+    """include/libcluster.h:409-419 (symmetric GMC: one Dirichlet per group).  X is a list of (N_j, D) arrays."""
+    F, m, rows = capi.learn(capi.ALGO_SGMC, [np.asarray(x, dtype=np.float64) for x in X], 1.0, prior, maxclusters,
+                            sparse, verbose, nthreads, device)
+    return _result(F, m, rows, True)

@@ -15,7 +15,7 @@ HEADER = PKG.parent / "include" / "libcluster_hip.h"
 
 LC_OK, LC_EINVAL, LC_ERUNTIME, LC_EHIP, LC_EDOMAIN = range(5)
 W_DIRICHLET, W_STICKBREAK, W_GDIRICHLET = 0, 1, 2
-ALGO_VDP, ALGO_BGMM, ALGO_GMC = 0, 1, 2
+ALGO_VDP, ALGO_BGMM, ALGO_GMC, ALGO_SGMC = 0, 1, 2, 3
 
 c_double_p = C.POINTER(C.c_double)
 c_int64_p = C.POINTER(C.c_int64)
@@ -94,6 +94,8 @@ def lib() -> C.CDLL:
     L.lc_learn.argtypes = [C.c_int, C.c_int, C.POINTER(c_double_p), c_int64_p, C.c_int, C.c_int64, C.c_int64,
                            C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_int,
                            C.POINTER(C.c_void_p), c_double_p]
+    L.lc_cluster.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_uint,
+                             C.POINTER(C.c_void_p), c_double_p]
     L.lc_model_free.argtypes = [C.c_void_p]
     L.lc_model_dims.argtypes = [C.c_void_p, c_int_p, c_int_p, c_int_p]
     L.lc_model_rounds.argtypes = [C.c_void_p, c_int_p]
@@ -323,6 +325,14 @@ class Context:
         if model is None:
             model = Model(mh, ctx=self)
         return F.value, tr[: nit.value].copy(), model
+
+
+    def cluster(self, wkind, wprior=1.0, clusterprior=1.0, maxclusters=-1, sparse=False, verbose=False, nthreads=1):
+        """cluster() (model selection) on the data resident in this context -> (F, Model)."""
+        mh, F = C.c_void_p(), C.c_double()
+        check(lib().lc_cluster(self._h, wkind, wprior, clusterprior, maxclusters, int(sparse), int(verbose), nthreads,
+                               C.byref(mh), C.byref(F)))
+        return F.value, Model(mh, ctx=self)
 
 
 class Model:

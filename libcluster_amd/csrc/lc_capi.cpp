@@ -344,7 +344,7 @@ int lc_learn(int algo, int J, const double* const* Xj, const int64_t* Nj, int D,
     need(Xj, "Xj");
     need(Nj, "Nj");
     need(out, "out");
-    if (algo < 0 || algo > 2) throw std::invalid_argument("unknown algorithm");
+    if (algo < 0 || algo > 3) throw std::invalid_argument("unknown algorithm");
     if ((algo == LC_ALGO_VDP || algo == LC_ALGO_BGMM) && J != 1)
       throw std::invalid_argument("learnVDP/learnBGMM take a single observation matrix");
     if (nthreads < 1) throw std::invalid_argument("Must specify at least one thread for execution!");  // cluster.cpp:576-577
@@ -354,13 +354,6 @@ int lc_learn(int algo, int J, const double* const* Xj, const int64_t* Nj, int D,
     m->D = D;
     lcc::Context& ctx = m->ctx->impl;
     ctx.set_data(J, Xj, Nj, D, rs, cs);
-    lce::HostData host;
-    host.J = J;
-    host.D = D;
-    host.X.assign(Xj, Xj + J);
-    host.N.assign(Nj, Nj + J);
-    host.row_stride = rs;
-    host.col_stride = cs;
     if (algo == LC_ALGO_VDP) {
       if (verbose) std::cout << "Learning VDP..." << std::endl;  // cluster.cpp:647-648
       m->model.wkind = lch::W_STICKBREAK;
@@ -369,18 +362,46 @@ int lc_learn(int algo, int J, const double* const* Xj, const int64_t* Nj, int D,
       if (verbose) std::cout << "Learning Bayesian GMM..." << std::endl;  // :678-679
       m->model.wkind = lch::W_DIRICHLET;
       m->model.weights.emplace_back(lch::W_DIRICHLET, wprior);  // :684
-    } else {
+    } else if (algo == LC_ALGO_GMC) {
       if (verbose) std::cout << "Learning " << (sparse ? "(sparse) " : "") << "GMC..." << std::endl;  // :775-779
       m->model.wkind = lch::W_GDIRICHLET;
+    } else {
+      if (verbose) std::cout << "Learning " << (sparse ? "(sparse) " : "") << "Symmetric GMC..." << std::endl;  // :799-803
+      m->model.wkind = lch::W_DIRICHLET;
     }
     lce::ClusterOptions co;
     co.clusterprior = clusterprior;
     co.maxclusters = maxclusters;
-    co.sparse = (algo == LC_ALGO_GMC) && sparse;  // learnVDP/BGMM pass sparse=false, :657/:688
+    co.sparse = (algo == LC_ALGO_GMC || algo == LC_ALGO_SGMC) && sparse;  // learnVDP/BGMM pass sparse=false, :657/:688
     co.verbose = verbose != 0;
     co.nthreads = nthreads;
     co.trace = &m->rounds;
-    const double f = lce::cluster(ctx, host, m->model, co);
+    const double f = lce::cluster(ctx, m->model, co);
+    if (F) *F = f;
+    *out = m.release();
+  });
+}
+
+int lc_cluster(lc_ctx* ctx, int wkind, double wprior, double clusterprior, int maxclusters, int sparse, int verbose,
+               unsigned nthreads, lc_model** out, double* F) {
+  return guarded([&] {
+    need(ctx, "ctx");
+    need(out, "out");
+    if (wkind < 0 || wkind > 2) throw std::invalid_argument("unknown weight kind");
+    if (nthreads < 1) throw std::invalid_argument("Must specify at least one thread for execution!");
+    std::unique_ptr<lc_model> m(new lc_model());
+    m->ctx = ctx;
+    m->D = ctx->impl.D();
+    m->model.wkind = wkind;
+    if (ctx->impl.J() == 1 && wkind != lch::W_GDIRICHLET) m->model.weights.emplace_back(wkind, wprior);
+    lce::ClusterOptions co;
+    co.clusterprior = clusterprior;
+    co.maxclusters = maxclusters;
+    co.sparse = sparse != 0;
+    co.verbose = verbose != 0;
+    co.nthreads = nthreads;
+    co.trace = &m->rounds;
+    const double f = lce::cluster(ctx->impl, m->model, co);
     if (F) *F = f;
     *out = m.release();
   });

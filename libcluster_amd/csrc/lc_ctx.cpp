@@ -253,17 +253,76 @@ void Context::qz_clone_to_alt() {
 
 void Context::qz_swap_alt() { cur_ ^= 1; }
 
-void Context::qz_split_column(int k, const std::vector<int64_t>& rows) {
+// ---------------------------------------------------------------------------
+// split search on the device
+// ---------------------------------------------------------------------------
+void Context::select_rows(int k, double thresh, RowSelection& sel) {
+  const QZ& q = qz_[cur_];
+  if (k < 0 || k >= q.K) throw std::invalid_argument("qZ column out of range");
+  LC_HIP(hipSetDevice(device_));
+  sel.M = 0;
+  sel.starts.assign((size_t)J_ + 1, 0);
+  sel.starts_d.reserve((size_t)J_ + 1);
+  if (NP_ == 0) {
+    LC_HIP(hipMemsetAsync(sel.starts_d.p, 0, (size_t)(J_ + 1) * sizeof(int64_t), stream_));
+    return;
+  }
+  const double* col = q.buf.p + (size_t)k * NP_;
+  const int nb = lck::select_blocks(NP_);
+  selcnt_.reserve((size_t)nb);
+  seloff_.reserve((size_t)nb);
+  LC_HIP(lck::launch_select_count(col, NP_, thresh, selcnt_.p, stream_));
+  std::vector<int> cnt((size_t)nb);
+  LC_HIP(hipMemcpyAsync(cnt.data(), selcnt_.p, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, stream_));
+  LC_HIP(hipStreamSynchronize(stream_));
+  std::vector<int64_t> off((size_t)nb);
+  int64_t tot = 0;
+  for (int b = 0; b < nb; ++b) {
+    off[(size_t)b] = tot;
+    tot += cnt[(size_t)b];
+  }
+  sel.M = tot;
+  sel.idx.reserve((size_t)std::max<int64_t>(tot, 1));
+  LC_HIP(hipMemcpyAsync(seloff_.p, off.data(), (size_t)nb * sizeof(int64_t), hipMemcpyHostToDevice, stream_));
+  LC_HIP(lck::launch_select_compact(col, NP_, thresh, seloff_.p, sel.idx.p, stream_));
+  LC_HIP(lck::launch_group_starts(sel.idx.p, tot, goff_d_.p, J_, sel.starts_d.p, stream_));
+  LC_HIP(hipMemcpyAsync(sel.starts.data(), sel.starts_d.p, (size_t)(J_ + 1) * sizeof(int64_t), hipMemcpyDeviceToHost,
+                        stream_));
+  LC_HIP(hipStreamSynchronize(stream_));  // `off` goes out of scope; starts are needed by the caller
+}
+
+void Context::set_data_gather(const Context& src, const RowSelection& sel) {
+  if (src.device_ != device_) throw std::invalid_argument("contexts live on different devices");
+  std::vector<int64_t> mj((size_t)src.J_);
+  for (int j = 0; j < src.J_; ++j) mj[(size_t)j] = sel.starts[(size_t)j + 1] - sel.starts[(size_t)j];
+  build_layout(src.J_, mj.data(), src.D_);
+  if (NP_ == 0) return;
+  LC_HIP(hipMemsetAsync(X_.p, 0, (size_t)NP_ * DP_ * sizeof(double), stream_));
+  LC_HIP(lck::launch_gather_rows(src.X_.p, DP_, sel.idx.p, sel.M, sel.starts_d.p, goff_d_.p, J_, X_.p, stream_));
+}
+
+void Context::qz_init_split(const double* m, const double* v) {
+  ensure_qz(qz_[cur_], 2, false);
+  qz_[cur_].K = 2;
+  if (NP_ == 0) return;
+  std::vector<double> mv((size_t)2 * DP_, 0.0);
+  std::copy(m, m + D_, mv.begin());
+  std::copy(v, v + D_, mv.begin() + DP_);
+  mv_.reserve(mv.size());
+  LC_HIP(hipMemcpyAsync(mv_.p, mv.data(), mv.size() * sizeof(double), hipMemcpyHostToDevice, stream_));
+  LC_HIP(lck::launch_split_init(X_.p, DP_, D_, NP_, J_ > 1 ? rginfo_.p : nullptr, Nj_[0], mv_.p, qz_[cur_].buf.p, NP_,
+                                stream_));
+  LC_HIP(hipStreamSynchronize(stream_));  // mv is a local
+}
+
+void Context::qz_split_from(const Context& sub, const RowSelection& sel, int k) {
   QZ& q = qz_[cur_];
   if (k < 0 || k >= q.K) throw std::invalid_argument("split column out of range");
+  if (sub.qz_[sub.cur_].K < 2) throw std::invalid_argument("sub-problem has no second column");
   if (q.K + 1 > q.cap) ensure_qz(q, q.K + 1, true);
   LC_HIP(hipMemsetAsync(q.buf.p + (size_t)NP_ * q.K, 0, (size_t)NP_ * sizeof(double), stream_));
-  if (!rows.empty()) {
-    idx_.reserve(rows.size());
-    LC_HIP(hipMemcpyAsync(idx_.p, rows.data(), rows.size() * sizeof(int64_t), hipMemcpyHostToDevice, stream_));
-    LC_HIP(lck::launch_move_rows(q.buf.p, NP_, k, q.K, idx_.p, (int64_t)rows.size(), stream_));
-    LC_HIP(hipStreamSynchronize(stream_));  // rows' storage may go away
-  }
+  LC_HIP(lck::launch_aug_from_sub(q.buf.p, NP_, k, q.K, sel.idx.p, sel.M, sel.starts_d.p, sub.goff_d_.p, J_,
+                                  sub.qz_[sub.cur_].buf.p + (size_t)sub.NP_, stream_));
   q.K += 1;
 }
 

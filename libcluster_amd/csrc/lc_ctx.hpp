@@ -36,6 +36,14 @@ struct DevBuf {
   void reserve(size_t n);
 };
 
+// an ordered set of (padded, global) row indices of one context, kept on the device
+struct RowSelection {
+  DevBuf<int64_t> idx;          // [M] ascending
+  DevBuf<int64_t> starts_d;     // [J+1] first position of every group inside idx
+  std::vector<int64_t> starts;  // host copy
+  int64_t M = 0;
+};
+
 struct KernelTimes {
   double estep_ms = 0, suffstat_ms = 0;
   int64_t estep_calls = 0, suffstat_calls = 0;
@@ -84,9 +92,16 @@ class Context {
   void qz_keep_columns(const std::vector<int>& keep);    // prune_clusters
   void qz_clone_to_alt();                                // alt <- copy of current (capacity K+1)
   void qz_swap_alt();                                    // current <-> alt
-  // auglabels on the current buffer: rows (global padded indices) move column k -> new column K
-  void qz_split_column(int k, const std::vector<int64_t>& rows);
-  int64_t padded_row(int j, int64_t n) const { return goff_[j] + n; }
+  // ---- split search on the device (partobs / splitobs / auglabels) ----------
+  // rows with qZ[.,k] > thresh, in order (partobs' index part, comutils.cpp:56-72)
+  void select_rows(int k, double thresh, RowSelection& sel);
+  // this context := the selected rows of src, group structure kept (partobs' copy part)
+  void set_data_gather(const Context& src, const RowSelection& sel);
+  // qZ := [s, 1-s], s = ((x-m).v >= 0)   (splitobs + cluster.cpp:446-449); m, v: D host doubles
+  void qz_init_split(const double* m, const double* v);
+  // auglabels (comutils.cpp:75-104) on the current buffer (K -> K+1 columns): selected rows whose
+  // refined second responsibility in `sub` exceeds 0.5 move their column-k mass to the new column
+  void qz_split_from(const Context& sub, const RowSelection& sel, int k);
 
   // ---- hot path -------------------------------------------------------------
   // A: K x D x D row-major lower-triangular whiteners, m: K x D, c: J x K.
@@ -130,7 +145,9 @@ class Context {
 
   DevBuf<double> params_, ctab_, fzpart_, llpart_, red_, sspart_, ssout_;
   DevBuf<unsigned char> smask_;
-  DevBuf<int64_t> idx_;
+  DevBuf<int> selcnt_;
+  DevBuf<int64_t> seloff_;
+  DevBuf<double> mv_;
   std::vector<double> hpack_, hred_, hss_;
 
   bool timing_ = false;

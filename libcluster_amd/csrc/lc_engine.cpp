@@ -187,8 +187,7 @@ static bool prune_clusters(lcc::Context& ctx, Model& model, bool verbose) {
 // ---------------------------------------------------------------------------
 // cluster.cpp:366-495
 // ---------------------------------------------------------------------------
-static bool split_gr(lcc::Context& ctx, const HostData& host, Model& model, std::vector<int>& tally, double F,
-                     const ClusterOptions& opt) {
+static bool split_gr(lcc::Context& ctx, Model& model, std::vector<int>& tally, double F, const ClusterOptions& opt) {
   const int J = ctx.J(), K = (int)model.clusters.size(), D = ctx.D();
   if (K >= opt.maxclusters && opt.maxclusters >= 0) return false;
   if (ctx.distributed()) throw std::runtime_error("the split search is single-process in this build");
@@ -209,62 +208,35 @@ static bool split_gr(lcc::Context& ctx, const HostData& host, Model& model, std:
   }
   std::sort(ord.begin(), ord.end(), greedcomp);  // :418
 
-  std::vector<std::vector<int64_t>> mapidx(J);
-  std::vector<std::vector<double>> Xk(J), qZref(J);
-  std::vector<double> col;
-  std::vector<unsigned char> splitk;
   const double prior = model.clusters[0].prior;
+  lcc::RowSelection sel;
+  std::vector<double> njs;
+  std::vector<double> eigv;
 
   for (const GreedOrder& o : ord) {
     const int k = o.k;
     ++tally[k];
     if (model.clusters[k].N < 4) continue;  // :432
 
-    // partobs + splitobs per group (:438-453)
-    int64_t scount = 0, Mtot = 0;
-    for (int j = 0; j < J; ++j) {
-      const int64_t n = ctx.N(j);
-      col.resize((size_t)n);
-      ctx.qz_get_column(j, k, col.data());
-      mapidx[j].clear();
-      for (int64_t r = 0; r < n; ++r)
-        if (col[(size_t)r] > 0.5) mapidx[j].push_back(r);
-      const int64_t M = (int64_t)mapidx[j].size();
-      Xk[j].resize((size_t)M * D);
-      for (int64_t t = 0; t < M; ++t) {
-        const double* src = host.X[j] + mapidx[j][(size_t)t] * host.row_stride;
-        for (int d = 0; d < D; ++d) Xk[j][(size_t)t * D + d] = src[d * host.col_stride];
-      }
-      Mtot += M;
-      model.clusters[k].splitobs(Xk[j].data(), M, D, splitk);
-      qZref[j].assign((size_t)M * 2, 0.0);
-      for (int64_t t = 0; t < M; ++t) {
-        qZref[j][(size_t)t * 2 + 0] = splitk[(size_t)t] ? 1.0 : 0.0;
-        qZref[j][(size_t)t * 2 + 1] = splitk[(size_t)t] ? 0.0 : 1.0;
-        scount += splitk[(size_t)t] ? 1 : 0;
-      }
-    }
+    // partobs + splitobs per group (:438-453), on the device: ordered compaction of the rows with
+    // q_k > 0.5, device-to-device gather into a fresh context, projection on the principal axis
+    ctx.select_rows(k, 0.5, sel);
+    const int64_t Mtot = sel.M;
+    lch::eigpower(model.clusters[k].iW, D, eigv);  // distributions.cpp:380
+    lcc::Context sub(ctx.device(), ctx.stream());
+    sub.set_data_gather(ctx, sel);
+    sub.qz_init_split(model.clusters[k].m.data(), eigv.data());
+    njs.assign((size_t)J * 2, 0.0);
+    sub.colsums(njs.data());
+    double sc = 0.0;
+    for (int j = 0; j < J; ++j) sc += njs[(size_t)j * 2];
+    const int64_t scount = (int64_t)std::llround(sc);
     if (scount < 2 || scount > Mtot - 2) continue;  // :456
 
     // refine the split on the selected observations (:459-462)
     Model ms;
     ms.wkind = model.wkind;
     {
-      lcc::Context sub(ctx.device(), ctx.stream());
-      std::vector<const double*> xp(J);
-      std::vector<int64_t> mj(J);
-      for (int j = 0; j < J; ++j) {
-        xp[j] = Xk[j].data();
-        mj[j] = (int64_t)mapidx[j].size();
-      }
-      sub.set_data(J, xp.data(), mj.data(), D, D, 1);
-      // every group must be written so that K is consistent, including empty ones
-      bool first = true;
-      for (int j = 0; j < J; ++j) {
-        if (mj[j] == 0 && !first) continue;
-        sub.qz_set(j, qZref[j].data(), 2, 2, 1);
-        first = false;
-      }
       VbemOptions vo;
       vo.clusterprior = prior;
       vo.maxit = (int)lch::SPLITITER;
@@ -272,21 +244,12 @@ static bool split_gr(lcc::Context& ctx, const HostData& host, Model& model, std:
       vo.nthreads = opt.nthreads;
       vbem(sub, ms, vo);
       if (anyempty(ms.clusters)) continue;  // :464
-      for (int j = 0; j < J; ++j) {
-        col.resize((size_t)mj[j]);
-        sub.qz_get_column(j, 1, col.data());
-        for (int64_t t = 0; t < mj[j]; ++t) qZref[j][(size_t)t * 2 + 1] = col[(size_t)t];
-      }
     }
 
     // auglabels (:468-470, comutils.cpp:75-104) on a copy of qZ
-    std::vector<int64_t> rows;
-    for (int j = 0; j < J; ++j)
-      for (size_t t = 0; t < mapidx[j].size(); ++t)
-        if (qZref[j][t * 2 + 1] > 0.5) rows.push_back(ctx.padded_row(j, mapidx[j][t]));
     ctx.qz_clone_to_alt();
     ctx.qz_swap_alt();
-    ctx.qz_split_column(k, rows);
+    ctx.qz_split_from(sub, sel, k);
 
     // free energy of the split with all data (:473)
     VbemOptions vo;
@@ -318,7 +281,7 @@ static bool split_gr(lcc::Context& ctx, const HostData& host, Model& model, std:
 // ---------------------------------------------------------------------------
 // cluster.cpp:564-629
 // ---------------------------------------------------------------------------
-double cluster(lcc::Context& ctx, const HostData& host, Model& model, const ClusterOptions& opt) {
+double cluster(lcc::Context& ctx, Model& model, const ClusterOptions& opt) {
   if (opt.nthreads < 1) throw std::invalid_argument("Must specify at least one thread for execution!");
   ctx.qz_fill(1, 1.0);  // :583-585
   std::vector<int> tally;
@@ -340,7 +303,7 @@ double cluster(lcc::Context& ctx, const HostData& host, Model& model, const Clus
     if (!(nkeep >= opt.maxclusters && opt.maxclusters >= 0)) data_loglik(ctx, model);  // split_gr will need it
     prune_clusters(ctx, model, opt.verbose);
     if (opt.verbose) std::cout << '<' << std::flush;
-    issplit = split_gr(ctx, host, model, tally, F, opt);
+    issplit = split_gr(ctx, model, tally, F, opt);
     if (opt.verbose) std::cout << '>' << std::endl;
   }
   if (opt.verbose) {

@@ -14,15 +14,6 @@
 
 namespace lce {
 
-// borrowed view of the caller's host observations (needed by the split
-// heuristic's partobs gather, src/comutils.cpp:56-72)
-struct HostData {
-  int J = 0, D = 0;
-  std::vector<const double*> X;
-  std::vector<int64_t> N;
-  int64_t row_stride = 0, col_stride = 0;
-};
-
 struct Model {
   int wkind = lch::W_DIRICHLET;
   std::vector<lch::WeightState> weights;      // J
@@ -53,8 +44,9 @@ struct ClusterOptions {
   std::vector<std::pair<int, std::vector<double>>>* trace = nullptr;  // (K, F per iteration) per round
 };
 
-// cluster.cpp:564-629.  ctx must hold the data; model.weights may be pre-seeded
-// (learnVDP/learnBGMM pass the caller's weight prior in element 0).
-double cluster(lcc::Context& ctx, const HostData& host, Model& model, const ClusterOptions& opt);
+// cluster.cpp:564-629.  ctx must hold the data (host upload or device-resident); model.weights may be
+// pre-seeded (learnVDP/learnBGMM pass the caller's weight prior in element 0).  The whole loop,
+// split search included, runs against device-resident X and qZ.
+double cluster(lcc::Context& ctx, Model& model, const ClusterOptions& opt);
 
 }  // namespace lce

@@ -68,11 +68,20 @@ hipError_t launch_group_colsum(const double* qZ, int64_t ldq, int K, const int64
 // qZ[:, 0..K) = value on valid rows, 0 on pad rows
 hipError_t launch_fill_qz(double* qZ, int64_t ldq, int K, const int* rginfo, int64_t nrows, int64_t nrg, double value,
                           hipStream_t stream);
-// auglabels (src/comutils.cpp:75-104): for i<n: r=idx[i]; qZ[K][r]=qZ[k][r]; qZ[k][r]=0
-hipError_t launch_move_rows(double* qZ, int64_t ldq, int k, int K, const int64_t* idx, int64_t n, hipStream_t stream);
-// splitobs projection (src/distributions.cpp:373-385): out[row] = sum_d (x[row][d]-m[d])*v[d] >= 0
-hipError_t launch_project(const double* X, int DP, int64_t NP, const double* mv /*[2*DP]: m then v*/,
-                          unsigned char* out, hipStream_t stream);
+// ---- split-search data passes (partobs / splitobs / auglabels on the device) ----
+int select_blocks(int64_t NP);  // number of per-block counts select_count produces
+hipError_t launch_select_count(const double* qcol, int64_t NP, double thresh, int* counts, hipStream_t stream);
+hipError_t launch_select_compact(const double* qcol, int64_t NP, double thresh, const int64_t* offsets, int64_t* idx,
+                                 hipStream_t stream);
+hipError_t launch_group_starts(const int64_t* idx, int64_t M, const int64_t* goff, int J, int64_t* starts,
+                               hipStream_t stream);
+hipError_t launch_gather_rows(const double* X, int DP, const int64_t* idx, int64_t M, const int64_t* starts,
+                              const int64_t* goff_sub, int J, double* Xdst, hipStream_t stream);
+hipError_t launch_split_init(const double* X, int DP, int D, int64_t NP, const int* rginfo, int64_t nrows,
+                             const double* mv, double* q, int64_t ldq, hipStream_t stream);
+hipError_t launch_aug_from_sub(double* q, int64_t ldq, int k, int K, const int64_t* idx, int64_t M,
+                               const int64_t* starts, const int64_t* goff_sub, int J, const double* qsub1,
+                               hipStream_t stream);
 
 // synthetic mixture generator (bench): Philox4x32-10, counter = global row.
 struct SynthLaunch {

@@ -712,35 +712,171 @@ hipError_t launch_fill_qz(double* qZ, int64_t ldq, int K, const int* rginfo, int
   return hipGetLastError();
 }
 
-__global__ void __launch_bounds__(256) move_rows_kernel(double* qZ, int64_t ldq, int k, int K, const int64_t* idx,
-                                                        int64_t n) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int64_t r = idx[i];
-  qZ[(int64_t)K * ldq + r] = qZ[(int64_t)k * ldq + r];
-  qZ[(int64_t)k * ldq + r] = 0.0;
+// ===========================================================================
+// split-search data passes: partobs / splitobs / auglabels
+// ===========================================================================
+// partobs (src/comutils.cpp:56-72) selects the rows with q_k > 0.5 in order.  Two passes over the
+// column: per-block counts, then (after the host scans the ~N/1024 counts) an ordered compaction.
+constexpr int SEL_ROWS = 1024;  // rows per 256-thread block, 4 consecutive rows per thread
+
+__global__ void __launch_bounds__(256) select_count_kernel(const double* qcol, int64_t NP, double thresh,
+                                                           int* counts) {
+  __shared__ int sh[256];
+  const int64_t r0 = (int64_t)blockIdx.x * SEL_ROWS + threadIdx.x * 4;
+  int c = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (r0 + i < NP && qcol[r0 + i] > thresh) ++c;
+  sh[threadIdx.x] = c;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) counts[blockIdx.x] = sh[0];
 }
 
-hipError_t launch_move_rows(double* qZ, int64_t ldq, int k, int K, const int64_t* idx, int64_t n,
-                            hipStream_t stream) {
-  if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(move_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, qZ, ldq, k, K, idx, n);
+__global__ void __launch_bounds__(256) select_compact_kernel(const double* qcol, int64_t NP, double thresh,
+                                                             const int64_t* offsets, int64_t* idx) {
+  __shared__ int sh[256];
+  const int64_t r0 = (int64_t)blockIdx.x * SEL_ROWS + threadIdx.x * 4;
+  bool f[4];
+  int c = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[i] = r0 + i < NP && qcol[r0 + i] > thresh;
+    c += f[i] ? 1 : 0;
+  }
+  sh[threadIdx.x] = c;
+  __syncthreads();
+  // inclusive Hillis-Steele scan over the 256 per-thread counts
+  for (int d = 1; d < 256; d <<= 1) {
+    const int v = (int)threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
+    __syncthreads();
+    sh[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int64_t pos = offsets[blockIdx.x] + sh[threadIdx.x] - c;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (f[i]) idx[pos++] = r0 + i;
+}
+
+hipError_t launch_select_count(const double* qcol, int64_t NP, double thresh, int* counts, hipStream_t stream) {
+  if (NP <= 0) return hipSuccess;
+  const unsigned nb = (unsigned)((NP + SEL_ROWS - 1) / SEL_ROWS);
+  hipLaunchKernelGGL(select_count_kernel, dim3(nb), dim3(256), 0, stream, qcol, NP, thresh, counts);
   return hipGetLastError();
 }
 
-__global__ void __launch_bounds__(256) project_kernel(const double* X, int DP, int64_t NP, const double* mv,
-                                                      unsigned char* out) {
-  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= NP) return;
-  double s = 0.0;
-  for (int d = 0; d < DP; ++d) s += (X[row * DP + d] - mv[d]) * mv[DP + d];
-  out[row] = s >= 0.0 ? 1 : 0;
+hipError_t launch_select_compact(const double* qcol, int64_t NP, double thresh, const int64_t* offsets, int64_t* idx,
+                                 hipStream_t stream) {
+  if (NP <= 0) return hipSuccess;
+  const unsigned nb = (unsigned)((NP + SEL_ROWS - 1) / SEL_ROWS);
+  hipLaunchKernelGGL(select_compact_kernel, dim3(nb), dim3(256), 0, stream, qcol, NP, thresh, offsets, idx);
+  return hipGetLastError();
+}
+int select_blocks(int64_t NP) { return (int)((NP + SEL_ROWS - 1) / SEL_ROWS); }
+
+// starts[j] = first position p with idx[p] >= goff[j]  (idx ascending), j = 0..J
+__global__ void group_starts_kernel(const int64_t* idx, int64_t M, const int64_t* goff, int J, int64_t* starts) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j > J) return;
+  const int64_t key = goff[j];
+  int64_t lo = 0, hi = M;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (idx[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  starts[j] = lo;
 }
 
-hipError_t launch_project(const double* X, int DP, int64_t NP, const double* mv, unsigned char* out,
-                          hipStream_t stream) {
+hipError_t launch_group_starts(const int64_t* idx, int64_t M, const int64_t* goff, int J, int64_t* starts,
+                               hipStream_t stream) {
+  hipLaunchKernelGGL(group_starts_kernel, dim3((unsigned)((J + 1 + 63) / 64)), dim3(64), 0, stream, idx, M, goff, J,
+                     starts);
+  return hipGetLastError();
+}
+
+// position p of the selection -> (group j, destination row in the gathered, re-padded layout)
+__device__ __forceinline__ int64_t sel_dst_row(int64_t p, const int64_t* starts, const int64_t* goff_sub, int J) {
+  int lo = 0, hi = J;  // largest j with starts[j] <= p
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (starts[mid] <= p) lo = mid; else hi = mid;
+  }
+  return goff_sub[lo] + (p - starts[lo]);
+}
+
+// Xk = X(rows idx): partobs' copy, device to device; one thread per (selected row, double2)
+__global__ void __launch_bounds__(256) gather_rows_kernel(const double* X, int DP, const int64_t* idx, int64_t M,
+                                                          const int64_t* starts, const int64_t* goff_sub, int J,
+                                                          double* Xdst) {
+  const int per = DP / 2;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= M * per) return;
+  const int64_t p = t / per;
+  const int c2 = (int)(t % per);
+  const int64_t dst = sel_dst_row(p, starts, goff_sub, J);
+  reinterpret_cast<double2*>(Xdst + dst * DP)[c2] = reinterpret_cast<const double2*>(X + idx[p] * DP)[c2];
+}
+
+hipError_t launch_gather_rows(const double* X, int DP, const int64_t* idx, int64_t M, const int64_t* starts,
+                              const int64_t* goff_sub, int J, double* Xdst, hipStream_t stream) {
+  if (M <= 0) return hipSuccess;
+  const int64_t n = M * (DP / 2);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, X, DP, idx, M, starts,
+                     goff_sub, J, Xdst);
+  return hipGetLastError();
+}
+
+// splitobs (src/distributions.cpp:373-385) + the initial split responsibilities (cluster.cpp:446-449):
+// q[0][row] = (sum_d (x_d - m_d) v_d >= 0), q[1][row] = 1 - q[0][row]; pad rows 0.  mv = [m(DP), v(DP)].
+__global__ void __launch_bounds__(256) split_init_kernel(const double* X, int DP, int D, int64_t NP, const int* rginfo,
+                                                         int64_t nrows, const double* mv, double* q, int64_t ldq) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= NP) return;
+  const bool ok = rginfo ? (row & 15) < (rginfo[row >> 4] & 31) : row < nrows;
+  double q0 = 0.0, q1 = 0.0;
+  if (ok) {
+    double s = 0.0;
+    for (int d = 0; d < D; ++d) s += (X[row * DP + d] - mv[d]) * mv[DP + d];
+    q0 = s >= 0.0 ? 1.0 : 0.0;
+    q1 = 1.0 - q0;
+  }
+  q[row] = q0;
+  q[ldq + row] = q1;
+}
+
+hipError_t launch_split_init(const double* X, int DP, int D, int64_t NP, const int* rginfo, int64_t nrows,
+                             const double* mv, double* q, int64_t ldq, hipStream_t stream) {
   if (NP <= 0) return hipSuccess;
-  hipLaunchKernelGGL(project_kernel, dim3((unsigned)((NP + 255) / 256)), dim3(256), 0, stream, X, DP, NP, mv, out);
+  hipLaunchKernelGGL(split_init_kernel, dim3((unsigned)((NP + 255) / 256)), dim3(256), 0, stream, X, DP, D, NP, rginfo,
+                     nrows, mv, q, ldq);
+  return hipGetLastError();
+}
+
+// auglabels (src/comutils.cpp:75-104) straight from the refined sub-problem: every selected row whose
+// second refined responsibility exceeds 0.5 moves its column-k mass to the new column K
+__global__ void __launch_bounds__(256) aug_from_sub_kernel(double* q, int64_t ldq, int k, int K, const int64_t* idx,
+                                                           int64_t M, const int64_t* starts, const int64_t* goff_sub,
+                                                           int J, const double* qsub1) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= M) return;
+  const int64_t sub = sel_dst_row(p, starts, goff_sub, J);
+  if (qsub1[sub] > 0.5) {
+    const int64_t r = idx[p];
+    q[(int64_t)K * ldq + r] = q[(int64_t)k * ldq + r];
+    q[(int64_t)k * ldq + r] = 0.0;
+  }
+}
+
+hipError_t launch_aug_from_sub(double* q, int64_t ldq, int k, int K, const int64_t* idx, int64_t M,
+                               const int64_t* starts, const int64_t* goff_sub, int J, const double* qsub1,
+                               hipStream_t stream) {
+  if (M <= 0) return hipSuccess;
+  hipLaunchKernelGGL(aug_from_sub_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, stream, q, ldq, k, K, idx, M,
+                     starts, goff_sub, J, qsub1);
   return hipGetLastError();
 }
 

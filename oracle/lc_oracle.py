@@ -629,6 +629,16 @@ def learnGMC(X, clusterprior=PRIORVAL, maxclusters=-1, sparse=False,
     return F, qZ, w, clusters
 
 
+def learnSGMC(X, clusterprior=PRIORVAL, maxclusters=-1, sparse=False,
+              verbose=False, trace=None, events=None):
+    """src/cluster.cpp:787-807 -> (F, qZ, weights, clusters)."""
+    w, clusters = [], []
+    Xl = [np.asarray(x, dtype=np.float64) for x in X]
+    F, qZ = cluster(Xl, w, clusters, clusterprior, maxclusters, sparse, verbose,
+                    Dirichlet, trace, events)
+    return F, qZ, w, clusters
+
+
 # ---------------------------------------------------------------------------
 # fixed-K harness (no reference entry point: vbem is file-static there,
 # cluster.cpp:177).  Used by parity tests and bench.py's cpu_baseline check.

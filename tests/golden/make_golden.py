@@ -145,7 +145,7 @@ def main():
     Xcat = np.vstack(X)
     out = {}
     for name, fn, arg in (("learnBGMM", o.learnBGMM, Xcat), ("learnVDP", o.learnVDP, Xcat),
-                          ("learnGMC", o.learnGMC, X)):
+                          ("learnGMC", o.learnGMC, X), ("learnSGMC", o.learnSGMC, X)):
         tr, ev = [], []
         F, qZ, w, cl = fn(arg, trace=tr, events=ev)
         wl = w if isinstance(w, list) else [w]

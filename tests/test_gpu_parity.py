@@ -231,3 +231,35 @@ def test_eloglike_matches_oracle():
         got = ctx.eloglike([c.nu for c in cl], [c.beta for c in cl], np.stack([c.m for c in cl]),
                            np.stack([c.iW for c in cl]), [c.logdW for c in cl], [N])[0]
     np.testing.assert_allclose(got, ref, rtol=1e-10, atol=1e-10)
+
+
+def test_learnSGMC_on_reference_test_data(xcat, xcat_traces):
+    """learnSGMC (include/libcluster.h:409-419): Dirichlet weights per group, same kernels."""
+    import libcluster_amd as lc
+
+    _check_learn(lc.learnSGMC(xcat["X"]), xcat_traces["learnSGMC"], [10] * 12)
+
+
+def test_cluster_on_device_resident_data_matches_oracle():
+    """Model selection end to end on data that never leaves the GPU (lc_ctx_synth + lc_cluster):
+    the split search's partobs / splitobs / auglabels run on the device.  Same rounds, K and F as the oracle."""
+    rng = np.random.default_rng(21)
+    N, D, Kt = 6000, 5, 4
+    mu = rng.normal(0, 6.0, (Kt, D))
+    L = np.stack([np.linalg.cholesky((lambda B: B @ B.T / D + 0.5 * np.eye(D))(rng.normal(size=(D, D))))
+                  for _ in range(Kt)])
+    with capi.Context(0) as ctx:
+        ctx.synth(N, D, Kt, mu, L, 77, 0, 0.9)
+        X = ctx.get_rows(0, 0, N)
+        F, model = ctx.cluster(capi.W_STICKBREAK, nthreads=4)
+        rounds = model.rounds()
+        K = model.dims()[1]
+        q = ctx.get_qz([N])[0]
+        model.close()
+    tr = []
+    Fo, qo, _, clo = o.learnVDP(X, trace=tr)
+    assert K == len(clo) and [k for k, _ in rounds] == [k for k, _ in tr]
+    for (_, a), (_, b) in zip(rounds, tr):
+        np.testing.assert_allclose(a, b, rtol=1e-8)
+    assert abs(F - Fo) <= 1e-8 * abs(Fo)
+    assert_q_close(q, qo, rtol=1e-6)
