@@ -335,6 +335,18 @@ void Context::allreduce(double* dbuf, int64_t count) {
   if (rc != 0) throw std::runtime_error("all-reduce hook failed with status " + std::to_string(rc));
 }
 
+double Context::allreduce_value(double v) {
+  if (!ar_fn_) return v;
+  LC_HIP(hipSetDevice(device_));
+  red_.reserve(1);
+  LC_HIP(hipMemcpyAsync(red_.p, &v, sizeof(double), hipMemcpyHostToDevice, stream_));
+  allreduce(red_.p, 1);
+  double out = 0.0;
+  LC_HIP(hipMemcpyAsync(&out, red_.p, sizeof(double), hipMemcpyDeviceToHost, stream_));
+  LC_HIP(hipStreamSynchronize(stream_));
+  return out;
+}
+
 void Context::estep(int K, const double* A, const double* m, const double* c, double* Fz, double* LLk, bool raw) {
   if (K < 1) throw std::invalid_argument("K must be >= 1");
   if (NP_ == 0 && !ar_fn_) {

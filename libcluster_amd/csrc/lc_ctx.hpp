@@ -82,6 +82,13 @@ class Context {
     ar_user_ = user;
   }
   bool distributed() const { return ar_fn_ != nullptr; }
+  // sum of one host value over all ranks (identity without a hook); via the device hook
+  double allreduce_value(double v);
+  // a context for a sub-problem of this one: same device, stream and all-reduce hook
+  void inherit_comm(const Context& parent) {
+    ar_fn_ = parent.ar_fn_;
+    ar_user_ = parent.ar_user_;
+  }
 
   // ---- qZ -----------------------------------------------------------------
   void qz_fill(int K, double value);  // K columns = value on valid rows

@@ -190,7 +190,6 @@ static bool prune_clusters(lcc::Context& ctx, Model& model, bool verbose) {
 static bool split_gr(lcc::Context& ctx, Model& model, std::vector<int>& tally, double F, const ClusterOptions& opt) {
   const int J = ctx.J(), K = (int)model.clusters.size(), D = ctx.D();
   if (K >= opt.maxclusters && opt.maxclusters >= 0) return false;
-  if (ctx.distributed()) throw std::runtime_error("the split search is single-process in this build");
   tally.resize(K, 0);
 
   // cluster free energies and data likelihoods (:391-415).  The data term
@@ -220,10 +219,13 @@ static bool split_gr(lcc::Context& ctx, Model& model, std::vector<int>& tally, d
 
     // partobs + splitobs per group (:438-453), on the device: ordered compaction of the rows with
     // q_k > 0.5, device-to-device gather into a fresh context, projection on the principal axis
+    // Row-sharded runs: every rank gathers its own selected rows; the counts that steer the
+    // control flow (Mtot, scount, N_k) are all-reduced, so all ranks take the same branches.
     ctx.select_rows(k, 0.5, sel);
-    const int64_t Mtot = sel.M;
+    const int64_t Mtot = (int64_t)std::llround(ctx.allreduce_value((double)sel.M));
     lch::eigpower(model.clusters[k].iW, D, eigv);  // distributions.cpp:380
     lcc::Context sub(ctx.device(), ctx.stream());
+    sub.inherit_comm(ctx);
     sub.set_data_gather(ctx, sel);
     sub.qz_init_split(model.clusters[k].m.data(), eigv.data());
     njs.assign((size_t)J * 2, 0.0);

@@ -1,0 +1,44 @@
+"""Row-sharded model selection across ranks on the GPU box.  Runs FIRST (file name) and only
+through child processes: this pytest process must not have touched the GPU when it starts them."""
+import json
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+pytestmark = pytest.mark.gpu
+
+
+def _run(cmd, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=e, cwd=str(ROOT))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = [x for x in r.stdout.splitlines() if x.startswith("RESULT ")][-1]
+    return json.loads(line[len("RESULT "):])
+
+
+def test_two_rank_cluster_equals_single_rank(lib):
+    """cluster() (VBEM + prune + split search) with rows sharded over two ranks -- all-reduced
+    statistics, Fz, LL_k, selection counts -- takes the same decisions and reaches the same F as one rank."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = str(ROOT / "tools" / "dist_cluster_check.py")
+    args = ["30000", "6", "5"]
+    one = _run([sys.executable, script, *args])
+    two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                "--master-addr", "127.0.0.1", "--master-port", str(port), script, *args],
+               {"LC_DIST_BACKEND": "gloo", "LC_ALL_RANKS_ON_GPU0": "1"})
+    assert two["world"] == 2 and one["world"] == 1
+    assert one["K"] == two["K"] == 5
+    assert [k for k, _ in one["rounds"]] == [k for k, _ in two["rounds"]]
+    for (_, a), (_, b) in zip(one["rounds"], two["rounds"]):
+        np.testing.assert_allclose(a, b, rtol=1e-10)
+    assert abs(one["F"] - two["F"]) <= 1e-10 * abs(one["F"])
+    np.testing.assert_allclose(one["N"], two["N"], rtol=1e-9)

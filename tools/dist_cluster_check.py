@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Model selection (lc_cluster) on row-sharded synthetic data, one process per rank.
+
+    python tools/dist_cluster_check.py N D K                      # single rank
+    LC_DIST_BACKEND=gloo LC_ALL_RANKS_ON_GPU0=1 python -m torch.distributed.run --nproc-per-node 2 \
+        --master-addr 127.0.0.1 --master-port P tools/dist_cluster_check.py N D K
+
+Rank r generates rows [r*N/W, (r+1)*N/W) of the same Philox stream, so every world size sees the
+same data set; rank 0 prints one JSON line (F, K, rounds).  With nccl (default) ranks use their own
+GPU; gloo + LC_ALL_RANKS_ON_GPU0 exercises the multi-rank path on a 1-GPU box."""
+import json
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import torch  # noqa: E402
+
+from libcluster_amd import capi  # noqa: E402
+from libcluster_amd import dist as lcd  # noqa: E402
+
+N, D, Kt = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+dev = 0 if os.environ.get("LC_ALL_RANKS_ON_GPU0") else int(os.environ.get("LOCAL_RANK", "0"))
+torch.cuda.set_device(dev)
+if world > 1:
+    import torch.distributed as dist
+
+    backend = os.environ.get("LC_DIST_BACKEND", "nccl")
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group(backend)
+rng = np.random.default_rng(3)
+mu = rng.normal(0, 5.0, (Kt, D))
+L = np.stack([np.linalg.cholesky((lambda B: B @ B.T / D + 0.5 * np.eye(D))(rng.normal(size=(D, D)))) for _ in range(Kt)])
+lo, hi = lcd.shard_rows(N, world, rank)
+with capi.Context(dev, torch.cuda.current_stream().cuda_stream) as ctx:
+    ctx.synth(hi - lo, D, Kt, mu, L, 4242, lo, 0.9)
+    if world > 1:
+        ctx.set_allreduce(lcd.make_device_hook(dev))
+    F, model = ctx.cluster(capi.W_DIRICHLET, nthreads=4)
+    out = {"world": world, "F": F, "K": model.dims()[1], "rounds": model.rounds(),
+           "N": [model.cluster(k)["N"] for k in range(model.dims()[1])]}
+    model.close()
+if rank == 0:
+    print("RESULT " + json.dumps(out), flush=True)
+if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
