@@ -39,8 +39,8 @@ CONFIGS = {
     "2": dict(N=1_000_000, D=16, K=8, w="Dirichlet", seed=1002, label="BASELINE configs[1]: BGMM N=1M D=16 K=8"),
     "3": dict(N=10_000_000, D=64, K=32, w="StickBreak", seed=1003,
               label="BASELINE configs[2]: VDP N=10M D=64 K=32"),
-    "5": dict(N=4_000_000, D=128, K=64, w="Dirichlet", seed=1005,
-              label="BASELINE configs[4] shape per GPU (single group): N=4M D=128 K=64"),
+    "5": dict(N=4_000_000, D=128, K=64, w="GDirichlet", seed=1005, J=8,
+              label="BASELINE configs[4] per GPU: GMC, 8 groups x 500k rows, D=128 K=64 (64 groups on 8 GPUs)"),
     "tiny": dict(N=200_000, D=16, K=4, w="Dirichlet", seed=7, label="smoke: N=200k D=16 K=4"),
 }
 
@@ -68,7 +68,7 @@ def cpu_baseline(ctx, model, cfg, wkind_name, sample_rows):
     import lc_oracle_c as oc
 
     D, K = cfg["D"], cfg["K"]
-    n = min(sample_rows, cfg["N"])
+    n = min(sample_rows, cfg["N"] // cfg.get("J", 1))  # rows of group 0
     X = ctx.get_rows(0, 0, n)
     cl = [model.cluster(k) for k in range(K)]
     el, _ = model.weights(0)
@@ -97,28 +97,38 @@ def cpu_baseline(ctx, model, cfg, wkind_name, sample_rows):
     }
 
 
+def group_mix(cfg, gids):
+    """Per-group mixing proportions Dir(0.5 * 1_K), a function of the GLOBAL group id."""
+    return np.stack([np.random.default_rng([cfg["seed"], int(g)]).dirichlet(np.full(cfg["K"], 0.5)) for g in gids])
+
+
 def parity(capi, cfg, wkind, mu, L, device, rows=20000, iters=3):
     """Free-energy / qZ delta of the GPU path vs the numpy oracle on identical inputs
-    (the first `rows` rows of the Philox stream, same initial qZ)."""
+    (the first `rows` rows of the Philox stream of every group, same initial qZ)."""
     sys.path.insert(0, str(ROOT / "oracle"))
     import lc_oracle as o
 
-    D, K = cfg["D"], cfg["K"]
+    D, K, J = cfg["D"], cfg["K"], cfg.get("J", 1)
+    nj = [rows // J] * J
     with capi.Context(device) as c2:
-        c2.synth(rows, D, K, mu, L, cfg["seed"], 0, 0.9)
-        X = c2.get_rows(0, 0, rows)
-        q0 = c2.get_qz([rows])[0]
+        if J == 1:
+            c2.synth(rows, D, K, mu, L, cfg["seed"], 0, 0.9)
+        else:
+            c2.synth_groups(nj, D, K, mu, L, cfg["seed"], mix=group_mix(cfg, range(J)), group_ids=list(range(J)))
+        X = [c2.get_rows(j, 0, nj[j]) for j in range(J)]
+        q0 = c2.get_qz(nj)
         F, tr, m = c2.vbem(wkind, fixed_iters=iters, nthreads=8)
-        q = c2.get_qz([rows])[0]
+        q = c2.get_qz(nj)
         m.close()
-    wf = {"Dirichlet": o.Dirichlet, "StickBreak": o.StickBreak}[cfg["w"]]
-    Ftr, _, qT, _, _ = o.vbem_fixed([X], [q0], wf, 1.0, iters)
-    big = qT[0] > 1e-12
+    wf = {"Dirichlet": o.Dirichlet, "StickBreak": o.StickBreak, "GDirichlet": o.GDirichlet}[cfg["w"]]
+    Ftr, _, qT, _, _ = o.vbem_fixed(X, q0, wf, 1.0, iters)
+    q, qT = np.vstack(q), np.vstack(qT)
+    big = qT > 1e-12
     return {
         "rows": rows, "iters": iters, "F_gpu": float(tr[-1]), "F_cpu": float(Ftr[-1]),
         "rel_dF": float(abs(tr[-1] - Ftr[-1]) / abs(Ftr[-1])),
-        "max_rel_dqZ": float(np.max(np.abs(q[big] - qT[0][big]) / qT[0][big])),
-        "max_abs_dqZ": float(np.max(np.abs(q - qT[0]))),
+        "max_rel_dqZ": float(np.max(np.abs(q[big] - qT[big]) / qT[big])),
+        "max_abs_dqZ": float(np.max(np.abs(q - qT))),
     }
 
 
@@ -164,13 +174,19 @@ def main():
     if args.rows:
         cfg["N"] = args.rows
     N, D, K = cfg["N"], cfg["D"], cfg["K"]
-    wkind = {"Dirichlet": capi.W_DIRICHLET, "StickBreak": capi.W_STICKBREAK}[cfg["w"]]
+    wkind = {"Dirichlet": capi.W_DIRICHLET, "StickBreak": capi.W_STICKBREAK, "GDirichlet": capi.W_GDIRICHLET}[cfg["w"]]
+    J = cfg.get("J", 1)
     mu, L = mixture(D, K, cfg["seed"])
     nthreads = max(1, min(32, (os.cpu_count() or 2) // max(1, world)))
 
     stream = torch.cuda.current_stream().cuda_stream
     ctx = capi.Context(local_rank, stream)
-    ctx.synth(N, D, K, mu, L, cfg["seed"], rank * N, 0.9)
+    if J == 1:
+        ctx.synth(N, D, K, mu, L, cfg["seed"], rank * N, 0.9)  # this rank's row block of the one stream
+    else:
+        gids = list(range(rank * J, (rank + 1) * J))  # whole groups per rank
+        ctx.synth_groups([N // J] * J, D, K, mu, L, cfg["seed"], mix=group_mix(cfg, gids), group_ids=gids)
+        ctx.set_sharding(True)
     if world > 1:
         ctx.set_allreduce(lcd.make_device_hook(local_rank))
 
@@ -223,7 +239,9 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": cfg["label"], "rows_per_gpu": N, "D": D, "K": K, "weights": cfg["w"],
-                       "seed": cfg["seed"], "parallelism": f"rows sharded x{world}, all-reduce of suff-stats"},
+                       "seed": cfg["seed"], "groups_per_gpu": J,
+                       "parallelism": (f"rows sharded x{world}" if J == 1 else f"whole groups sharded x{world}")
+                       + ", all-reduce of suff-stats"},
             "free_energy": float(F),
             "kernels": {"estep_ms": est, "suffstat_ms": sst, "estep_calls": kt["estep_calls"],
                         "suffstat_calls": kt["suffstat_calls"],

@@ -69,6 +69,11 @@ int lc_ctx_set_data(lc_ctx* ctx, int J, const double* const* Xj, const int64_t* 
  * row-major lower Cholesky factors (host pointers). */
 int lc_ctx_synth(lc_ctx* ctx, int64_t N, int D, int K, const double* mu, const double* L, uint64_t seed,
                  int64_t row_offset, double hard);
+/* Grouped variant (GMC workload): J groups of Nj rows; cdf = J x K cumulative mixing proportions of
+ * each group (NULL: uniform labels); group_ids = J global group ids used as Philox counters, so a group is
+ * identical on whichever rank generates it (NULL: 0..J-1). */
+int lc_ctx_synth_groups(lc_ctx* ctx, int J, const int64_t* Nj, int D, int K, const double* mu, const double* L,
+                        const double* cdf, uint64_t seed, const int64_t* group_ids, double hard);
 /* rows [row0,row0+n) of group j -> row-major n x D host buffer */
 int lc_ctx_get_rows(lc_ctx* ctx, int j, int64_t row0, int64_t n, double* out);
 
@@ -116,6 +121,11 @@ int lc_colsums(lc_ctx* ctx, double* Njk);
  * enqueued on `stream`; return 0 on success. */
 typedef int (*lc_allreduce_fn)(void* user, void* device_buf, int64_t count, void* stream);
 int lc_ctx_set_allreduce(lc_ctx* ctx, lc_allreduce_fn fn, void* user);
+/* How a distributed run is sharded.  0 (default): every rank holds rows of the SAME groups (BGMM / VDP row
+ * blocks; also GMC with every group split by rows) -- statistics and per-group counts are summed.
+ * 1: every rank holds WHOLE, different groups (GMC) -- cluster statistics, Fz, LL_k and the
+ * weights' free energy are summed, the per-group counts N_jk and the group weights stay local. */
+int lc_ctx_set_sharding(lc_ctx* ctx, int whole_groups);
 
 /* ---- kernel timing (hipEvents on the context's stream) ------------------ */
 int lc_ctx_timing_enable(lc_ctx* ctx, int on);

@@ -74,6 +74,9 @@ def lib() -> C.CDLL:
     L.lc_ctx_set_data.argtypes = [C.c_void_p, C.c_int, C.POINTER(c_double_p), c_int64_p, C.c_int, C.c_int64, C.c_int64]
     L.lc_ctx_synth.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, c_double_p, c_double_p, C.c_uint64,
                                C.c_int64, C.c_double]
+    L.lc_ctx_synth_groups.argtypes = [C.c_void_p, C.c_int, c_int64_p, C.c_int, C.c_int, c_double_p, c_double_p,
+                                      c_double_p, C.c_uint64, c_int64_p, C.c_double]
+    L.lc_ctx_set_sharding.argtypes = [C.c_void_p, C.c_int]
     L.lc_ctx_get_rows.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, c_double_p]
     L.lc_ctx_set_qz.argtypes = [C.c_void_p, C.c_int, c_double_p, C.c_int, C.c_int64, C.c_int64]
     L.lc_ctx_get_qz.argtypes = [C.c_void_p, C.c_int, c_double_p, C.c_int64, C.c_int64]
@@ -189,6 +192,23 @@ class Context:
         L = np.ascontiguousarray(L, dtype=np.float64)
         assert mu.shape == (K, D) and L.shape == (K, D, D)
         check(lib().lc_ctx_synth(self._h, N, D, K, dptr(mu), dptr(L), seed, row_offset, hard))
+
+    def synth_groups(self, Nj, D, K, mu, L, seed, mix=None, group_ids=None, hard=0.9):
+        """J groups of Nj rows; mix: (J, K) mixing proportions per group (None = uniform)."""
+        Nj = np.ascontiguousarray(Nj, dtype=np.int64)
+        J = Nj.size
+        mu = np.ascontiguousarray(mu, dtype=np.float64)
+        L = np.ascontiguousarray(L, dtype=np.float64)
+        cdf = None
+        if mix is not None:
+            cdf = np.ascontiguousarray(np.cumsum(np.asarray(mix, dtype=np.float64), axis=1))
+            assert cdf.shape == (J, K)
+        gid = None if group_ids is None else np.ascontiguousarray(group_ids, dtype=np.int64)
+        check(lib().lc_ctx_synth_groups(self._h, J, Nj.ctypes.data_as(c_int64_p), D, K, dptr(mu), dptr(L), dptr(cdf),
+                                        seed, None if gid is None else gid.ctypes.data_as(c_int64_p), hard))
+
+    def set_sharding(self, whole_groups: bool):
+        check(lib().lc_ctx_set_sharding(self._h, int(whole_groups)))
 
     def dims(self):
         J, D, K, N = C.c_int(), C.c_int(), C.c_int(), C.c_int64()

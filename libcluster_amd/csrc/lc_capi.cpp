@@ -129,6 +129,24 @@ int lc_ctx_synth(lc_ctx* ctx, int64_t N, int D, int K, const double* mu, const d
   });
 }
 
+int lc_ctx_synth_groups(lc_ctx* ctx, int J, const int64_t* Nj, int D, int K, const double* mu, const double* L,
+                        const double* cdf, uint64_t seed, const int64_t* group_ids, double hard) {
+  return guarded([&] {
+    need(ctx, "ctx");
+    need(Nj, "Nj");
+    need(mu, "mu");
+    need(L, "L");
+    ctx->impl.synth_groups(J, Nj, D, K, mu, L, cdf, seed, group_ids, 0, hard);
+  });
+}
+
+int lc_ctx_set_sharding(lc_ctx* ctx, int whole_groups) {
+  return guarded([&] {
+    need(ctx, "ctx");
+    ctx->impl.set_group_sharded(whole_groups != 0);
+  });
+}
+
 int lc_ctx_get_rows(lc_ctx* ctx, int j, int64_t row0, int64_t n, double* out) {
   return guarded([&] {
     need(ctx, "ctx");

@@ -118,13 +118,28 @@ void Context::set_data(int J, const double* const* Xj, const int64_t* Nj, int D,
 
 void Context::synth(int64_t N, int D, int K, const double* mu, const double* L, uint64_t seed, int64_t row_offset,
                     double hard) {
+  synth_groups(1, &N, D, K, mu, L, nullptr, seed, nullptr, row_offset, hard);
+}
+
+void Context::synth_groups(int J, const int64_t* Nj, int D, int K, const double* mu, const double* L,
+                           const double* cdf, uint64_t seed, const int64_t* group_ids, int64_t row_offset,
+                           double hard) {
   if (K < 1) throw std::invalid_argument("K must be >= 1");
-  build_layout(1, &N, D);
-  DevBuf<double> dmu, dL;
+  build_layout(J, Nj, D);
+  DevBuf<double> dmu, dL, dcdf;
+  DevBuf<int64_t> dgid;
+  if (group_ids) {
+    dgid.reserve((size_t)J);
+    LC_HIP(hipMemcpyAsync(dgid.p, group_ids, (size_t)J * sizeof(int64_t), hipMemcpyHostToDevice, stream_));
+  }
   dmu.reserve((size_t)K * D);
   dL.reserve((size_t)K * D * D);
   LC_HIP(hipMemcpyAsync(dmu.p, mu, (size_t)K * D * sizeof(double), hipMemcpyHostToDevice, stream_));
   LC_HIP(hipMemcpyAsync(dL.p, L, (size_t)K * D * D * sizeof(double), hipMemcpyHostToDevice, stream_));
+  if (cdf) {
+    dcdf.reserve((size_t)J * K);
+    LC_HIP(hipMemcpyAsync(dcdf.p, cdf, (size_t)J * K * sizeof(double), hipMemcpyHostToDevice, stream_));
+  }
   ensure_qz(qz_[cur_], K, false);
   qz_[cur_].K = K;
   lck::SynthLaunch a;
@@ -134,13 +149,18 @@ void Context::synth(int64_t N, int D, int K, const double* mu, const double* L, 
   a.X = X_.p;
   a.qZ = qz_[cur_].buf.p;
   a.ldq = NP_;
-  a.nrows = N;
+  a.nrows = Nj[0];
   a.NP = NP_;
   a.row_offset = row_offset;
   a.seed = seed;
   a.mu = dmu.p;
   a.L = dL.p;
   a.hard = hard;
+  a.rginfo = J > 1 ? rginfo_.p : nullptr;
+  a.goff = J > 1 ? goff_d_.p : nullptr;
+  a.cdf = cdf ? dcdf.p : nullptr;
+  a.gids = group_ids ? dgid.p : nullptr;
+  a.group_base = 0;
   LC_HIP(lck::launch_synth(a, stream_));
   LC_HIP(hipStreamSynchronize(stream_));
 }
@@ -336,15 +356,18 @@ void Context::allreduce(double* dbuf, int64_t count) {
 }
 
 double Context::allreduce_value(double v) {
-  if (!ar_fn_) return v;
+  allreduce_values(&v, 1);
+  return v;
+}
+
+void Context::allreduce_values(double* v, int n) {
+  if (!ar_fn_ || n <= 0) return;
   LC_HIP(hipSetDevice(device_));
-  red_.reserve(1);
-  LC_HIP(hipMemcpyAsync(red_.p, &v, sizeof(double), hipMemcpyHostToDevice, stream_));
-  allreduce(red_.p, 1);
-  double out = 0.0;
-  LC_HIP(hipMemcpyAsync(&out, red_.p, sizeof(double), hipMemcpyDeviceToHost, stream_));
+  red_.reserve((size_t)n);
+  LC_HIP(hipMemcpyAsync(red_.p, v, (size_t)n * sizeof(double), hipMemcpyHostToDevice, stream_));
+  allreduce(red_.p, n);
+  LC_HIP(hipMemcpyAsync(v, red_.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, stream_));
   LC_HIP(hipStreamSynchronize(stream_));
-  return out;
 }
 
 void Context::estep(int K, const double* A, const double* m, const double* c, double* Fz, double* LLk, bool raw) {
@@ -488,7 +511,9 @@ void Context::suffstat(const unsigned char* smask, double* Nk, double* xs, doubl
   } else {
     LC_HIP(hipMemsetAsync(ssout_.p, 0, nout * sizeof(double), stream_));
   }
-  allreduce(ssout_.p, (int64_t)nout);
+  // rows of the same groups on every rank: everything is summed.  Whole groups per rank: the K
+  // cluster records are summed, the per-group counts are local by construction.
+  allreduce(ssout_.p, group_sharded_ ? (int64_t)K * SS : (int64_t)nout);
   hss_.resize(nout);
   LC_HIP(hipMemcpyAsync(hss_.data(), ssout_.p, nout * sizeof(double), hipMemcpyDeviceToHost, stream_));
   LC_HIP(hipStreamSynchronize(stream_));
@@ -526,7 +551,7 @@ void Context::colsums(double* Njk) {
     LC_HIP(lck::launch_group_colsum(qz_[cur_].buf.p, NP_, K, goff_d_.p, J_, red_.p, stream_));
   else
     LC_HIP(hipMemsetAsync(red_.p, 0, (size_t)J_ * K * sizeof(double), stream_));
-  allreduce(red_.p, (int64_t)J_ * K);
+  if (!group_sharded_) allreduce(red_.p, (int64_t)J_ * K);
   LC_HIP(hipMemcpyAsync(Njk, red_.p, (size_t)J_ * K * sizeof(double), hipMemcpyDeviceToHost, stream_));
   LC_HIP(hipStreamSynchronize(stream_));
 }

@@ -63,6 +63,10 @@ class Context {
   // Single-group synthetic mixture generated on the device (+ initial qZ, K columns)
   void synth(int64_t N, int D, int K, const double* mu, const double* L, uint64_t seed, int64_t row_offset,
              double hard);
+  // J groups; cdf: J x K cumulative mixing proportions (host) or null; group_ids: J global ids (Philox
+  // counters: a group looks the same on whichever rank generates it) or null = 0..J-1
+  void synth_groups(int J, const int64_t* Nj, int D, int K, const double* mu, const double* L, const double* cdf,
+                    uint64_t seed, const int64_t* group_ids, int64_t row_offset, double hard);
   // rows [row0, row0+n) of group j -> row-major n x D host buffer
   void get_rows(int j, int64_t row0, int64_t n, double* out) const;
 
@@ -84,10 +88,17 @@ class Context {
   bool distributed() const { return ar_fn_ != nullptr; }
   // sum of one host value over all ranks (identity without a hook); via the device hook
   double allreduce_value(double v);
+  void allreduce_values(double* v, int n);
+  // Sharding of a distributed run: false (default) = every rank holds rows of the SAME groups (BGMM/VDP
+  // row blocks): counts are summed; true = every rank holds WHOLE, different groups (GMC): the per-group
+  // counts stay local, only cluster statistics and scalars are summed.
+  void set_group_sharded(bool on) { group_sharded_ = on; }
+  bool group_sharded() const { return group_sharded_ && ar_fn_ != nullptr; }
   // a context for a sub-problem of this one: same device, stream and all-reduce hook
   void inherit_comm(const Context& parent) {
     ar_fn_ = parent.ar_fn_;
     ar_user_ = parent.ar_user_;
+    group_sharded_ = parent.group_sharded_;
   }
 
   // ---- qZ -----------------------------------------------------------------
@@ -140,6 +151,7 @@ class Context {
   hipStream_t stream_;
   allreduce_fn ar_fn_ = nullptr;
   void* ar_user_ = nullptr;
+  bool group_sharded_ = false;
 
   int J_ = 0, D_ = 0, DP_ = 0;
   std::vector<int64_t> Nj_, goff_;  // goff_: padded row offsets, size J+1

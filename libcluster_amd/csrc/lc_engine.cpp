@@ -129,6 +129,7 @@ double vbem(lcc::Context& ctx, Model& model, const VbemOptions& opt) {
     // fenergy (:145-165)
     double Fw = 0.0, Fc = 0.0;
     for (const auto& w : model.weights) Fw += w.fenergy();
+    if (ctx.group_sharded()) Fw = ctx.allreduce_value(Fw);  // other ranks hold the other groups' weights
     std::vector<double> fck(K);
     parallel_for(K, opt.nthreads, 1.0 * D * D, [&](int k) { fck[k] = model.clusters[k].fenergy(); });
     for (int k = 0; k < K; ++k) Fc += fck[k];
@@ -197,14 +198,18 @@ static bool split_gr(lcc::Context& ctx, Model& model, std::vector<int>& tally, d
   std::vector<double> Njk((size_t)J * K);
   ctx.colsums(Njk.data());
   std::vector<GreedOrder> ord(K);
+  std::vector<double> wt(K);
   for (int k = 0; k < K; ++k) {
     ord[k].k = k;
     ord[k].tally = tally[k];
     ord[k].Fk = model.clusters[k].fenergy();
     const double cst = model.clusters[k].eloglike_const();
-    for (int j = 0; j < J; ++j) ord[k].Fk -= (model.weights[j].Elogpi[k] + cst) * Njk[(size_t)j * K + k];
-    ord[k].Fk -= model.LLk[k];
+    double wterm = 0.0;
+    for (int j = 0; j < J; ++j) wterm += (model.weights[j].Elogpi[k] + cst) * Njk[(size_t)j * K + k];
+    wt[k] = wterm;
   }
+  if (ctx.group_sharded()) ctx.allreduce_values(wt.data(), K);  // sum over the groups of all ranks
+  for (int k = 0; k < K; ++k) ord[k].Fk -= wt[k] + model.LLk[k];
   std::sort(ord.begin(), ord.end(), greedcomp);  // :418
 
   const double prior = model.clusters[0].prior;
@@ -232,6 +237,7 @@ static bool split_gr(lcc::Context& ctx, Model& model, std::vector<int>& tally, d
     sub.colsums(njs.data());
     double sc = 0.0;
     for (int j = 0; j < J; ++j) sc += njs[(size_t)j * 2];
+    if (ctx.group_sharded()) sc = ctx.allreduce_value(sc);
     const int64_t scount = (int64_t)std::llround(sc);
     if (scount < 2 || scount > Mtot - 2) continue;  // :456
 

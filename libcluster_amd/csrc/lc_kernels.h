@@ -96,6 +96,13 @@ struct SynthLaunch {
   const double* mu;        // [K x D]
   const double* L;         // [K x D x D] lower Cholesky factors, row-major
   double hard;             // q on the true label (0.9); rest (1-hard)/(K-1)
+  // grouped data (all null / 0 for a single group): row-group info, padded group offsets, per-group
+  // cumulative mixing proportions [J x K] (null = uniform labels), global id of local group 0
+  const int* rginfo = nullptr;
+  const int64_t* goff = nullptr;
+  const double* cdf = nullptr;
+  const int64_t* gids = nullptr;  // [J] global group ids (Philox counters), or null: group_base + local index
+  int64_t group_base = 0;
 };
 hipError_t launch_synth(const SynthLaunch& a, hipStream_t stream);
 

@@ -903,31 +903,58 @@ __device__ __forceinline__ double u01(uint32_t a, uint32_t b) {
   return ((double)v + 0.5) * (1.0 / 9007199254740992.0);
 }
 
-// 16 rows per 256-thread block; eps staged in LDS
+// 16 rows (one row-group => one group of observations) per 256-thread block; eps staged in LDS.
+// Philox counter = (group id << 40) + row inside the group (+ row_offset), so any shard of any group can
+// be regenerated independently.  Labels: uniform, or by inverse CDF of the group's mixing proportions.
 __global__ void __launch_bounds__(256) synth_kernel(SynthLaunch a) {
   extern __shared__ double eps[];  // [16][DP]
   __shared__ int zlab[16];
   const int DP = a.DP, D = a.D, K = a.K;
   const int64_t row0 = (int64_t)blockIdx.x * 16;
+  int grp = 0, nvalid;
+  if (a.rginfo) {
+    const int info = a.rginfo[blockIdx.x];
+    grp = info >> 5;
+    nvalid = info & 31;
+  } else {
+    const int64_t rem = a.nrows - row0;
+    nvalid = rem >= 16 ? 16 : (rem > 0 ? (int)rem : 0);
+  }
+  const int64_t ingrp0 = row0 - (a.goff ? a.goff[grp] : 0);  // row inside its group
+  const uint64_t gid = a.gids ? (uint64_t)a.gids[grp] : (uint64_t)(a.group_base + grp);
+  const uint64_t gbase = (gid << 40) + (uint64_t)(a.row_offset + ingrp0);
   const uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32);
   const int npair = (D + 1) / 2;
   for (int t = threadIdx.x; t < 16 * npair; t += 256) {
     const int r = t / npair, p = t % npair;
-    const uint64_t g = (uint64_t)(a.row_offset + row0 + r);
+    const uint64_t g = gbase + (uint64_t)r;
     uint32_t o[4];
     philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)p, 1u, k0, k1, o);
     const double u1 = u01(o[0], o[1]), u2 = u01(o[2], o[3]);
     const double rad = sqrt(-2.0 * log(u1));
-    double s, c;
-    sincos(6.283185307179586476925 * u2, &s, &c);
-    eps[r * DP + 2 * p] = rad * c;
-    if (2 * p + 1 < D) eps[r * DP + 2 * p + 1] = rad * s;
+    double sn, cs;
+    sincos(6.283185307179586476925 * u2, &sn, &cs);
+    eps[r * DP + 2 * p] = rad * cs;
+    if (2 * p + 1 < D) eps[r * DP + 2 * p + 1] = rad * sn;
   }
   if (threadIdx.x < 16) {
-    const uint64_t g = (uint64_t)(a.row_offset + row0 + threadIdx.x);
+    const uint64_t g = gbase + (uint64_t)threadIdx.x;
     uint32_t o[4];
     philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), 0u, 2u, k0, k1, o);
-    zlab[threadIdx.x] = (int)(o[0] % (uint32_t)K);
+    int z;
+    if (a.cdf) {
+      const double u = u01(o[0], o[1]);
+      const double* c = a.cdf + (int64_t)grp * K;
+      z = K - 1;
+      for (int k = 0; k < K - 1; ++k)
+        if (u < c[k]) {
+          z = k;
+          break;
+        }
+    } else {
+      z = (int)(o[0] % (uint32_t)K);
+    }
+    zlab[threadIdx.x] = z;
   }
   __syncthreads();
   for (int t = threadIdx.x; t < 16 * DP; t += 256) {
@@ -935,7 +962,7 @@ __global__ void __launch_bounds__(256) synth_kernel(SynthLaunch a) {
     const int64_t row = row0 + r;
     if (row >= a.NP) continue;
     double v = 0.0;
-    if (row < a.nrows && i < D) {
+    if (r < nvalid && i < D) {
       const int z = zlab[r];
       const double* Lz = a.L + ((int64_t)z * D + i) * D;
       v = a.mu[(int64_t)z * D + i];
@@ -949,7 +976,7 @@ __global__ void __launch_bounds__(256) synth_kernel(SynthLaunch a) {
       const int64_t row = row0 + r;
       if (row >= a.NP) continue;
       double q = 0.0;
-      if (row < a.nrows) q = K == 1 ? 1.0 : (k == zlab[r] ? a.hard : (1.0 - a.hard) / (K - 1));
+      if (r < nvalid) q = K == 1 ? 1.0 : (k == zlab[r] ? a.hard : (1.0 - a.hard) / (K - 1));
       a.qZ[(int64_t)k * a.ldq + row] = q;
     }
   }

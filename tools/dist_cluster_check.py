@@ -22,6 +22,7 @@ from libcluster_amd import capi  # noqa: E402
 from libcluster_amd import dist as lcd  # noqa: E402
 
 N, D, Kt = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+MODE = sys.argv[4] if len(sys.argv) > 4 else "rows"  # "rows": BGMM, row blocks; "groups": GMC, whole groups per rank
 rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 dev = 0 if os.environ.get("LC_ALL_RANKS_ON_GPU0") else int(os.environ.get("LOCAL_RANK", "0"))
 torch.cuda.set_device(dev)
@@ -36,12 +37,22 @@ if world > 1:
 rng = np.random.default_rng(3)
 mu = rng.normal(0, 5.0, (Kt, D))
 L = np.stack([np.linalg.cholesky((lambda B: B @ B.T / D + 0.5 * np.eye(D))(rng.normal(size=(D, D)))) for _ in range(Kt)])
-lo, hi = lcd.shard_rows(N, world, rank)
 with capi.Context(dev, torch.cuda.current_stream().cuda_stream) as ctx:
-    ctx.synth(hi - lo, D, Kt, mu, L, 4242, lo, 0.9)
+    if MODE == "rows":
+        lo, hi = lcd.shard_rows(N, world, rank)
+        ctx.synth(hi - lo, D, Kt, mu, L, 4242, lo, 0.9)
+        wkind = capi.W_DIRICHLET
+    else:
+        J = 6
+        sizes = [N // J + 37 * j for j in range(J)]
+        mix = np.random.default_rng(8).dirichlet(np.full(Kt, 0.5), J)  # per-group mixing proportions
+        mine = lcd.shard_groups(sizes, world, rank)
+        ctx.synth_groups([sizes[j] for j in mine], D, Kt, mu, L, 4242, mix=mix[mine], group_ids=mine)
+        ctx.set_sharding(True)
+        wkind = capi.W_GDIRICHLET
     if world > 1:
         ctx.set_allreduce(lcd.make_device_hook(dev))
-    F, model = ctx.cluster(capi.W_DIRICHLET, nthreads=4)
+    F, model = ctx.cluster(wkind, nthreads=4)
     out = {"world": world, "F": F, "K": model.dims()[1], "rounds": model.rounds(),
            "N": [model.cluster(k)["N"] for k in range(model.dims()[1])]}
     model.close()
