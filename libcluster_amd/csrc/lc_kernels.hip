@@ -473,34 +473,93 @@ __global__ void __launch_bounds__(256, (DP <= 64 ? 2 : 1)) suffstat_kernel(Suffs
     if (nk > 0) {
       const double* xb = xbuf + buf * XBUF + hi * LD + lo2;
       const double* qb = qbuf + ((buf * nwaves + wave) * CPW) * BR + hi;
-      const int nstep = (int)(((r1 - b0) < BR ? (r1 - b0) : BR) / 4);
-      for (int st = 0; st < nstep; ++st) {
-        // fragments: xr[jb][s] = x[row 4*st+hi][16*jb + 4*((blk+s)&3) + lo2]
-        double xr[NB][4];
+      if constexpr (DP > 64) {
+        // One wave per SIMD (the accumulators need > 256 registers): nothing else hides the LDS
+        // latency, so the step loop is software-pipelined by hand, unrolled by two with two register
+        // sets (unrotated fragments + q of a step) that swap roles -- no copies.  A step fetches its
+        // rotated fragments at the top (first needed after the unrotated MFMAs) and the unrotated
+        // fragments and q of the NEXT step; only the first step of a batch waits on LDS.  All BR/4
+        // steps run (rows past the chunk end were staged as zeros with q = 0); the last step's prefetch
+        // reads one step past the tile: inside the LDS allocation, never used.
+        double xA[NB], qA[CPW], xB[NB], qB[CPW];
 #pragma unroll
-        for (int jb = 0; jb < NB; ++jb)
+        for (int jb = 0; jb < NB; ++jb) xA[jb] = xb[16 * jb + 4 * blk];
 #pragma unroll
-          for (int s = 0; s < 4; ++s) xr[jb][s] = xb[st * 4 * LD + 16 * jb + 4 * ((blk + s) & 3)];
-#pragma unroll
-        for (int c = 0; c < CPW; ++c) {
-          const double q = qb[c * BR + st * 4];
-          double qx[NB];
+        for (int c = 0; c < CPW; ++c) qA[c] = qb[c * BR];
+        auto step = [&](int st, const double (&x0)[NB], const double (&q)[CPW], double (&x0n)[NB],
+                        double (&qn)[CPW]) {
+          double xr[NB][4];
 #pragma unroll
           for (int jb = 0; jb < NB; ++jb) {
-            qx[jb] = q * xr[jb][0];
-            sacc[c][jb] += qx[jb];
+            xr[jb][0] = x0[jb];
+#pragma unroll
+            for (int s2 = 1; s2 < 4; ++s2) xr[jb][s2] = xb[st * 4 * LD + 16 * jb + 4 * ((blk + s2) & 3)];
           }
-          nacc[c] += q;
-          int idx = 0;
 #pragma unroll
-          for (int jbp = 0; jbp < NB; ++jbp) {
+          for (int jb = 0; jb < NB; ++jb) x0n[jb] = xb[(st + 1) * 4 * LD + 16 * jb + 4 * blk];
 #pragma unroll
-            for (int jb = 0; jb <= jbp; ++jb) {
+          for (int c = 0; c < CPW; ++c) qn[c] = qb[c * BR + (st + 1) * 4];
 #pragma unroll
-              for (int s = 0; s < 4; ++s) {
-                if (s < 3 || jb < jbp) {
-                  acc[c][idx] = mfma4(xr[jbp][s], qx[jb], acc[c][idx]);
-                  ++idx;
+          for (int c = 0; c < CPW; ++c) {
+            double qx[NB];
+#pragma unroll
+            for (int jb = 0; jb < NB; ++jb) {
+              qx[jb] = q[c] * xr[jb][0];
+              sacc[c][jb] += qx[jb];
+            }
+            nacc[c] += q[c];
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {  // unrotated operands first
+              int idx = 0;
+#pragma unroll
+              for (int jbp = 0; jbp < NB; ++jbp)
+#pragma unroll
+                for (int jb = 0; jb <= jbp; ++jb)
+#pragma unroll
+                  for (int s2 = 0; s2 < 4; ++s2)
+                    if (s2 < 3 || jb < jbp) {
+                      if ((pass == 0) == (s2 == 0)) acc[c][idx] = mfma4(xr[jbp][s2], qx[jb], acc[c][idx]);
+                      ++idx;
+                    }
+            }
+          }
+        };
+        static_assert((BR / 4) % 2 == 0, "step loop is unrolled by two");
+#pragma unroll 1
+        for (int st = 0; st < BR / 4; st += 2) {
+          step(st, xA, qA, xB, qB);
+          step(st + 1, xB, qB, xA, qA);
+        }
+      } else {
+        const int nstep = (int)(((r1 - b0) < BR ? (r1 - b0) : BR) / 4);
+        for (int st = 0; st < nstep; ++st) {
+          // fragments: xr[jb][s] = x[row 4*st+hi][16*jb + 4*((blk+s)&3) + lo2]
+          double xr[NB][4];
+  #pragma unroll
+          for (int jb = 0; jb < NB; ++jb)
+  #pragma unroll
+            for (int s = 0; s < 4; ++s) xr[jb][s] = xb[st * 4 * LD + 16 * jb + 4 * ((blk + s) & 3)];
+  #pragma unroll
+          for (int c = 0; c < CPW; ++c) {
+            const double q = qb[c * BR + st * 4];
+            double qx[NB];
+  #pragma unroll
+            for (int jb = 0; jb < NB; ++jb) {
+              qx[jb] = q * xr[jb][0];
+              sacc[c][jb] += qx[jb];
+            }
+            nacc[c] += q;
+            int idx = 0;
+  #pragma unroll
+            for (int jbp = 0; jbp < NB; ++jbp) {
+  #pragma unroll
+              for (int jb = 0; jb <= jbp; ++jb) {
+  #pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                  if (s < 3 || jb < jbp) {
+                    acc[c][idx] = mfma4(xr[jbp][s], qx[jb], acc[c][idx]);
+                    ++idx;
+                  }
                 }
               }
             }
