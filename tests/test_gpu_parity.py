@@ -263,3 +263,32 @@ def test_cluster_on_device_resident_data_matches_oracle():
         np.testing.assert_allclose(a, b, rtol=1e-8)
     assert abs(F - Fo) <= 1e-8 * abs(Fo)
     assert_q_close(q, qo, rtol=1e-6)
+
+
+def test_random_shapes_sweep():
+    """Many small random shapes (D = 1..128, K = 1..70, J = 1..5, ragged and tiny groups, rows not a
+    multiple of 16/32/256) through suff-stats + E-step + one fixed-K VBEM iteration, against the oracle."""
+    rng = np.random.default_rng(20261001)
+    for trial in range(40):
+        D = int(rng.choice([1, 2, 3, 5, 15, 16, 17, 31, 32, 33, 47, 64, 65, 100, 128]))
+        K = int(rng.choice([1, 2, 3, 4, 7, 8, 9, 16, 31, 33, 70]))
+        J = int(rng.integers(1, 6))
+        Ns = [int(rng.choice([1, 2, 15, 16, 17, 31, 33, 100, 257, 600])) for _ in range(J)]
+        if sum(Ns) * K * D > 6_000_000:
+            Ns = [min(n, 64) for n in Ns]
+        X = [rng.normal(size=(n, D)) * 1.3 + rng.integers(0, 3, (n, 1)) for n in Ns]
+        q0 = [rng.dirichlet(np.ones(K) * 0.5, n) for n in Ns]
+        wname = ["Dirichlet", "StickBreak", "GDirichlet"][trial % 3]
+        Ftr, Fztr, qT, _, clT = o.vbem_fixed(X, q0, WF[wname], 1.0, 1)
+        with capi.Context(0) as ctx:
+            ctx.set_data(X)
+            ctx.set_qz(q0)
+            F, tr, model = ctx.vbem(WK[wname], fixed_iters=1)
+            q = ctx.get_qz(Ns)
+            Ng = [model.cluster(k)["N"] for k in range(K)]
+            model.close()
+        msg = f"trial {trial}: D={D} K={K} Ns={Ns} {wname}"
+        assert abs(tr[0] - Ftr[0]) <= 1e-9 * abs(Ftr[0]), msg
+        np.testing.assert_allclose(Ng, [c.getN() for c in clT], rtol=1e-10, atol=1e-12, err_msg=msg)
+        for j in range(J):
+            assert_q_close(q[j], qT[j], rtol=1e-8)
