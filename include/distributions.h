@@ -42,6 +42,13 @@ struct CtxGuard {
   CtxGuard() : c(0) { check(lc_ctx_create(0, 0, &c)); }
   ~CtxGuard() { lc_ctx_destroy(c); }
 };
+inline void upload(lc_ctx* c, const lcmat::MatrixXd& X) {
+  int64_t rs, cs;
+  lcmat::strides(X, rs, cs);
+  const double* p = X.data();
+  const int64_t n = (int64_t)X.rows();
+  check(lc_ctx_set_data(c, 1, &p, &n, (int)X.cols(), rs, cs));
+}
 }  // namespace detail
 
 /* ---- weights: reference distributions.h:60-189 --------------------------- */
@@ -139,7 +146,7 @@ class GaussWish : public ClusterDist {
     if ((unsigned)X.cols() != D) throw std::invalid_argument("Mismatched dims. of cluster params and obs.!");
     if (qZk.rows() != X.rows()) throw std::invalid_argument("qZk and X ar not the same length!");
     detail::CtxGuard g;
-    upload(g.c, X);
+    detail::upload(g.c, X);
     detail::check(lc_ctx_set_qz(g.c, 0, qZk.data(), 1, 1, (int64_t)qZk.size()));
     double n = 0.0;
     std::vector<double> xs(D), xxs((size_t)D * D);
@@ -172,7 +179,7 @@ class GaussWish : public ClusterDist {
   lcmat::VectorXd Eloglike(const lcmat::MatrixXd& X) const {
     if ((unsigned)X.cols() != D) throw std::invalid_argument("Arguments do not have the same dimensionality");
     detail::CtxGuard g;
-    upload(g.c, X);
+    detail::upload(g.c, X);
     detail::check(lc_eloglike(g.c, 1, &nu, &beta, m_.data(), iW_.data(), &logdW));
     lcmat::VectorXd out(X.rows());
     detail::check(lc_ctx_get_qz(g.c, 0, out.data(), 1, (int64_t)X.rows()));
@@ -239,19 +246,194 @@ class GaussWish : public ClusterDist {
     m_.assign(m, m + D);
     iW_.assign(iW, iW + (size_t)D * D);
   }
+  /* additive: cluster k of a learnt model (used by libcluster.h's learners) */
+  static GaussWish from_model_(lc_model* mdl, int k, double clusterprior, unsigned D, double Fk) {
+    std::vector<double> m(D), iW((size_t)D * D);
+    double N, nu, beta, logdW;
+    detail::check(lc_model_cluster(mdl, k, &N, m.data(), 0, &nu, &beta, iW.data(), &logdW));
+    GaussWish c(clusterprior, D);
+    c.set_posterior_(N, nu, beta, m.data(), iW.data(), logdW, Fk);
+    return c;
+  }
 
  private:
-  static void upload(lc_ctx* c, const lcmat::MatrixXd& X) {
-    int64_t rs, cs;
-    lcmat::strides(X, rs, cs);
-    const double* p = X.data();
-    const int64_t n = (int64_t)X.rows();
-    detail::check(lc_ctx_set_data(c, 1, &p, &n, (int)X.cols(), rs, cs));
-  }
   double nu, beta, logdW, F_;
   std::vector<double> m_, iW_; /* row-major D x D */
   double N_s;
   std::vector<double> x_s, xx_s;
+};
+
+/* ---- diagonal Gaussian clusters: reference distributions.h:334-399, distributions.cpp:405-517 ------------- */
+class NormGamma : public ClusterDist {
+ public:
+  NormGamma(const double clustwidth, const unsigned int D) : ClusterDist(clustwidth, D), F_(0.0), cst_(0.0) {
+    if (clustwidth <= 0) throw std::invalid_argument("clustwidth must be > 0!"); /* distributions.cpp:414-415 */
+    clearobs();
+  }
+
+  /* distributions.cpp:426-438, accumulated on the GPU (diagonal suff-stat kernel) */
+  void addobs(const lcmat::VectorXd& qZk, const lcmat::MatrixXd& X) {
+    if ((unsigned)X.cols() != D) throw std::invalid_argument("Mismatched dims. of cluster params and obs.!");
+    if (qZk.rows() != X.rows()) throw std::invalid_argument("qZk and X ar not the same length!");
+    detail::CtxGuard g;
+    detail::upload(g.c, X);
+    detail::check(lc_ctx_set_qz(g.c, 0, qZk.data(), 1, 1, (int64_t)qZk.size()));
+    double n = 0.0;
+    std::vector<double> xs(D), xxs(D);
+    detail::check(lc_suffstat_diag(g.c, 0, &n, xs.data(), xxs.data(), 0));
+    N_s += n;
+    for (unsigned d = 0; d < D; ++d) { x_s[d] += xs[d]; xx_s[d] += xxs[d]; }
+  }
+
+  void update() { /* distributions.cpp:441-464 */
+    detail::check(lc_ng_mstep(prior, (int)D, N_s, x_s.data(), xx_s.data(), &nu, &beta, m_.data(), L_.data(), &logL,
+                              &F_, &cst_));
+    N = N_s;
+  }
+
+  void clearobs() { /* distributions.cpp:467-480 */
+    N_s = 0.0;
+    x_s.assign(D, 0.0);
+    xx_s.assign(D, 0.0);
+    m_.assign(D, 0.0);
+    L_.assign(D, 0.0);
+    detail::check(lc_ng_mstep(prior, (int)D, 0.0, x_s.data(), xx_s.data(), &nu, &beta, m_.data(), L_.data(), &logL,
+                              &F_, &cst_));
+  }
+
+  /* distributions.cpp:483-492, evaluated by the diagonal E-step kernel in raw mode */
+  lcmat::VectorXd Eloglike(const lcmat::MatrixXd& X) const {
+    if ((unsigned)X.cols() != D) throw std::invalid_argument("Arguments do not have the same dimensionality");
+    std::vector<double> w2(D), w1(D, 0.0);
+    for (unsigned d = 0; d < D; ++d) w2[d] = -0.5 * nu / L_[d];
+    detail::CtxGuard g;
+    detail::upload(g.c, X);
+    detail::check(lc_estep_diag(g.c, 1, m_.data(), w2.data(), w1.data(), &cst_, 1, 0, 0));
+    lcmat::VectorXd out(X.rows());
+    detail::check(lc_ctx_get_qz(g.c, 0, out.data(), 1, (int64_t)X.rows()));
+    return out;
+  }
+
+  ArrayXb splitobs(const lcmat::MatrixXd& X) const { /* distributions.cpp:495-505 */
+    unsigned ax = 0;
+    for (unsigned d = 1; d < D; ++d)
+      if (L_[d] > L_[ax]) ax = d;
+    ArrayXb out(X.rows());
+    for (std::ptrdiff_t r = 0; r < X.rows(); ++r) out(r) = (X(r, ax) - m_[ax]) >= 0.0;
+    return out;
+  }
+
+  double fenergy() const { return F_; } /* distributions.cpp:508-517, evaluated at update() */
+
+  lcmat::RowVectorXd getmean() const { /* distributions.h:370 */
+    lcmat::RowVectorXd r(D);
+    for (unsigned d = 0; d < D; ++d) r(d) = m_[d];
+    return r;
+  }
+  lcmat::RowVectorXd getcov() const { /* distributions.h:375: L * nu, as the reference defines it */
+    lcmat::RowVectorXd r(D);
+    for (unsigned d = 0; d < D; ++d) r(d) = L_[d] * nu;
+    return r;
+  }
+  virtual ~NormGamma() {}
+
+  static NormGamma from_model_(lc_model* mdl, int k, double clusterprior, unsigned D, double Fk) {
+    NormGamma c(clusterprior, D);
+    detail::check(lc_model_cluster(mdl, k, &c.N, c.m_.data(), 0, &c.nu, &c.beta, c.L_.data(), &c.logL));
+    c.F_ = Fk;
+    /* distributions.cpp:486-488 */
+    c.cst_ = 0.5 * (D * (lc_digamma(c.nu) - std::log(2 * 3.14159265358979323846) - 1.0 / c.beta) - c.logL);
+    return c;
+  }
+
+ private:
+  double nu, beta, logL, F_, cst_;
+  std::vector<double> m_, L_;
+  double N_s;
+  std::vector<double> x_s, xx_s;
+};
+
+/* ---- exponential clusters: reference distributions.h:406-456, distributions.cpp:524-589 ------------------- */
+class ExpGamma : public ClusterDist {
+ public:
+  ExpGamma(const double obsmag, const unsigned int D) : ClusterDist(obsmag, D), F_(0.0), cst_(0.0) { clearobs(); }
+
+  /* distributions.cpp:533-542 */
+  void addobs(const lcmat::VectorXd& qZk, const lcmat::MatrixXd& X) {
+    if ((unsigned)X.cols() != D) throw std::invalid_argument("Mismatched dims. of cluster params and obs.!");
+    if (qZk.rows() != X.rows()) throw std::invalid_argument("qZk and X ar not the same length!");
+    detail::CtxGuard g;
+    detail::upload(g.c, X);
+    detail::check(lc_ctx_set_qz(g.c, 0, qZk.data(), 1, 1, (int64_t)qZk.size()));
+    double n = 0.0;
+    std::vector<double> xs(D);
+    detail::check(lc_suffstat_diag(g.c, 0, &n, xs.data(), 0, 0));
+    N_s += n;
+    for (unsigned d = 0; d < D; ++d) x_s[d] += xs[d];
+  }
+
+  void update() { /* distributions.cpp:545-552 */
+    detail::check(lc_eg_mstep(prior, (int)D, N_s, x_s.data(), &a, ib_.data(), &logb, &F_, &cst_));
+    N = N_s;
+  }
+
+  void clearobs() { /* distributions.cpp:555-565 */
+    N_s = 0.0;
+    x_s.assign(D, 0.0);
+    ib_.assign(D, 0.0);
+    detail::check(lc_eg_mstep(prior, (int)D, 0.0, x_s.data(), &a, ib_.data(), &logb, &F_, &cst_));
+  }
+
+  /* distributions.cpp:568-572 */
+  lcmat::VectorXd Eloglike(const lcmat::MatrixXd& X) const {
+    if ((unsigned)X.cols() != D) throw std::invalid_argument("Arguments do not have the same dimensionality");
+    std::vector<double> z(D, 0.0), w1(D);
+    for (unsigned d = 0; d < D; ++d) w1[d] = -a * ib_[d];
+    detail::CtxGuard g;
+    detail::upload(g.c, X);
+    detail::check(lc_estep_diag(g.c, 1, z.data(), z.data(), w1.data(), &cst_, 1, 0, 0));
+    lcmat::VectorXd out(X.rows());
+    detail::check(lc_ctx_get_qz(g.c, 0, out.data(), 1, (int64_t)X.rows()));
+    return out;
+  }
+
+  ArrayXb splitobs(const lcmat::MatrixXd& X) const { /* distributions.cpp:575-581 */
+    std::vector<double> xv(X.rows());
+    double mean = 0.0;
+    for (std::ptrdiff_t r = 0; r < X.rows(); ++r) {
+      double s = 0.0;
+      for (unsigned d = 0; d < D; ++d) s += X(r, d) * (a * ib_[d]);
+      xv[r] = s;
+      mean += s;
+    }
+    if (X.rows() > 0) mean /= (double)X.rows();
+    ArrayXb out(X.rows());
+    for (std::ptrdiff_t r = 0; r < X.rows(); ++r) out(r) = xv[r] > mean;
+    return out;
+  }
+
+  double fenergy() const { return F_; } /* distributions.cpp:584-589 */
+
+  lcmat::RowVectorXd getrate() { /* distributions.h:433 */
+    lcmat::RowVectorXd r(D);
+    for (unsigned d = 0; d < D; ++d) r(d) = a * ib_[d];
+    return r;
+  }
+  virtual ~ExpGamma() {}
+
+  static ExpGamma from_model_(lc_model* mdl, int k, double clusterprior, unsigned D, double Fk) {
+    ExpGamma c(clusterprior, D);
+    detail::check(lc_model_cluster(mdl, k, &c.N, 0, 0, &c.a, 0, c.ib_.data(), &c.logb));
+    c.F_ = Fk;
+    c.cst_ = D * lc_digamma(c.a) - c.logb; /* distributions.cpp:570 */
+    return c;
+  }
+
+ private:
+  double a, logb, F_, cst_;
+  std::vector<double> ib_;
+  double N_s;
+  std::vector<double> x_s;
 };
 
 }  // namespace distributions

@@ -38,9 +38,9 @@ struct ModelGuard {
   ModelGuard() : m(0) {}
   ~ModelGuard() { if (m) lc_model_free(m); }
 };
-template <class W>
+template <class W, class C>
 inline double run(int algo, const vMatrixXd& X, vMatrixXd& qZ, std::vector<W>& weights,
-                  std::vector<distributions::GaussWish>& clusters, double wprior, double clusterprior, int maxclusters,
+                  std::vector<C>& clusters, double wprior, double clusterprior, int maxclusters,
                   bool sparse, bool verbose, unsigned nthreads) {
   using distributions::detail::check;
   const int J = (int)X.size();
@@ -91,15 +91,9 @@ inline double run(int algo, const vMatrixXd& X, vMatrixXd& qZ, std::vector<W>& w
     weights[j].update(Nk); /* same arithmetic as inside the learner => identical Elogweight() */
   }
   clusters.clear();
-  std::vector<double> m(D), iW((size_t)D * D), Fc(K), Fw(J);
+  std::vector<double> Fc(K), Fw(J);
   check(lc_model_fenergy(g.m, Fw.data(), Fc.data()));
-  for (int k = 0; k < K; ++k) {
-    double N, nu, beta, logdW;
-    check(lc_model_cluster(g.m, k, &N, m.data(), 0, &nu, &beta, iW.data(), &logdW));
-    distributions::GaussWish c(clusterprior, (unsigned)D);
-    c.set_posterior_(N, nu, beta, m.data(), iW.data(), logdW, Fc[k]);
-    clusters.push_back(c);
-  }
+  for (int k = 0; k < K; ++k) clusters.push_back(C::from_model_(g.m, k, clusterprior, (unsigned)D, Fc[k]));
   return F;
 }
 }  // namespace detail
@@ -147,6 +141,52 @@ inline double learnSGMC(const vMatrixXd& X, vMatrixXd& qZ, std::vector<distribut
                         const int maxclusters = -1, const bool sparse = false, const bool verbose = false,
                         const unsigned int nthreads = detail::default_threads()) {
   return detail::run(LC_ALGO_SGMC, X, qZ, weights, clusters, 1.0, clusterprior, maxclusters, sparse, verbose,
+                     nthreads);
+}
+
+/* include/libcluster.h:262-271, src/cluster.cpp:697-726 */
+inline double learnDGMM(const lcmat::MatrixXd& X, lcmat::MatrixXd& qZ, distributions::Dirichlet& weights,
+                        std::vector<distributions::NormGamma>& clusters, const double clusterprior = PRIORVAL,
+                        const int maxclusters = -1, const bool verbose = false,
+                        const unsigned int nthreads = detail::default_threads()) {
+  vMatrixXd vX(1, X), vq;
+  std::vector<distributions::Dirichlet> vw(1, weights);
+  const double F = detail::run(LC_ALGO_DGMM, vX, vq, vw, clusters, weights.prior(), clusterprior, maxclusters, false,
+                               verbose, nthreads);
+  qZ = vq[0];
+  weights = vw[0];
+  return F;
+}
+
+/* include/libcluster.h:306-315, src/cluster.cpp:729-760; std::invalid_argument if X has a negative entry */
+inline double learnBEMM(const lcmat::MatrixXd& X, lcmat::MatrixXd& qZ, distributions::Dirichlet& weights,
+                        std::vector<distributions::ExpGamma>& clusters, const double clusterprior = PRIORVAL,
+                        const int maxclusters = -1, const bool verbose = false,
+                        const unsigned int nthreads = detail::default_threads()) {
+  vMatrixXd vX(1, X), vq;
+  std::vector<distributions::Dirichlet> vw(1, weights);
+  const double F = detail::run(LC_ALGO_BEMM, vX, vq, vw, clusters, weights.prior(), clusterprior, maxclusters, false,
+                               verbose, nthreads);
+  qZ = vq[0];
+  weights = vw[0];
+  return F;
+}
+
+/* include/libcluster.h:462-472, src/cluster.cpp:810-831 */
+inline double learnDGMC(const vMatrixXd& X, vMatrixXd& qZ, std::vector<distributions::GDirichlet>& weights,
+                        std::vector<distributions::NormGamma>& clusters, const double clusterprior = PRIORVAL,
+                        const int maxclusters = -1, const bool sparse = false, const bool verbose = false,
+                        const unsigned int nthreads = detail::default_threads()) {
+  return detail::run(LC_ALGO_DGMC, X, qZ, weights, clusters, 1.0, clusterprior, maxclusters, sparse, verbose,
+                     nthreads);
+}
+
+/* include/libcluster.h:513-523, src/cluster.cpp:834-873; std::invalid_argument if X has a negative entry */
+inline double learnEGMC(const vMatrixXd& X, vMatrixXd& qZ, std::vector<distributions::GDirichlet>& weights,
+                        std::vector<distributions::ExpGamma>& clusters, const double clusterprior = PRIORVAL,
+                        const int maxclusters = -1, const bool sparse = false, const bool verbose = false,
+                        const unsigned int nthreads = detail::default_threads()) {
+  return detail::run(LC_ALGO_EGMC, X, qZ, weights, clusters, 1.0, clusterprior, maxclusters, sparse, verbose,
                      nthreads);
 }
 

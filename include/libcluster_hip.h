@@ -32,7 +32,18 @@ typedef enum { LC_OK = 0, LC_EINVAL = 1, LC_ERUNTIME = 2, LC_EHIP = 3, LC_EDOMAI
 /* weight distribution kinds: include/distributions.h:163 (Dirichlet), :103 (StickBreak), :147 (GDirichlet) */
 typedef enum { LC_W_DIRICHLET = 0, LC_W_STICKBREAK = 1, LC_W_GDIRICHLET = 2 } lc_weight_kind;
 /* learners: include/libcluster.h:177 (learnVDP), :218 (learnBGMM), :356 (learnGMC), :409 (learnSGMC) */
-typedef enum { LC_ALGO_VDP = 0, LC_ALGO_BGMM = 1, LC_ALGO_GMC = 2, LC_ALGO_SGMC = 3 } lc_algo;
+typedef enum {
+  LC_ALGO_VDP = 0,  /* learnVDP   cluster.cpp:636  StickBreak + GaussWish */
+  LC_ALGO_BGMM = 1, /* learnBGMM  cluster.cpp:667  Dirichlet  + GaussWish */
+  LC_ALGO_GMC = 2,  /* learnGMC   cluster.cpp:763  GDirichlet + GaussWish */
+  LC_ALGO_SGMC = 3, /* learnSGMC  cluster.cpp:787  Dirichlet  + GaussWish */
+  LC_ALGO_DGMM = 4, /* learnDGMM  cluster.cpp:697  Dirichlet  + NormGamma */
+  LC_ALGO_BEMM = 5, /* learnBEMM  cluster.cpp:730  Dirichlet  + ExpGamma  */
+  LC_ALGO_DGMC = 6, /* learnDGMC  cluster.cpp:811  GDirichlet + NormGamma */
+  LC_ALGO_EGMC = 7  /* learnEGMC  cluster.cpp:842  GDirichlet + ExpGamma  */
+} lc_algo;
+/* cluster parameter distributions (distributions.h:264, 334, 406) */
+typedef enum { LC_C_GAUSSWISH = 0, LC_C_NORMGAMMA = 1, LC_C_EXPGAMMA = 2 } lc_ckind;
 
 typedef struct lc_ctx lc_ctx;     /* device-resident data set + qZ + workspaces */
 typedef struct lc_model lc_model; /* weights + clusters (+ the context that holds qZ) */
@@ -112,6 +123,19 @@ int lc_eloglike(lc_ctx* ctx, int K, const double* nu, const double* beta, const 
  * 0 => group j contributes nothing to cluster k (cluster.cpp:67-79); NULL = dense.
  * Any output pointer may be NULL. */
 int lc_suffstat(lc_ctx* ctx, const unsigned char* smask, double* Nk, double* xs, double* xxs, double* Njk);
+/* The diagonal / exponential families (NormGamma, ExpGamma: distributions.cpp:418-590).
+ * updateSS + K x NormGamma::addobs / ExpGamma::addobs (distributions.cpp:426-438, 533-542) for ALL groups:
+ * Nk[K], xs[K*D] = sum_n q_nk x_n, xxs[K*D] = sum_n q_nk x_n.^2 (NULL for ExpGamma), Njk[J*K]. */
+int lc_suffstat_diag(lc_ctx* ctx, const unsigned char* smask, double* Nk, double* xs, double* xxs, double* Njk);
+/* vbexpectation with clusters whose Eloglike is separable over dimensions:
+ *   log q~_nk = c_jk + sum_d [ w2_kd (x_nd - a_kd)^2 + w1_kd x_nd ]         a, w2, w1: K*D each, c: J*K
+ * NormGamma::Eloglike (distributions.cpp:483-492): a = m, w2 = -nu/(2L), w1 = 0,
+ *   c = Elogpi + 0.5*(D*(psi(nu) - ln 2pi - 1/beta) - logL).
+ * ExpGamma::Eloglike (distributions.cpp:568-572): a = 0, w2 = 0, w1 = -a*ib, c = Elogpi + D*psi(a) - logb.
+ * raw != 0: no weights/normalisation, column k of qZ receives log q~ (the Eloglike columns).
+ * Fz / LLk as lc_estep. */
+int lc_estep_diag(lc_ctx* ctx, int K, const double* a, const double* w2, const double* w1, const double* c, int raw,
+                  double* Fz, double* LLk);
 /* qZ[j].colwise().sum() for every group (cluster.cpp:62, 546) */
 int lc_colsums(lc_ctx* ctx, double* Njk);
 
@@ -136,20 +160,23 @@ int lc_ctx_timing_get(lc_ctx* ctx, double* estep_ms, int64_t* estep_calls, doubl
 /* ======================================================================== *
  * Variational Bayes EM on a context (vbem, cluster.cpp:177-239).
  * The model is created on first use (*model == NULL) with `wkind` weights of
- * prior `wprior` and Gauss-Wishart clusters of prior `clusterprior`.
+ * prior `wprior` and `ckind` clusters (lc_ckind) of prior `clusterprior`.
  * fixed_iters >= 0 runs exactly that many iterations without the convergence
  * and free-energy-increase tests (bench / parity harness: the reference has no
  * public fixed-K entry point).  Ftrace (may be NULL) gets
  * up to ntrace values of F, one per iteration; *niter the iterations run.
  * ======================================================================== */
-int lc_vbem(lc_ctx* ctx, lc_model** model, int wkind, double wprior, double clusterprior, int maxit, int sparse,
-            int fixed_iters, int verbose, unsigned nthreads, double* F, int* niter, double* Ftrace, int ntrace);
+int lc_vbem(lc_ctx* ctx, lc_model** model, int wkind, int ckind, double wprior, double clusterprior, int maxit,
+            int sparse, int fixed_iters, int verbose, unsigned nthreads, double* F, int* niter, double* Ftrace,
+            int ntrace);
 
-/* learnVDP / learnBGMM / learnGMC / learnSGMC (cluster.cpp:636-695, 763-807): uploads X,
+/* learnVDP / learnBGMM / learnDGMM / learnBEMM / learnGMC / learnSGMC / learnDGMC / learnEGMC
+ * (cluster.cpp:636-873; lc_algo): uploads X,
  * runs the model-selection loop, returns the model (which owns its context so
  * qZ can be fetched).  wprior: StickBreak concentration / Dirichlet alpha the
  * caller's `weights` argument carried (1.0 = default-constructed); ignored
- * for GMC / SGMC (default-constructed GDirichlet / Dirichlet per group, cluster.cpp:192). */
+ * for the multi-group learners (default-constructed GDirichlet / Dirichlet per group, cluster.cpp:192).
+ * BEMM / EGMC: LC_EINVAL "X has to be in the range [0, inf)!" on a negative observation (cluster.cpp:742, 862). */
 int lc_learn(int algo, int J, const double* const* Xj, const int64_t* Nj, int D, int64_t row_stride,
              int64_t col_stride, double wprior, double clusterprior, int maxclusters, int sparse, int verbose,
              unsigned nthreads, int device, lc_model** out, double* F);
@@ -159,8 +186,8 @@ int lc_learn(int algo, int J, const double* const* Xj, const int64_t* Nj, int D,
  * split search (partobs / splitobs / auglabels, cluster.cpp:438-470) runs on the device too.
  * wkind / wprior as in lc_vbem (GDirichlet and per-group Dirichlet ignore wprior for new groups).
  * The returned model borrows ctx (keep it alive while reading qZ through the model). */
-int lc_cluster(lc_ctx* ctx, int wkind, double wprior, double clusterprior, int maxclusters, int sparse, int verbose,
-               unsigned nthreads, lc_model** out, double* F);
+int lc_cluster(lc_ctx* ctx, int wkind, int ckind, double wprior, double clusterprior, int maxclusters, int sparse,
+               int verbose, unsigned nthreads, lc_model** out, double* F);
 
 /* ---- model accessors ----------------------------------------------------- */
 int lc_model_free(lc_model* m);
@@ -170,8 +197,13 @@ int lc_model_round(lc_model* m, int r, int* K, int* niter, double* F, int nF); /
 int lc_model_get_qz(lc_model* m, int j, double* q, int64_t row_stride, int64_t col_stride);
 /* WeightDist::Elogweight() / getNk() of group j (K values each; may be NULL) */
 int lc_model_weights(lc_model* m, int j, double* Elogweight, double* Nk);
-/* GaussWish k: getN(), getmean() [D], getcov() [D*D row-major] and the posterior
- * hyper-parameters nu, beta, iW [D*D], logdW (any pointer may be NULL) */
+int lc_model_kinds(lc_model* m, int* wkind, int* ckind);
+/* Cluster k (any pointer may be NULL).
+ * GaussWish: getN(), getmean() [D], getcov() [D*D row-major], posterior nu, beta, iW [D*D], logdW.
+ * NormGamma: getN(), getmean() [D], cov [D] = getcov() = L*nu (distributions.h:375), nu, beta, iW [D] = L,
+ *            logdW = logL.
+ * ExpGamma:  getN(), mean [D] = getrate() = a*ib (distributions.h:433), cov must be NULL, nu = a, beta = 0,
+ *            iW [D] = ib, logdW = logb. */
 int lc_model_cluster(lc_model* m, int k, double* N, double* mean, double* cov, double* nu, double* beta, double* iW,
                      double* logdW);
 int lc_model_fenergy(lc_model* m, double* Fw /*[J]*/, double* Fc /*[K]*/);
@@ -188,6 +220,13 @@ int lc_weights_update(int wkind, double wprior, const double* Nk, int K, double*
  * E-step whitener A (D*D) and Eloglike constant.  Any output may be NULL. */
 int lc_gw_mstep(double clustwidth, int D, double Ns, const double* xs, const double* xxs, double* nu, double* beta,
                 double* m, double* iW, double* logdW, double* fenergy, double* A, double* eloglike_const);
+/* NormGamma: addobs sums -> update() (distributions.cpp:441-464), fenergy (:508-517), Eloglike constant (:486-488).
+ * xs, xxs: D values each (sum q x, sum q x.^2). */
+int lc_ng_mstep(double clustwidth, int D, double Ns, const double* xs, const double* xxs, double* nu, double* beta,
+                double* m, double* L, double* logL, double* fenergy, double* eloglike_const);
+/* ExpGamma: addobs sums -> update() (distributions.cpp:545-552), fenergy (:584-589), Eloglike constant (:570). */
+int lc_eg_mstep(double obsmag, int D, double Ns, const double* xs, double* a, double* ib, double* logb,
+                double* fenergy, double* eloglike_const);
 
 #ifdef __cplusplus
 }

@@ -9,4 +9,5 @@ learnGMC with the reference Python binding's return shape) and `dist`
 a CPU implementation of the data path.
 """
 from . import capi  # noqa: F401
-from .api import learnBGMM, learnGMC, learnSGMC, learnVDP  # noqa: F401
+from .api import (learnBEMM, learnBGMM, learnDGMC, learnDGMM, learnEGMC, learnGMC, learnSGMC,  # noqa: F401
+                  learnVDP)

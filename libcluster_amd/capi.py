@@ -15,7 +15,8 @@ HEADER = PKG.parent / "include" / "libcluster_hip.h"
 
 LC_OK, LC_EINVAL, LC_ERUNTIME, LC_EHIP, LC_EDOMAIN = range(5)
 W_DIRICHLET, W_STICKBREAK, W_GDIRICHLET = 0, 1, 2
-ALGO_VDP, ALGO_BGMM, ALGO_GMC, ALGO_SGMC = 0, 1, 2, 3
+ALGO_VDP, ALGO_BGMM, ALGO_GMC, ALGO_SGMC, ALGO_DGMM, ALGO_BEMM, ALGO_DGMC, ALGO_EGMC = range(8)
+C_GAUSSWISH, C_NORMGAMMA, C_EXPGAMMA = 0, 1, 2
 
 c_double_p = C.POINTER(C.c_double)
 c_int64_p = C.POINTER(C.c_int64)
@@ -87,18 +88,21 @@ def lib() -> C.CDLL:
                                      c_double_p, c_ubyte_p, c_double_p, c_double_p]
     L.lc_eloglike.argtypes = [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]
     L.lc_suffstat.argtypes = [C.c_void_p, c_ubyte_p, c_double_p, c_double_p, c_double_p, c_double_p]
+    L.lc_suffstat_diag.argtypes = [C.c_void_p, c_ubyte_p, c_double_p, c_double_p, c_double_p, c_double_p]
+    L.lc_estep_diag.argtypes = [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int,
+                                c_double_p, c_double_p]
     L.lc_colsums.argtypes = [C.c_void_p, c_double_p]
     L.lc_ctx_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p]
     L.lc_ctx_timing_enable.argtypes = [C.c_void_p, C.c_int]
     L.lc_ctx_timing_reset.argtypes = [C.c_void_p]
     L.lc_ctx_timing_get.argtypes = [C.c_void_p, c_double_p, c_int64_p, c_double_p, c_int64_p]
-    L.lc_vbem.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_double, C.c_double, C.c_int, C.c_int,
-                          C.c_int, C.c_int, C.c_uint, c_double_p, c_int_p, c_double_p, C.c_int]
+    L.lc_vbem.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
+                          C.c_int, C.c_int, C.c_int, C.c_uint, c_double_p, c_int_p, c_double_p, C.c_int]
     L.lc_learn.argtypes = [C.c_int, C.c_int, C.POINTER(c_double_p), c_int64_p, C.c_int, C.c_int64, C.c_int64,
                            C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_int,
                            C.POINTER(C.c_void_p), c_double_p]
-    L.lc_cluster.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_uint,
-                             C.POINTER(C.c_void_p), c_double_p]
+    L.lc_cluster.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int,
+                             C.c_uint, C.POINTER(C.c_void_p), c_double_p]
     L.lc_model_free.argtypes = [C.c_void_p]
     L.lc_model_dims.argtypes = [C.c_void_p, c_int_p, c_int_p, c_int_p]
     L.lc_model_rounds.argtypes = [C.c_void_p, c_int_p]
@@ -107,10 +111,15 @@ def lib() -> C.CDLL:
     L.lc_model_weights.argtypes = [C.c_void_p, C.c_int, c_double_p, c_double_p]
     L.lc_model_cluster.argtypes = [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
                                    c_double_p, c_double_p]
+    L.lc_model_kinds.argtypes = [C.c_void_p, c_int_p, c_int_p]
     L.lc_model_fenergy.argtypes = [C.c_void_p, c_double_p, c_double_p]
     L.lc_weights_update.argtypes = [C.c_int, C.c_double, c_double_p, C.c_int, c_double_p, c_double_p]
     L.lc_gw_mstep.argtypes = [C.c_double, C.c_int, C.c_double, c_double_p, c_double_p, c_double_p, c_double_p,
                               c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]
+    L.lc_ng_mstep.argtypes = [C.c_double, C.c_int, C.c_double, c_double_p, c_double_p, c_double_p, c_double_p,
+                              c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]
+    L.lc_eg_mstep.argtypes = [C.c_double, C.c_int, C.c_double, c_double_p, c_double_p, c_double_p, c_double_p,
+                              c_double_p, c_double_p]
     _lib = L
     return L
 
@@ -295,6 +304,26 @@ class Context:
         check(lib().lc_suffstat(self._h, sm, dptr(Nk), dptr(xs), dptr(xxs), dptr(Njk)))
         return Nk, xs, xxs, Njk
 
+    def suffstat_diag(self, smask=None, second=True):
+        """NormGamma / ExpGamma statistics: N_k, sum q x, sum q x.^2 (None when second=False), N_jk."""
+        J, D, _, K = self.dims()
+        Nk, xs, Njk = np.zeros(K), np.zeros((K, D)), np.zeros((J, K))
+        xxs = np.zeros((K, D)) if second else None
+        sm = None
+        if smask is not None:
+            smask = np.ascontiguousarray(smask, dtype=np.uint8)
+            sm = smask.ctypes.data_as(c_ubyte_p)
+        check(lib().lc_suffstat_diag(self._h, sm, dptr(Nk), dptr(xs), dptr(xxs), dptr(Njk)))
+        return Nk, xs, xxs, Njk
+
+    def estep_diag(self, a, w2, w1, c, raw=False):
+        a, w2, w1, c = (np.ascontiguousarray(v, dtype=np.float64) for v in (a, w2, w1, c))
+        K = a.shape[0]
+        Fz = C.c_double()
+        ll = np.zeros(K)
+        check(lib().lc_estep_diag(self._h, K, dptr(a), dptr(w2), dptr(w1), dptr(c), int(raw), C.byref(Fz), dptr(ll)))
+        return Fz.value, ll
+
     def colsums(self):
         J, _, _, K = self.dims()
         out = np.zeros((J, K))
@@ -336,22 +365,23 @@ class Context:
         check(lib().lc_ctx_synchronize(self._h))
 
     def vbem(self, wkind, wprior=1.0, clusterprior=1.0, maxit=-1, sparse=False, fixed_iters=-1, verbose=False,
-             nthreads=1, model=None, ntrace=4096):
+             nthreads=1, model=None, ntrace=4096, ckind=C_GAUSSWISH):
         mh = model._h if model is not None else C.c_void_p()
         F, nit = C.c_double(), C.c_int()
         tr = np.zeros(ntrace)
-        check(lib().lc_vbem(self._h, C.byref(mh), wkind, wprior, clusterprior, maxit, int(sparse), fixed_iters,
+        check(lib().lc_vbem(self._h, C.byref(mh), wkind, ckind, wprior, clusterprior, maxit, int(sparse), fixed_iters,
                             int(verbose), nthreads, C.byref(F), C.byref(nit), dptr(tr), ntrace))
         if model is None:
             model = Model(mh, ctx=self)
         return F.value, tr[: nit.value].copy(), model
 
 
-    def cluster(self, wkind, wprior=1.0, clusterprior=1.0, maxclusters=-1, sparse=False, verbose=False, nthreads=1):
+    def cluster(self, wkind, wprior=1.0, clusterprior=1.0, maxclusters=-1, sparse=False, verbose=False, nthreads=1,
+                ckind=C_GAUSSWISH):
         """cluster() (model selection) on the data resident in this context -> (F, Model)."""
         mh, F = C.c_void_p(), C.c_double()
-        check(lib().lc_cluster(self._h, wkind, wprior, clusterprior, maxclusters, int(sparse), int(verbose), nthreads,
-                               C.byref(mh), C.byref(F)))
+        check(lib().lc_cluster(self._h, wkind, ckind, wprior, clusterprior, maxclusters, int(sparse), int(verbose),
+                               nthreads, C.byref(mh), C.byref(F)))
         return F.value, Model(mh, ctx=self)
 
 
@@ -403,14 +433,30 @@ class Model:
         check(lib().lc_model_weights(self._h, j, dptr(e), dptr(n)))
         return e, n
 
+    def kinds(self):
+        w, c = C.c_int(), C.c_int()
+        check(lib().lc_model_kinds(self._h, C.byref(w), C.byref(c)))
+        return w.value, c.value
+
     def cluster(self, k):
+        """Posterior of cluster k.  GaussWish: mean, cov (D x D), nu, beta, iW, logdW.  NormGamma: mean, cov (D,
+        = L*nu as the reference's getcov), nu, beta, L, logL.  ExpGamma: rate (= a*ib), a, ib, logb."""
         _, _, D = self.dims()
+        ck = self.kinds()[1]
         N, nu, beta, logdW = C.c_double(), C.c_double(), C.c_double(), C.c_double()
-        mean, cov, iW = np.zeros(D), np.zeros((D, D)), np.zeros((D, D))
+        if ck == C_GAUSSWISH:
+            mean, cov, iW = np.zeros(D), np.zeros((D, D)), np.zeros((D, D))
+        else:
+            mean, cov, iW = np.zeros(D), (np.zeros(D) if ck == C_NORMGAMMA else None), np.zeros(D)
         check(lib().lc_model_cluster(self._h, k, C.byref(N), dptr(mean), dptr(cov), C.byref(nu), C.byref(beta),
                                      dptr(iW), C.byref(logdW)))
-        return {"N": N.value, "mean": mean, "cov": cov, "nu": nu.value, "beta": beta.value, "iW": iW,
-                "logdW": logdW.value}
+        if ck == C_GAUSSWISH:
+            return {"N": N.value, "mean": mean, "cov": cov, "nu": nu.value, "beta": beta.value, "iW": iW,
+                    "logdW": logdW.value}
+        if ck == C_NORMGAMMA:
+            return {"N": N.value, "mean": mean, "cov": cov, "nu": nu.value, "beta": beta.value, "L": iW,
+                    "logL": logdW.value}
+        return {"N": N.value, "rate": mean, "a": nu.value, "ib": iW, "logb": logdW.value}
 
     def fenergy(self):
         J, K, _ = self.dims()
@@ -448,3 +494,24 @@ def gw_mstep(clustwidth, Ns, xs, xxs):
                             C.byref(logdW), C.byref(fe), dptr(A), C.byref(cst)))
     return {"nu": nu.value, "beta": beta.value, "m": m, "iW": iW, "logdW": logdW.value, "fenergy": fe.value,
             "A": A, "eloglike_const": cst.value}
+
+
+def ng_mstep(clustwidth, Ns, xs, xxs):
+    xs = np.ascontiguousarray(xs, dtype=np.float64)
+    xxs = np.ascontiguousarray(xxs, dtype=np.float64)
+    D = xs.size
+    nu, beta, logL, fe, cst = (C.c_double() for _ in range(5))
+    m, L = np.zeros(D), np.zeros(D)
+    check(lib().lc_ng_mstep(clustwidth, D, Ns, dptr(xs), dptr(xxs), C.byref(nu), C.byref(beta), dptr(m), dptr(L),
+                            C.byref(logL), C.byref(fe), C.byref(cst)))
+    return {"nu": nu.value, "beta": beta.value, "m": m, "L": L, "logL": logL.value, "fenergy": fe.value,
+            "eloglike_const": cst.value}
+
+
+def eg_mstep(obsmag, Ns, xs):
+    xs = np.ascontiguousarray(xs, dtype=np.float64)
+    D = xs.size
+    a, logb, fe, cst = (C.c_double() for _ in range(4))
+    ib = np.zeros(D)
+    check(lib().lc_eg_mstep(obsmag, D, Ns, dptr(xs), C.byref(a), dptr(ib), C.byref(logb), C.byref(fe), C.byref(cst)))
+    return {"a": a.value, "ib": ib, "logb": logb.value, "fenergy": fe.value, "eloglike_const": cst.value}

@@ -277,6 +277,25 @@ int lc_suffstat(lc_ctx* ctx, const unsigned char* smask, double* Nk, double* xs,
   });
 }
 
+int lc_suffstat_diag(lc_ctx* ctx, const unsigned char* smask, double* Nk, double* xs, double* xxs, double* Njk) {
+  return guarded([&] {
+    need(ctx, "ctx");
+    ctx->impl.suffstat_diag(smask, Nk, xs, xxs, Njk);
+  });
+}
+
+int lc_estep_diag(lc_ctx* ctx, int K, const double* a, const double* w2, const double* w1, const double* c, int raw,
+                  double* Fz, double* LLk) {
+  return guarded([&] {
+    need(ctx, "ctx");
+    need(a, "a");
+    need(w2, "w2");
+    need(w1, "w1");
+    need(c, "c");
+    ctx->impl.estep_diag(K, a, w2, w1, c, Fz, LLk, raw != 0);
+  });
+}
+
 int lc_colsums(lc_ctx* ctx, double* Njk) {
   return guarded([&] {
     need(ctx, "ctx");
@@ -319,12 +338,14 @@ int lc_ctx_timing_get(lc_ctx* ctx, double* estep_ms, int64_t* estep_calls, doubl
 }
 
 // ---------------------------------------------------------------------------
-int lc_vbem(lc_ctx* ctx, lc_model** model, int wkind, double wprior, double clusterprior, int maxit, int sparse,
-            int fixed_iters, int verbose, unsigned nthreads, double* F, int* niter, double* Ftrace, int ntrace) {
+int lc_vbem(lc_ctx* ctx, lc_model** model, int wkind, int ckind, double wprior, double clusterprior, int maxit,
+            int sparse, int fixed_iters, int verbose, unsigned nthreads, double* F, int* niter, double* Ftrace,
+            int ntrace) {
   return guarded([&] {
     need(ctx, "ctx");
     need(model, "model");
     if (wkind < 0 || wkind > 2) throw std::invalid_argument("unknown weight kind");
+    if (ckind < 0 || ckind > 2) throw std::invalid_argument("unknown cluster kind");
     if (nthreads < 1) throw std::invalid_argument("Must specify at least one thread for execution!");
     std::unique_ptr<lc_model> fresh;
     lc_model* m = *model;
@@ -332,8 +353,11 @@ int lc_vbem(lc_ctx* ctx, lc_model** model, int wkind, double wprior, double clus
       fresh.reset(new lc_model());
       m = fresh.get();
       m->model.wkind = wkind;
+      m->model.ckind = ckind;
       m->D = ctx->impl.D();
       for (int j = 0; j < ctx->impl.J(); ++j) m->model.weights.emplace_back(wkind, wprior);
+    } else if (m->model.wkind != wkind || m->model.ckind != ckind) {
+      throw std::invalid_argument("model was created with other distribution kinds");
     }
     m->ctx = ctx;
     std::vector<double> tr;
@@ -362,35 +386,68 @@ int lc_learn(int algo, int J, const double* const* Xj, const int64_t* Nj, int D,
     need(Xj, "Xj");
     need(Nj, "Nj");
     need(out, "out");
-    if (algo < 0 || algo > 3) throw std::invalid_argument("unknown algorithm");
-    if ((algo == LC_ALGO_VDP || algo == LC_ALGO_BGMM) && J != 1)
-      throw std::invalid_argument("learnVDP/learnBGMM take a single observation matrix");
+    if (algo < 0 || algo > LC_ALGO_EGMC) throw std::invalid_argument("unknown algorithm");
+    const bool single = algo == LC_ALGO_VDP || algo == LC_ALGO_BGMM || algo == LC_ALGO_DGMM || algo == LC_ALGO_BEMM;
+    if (single && J != 1) throw std::invalid_argument("this algorithm takes a single observation matrix");
     if (nthreads < 1) throw std::invalid_argument("Must specify at least one thread for execution!");  // cluster.cpp:576-577
+    if (algo == LC_ALGO_BEMM || algo == LC_ALGO_EGMC) {  // cluster.cpp:742-743, 862-864 (before anything is printed)
+      for (int j = 0; j < J; ++j) {
+        need(Xj[j], "Xj[j]");
+        for (int64_t i = 0; i < Nj[j]; ++i)
+          for (int d = 0; d < D; ++d)
+            if (Xj[j][i * rs + d * cs] < 0) throw std::invalid_argument("X has to be in the range [0, inf)!");
+      }
+    }
     std::unique_ptr<lc_model> m(new lc_model());
     m->owned_ctx.reset(new lc_ctx(device, nullptr));
     m->ctx = m->owned_ctx.get();
     m->D = D;
     lcc::Context& ctx = m->ctx->impl;
     ctx.set_data(J, Xj, Nj, D, rs, cs);
-    if (algo == LC_ALGO_VDP) {
-      if (verbose) std::cout << "Learning VDP..." << std::endl;  // cluster.cpp:647-648
-      m->model.wkind = lch::W_STICKBREAK;
-      m->model.weights.emplace_back(lch::W_STICKBREAK, wprior);  // vecweights(1, weights), :653
-    } else if (algo == LC_ALGO_BGMM) {
-      if (verbose) std::cout << "Learning Bayesian GMM..." << std::endl;  // :678-679
-      m->model.wkind = lch::W_DIRICHLET;
-      m->model.weights.emplace_back(lch::W_DIRICHLET, wprior);  // :684
-    } else if (algo == LC_ALGO_GMC) {
-      if (verbose) std::cout << "Learning " << (sparse ? "(sparse) " : "") << "GMC..." << std::endl;  // :775-779
-      m->model.wkind = lch::W_GDIRICHLET;
-    } else {
-      if (verbose) std::cout << "Learning " << (sparse ? "(sparse) " : "") << "Symmetric GMC..." << std::endl;  // :799-803
-      m->model.wkind = lch::W_DIRICHLET;
+    const char* sp = sparse ? "(sparse) " : "";
+    switch (algo) {
+      case LC_ALGO_VDP:
+        if (verbose) std::cout << "Learning VDP..." << std::endl;  // cluster.cpp:647-648
+        m->model.wkind = lch::W_STICKBREAK;
+        break;
+      case LC_ALGO_BGMM:
+        if (verbose) std::cout << "Learning Bayesian GMM..." << std::endl;  // :678-679
+        m->model.wkind = lch::W_DIRICHLET;
+        break;
+      case LC_ALGO_DGMM:
+        if (verbose) std::cout << "Learning Bayesian diagonal GMM..." << std::endl;  // :708-709
+        m->model.wkind = lch::W_DIRICHLET;
+        m->model.ckind = lch::C_NORMGAMMA;
+        break;
+      case LC_ALGO_BEMM:
+        if (verbose) std::cout << "Learning Bayesian EMM..." << std::endl;  // :745-746
+        m->model.wkind = lch::W_DIRICHLET;
+        m->model.ckind = lch::C_EXPGAMMA;
+        break;
+      case LC_ALGO_GMC:
+        if (verbose) std::cout << "Learning " << sp << "GMC..." << std::endl;  // :775-779
+        m->model.wkind = lch::W_GDIRICHLET;
+        break;
+      case LC_ALGO_SGMC:
+        if (verbose) std::cout << "Learning " << sp << "Symmetric GMC..." << std::endl;  // :799-803
+        m->model.wkind = lch::W_DIRICHLET;
+        break;
+      case LC_ALGO_DGMC:
+        if (verbose) std::cout << "Learning " << sp << "Diagonal GMC..." << std::endl;  // :825-829
+        m->model.wkind = lch::W_GDIRICHLET;
+        m->model.ckind = lch::C_NORMGAMMA;
+        break;
+      default:
+        if (verbose) std::cout << "Learning " << sp << "Exponential GMC..." << std::endl;  // :866-868
+        m->model.wkind = lch::W_GDIRICHLET;
+        m->model.ckind = lch::C_EXPGAMMA;
+        break;
     }
+    if (single) m->model.weights.emplace_back(m->model.wkind, wprior);  // vecweights(1, weights), :653/:684/:715/:752
     lce::ClusterOptions co;
     co.clusterprior = clusterprior;
     co.maxclusters = maxclusters;
-    co.sparse = (algo == LC_ALGO_GMC || algo == LC_ALGO_SGMC) && sparse;  // learnVDP/BGMM pass sparse=false, :657/:688
+    co.sparse = !single && sparse;  // the single-matrix learners pass sparse=false, :657/:688/:719/:756
     co.verbose = verbose != 0;
     co.nthreads = nthreads;
     co.trace = &m->rounds;
@@ -400,17 +457,19 @@ int lc_learn(int algo, int J, const double* const* Xj, const int64_t* Nj, int D,
   });
 }
 
-int lc_cluster(lc_ctx* ctx, int wkind, double wprior, double clusterprior, int maxclusters, int sparse, int verbose,
-               unsigned nthreads, lc_model** out, double* F) {
+int lc_cluster(lc_ctx* ctx, int wkind, int ckind, double wprior, double clusterprior, int maxclusters, int sparse,
+               int verbose, unsigned nthreads, lc_model** out, double* F) {
   return guarded([&] {
     need(ctx, "ctx");
     need(out, "out");
     if (wkind < 0 || wkind > 2) throw std::invalid_argument("unknown weight kind");
+    if (ckind < 0 || ckind > 2) throw std::invalid_argument("unknown cluster kind");
     if (nthreads < 1) throw std::invalid_argument("Must specify at least one thread for execution!");
     std::unique_ptr<lc_model> m(new lc_model());
     m->ctx = ctx;
     m->D = ctx->impl.D();
     m->model.wkind = wkind;
+    m->model.ckind = ckind;
     if (ctx->impl.J() == 1 && wkind != lch::W_GDIRICHLET) m->model.weights.emplace_back(wkind, wprior);
     lce::ClusterOptions co;
     co.clusterprior = clusterprior;
@@ -477,22 +536,53 @@ int lc_model_weights(lc_model* m, int j, double* Elogweight, double* Nk) {
   });
 }
 
+int lc_model_kinds(lc_model* m, int* wkind, int* ckind) {
+  return guarded([&] {
+    need(m, "model");
+    if (wkind) *wkind = m->model.wkind;
+    if (ckind) *ckind = m->model.ckind;
+  });
+}
+
 int lc_model_cluster(lc_model* m, int k, double* N, double* mean, double* cov, double* nu, double* beta, double* iW,
                      double* logdW) {
   return guarded([&] {
     need(m, "model");
     if (k < 0 || k >= (int)m->model.clusters.size()) throw std::invalid_argument("cluster index out of range");
-    const lch::GaussWishState& c = m->model.clusters[(size_t)k];
-    if (N) *N = c.N;
-    if (mean) std::copy(c.m.begin(), c.m.end(), mean);
-    if (cov) {
-      const std::vector<double> cv = c.getcov();
-      std::copy(cv.begin(), cv.end(), cov);
+    const lch::ClusterAny& ca = m->model.clusters[(size_t)k];
+    if (N) *N = ca.N();
+    if (ca.kind == lch::C_GAUSSWISH) {
+      const lch::GaussWishState& c = ca.gw;
+      if (mean) std::copy(c.m.begin(), c.m.end(), mean);
+      if (cov) {
+        const std::vector<double> cv = c.getcov();
+        std::copy(cv.begin(), cv.end(), cov);
+      }
+      if (nu) *nu = c.nu;
+      if (beta) *beta = c.beta;
+      if (iW) std::copy(c.iW.begin(), c.iW.end(), iW);
+      if (logdW) *logdW = c.logdW;
+    } else if (ca.kind == lch::C_NORMGAMMA) {
+      // cov [D] = getcov() = L*nu (distributions.h:375, as the reference defines it); iW [D] = L; logdW = logL
+      const lch::NormGammaState& c = ca.ng;
+      if (mean) std::copy(c.m.begin(), c.m.end(), mean);
+      if (cov)
+        for (int d = 0; d < c.D; ++d) cov[d] = c.L[(size_t)d] * c.nu;
+      if (nu) *nu = c.nu;
+      if (beta) *beta = c.beta;
+      if (iW) std::copy(c.L.begin(), c.L.end(), iW);
+      if (logdW) *logdW = c.logL;
+    } else {
+      // mean [D] = getrate() = a*ib (distributions.h:433; the family has no getmean); nu = a; iW [D] = ib; logdW = logb
+      const lch::ExpGammaState& c = ca.eg;
+      if (mean)
+        for (int d = 0; d < c.D; ++d) mean[d] = c.a * c.ib[(size_t)d];
+      if (cov) throw std::invalid_argument("Exponential clusters have no covariance");
+      if (nu) *nu = c.a;
+      if (beta) *beta = 0.0;
+      if (iW) std::copy(c.ib.begin(), c.ib.end(), iW);
+      if (logdW) *logdW = c.logb;
     }
-    if (nu) *nu = c.nu;
-    if (beta) *beta = c.beta;
-    if (iW) std::copy(c.iW.begin(), c.iW.end(), iW);
-    if (logdW) *logdW = c.logdW;
   });
 }
 
@@ -539,6 +629,39 @@ int lc_gw_mstep(double clustwidth, int D, double Ns, const double* xs, const dou
       const std::vector<double> a = g.whitener();
       std::copy(a.begin(), a.end(), A);
     }
+    if (eloglike_const) *eloglike_const = g.eloglike_const();
+  });
+}
+
+int lc_ng_mstep(double clustwidth, int D, double Ns, const double* xs, const double* xxs, double* nu, double* beta,
+                double* m, double* L, double* logL, double* fenergy, double* eloglike_const) {
+  return guarded([&] {
+    need(xs, "xs");
+    need(xxs, "xxs");
+    lch::NormGammaState g(clustwidth, D);
+    g.addstats(Ns, xs, xxs);
+    g.update();
+    if (nu) *nu = g.nu;
+    if (beta) *beta = g.beta;
+    if (m) std::copy(g.m.begin(), g.m.end(), m);
+    if (L) std::copy(g.L.begin(), g.L.end(), L);
+    if (logL) *logL = g.logL;
+    if (fenergy) *fenergy = g.fenergy();
+    if (eloglike_const) *eloglike_const = g.eloglike_const();
+  });
+}
+
+int lc_eg_mstep(double obsmag, int D, double Ns, const double* xs, double* a, double* ib, double* logb,
+                double* fenergy, double* eloglike_const) {
+  return guarded([&] {
+    need(xs, "xs");
+    lch::ExpGammaState g(obsmag, D);
+    g.addstats(Ns, xs, nullptr);
+    g.update();
+    if (a) *a = g.a;
+    if (ib) std::copy(g.ib.begin(), g.ib.end(), ib);
+    if (logb) *logb = g.logb;
+    if (fenergy) *fenergy = g.fenergy();
     if (eloglike_const) *eloglike_const = g.eloglike_const();
   });
 }

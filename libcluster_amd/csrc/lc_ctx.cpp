@@ -331,8 +331,32 @@ void Context::qz_init_split(const double* m, const double* v) {
   mv_.reserve(mv.size());
   LC_HIP(hipMemcpyAsync(mv_.p, mv.data(), mv.size() * sizeof(double), hipMemcpyHostToDevice, stream_));
   LC_HIP(lck::launch_split_init(X_.p, DP_, D_, NP_, J_ > 1 ? rginfo_.p : nullptr, Nj_[0], mv_.p, qz_[cur_].buf.p, NP_,
-                                stream_));
+                                0, nullptr, stream_));
   LC_HIP(hipStreamSynchronize(stream_));  // mv is a local
+}
+
+void Context::qz_init_split_mean(const double* v) {
+  ensure_qz(qz_[cur_], 2, false);
+  qz_[cur_].K = 2;
+  if (NP_ == 0) return;
+  std::vector<double> mv((size_t)2 * DP_, 0.0);
+  std::copy(v, v + D_, mv.begin() + DP_);
+  mv_.reserve(mv.size() + (size_t)J_);
+  LC_HIP(hipMemcpyAsync(mv_.p, mv.data(), mv.size() * sizeof(double), hipMemcpyHostToDevice, stream_));
+  const int* rgi = J_ > 1 ? rginfo_.p : nullptr;
+  // pass 1: the projections x.v land in column 0; their per-group sums give the means
+  LC_HIP(lck::launch_split_init(X_.p, DP_, D_, NP_, rgi, Nj_[0], mv_.p, qz_[cur_].buf.p, NP_, 1, nullptr, stream_));
+  std::vector<double> sums((size_t)J_ * 2);
+  red_.reserve((size_t)J_ * 2);
+  LC_HIP(lck::launch_group_colsum(qz_[cur_].buf.p, NP_, 2, goff_d_.p, J_, red_.p, stream_));
+  LC_HIP(hipMemcpyAsync(sums.data(), red_.p, sums.size() * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  LC_HIP(hipStreamSynchronize(stream_));
+  std::vector<double> thr((size_t)J_);
+  for (int j = 0; j < J_; ++j) thr[(size_t)j] = Nj_[j] > 0 ? sums[(size_t)j * 2] / (double)Nj_[j] : 0.0;  // XdotL.sum()/size
+  double* thr_d = mv_.p + mv.size();
+  LC_HIP(hipMemcpyAsync(thr_d, thr.data(), thr.size() * sizeof(double), hipMemcpyHostToDevice, stream_));
+  LC_HIP(lck::launch_split_init(X_.p, DP_, D_, NP_, rgi, Nj_[0], mv_.p, qz_[cur_].buf.p, NP_, 2, thr_d, stream_));
+  LC_HIP(hipStreamSynchronize(stream_));
 }
 
 void Context::qz_split_from(const Context& sub, const RowSelection& sel, int k) {
@@ -554,6 +578,151 @@ void Context::colsums(double* Njk) {
   if (!group_sharded_) allreduce(red_.p, (int64_t)J_ * K);
   LC_HIP(hipMemcpyAsync(Njk, red_.p, (size_t)J_ * K * sizeof(double), hipMemcpyDeviceToHost, stream_));
   LC_HIP(hipStreamSynchronize(stream_));
+}
+
+void Context::estep_diag(int K, const double* av, const double* w2, const double* w1, const double* c, double* Fz,
+                         double* LLk, bool raw) {
+  if (K < 1) throw std::invalid_argument("K must be >= 1");
+  if (NP_ == 0 && !ar_fn_) {
+    if (Fz) *Fz = -0.0;
+    if (LLk) std::fill(LLk, LLk + K, 0.0);
+    qz_[cur_].K = K;
+    return;
+  }
+  LC_HIP(hipSetDevice(device_));
+  const int D = D_, DP = DP_;
+  hpack_.assign((size_t)K * 3 * DP + (size_t)J_ * K, 0.0);
+  for (int k = 0; k < K; ++k) {
+    double* P = hpack_.data() + (size_t)k * 3 * DP;
+    std::copy(av + (size_t)k * D, av + (size_t)(k + 1) * D, P);
+    std::copy(w2 + (size_t)k * D, w2 + (size_t)(k + 1) * D, P + DP);
+    std::copy(w1 + (size_t)k * D, w1 + (size_t)(k + 1) * D, P + 2 * DP);
+  }
+  std::memcpy(hpack_.data() + (size_t)K * 3 * DP, c, (size_t)J_ * K * sizeof(double));
+  params_.reserve(hpack_.size());
+  LC_HIP(hipMemcpyAsync(params_.p, hpack_.data(), hpack_.size() * sizeof(double), hipMemcpyHostToDevice, stream_));
+  ensure_qz(qz_[cur_], K, false);
+  qz_[cur_].K = K;
+  const int64_t nrg = NP_ / lck::RG, grid = lck::estep_diag_grid(nrg);
+  fzpart_.reserve((size_t)std::max<int64_t>(grid, 1));
+  llpart_.reserve((size_t)std::max<int64_t>(grid, 1) * K);
+  red_.reserve((size_t)1 + K);
+  lck::DiagEstepLaunch a;
+  a.DP = DP;
+  a.D = D;
+  a.X = X_.p;
+  a.nrg = nrg;
+  a.rginfo = J_ > 1 ? rginfo_.p : nullptr;
+  a.nrows = Nj_[0];
+  a.params = params_.p;
+  a.ctab = params_.p + (size_t)K * 3 * DP;
+  a.K = K;
+  a.qZ = qz_[cur_].buf.p;
+  a.ldq = NP_;
+  a.fz_part = fzpart_.p;
+  a.ll_part = LLk ? llpart_.p : nullptr;
+  a.raw = raw ? 1 : 0;
+  EvPair ev{};
+  if (timing_) {
+    LC_HIP(hipEventCreate(&ev.a));
+    LC_HIP(hipEventCreate(&ev.b));
+    ev.kind = 0;
+    LC_HIP(hipEventRecord(ev.a, stream_));
+  }
+  LC_HIP(lck::launch_estep_diag(a, stream_));
+  if (timing_) {
+    LC_HIP(hipEventRecord(ev.b, stream_));
+    pending_.push_back(ev);
+  }
+  if (raw) {
+    LC_HIP(hipStreamSynchronize(stream_));
+    return;
+  }
+  if (grid > 0) {
+    LC_HIP(lck::launch_reduce_partials(fzpart_.p, (int)grid, 1, red_.p, stream_));
+    if (LLk) LC_HIP(lck::launch_reduce_partials(llpart_.p, (int)grid, K, red_.p + 1, stream_));
+    else LC_HIP(hipMemsetAsync(red_.p + 1, 0, (size_t)K * sizeof(double), stream_));
+  } else {
+    LC_HIP(hipMemsetAsync(red_.p, 0, (size_t)(1 + K) * sizeof(double), stream_));
+  }
+  allreduce(red_.p, 1 + K);
+  hred_.resize((size_t)1 + K);
+  LC_HIP(hipMemcpyAsync(hred_.data(), red_.p, (size_t)(1 + K) * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  LC_HIP(hipStreamSynchronize(stream_));
+  if (Fz) *Fz = hred_[0];
+  if (LLk) std::copy(hred_.begin() + 1, hred_.end(), LLk);
+}
+
+void Context::suffstat_diag(const unsigned char* smask, double* Nk, double* xs, double* xxs, double* Njk) {
+  const int K = qz_[cur_].K, D = D_, DP = DP_;
+  if (K < 1) throw std::invalid_argument("qZ has not been set");
+  LC_HIP(hipSetDevice(device_));
+  const int64_t SS = 1 + 2 * (int64_t)DP;
+  const size_t nout = (size_t)K * SS + (size_t)J_ * K;
+  ssout_.reserve(nout);
+  double* njk_d = ssout_.p + (size_t)K * SS;
+  if (NP_ > 0) {
+    // ~8 blocks per CU, whole 32-row tiles
+    int64_t want = std::min<int64_t>(2048, (NP_ + 255) / 256);
+    if (want < 1) want = 1;
+    int64_t rows = ((NP_ + want - 1) / want + 31) / 32 * 32;
+    const int nchunks = (int)((NP_ + rows - 1) / rows);
+    sspart_.reserve((size_t)nchunks * K * SS);
+    lck::DiagStatLaunch a;
+    a.DP = DP;
+    a.X = X_.p;
+    a.NP = NP_;
+    a.qZ = qz_[cur_].buf.p;
+    a.ldq = NP_;
+    a.K = K;
+    a.rginfo = nullptr;
+    a.smask = nullptr;
+    if (smask && J_ > 1) {
+      smask_.reserve((size_t)J_ * K);
+      LC_HIP(hipMemcpyAsync(smask_.p, smask, (size_t)J_ * K, hipMemcpyHostToDevice, stream_));
+      a.rginfo = rginfo_.p;
+      a.smask = smask_.p;
+    }
+    a.partial = sspart_.p;
+    a.nchunks = nchunks;
+    a.chunk_rows = rows;
+    EvPair ev{};
+    if (timing_) {
+      LC_HIP(hipEventCreate(&ev.a));
+      LC_HIP(hipEventCreate(&ev.b));
+      ev.kind = 1;
+      LC_HIP(hipEventRecord(ev.a, stream_));
+    }
+    LC_HIP(lck::launch_suffstat_diag(a, stream_));
+    if (timing_) {
+      LC_HIP(hipEventRecord(ev.b, stream_));
+      pending_.push_back(ev);
+    }
+    LC_HIP(lck::launch_reduce_partials(sspart_.p, nchunks, (int64_t)K * SS, ssout_.p, stream_));
+    if (J_ > 1) LC_HIP(lck::launch_group_colsum(qz_[cur_].buf.p, NP_, K, goff_d_.p, J_, njk_d, stream_));
+    else LC_HIP(hipMemsetAsync(njk_d, 0, (size_t)K * sizeof(double), stream_));
+  } else {
+    LC_HIP(hipMemsetAsync(ssout_.p, 0, nout * sizeof(double), stream_));
+  }
+  allreduce(ssout_.p, group_sharded_ ? (int64_t)K * SS : (int64_t)nout);
+  hss_.resize(nout);
+  LC_HIP(hipMemcpyAsync(hss_.data(), ssout_.p, nout * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  LC_HIP(hipStreamSynchronize(stream_));
+  for (int k = 0; k < K; ++k) {
+    const double* rec = hss_.data() + (size_t)k * SS;
+    const bool off = smask && J_ == 1 && !smask[k];
+    if (Nk) Nk[k] = off ? 0.0 : rec[0];
+    for (int d = 0; d < D; ++d) {
+      if (xs) xs[(size_t)k * D + d] = off ? 0.0 : rec[1 + d];
+      if (xxs) xxs[(size_t)k * D + d] = off ? 0.0 : rec[1 + DP + d];
+    }
+  }
+  if (Njk) {
+    if (J_ == 1)
+      for (int k = 0; k < K; ++k) Njk[k] = hss_[(size_t)k * SS];
+    else
+      std::copy(hss_.begin() + (size_t)K * SS, hss_.end(), Njk);
+  }
 }
 
 // ---------------------------------------------------------------------------

@@ -117,6 +117,8 @@ class Context {
   void set_data_gather(const Context& src, const RowSelection& sel);
   // qZ := [s, 1-s], s = ((x-m).v >= 0)   (splitobs + cluster.cpp:446-449); m, v: D host doubles
   void qz_init_split(const double* m, const double* v);
+  // ExpGamma::splitobs (distributions.cpp:575-581): s = (x.v > mean over the group's rows of x.v)
+  void qz_init_split_mean(const double* v);
   // auglabels (comutils.cpp:75-104) on the current buffer (K -> K+1 columns): selected rows whose
   // refined second responsibility in `sub` exceeds 0.5 move their column-k mass to the new column
   void qz_split_from(const Context& sub, const RowSelection& sel, int k);
@@ -131,6 +133,12 @@ class Context {
   // Nk[K], xs[K*D], xxs[K*D*D] (row-major, symmetric), Njk[J*K].
   void suffstat(const unsigned char* smask, double* Nk, double* xs, double* xxs, double* Njk);
   void colsums(double* Njk);  // J x K column sums of the current qZ
+  // Diagonal / exponential families: log q~[n,k] = c_jk + sum_d (w2_kd (x_nd - a_kd)^2 + w1_kd x_nd);
+  // a, w2, w1: K x D host arrays.  Same outputs as estep().
+  void estep_diag(int K, const double* a, const double* w2, const double* w1, const double* c, double* Fz,
+                  double* LLk, bool raw = false);
+  // N_k, x_s = sum q x [K*D], xx_s = sum q x^2 [K*D] (elementwise), Njk[J*K]
+  void suffstat_diag(const unsigned char* smask, double* Nk, double* xs, double* xxs, double* Njk);
 
   // ---- timing ---------------------------------------------------------------
   void timing_enable(bool on) { timing_ = on; }

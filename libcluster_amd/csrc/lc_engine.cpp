@@ -10,7 +10,7 @@
 
 namespace lce {
 
-using lch::GaussWishState;
+using lch::ClusterAny;
 using lch::WeightState;
 
 namespace {
@@ -41,10 +41,21 @@ void parallel_for(int n, unsigned nthreads, double work_per_item, F fn) {
     if (e) std::rethrow_exception(e);
 }
 
-bool anyempty(const std::vector<GaussWishState>& c) {  // src/comutils.h:114-123
+bool anyempty(const std::vector<ClusterAny>& c) {  // src/comutils.h:114-123
   for (const auto& x : c)
-    if (x.N <= 1) return true;
+    if (x.N() <= 1) return true;
   return false;
+}
+
+// E-step of the model's family with the parameters stored in the model (vbem's last iteration)
+void run_estep(lcc::Context& ctx, Model& model, int K, double* Fz, double* LLk) {
+  const int D = ctx.D();
+  if (model.ckind == lch::C_GAUSSWISH) {
+    ctx.estep(K, model.lastA.data(), model.lastm.data(), model.lastc.data(), Fz, LLk);
+  } else {
+    const double* a = model.lastA.data();
+    ctx.estep_diag(K, a, a + (size_t)K * D, a + (size_t)2 * K * D, model.lastc.data(), Fz, LLk);
+  }
 }
 
 struct GreedOrder {  // src/comutils.h:44-49
@@ -67,19 +78,22 @@ double vbem(lcc::Context& ctx, Model& model, const VbemOptions& opt) {
   if (K < 1) throw std::invalid_argument("qZ must have at least one column");
 
   // weights.resize(J, W()); clusters.resize(K, C(clusterprior, D))  (:192-193)
+  const int ck = model.ckind;
+  const bool full = ck == lch::C_GAUSSWISH;
   if ((int)model.weights.size() > J) model.weights.resize(J);
   while ((int)model.weights.size() < J) model.weights.emplace_back(model.wkind, lch::ALPHA1PRIOR);
   if ((int)model.clusters.size() > K) model.clusters.resize(K);
-  while ((int)model.clusters.size() < K) model.clusters.emplace_back(opt.clusterprior, D);
+  while ((int)model.clusters.size() < K) model.clusters.emplace_back(ck, opt.clusterprior, D);
   for (const auto& c : model.clusters)
-    if (c.D != D) throw std::invalid_argument("Mismatched dims. of cluster params and obs.!");
+    if (c.D() != D || c.kind != ck) throw std::invalid_argument("Mismatched dims. of cluster params and obs.!");
 
-  std::vector<double> Nk(K), xs((size_t)K * D), xxs((size_t)K * D * D), Njk((size_t)J * K);
+  const size_t XX = ClusterAny::xx_size(ck, D);
+  std::vector<double> Nk(K), xs((size_t)K * D), xxs((size_t)K * std::max<size_t>(XX, 1)), Njk((size_t)J * K);
   // the packed E-step parameters of the last iteration stay in the model (the split search
   // re-runs that E-step once to get its data term, see data_loglik)
   std::vector<double>&A = model.lastA, &m = model.lastm, &c = model.lastc;
-  A.assign((size_t)K * D * D, 0.0);
-  m.assign((size_t)K * D, 0.0);
+  A.assign(full ? (size_t)K * D * D : (size_t)3 * K * D, 0.0);
+  m.assign(full ? (size_t)K * D : 0, 0.0);
   c.assign((size_t)J * K, 0.0);
   std::vector<double> cst(K);
   std::vector<unsigned char> mask;
@@ -100,17 +114,35 @@ double vbem(lcc::Context& ctx, Model& model, const VbemOptions& opt) {
       for (size_t t = 0; t < mask.size(); ++t) mask[t] = Njk[t] >= lch::ZEROCUTOFF ? 1 : 0;
       maskp = mask.data();
     }
-    ctx.suffstat(maskp, Nk.data(), xs.data(), xxs.data(), Njk.data());
+    if (full) ctx.suffstat(maskp, Nk.data(), xs.data(), xxs.data(), Njk.data());
+    else ctx.suffstat_diag(maskp, Nk.data(), xs.data(), XX ? xxs.data() : nullptr, Njk.data());
     for (int j = 0; j < J; ++j) model.weights[j].update(Njk.data() + (size_t)j * K, K);
 
     // VBM for clusters (:215-217) + the per-cluster constants of the E-step
-    parallel_for(K, opt.nthreads, 2.0 * D * D * D, [&](int k) {
-      GaussWishState& cl = model.clusters[k];
-      cl.addstats(Nk[k], xs.data() + (size_t)k * D, xxs.data() + (size_t)k * D * D);
+    parallel_for(K, opt.nthreads, full ? 2.0 * D * D * D : 8.0 * D, [&](int k) {
+      ClusterAny& cl = model.clusters[k];
+      cl.addstats(Nk[k], xs.data() + (size_t)k * D, xxs.data() + (size_t)k * XX);
       cl.update();
-      const std::vector<double> Ak = cl.whitener();
-      std::copy(Ak.begin(), Ak.end(), A.begin() + (size_t)k * D * D);
-      std::copy(cl.m.begin(), cl.m.end(), m.begin() + (size_t)k * D);
+      if (full) {
+        const std::vector<double> Ak = cl.gw.whitener();
+        std::copy(Ak.begin(), Ak.end(), A.begin() + (size_t)k * D * D);
+        std::copy(cl.gw.m.begin(), cl.gw.m.end(), m.begin() + (size_t)k * D);
+      } else {
+        double* pa = A.data() + (size_t)k * D;              // a
+        double* pw2 = A.data() + (size_t)(K + k) * D;       // w2
+        double* pw1 = A.data() + (size_t)(2 * K + k) * D;   // w1
+        for (int d = 0; d < D; ++d) {
+          if (ck == lch::C_NORMGAMMA) {  // -nu/2 * (x-m)^2 / L   (distributions.cpp:486-491)
+            pa[d] = cl.ng.m[d];
+            pw2[d] = -0.5 * cl.ng.nu / cl.ng.L[d];
+            pw1[d] = 0.0;
+          } else {  // -a * x * ib   (distributions.cpp:570-571)
+            pa[d] = 0.0;
+            pw2[d] = 0.0;
+            pw1[d] = -cl.eg.a * cl.eg.ib[d];
+          }
+        }
+      }
       cst[k] = cl.eloglike_const();
     });
 
@@ -124,14 +156,14 @@ double vbem(lcc::Context& ctx, Model& model, const VbemOptions& opt) {
       }
     }
     double Fz = 0.0;
-    ctx.estep(K, A.data(), m.data(), c.data(), &Fz, nullptr);
+    run_estep(ctx, model, K, &Fz, nullptr);
 
     // fenergy (:145-165)
     double Fw = 0.0, Fc = 0.0;
     for (const auto& w : model.weights) Fw += w.fenergy();
     if (ctx.group_sharded()) Fw = ctx.allreduce_value(Fw);  // other ranks hold the other groups' weights
     std::vector<double> fck(K);
-    parallel_for(K, opt.nthreads, 1.0 * D * D, [&](int k) { fck[k] = model.clusters[k].fenergy(); });
+    parallel_for(K, opt.nthreads, full ? 1.0 * D * D : 8.0 * D, [&](int k) { fck[k] = model.clusters[k].fenergy(); });
     for (int k = 0; k < K; ++k) Fc += fck[k];
     F = Fc + Fw + Fz;
     if (opt.trace) opt.trace->push_back(F);
@@ -155,7 +187,7 @@ static void data_loglik(lcc::Context& ctx, Model& model) {
   const int K = (int)model.clusters.size();
   double Fz = 0.0;
   model.LLk.assign(K, 0.0);
-  ctx.estep(K, model.lastA.data(), model.lastm.data(), model.lastc.data(), &Fz, model.LLk.data());
+  run_estep(ctx, model, K, &Fz, model.LLk.data());
 }
 
 // ---------------------------------------------------------------------------
@@ -165,11 +197,11 @@ static bool prune_clusters(lcc::Context& ctx, Model& model, bool verbose) {
   const int K = (int)model.clusters.size(), J = ctx.J();
   std::vector<int> keep;
   for (int k = 0; k < K; ++k)
-    if (!(model.clusters[k].N < lch::ZEROCUTOFF)) keep.push_back(k);
+    if (!(model.clusters[k].N() < lch::ZEROCUTOFF)) keep.push_back(k);
   if ((int)keep.size() == K) return false;
   if (verbose) std::cout << '*' << std::flush;
   if (keep.empty()) throw std::runtime_error("all clusters are empty");
-  std::vector<GaussWishState> nc;
+  std::vector<ClusterAny> nc;
   std::vector<double> nll;
   for (int k : keep) {
     nc.push_back(std::move(model.clusters[k]));
@@ -212,7 +244,7 @@ static bool split_gr(lcc::Context& ctx, Model& model, std::vector<int>& tally, d
   for (int k = 0; k < K; ++k) ord[k].Fk -= wt[k] + model.LLk[k];
   std::sort(ord.begin(), ord.end(), greedcomp);  // :418
 
-  const double prior = model.clusters[0].prior;
+  const double prior = model.clusters[0].prior();
   lcc::RowSelection sel;
   std::vector<double> njs;
   std::vector<double> eigv;
@@ -220,7 +252,7 @@ static bool split_gr(lcc::Context& ctx, Model& model, std::vector<int>& tally, d
   for (const GreedOrder& o : ord) {
     const int k = o.k;
     ++tally[k];
-    if (model.clusters[k].N < 4) continue;  // :432
+    if (model.clusters[k].N() < 4) continue;  // :432
 
     // partobs + splitobs per group (:438-453), on the device: ordered compaction of the rows with
     // q_k > 0.5, device-to-device gather into a fresh context, projection on the principal axis
@@ -228,11 +260,24 @@ static bool split_gr(lcc::Context& ctx, Model& model, std::vector<int>& tally, d
     // control flow (Mtot, scount, N_k) are all-reduced, so all ranks take the same branches.
     ctx.select_rows(k, 0.5, sel);
     const int64_t Mtot = (int64_t)std::llround(ctx.allreduce_value((double)sel.M));
-    lch::eigpower(model.clusters[k].iW, D, eigv);  // distributions.cpp:380
     lcc::Context sub(ctx.device(), ctx.stream());
     sub.inherit_comm(ctx);
     sub.set_data_gather(ctx, sel);
-    sub.qz_init_split(model.clusters[k].m.data(), eigv.data());
+    {
+      const ClusterAny& cl = model.clusters[k];
+      if (cl.kind == lch::C_GAUSSWISH) {  // project on the principal axis of iW (distributions.cpp:373-385)
+        lch::eigpower(cl.gw.iW, D, eigv);
+        sub.qz_init_split(cl.gw.m.data(), eigv.data());
+      } else if (cl.kind == lch::C_NORMGAMMA) {  // threshold the widest dimension at its mean (:495-505)
+        eigv.assign(D, 0.0);
+        eigv[(size_t)cl.ng.split_axis()] = 1.0;
+        sub.qz_init_split(cl.ng.m.data(), eigv.data());
+      } else {  // rate-weighted sum against its mean over the group's rows (:575-581)
+        eigv.resize(D);
+        for (int d = 0; d < D; ++d) eigv[(size_t)d] = cl.eg.a * cl.eg.ib[(size_t)d];
+        sub.qz_init_split_mean(eigv.data());
+      }
+    }
     njs.assign((size_t)J * 2, 0.0);
     sub.colsums(njs.data());
     double sc = 0.0;
@@ -244,6 +289,7 @@ static bool split_gr(lcc::Context& ctx, Model& model, std::vector<int>& tally, d
     // refine the split on the selected observations (:459-462)
     Model ms;
     ms.wkind = model.wkind;
+    ms.ckind = model.ckind;
     {
       VbemOptions vo;
       vo.clusterprior = prior;
@@ -307,7 +353,7 @@ double cluster(lcc::Context& ctx, Model& model, const ClusterOptions& opt) {
     F = vbem(ctx, model, vo);
     if (opt.trace) opt.trace->emplace_back((int)model.clusters.size(), tr);
     int nkeep = 0;
-    for (const auto& cl : model.clusters) nkeep += !(cl.N < lch::ZEROCUTOFF);
+    for (const auto& cl : model.clusters) nkeep += !(cl.N() < lch::ZEROCUTOFF);
     if (!(nkeep >= opt.maxclusters && opt.maxclusters >= 0)) data_loglik(ctx, model);  // split_gr will need it
     prune_clusters(ctx, model, opt.verbose);
     if (opt.verbose) std::cout << '<' << std::flush;

@@ -17,9 +17,12 @@ namespace lce {
 struct Model {
   int wkind = lch::W_DIRICHLET;
   std::vector<lch::WeightState> weights;      // J
-  std::vector<lch::GaussWishState> clusters;  // K
+  int ckind = lch::C_GAUSSWISH;
+  std::vector<lch::ClusterAny> clusters;      // K
   std::vector<double> LLk;                    // data term of the last E-step, per cluster
-  std::vector<double> lastA, lastm, lastc;    // packed parameters of the last E-step (K*D*D, K*D, J*K)
+  // parameters of the last E-step: (A [K*D*D], m [K*D]) for Gauss-Wishart clusters, (a, w2, w1) [K*D each] in
+  // lastA = [a | w2 | w1] for the diagonal families; c [J*K]
+  std::vector<double> lastA, lastm, lastc;
 };
 
 struct VbemOptions {

@@ -385,4 +385,171 @@ struct GaussWishState {
   }
 };
 
+// ---------------------------------------------------------------------------
+// Diagonal Gaussian (Normal-Gamma) and Exponential (Gamma) cluster distributions
+// src/distributions.cpp:406-517 and :524-589.  Their E-step is
+//   log q~[n,k] = c_jk + sum_d ( w2_kd (x_nd - a_kd)^2 + w1_kd x_nd )
+// with (a, w2, w1) = (m, -nu/(2L), 0) for NormGamma and (0, 0, -a*ib) for ExpGamma.
+// ---------------------------------------------------------------------------
+constexpr double NUPRIOR = 1.0, APRIOR = 1.0;  // include/distributions.h:40,43
+
+struct NormGammaState {
+  int D = 0;
+  double prior = 0.0, N = 0.0;
+  double nu_p = NUPRIOR, beta_p = BETAPRIOR, logL_p = 0.0;
+  std::vector<double> m_p, L_p;
+  double nu = 0, beta = 0, logL = 0;
+  std::vector<double> m, L;
+  double N_s = 0;
+  std::vector<double> x_s, xx_s;
+
+  NormGammaState() {}
+  NormGammaState(double clustwidth, int D_) : D(D_), prior(clustwidth) {
+    if (!(clustwidth > 0.0)) throw std::invalid_argument("clustwidth must be > 0!");
+    if (D < 1) throw std::invalid_argument("D must be >= 1!");
+    m_p.assign(D, 0.0);
+    L_p.assign(D, nu_p * prior);  // :419
+    logL_p = D * std::log(nu_p * prior);
+    clearobs();
+  }
+  void clearobs() {  // :467-480
+    nu = nu_p;
+    beta = beta_p;
+    m = m_p;
+    L = L_p;
+    logL = logL_p;
+    N_s = 0.0;
+    x_s.assign(D, 0.0);
+    xx_s.assign(D, 0.0);
+  }
+  void addstats(double Ns, const double* xs, const double* xxs) {  // sums of :426-438
+    N_s += Ns;
+    for (int d = 0; d < D; ++d) {
+      x_s[d] += xs[d];
+      xx_s[d] += xxs[d];
+    }
+  }
+  void update() {  // :441-464
+    N = N_s;
+    beta = beta_p + N;
+    nu = nu_p + N / 2;
+    logL = 0.0;
+    for (int d = 0; d < D; ++d) {
+      double xk = 0.0, Sk = 0.0;
+      if (N_s > 0) {
+        xk = x_s[d] / N_s;
+        Sk = xx_s[d] - x_s[d] * x_s[d] / N_s;
+      }
+      m[d] = (beta_p * m_p[d] + x_s[d]) / beta;
+      L[d] = L_p[d] + Sk / 2 + (beta_p * N / (2 * beta)) * (xk - m_p[d]) * (xk - m_p[d]);
+      if (!(L[d] > 0.0)) throw std::invalid_argument("Calc log(L): Variance is zero or less!");
+      logL += std::log(L[d]);
+    }
+  }
+  // constant part of Eloglike (:490-491)
+  double eloglike_const() const { return 0.5 * (D * (digamma(nu) - std::log(2 * PI) - 1.0 / beta) - logL); }
+  double fenergy() const {  // :508-517; D/2 is an INTEGER division in the reference (unsigned D)
+    double t1 = 0.0, t2 = 0.0;
+    for (int d = 0; d < D; ++d) {
+      t1 += (m[d] - m_p[d]) * (m[d] - m_p[d]) / L[d];
+      t2 += L_p[d] / L[d];
+    }
+    return D * (lgam(nu_p) - lgam(nu) + N * digamma(nu) / 2 - nu) +
+           (D / 2) * (std::log(beta) - std::log(beta_p) - 1 + beta_p / beta) + beta_p * nu / 2 * t1 +
+           nu_p * (logL - logL_p) + nu * t2;
+  }
+  int split_axis() const {  // :499-501 (first maximum, like Eigen's maxCoeff)
+    int ax = 0;
+    for (int d = 1; d < D; ++d)
+      if (L[d] > L[ax]) ax = d;
+    return ax;
+  }
+};
+
+struct ExpGammaState {
+  int D = 0;
+  double prior = 0.0, N = 0.0;
+  double a_p = APRIOR, b_p = 0.0;
+  double a = 0, logb = 0;
+  std::vector<double> ib;
+  double N_s = 0;
+  std::vector<double> x_s;
+
+  ExpGammaState() {}
+  ExpGammaState(double obsmag, int D_) : D(D_), prior(obsmag), b_p(obsmag) {  // :524-530 (no argument check there)
+    if (D < 1) throw std::invalid_argument("D must be >= 1!");
+    clearobs();
+  }
+  void clearobs() {  // :555-565
+    a = a_p;
+    ib.assign(D, 1.0 / b_p);
+    logb = D * std::log(b_p);
+    N_s = 0.0;
+    x_s.assign(D, 0.0);
+  }
+  void addstats(double Ns, const double* xs, const double*) {  // sums of :533-542
+    N_s += Ns;
+    for (int d = 0; d < D; ++d) x_s[d] += xs[d];
+  }
+  void update() {  // :545-552
+    N = N_s;
+    a = a_p + N;
+    double s = 0.0;
+    for (int d = 0; d < D; ++d) {
+      ib[d] = 1.0 / (b_p + x_s[d]);
+      s += std::log(ib[d]);
+    }
+    logb = -s;
+  }
+  double eloglike_const() const { return D * digamma(a) - logb; }  // :570
+  double fenergy() const {  // :584-589
+    double sib = 0.0;
+    for (int d = 0; d < D; ++d) sib += ib[d];
+    return D * ((a - a_p) * digamma(a) - a - a_p * std::log(b_p) - lgam(a) + lgam(a_p)) + b_p * a * sib + a_p * logb;
+  }
+};
+
+// One cluster of any family: what the (family-agnostic) driver in lc_engine.cpp holds.  The reference
+// gets the same effect from its <W, C> templates (cluster.cpp:177, 564).
+enum ClusterKind { C_GAUSSWISH = 0, C_NORMGAMMA = 1, C_EXPGAMMA = 2 };
+
+struct ClusterAny {
+  int kind = C_GAUSSWISH;
+  GaussWishState gw;
+  NormGammaState ng;
+  ExpGammaState eg;
+
+  ClusterAny() {}
+  ClusterAny(int kind_, double prior, int D) : kind(kind_) {
+    if (kind == C_GAUSSWISH) gw = GaussWishState(prior, D);
+    else if (kind == C_NORMGAMMA) ng = NormGammaState(prior, D);
+    else if (kind == C_EXPGAMMA) eg = ExpGammaState(prior, D);
+    else throw std::invalid_argument("unknown cluster family");
+  }
+  int D() const { return kind == C_GAUSSWISH ? gw.D : kind == C_NORMGAMMA ? ng.D : eg.D; }
+  double N() const { return kind == C_GAUSSWISH ? gw.N : kind == C_NORMGAMMA ? ng.N : eg.N; }
+  double prior() const { return kind == C_GAUSSWISH ? gw.prior : kind == C_NORMGAMMA ? ng.prior : eg.prior; }
+  void clearobs() {
+    if (kind == C_GAUSSWISH) gw.clearobs();
+    else if (kind == C_NORMGAMMA) ng.clearobs();
+    else eg.clearobs();
+  }
+  void addstats(double Ns, const double* xs, const double* xxs) {
+    if (kind == C_GAUSSWISH) gw.addstats(Ns, xs, xxs);
+    else if (kind == C_NORMGAMMA) ng.addstats(Ns, xs, xxs);
+    else eg.addstats(Ns, xs, xxs);
+  }
+  void update() {
+    if (kind == C_GAUSSWISH) gw.update();
+    else if (kind == C_NORMGAMMA) ng.update();
+    else eg.update();
+  }
+  double fenergy() const { return kind == C_GAUSSWISH ? gw.fenergy() : kind == C_NORMGAMMA ? ng.fenergy() : eg.fenergy(); }
+  double eloglike_const() const {
+    return kind == C_GAUSSWISH ? gw.eloglike_const() : kind == C_NORMGAMMA ? ng.eloglike_const() : eg.eloglike_const();
+  }
+  // second-moment statistics per cluster: D*D (full), D (diagonal) or 0
+  static size_t xx_size(int kind, int D) { return kind == C_GAUSSWISH ? (size_t)D * D : kind == C_NORMGAMMA ? (size_t)D : 0; }
+};
+
 }  // namespace lch

@@ -68,6 +68,41 @@ hipError_t launch_group_colsum(const double* qZ, int64_t ldq, int K, const int64
 // qZ[:, 0..K) = value on valid rows, 0 on pad rows
 hipError_t launch_fill_qz(double* qZ, int64_t ldq, int K, const int* rginfo, int64_t nrows, int64_t nrg, double value,
                           hipStream_t stream);
+// ---- diagonal Gaussian / exponential families (NormGamma, ExpGamma) --------------------------
+struct DiagEstepLaunch {
+  int DP, D;
+  const double* X;
+  int64_t nrg;
+  const int* rginfo;
+  int64_t nrows;
+  const double* params;  // [K][3][DP]: a, w2, w1
+  const double* ctab;    // [J x K]
+  int K;
+  double* qZ;
+  int64_t ldq;
+  double* fz_part;       // [ceil(NP/64)]
+  double* ll_part;       // [ceil(NP/64) x K] or nullptr
+  int raw = 0;
+};
+inline int64_t estep_diag_grid(int64_t nrg) { return (nrg * RG + 63) / 64; }
+hipError_t launch_estep_diag(const DiagEstepLaunch& a, hipStream_t stream);
+
+struct DiagStatLaunch {
+  int DP;
+  const double* X;
+  int64_t NP;
+  const double* qZ;
+  int64_t ldq;
+  int K;
+  const int* rginfo;
+  const unsigned char* smask;
+  double* partial;       // [nchunks x K x (1 + 2 DP)]
+  int nchunks;
+  int64_t chunk_rows;    // multiple of 32
+  int k0 = 0, k1 = 0;    // cluster range of one launch (filled in by launch_suffstat_diag)
+};
+hipError_t launch_suffstat_diag(const DiagStatLaunch& a, hipStream_t stream);
+
 // ---- split-search data passes (partobs / splitobs / auglabels on the device) ----
 int select_blocks(int64_t NP);  // number of per-block counts select_count produces
 hipError_t launch_select_count(const double* qcol, int64_t NP, double thresh, int* counts, hipStream_t stream);
@@ -78,7 +113,8 @@ hipError_t launch_group_starts(const int64_t* idx, int64_t M, const int64_t* gof
 hipError_t launch_gather_rows(const double* X, int DP, const int64_t* idx, int64_t M, const int64_t* starts,
                               const int64_t* goff_sub, int J, double* Xdst, hipStream_t stream);
 hipError_t launch_split_init(const double* X, int DP, int D, int64_t NP, const int* rginfo, int64_t nrows,
-                             const double* mv, double* q, int64_t ldq, hipStream_t stream);
+                             const double* mv, double* q, int64_t ldq, int mode, const double* thr,
+                             hipStream_t stream);
 hipError_t launch_aug_from_sub(double* q, int64_t ldq, int k, int K, const int64_t* idx, int64_t M,
                                const int64_t* starts, const int64_t* goff_sub, int J, const double* qsub1,
                                hipStream_t stream);

@@ -689,6 +689,175 @@ hipError_t launch_suffstat(const SuffstatLaunch& a, hipStream_t stream) {
 }
 
 // ===========================================================================
+// Diagonal / exponential cluster families
+// ===========================================================================
+// NormGamma::Eloglike (src/distributions.cpp:483-492) and ExpGamma::Eloglike (:568-572) inside the same
+// vbexpectation (cluster.cpp:91-138):  log q~[n,k] = c_jk + sum_d ( w2_kd (x_nd - a_kd)^2 + w1_kd x_nd ).
+// O(N K D) flops against 8(D+K) bytes per row: HBM/VALU-balanced, no matrix instruction needed.
+// A 256-thread block owns 64 rows staged in LDS (coalesced load, conflict-free column reads with an odd
+// row stride); lane = row, wave w takes the clusters k = w mod 4; parameters are wave-uniform loads.
+__global__ void __launch_bounds__(256) estep_diag_kernel(DiagEstepLaunch a) {
+  extern __shared__ double lds[];
+  const int DP = a.DP, D = a.D, K = a.K, LD = DP + 1;
+  double* xt = lds;                 // [64][LD]
+  double* red = lds + 64 * LD;      // [4][64]
+  double* llw = red + 256;          // [K]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int64_t row0 = (int64_t)blockIdx.x * 64, NP = a.nrg * RG;
+  for (int idx = tid; idx < 64 * DP; idx += 256) {
+    const int r = idx / DP, d = idx % DP;
+    xt[r * LD + d] = row0 + r < NP ? a.X[(row0 + r) * DP + d] : 0.0;
+  }
+  __syncthreads();
+  const int64_t row = row0 + lane;
+  const bool inb = row < NP;
+  int grp = 0;
+  bool ok = false;
+  if (inb) {
+    if (a.rginfo) {
+      const int info = a.rginfo[row >> 4];
+      grp = info >> 5;
+      ok = (int)(row & 15) < (info & 31);
+    } else {
+      ok = row < a.nrows;
+    }
+  }
+  const double* xr = xt + lane * LD;
+  double mx = -INFINITY;
+  for (int k = w; k < K; k += 4) {
+    const double* pa = a.params + (int64_t)k * 3 * DP;
+    double acc = 0.0;
+    for (int d = 0; d < D; ++d) {
+      const double x = xr[d], t = x - pa[d];
+      acc = fma(pa[DP + d], t * t, acc);
+      acc = fma(pa[2 * DP + d], x, acc);
+    }
+    const double lq = a.ctab[(int64_t)grp * K + k] + acc;
+    mx = fmax(mx, lq);
+    if (inb) a.qZ[(int64_t)k * a.ldq + row] = lq;
+  }
+  if (a.raw) return;
+  red[w * 64 + lane] = mx;
+  __syncthreads();
+  mx = fmax(fmax(red[lane], red[64 + lane]), fmax(red[128 + lane], red[192 + lane]));
+  __syncthreads();
+  double se = 0.0;
+  if (inb)
+    for (int k = w; k < K; k += 4) se += exp(a.qZ[(int64_t)k * a.ldq + row] - mx);
+  red[w * 64 + lane] = se;
+  __syncthreads();
+  const double logZ = log(red[lane] + red[64 + lane] + red[128 + lane] + red[192 + lane]) + mx;
+  for (int k = w; k < K; k += 4) {
+    double ll = 0.0;
+    if (inb) {
+      double* qp = a.qZ + (int64_t)k * a.ldq + row;
+      const double lq = *qp;
+      const double q = ok ? exp(lq - logZ) : 0.0;
+      *qp = q;
+      if (a.ll_part && q > 0.0) ll = q * (lq - a.ctab[(int64_t)grp * K + k]);
+    }
+    if (a.ll_part) {
+      ll = wave_sum(ll);
+      if (lane == 0) llw[k] = ll;
+    }
+  }
+  double fz = (w == 0 && ok) ? logZ : 0.0;
+  fz = wave_sum(fz);
+  __syncthreads();
+  if (tid == 0) a.fz_part[blockIdx.x] = -fz;
+  if (a.ll_part)
+    for (int k = tid; k < K; k += 256) a.ll_part[(int64_t)blockIdx.x * K + k] = llw[k];
+}
+
+hipError_t launch_estep_diag(const DiagEstepLaunch& a, hipStream_t stream) {
+  const int64_t grid = (a.nrg * RG + 63) / 64;
+  if (grid <= 0) return hipSuccess;
+  const size_t shmem = (size_t)(64 * (a.DP + 1) + 256 + a.K) * sizeof(double);
+  static size_t attr_set = 0;
+  if (shmem > 64 * 1024 && shmem > attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(estep_diag_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e != hipSuccess) return e;
+    attr_set = shmem;
+  }
+  hipLaunchKernelGGL(estep_diag_kernel, dim3((unsigned)grid), dim3(256), shmem, stream, a);
+  return hipGetLastError();
+}
+
+// NormGamma::addobs (distributions.cpp:426-438) / ExpGamma::addobs (:533-542) for a range of clusters:
+// N_k = sum q, x_s = sum q x, xx_s = sum q x^2 (elementwise).  Thread = (cluster slot, dimension); a block
+// streams its row chunk through LDS in 32-row tiles and keeps up to DIAG_PMAX cluster passes in registers.
+constexpr int DIAG_PMAX = 16;
+__global__ void __launch_bounds__(256) suffstat_diag_kernel(DiagStatLaunch a) {
+  __shared__ double xt[32 * 128];
+  extern __shared__ double qt[];  // [kcount][32]
+  const int DP = a.DP, K = a.K;
+  const int slots = 256 / DP, s = threadIdx.x / DP, d = threadIdx.x % DP;
+  const int kcount = a.k1 - a.k0, passes = (kcount + slots - 1) / slots;
+  const int64_t r0 = (int64_t)blockIdx.x * a.chunk_rows;
+  const int64_t r1 = (r0 + a.chunk_rows) < a.NP ? (r0 + a.chunk_rows) : a.NP;
+  double n[DIAG_PMAX], xs[DIAG_PMAX], xx[DIAG_PMAX];
+#pragma unroll
+  for (int p = 0; p < DIAG_PMAX; ++p) n[p] = xs[p] = xx[p] = 0.0;
+  for (int64_t b0 = r0; b0 < r1; b0 += 32) {
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 32 * DP; idx += 256) {
+      const int r = idx / DP;
+      xt[idx] = b0 + r < r1 ? a.X[(b0 + r) * DP + idx % DP] : 0.0;
+    }
+    for (int idx = threadIdx.x; idx < 32 * kcount; idx += 256) {
+      const int k = a.k0 + idx / 32, r = idx % 32;
+      double q = 0.0;
+      if (b0 + r < r1) {
+        q = a.qZ[(int64_t)k * a.ldq + b0 + r];
+        if (a.smask && !a.smask[(int64_t)(a.rginfo[(b0 + r) >> 4] >> 5) * K + k]) q = 0.0;
+      }
+      qt[idx] = q;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < DIAG_PMAX; ++p) {
+      const int kk = p * slots + s;
+      if (p < passes && kk < kcount) {
+        for (int r = 0; r < 32; ++r) {
+          const double q = qt[kk * 32 + r], x = xt[r * DP + d];
+          const double qx = q * x;
+          n[p] += q;
+          xs[p] += qx;
+          xx[p] = fma(qx, x, xx[p]);
+        }
+      }
+    }
+  }
+  const int64_t SS = 1 + 2 * (int64_t)DP;
+#pragma unroll
+  for (int p = 0; p < DIAG_PMAX; ++p) {
+    const int kk = p * slots + s;
+    if (p < passes && kk < kcount) {
+      double* out = a.partial + ((int64_t)blockIdx.x * K + a.k0 + kk) * SS;
+      if (d == 0) out[0] = n[p];
+      out[1 + d] = xs[p];
+      out[1 + DP + d] = xx[p];
+    }
+  }
+}
+
+hipError_t launch_suffstat_diag(const DiagStatLaunch& a0, hipStream_t stream) {
+  if (a0.K <= 0 || a0.nchunks <= 0) return hipSuccess;
+  const int slots = 256 / a0.DP, kmax = DIAG_PMAX * slots;
+  for (int k0 = 0; k0 < a0.K; k0 += kmax) {
+    DiagStatLaunch a = a0;
+    a.k0 = k0;
+    a.k1 = k0 + kmax < a0.K ? k0 + kmax : a0.K;
+    const size_t shmem = (size_t)32 * (a.k1 - a.k0) * sizeof(double);
+    hipLaunchKernelGGL(suffstat_diag_kernel, dim3((unsigned)a.nchunks), dim3(256), shmem, stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+// ===========================================================================
 // small helpers
 // ===========================================================================
 __global__ void __launch_bounds__(256) reduce_partials_kernel(const double* partial, int nparts, int64_t n,
@@ -889,29 +1058,51 @@ hipError_t launch_gather_rows(const double* X, int DP, const int64_t* idx, int64
   return hipGetLastError();
 }
 
-// splitobs (src/distributions.cpp:373-385) + the initial split responsibilities (cluster.cpp:446-449):
-// q[0][row] = (sum_d (x_d - m_d) v_d >= 0), q[1][row] = 1 - q[0][row]; pad rows 0.  mv = [m(DP), v(DP)].
+// splitobs + the initial split responsibilities (cluster.cpp:446-449).  mode 0 (GaussWish
+// distributions.cpp:373-385, NormGamma :495-505): q0 = (sum_d (x_d - m_d) v_d >= 0); mode 1 (first pass of
+// ExpGamma :575-581): q0 = sum_d x_d v_d (the projection itself, for the per-group mean); mode 2 (second
+// pass): q0 = (q0 > thr[group]).  q1 = 1 - q0 in modes 0 and 2; pad rows 0.  mv = [m(DP), v(DP)].
 __global__ void __launch_bounds__(256) split_init_kernel(const double* X, int DP, int D, int64_t NP, const int* rginfo,
-                                                         int64_t nrows, const double* mv, double* q, int64_t ldq) {
+                                                         int64_t nrows, const double* mv, double* q, int64_t ldq,
+                                                         int mode, const double* thr) {
   const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= NP) return;
-  const bool ok = rginfo ? (row & 15) < (rginfo[row >> 4] & 31) : row < nrows;
+  int grp = 0;
+  bool ok;
+  if (rginfo) {
+    const int info = rginfo[row >> 4];
+    grp = info >> 5;
+    ok = (int)(row & 15) < (info & 31);
+  } else {
+    ok = row < nrows;
+  }
   double q0 = 0.0, q1 = 0.0;
   if (ok) {
-    double s = 0.0;
-    for (int d = 0; d < D; ++d) s += (X[row * DP + d] - mv[d]) * mv[DP + d];
-    q0 = s >= 0.0 ? 1.0 : 0.0;
-    q1 = 1.0 - q0;
+    if (mode == 2) {
+      q0 = q[row] > thr[grp] ? 1.0 : 0.0;
+      q1 = 1.0 - q0;
+    } else {
+      double s = 0.0;
+      if (mode == 0) {
+        for (int d = 0; d < D; ++d) s += (X[row * DP + d] - mv[d]) * mv[DP + d];
+        q0 = s >= 0.0 ? 1.0 : 0.0;
+        q1 = 1.0 - q0;
+      } else {
+        for (int d = 0; d < D; ++d) s += X[row * DP + d] * mv[DP + d];
+        q0 = s;
+      }
+    }
   }
   q[row] = q0;
   q[ldq + row] = q1;
 }
 
 hipError_t launch_split_init(const double* X, int DP, int D, int64_t NP, const int* rginfo, int64_t nrows,
-                             const double* mv, double* q, int64_t ldq, hipStream_t stream) {
+                             const double* mv, double* q, int64_t ldq, int mode, const double* thr,
+                             hipStream_t stream) {
   if (NP <= 0) return hipSuccess;
   hipLaunchKernelGGL(split_init_kernel, dim3((unsigned)((NP + 255) / 256)), dim3(256), 0, stream, X, DP, D, NP, rginfo,
-                     nrows, mv, q, ldq);
+                     nrows, mv, q, ldq, mode, thr);
   return hipGetLastError();
 }
 

@@ -362,6 +362,165 @@ class GaussWish:
         return self.iW / self.nu
 
 
+class NormGamma:
+    """Diagonal Gaussian clusters -- src/distributions.cpp:406-517, include/distributions.h:343-398."""
+
+    def __init__(self, clustwidth, D):
+        if clustwidth <= 0:
+            raise ValueError("clustwidth must be > 0!")
+        self.D = int(D)
+        self.prior = float(clustwidth)
+        self.N = 0.0
+        self.nu_p = NUPRIOR
+        self.beta_p = BETAPRIOR
+        self.m_p = np.zeros(D)
+        self.L_p = self.nu_p * self.prior * np.ones(D)  # :419
+        self.logL_p = float(np.log(self.L_p).sum())
+        self.clearobs()
+
+    def clearobs(self):  # :467-480
+        self.nu = self.nu_p
+        self.beta = self.beta_p
+        self.m = self.m_p.copy()
+        self.L = self.L_p.copy()
+        self.logL = self.logL_p
+        self.N_s = 0.0
+        self.x_s = np.zeros(self.D)
+        self.xx_s = np.zeros(self.D)
+
+    def addobs(self, qZk, X):  # :426-438
+        X = np.asarray(X, dtype=np.float64)
+        qZk = np.asarray(qZk, dtype=np.float64).reshape(-1)
+        if X.shape[1] != self.D:
+            raise ValueError("Mismatched dims. of cluster params and obs.!")
+        if qZk.shape[0] != X.shape[0]:
+            raise ValueError("qZk and X ar not the same length!")
+        qZkX = qZk[:, None] * X
+        self.N_s += qZk.sum()
+        self.x_s = self.x_s + qZkX.sum(axis=0)
+        self.xx_s = self.xx_s + (qZkX * X).sum(axis=0)
+
+    def addstats(self, N_s, x_s, xx_s):
+        self.N_s += float(N_s)
+        self.x_s = self.x_s + np.asarray(x_s, dtype=np.float64)
+        self.xx_s = self.xx_s + np.asarray(xx_s, dtype=np.float64)
+
+    def update(self):  # :441-464
+        xk = np.zeros(self.D)
+        Sk = np.zeros(self.D)
+        if self.N_s > 0:
+            xk = self.x_s / self.N_s
+            Sk = self.xx_s - self.x_s ** 2 / self.N_s
+        self.N = self.N_s
+        self.beta = self.beta_p + self.N
+        self.nu = self.nu_p + self.N / 2
+        self.m = (self.beta_p * self.m_p + self.x_s) / self.beta
+        self.L = self.L_p + Sk / 2 + (self.beta_p * self.N / (2 * self.beta)) * (xk - self.m_p) ** 2
+        if (self.L <= 0).any():
+            raise ValueError("Calc log(L): Variance is zero or less!")
+        self.logL = float(np.log(self.L).sum())
+
+    def Eloglike(self, X):  # :483-492
+        X = np.atleast_2d(np.asarray(X, dtype=np.float64))
+        Xmdist = ((X - self.m) ** 2) @ (1.0 / self.L)
+        return 0.5 * (self.D * (digamma(self.nu) - math.log(2 * math.pi) - 1 / self.beta)
+                      - self.logL - self.nu * Xmdist)
+
+    def splitobs(self, X):  # :495-505
+        X = np.atleast_2d(np.asarray(X, dtype=np.float64)).reshape(-1, self.D)
+        ax = int(np.argmax(self.L))
+        return (X[:, ax] - self.m[ax]) >= 0
+
+    def fenergy(self):  # :508-517 -- note D/2 is INTEGER division there (D is unsigned int)
+        iL = 1.0 / self.L
+        D = self.D
+        return float(
+            D * (gammaln(self.nu_p) - gammaln(self.nu) + self.N * digamma(self.nu) / 2 - self.nu)
+            + (D // 2) * (math.log(self.beta) - math.log(self.beta_p) - 1 + self.beta_p / self.beta)
+            + self.beta_p * self.nu / 2 * (((self.m - self.m_p) ** 2) @ iL)
+            + self.nu_p * (self.logL - self.logL_p)
+            + self.nu * (self.L_p @ iL)
+        )
+
+    def getN(self):
+        return self.N
+
+    def getprior(self):
+        return self.prior
+
+    def getmean(self):
+        return self.m
+
+    def getcov(self):  # distributions.h:375 returns L*nu (sic: the expected variance would be L/nu); kept as is
+        return self.L * self.nu
+
+
+class ExpGamma:
+    """Exponential clusters -- src/distributions.cpp:524-589, include/distributions.h:404-457."""
+
+    def __init__(self, obsmag, D):
+        self.D = int(D)
+        self.prior = float(obsmag)
+        self.N = 0.0
+        self.a_p = 1.0  # APRIOR, distributions.h:43
+        self.b_p = float(obsmag)
+        self.clearobs()
+
+    def clearobs(self):  # :555-565
+        self.a = self.a_p
+        self.ib = np.full(self.D, 1.0 / self.b_p)
+        self.logb = self.D * math.log(self.b_p)
+        self.N_s = 0.0
+        self.x_s = np.zeros(self.D)
+
+    def addobs(self, qZk, X):  # :533-542
+        X = np.asarray(X, dtype=np.float64)
+        qZk = np.asarray(qZk, dtype=np.float64).reshape(-1)
+        if X.shape[1] != self.D:
+            raise ValueError("Mismatched dims. of cluster params and obs.!")
+        if qZk.shape[0] != X.shape[0]:
+            raise ValueError("qZk and X ar not the same length!")
+        self.N_s += qZk.sum()
+        self.x_s = self.x_s + (qZk[:, None] * X).sum(axis=0)
+
+    def addstats(self, N_s, x_s, xx_s=None):
+        self.N_s += float(N_s)
+        self.x_s = self.x_s + np.asarray(x_s, dtype=np.float64)
+
+    def update(self):  # :545-552
+        self.N = self.N_s
+        self.a = self.a_p + self.N
+        self.ib = 1.0 / (self.b_p + self.x_s)
+        self.logb = -float(np.log(self.ib).sum())
+
+    def Eloglike(self, X):  # :568-572
+        X = np.atleast_2d(np.asarray(X, dtype=np.float64))
+        return self.D * digamma(self.a) - self.logb - self.a * (X @ self.ib)
+
+    def splitobs(self, X):  # :575-581
+        X = np.atleast_2d(np.asarray(X, dtype=np.float64)).reshape(-1, self.D)
+        XdotL = X @ (self.a * self.ib)
+        if XdotL.size == 0:
+            return np.zeros(0, dtype=bool)
+        return XdotL > (XdotL.sum() / XdotL.size)
+
+    def fenergy(self):  # :584-589
+        return float(
+            self.D * ((self.a - self.a_p) * digamma(self.a) - self.a - self.a_p * math.log(self.b_p)
+                      - gammaln(self.a) + gammaln(self.a_p))
+            + self.b_p * self.a * self.ib.sum() + self.a_p * self.logb
+        )
+
+    def getN(self):
+        return self.N
+
+    def getprior(self):
+        return self.prior
+
+    def getrate(self):  # distributions.h: getrate() = a * ib
+        return self.a * self.ib
+
+
 # ---------------------------------------------------------------------------
 # comutils
 # ---------------------------------------------------------------------------
@@ -442,7 +601,7 @@ def fenergy(weights, clusters, Fxz):
 
 
 def vbem(X, qZ, weights, clusters, clusterprior, maxit=-1, sparse=False,
-         verbose=False, wfactory=None, trace=None):
+         verbose=False, wfactory=None, trace=None, cfactory=None):
     """src/cluster.cpp:177-239.  ``qZ``, ``weights``, ``clusters`` are lists
     mutated in place (the reference takes them by mutable reference).
     ``trace`` (optional list) receives F after every iteration."""
@@ -452,7 +611,7 @@ def vbem(X, qZ, weights, clusters, clusterprior, maxit=-1, sparse=False,
     while len(weights) < J:  # weights.resize(J, W()) :192
         weights.append(wfactory())
     while len(clusters) < K:  # clusters.resize(K, C(prior, D)) :193
-        clusters.append(GaussWish(clusterprior, D))
+        clusters.append((cfactory or GaussWish)(clusterprior, D))
     # (resize also shrinks)
     del weights[J:]
     del clusters[K:]
@@ -508,7 +667,7 @@ def prune_clusters(qZ, weights, clusters, verbose=False):
 
 
 def split_gr(X, weights, clusters, qZ, tally, F, maxclusters, sparse, verbose,
-             wfactory, events=None):
+             wfactory, events=None, cfactory=None):
     """src/cluster.cpp:366-495."""
     J = len(X)
     K = len(clusters)
@@ -551,12 +710,12 @@ def split_gr(X, weights, clusters, qZ, tally, F, maxclusters, sparse, verbose,
             continue
         wspl, cspl = [], []
         vbem(Xk, qZref, wspl, cspl, clusters[0].getprior(), SPLITITER, sparse,
-             wfactory=wfactory)
+             wfactory=wfactory, cfactory=cfactory)
         if anyempty(cspl):
             continue
         qZaug = [auglabels(k, mapidx[j], qZref[j][:, 1] > 0.5, qZ[j]) for j in range(J)]
         Fsplit = vbem(X, qZaug, wspl, cspl, clusters[0].getprior(), 1, sparse,
-                      wfactory=wfactory)
+                      wfactory=wfactory, cfactory=cfactory)
         if anyempty(cspl):
             continue
         if verbose:
@@ -572,7 +731,7 @@ def split_gr(X, weights, clusters, qZ, tally, F, maxclusters, sparse, verbose,
 
 
 def cluster(X, weights, clusters, clusterprior, maxclusters, sparse, verbose,
-            wfactory, trace=None, events=None):
+            wfactory, trace=None, events=None, cfactory=None):
     """src/cluster.cpp:564-629 -> (F, qZ)."""
     J = len(X)
     qZ = [np.ones((X[j].shape[0], 1)) for j in range(J)]
@@ -582,14 +741,14 @@ def cluster(X, weights, clusters, clusterprior, maxclusters, sparse, verbose,
     while issplit:
         rtrace = [] if trace is not None else None
         F = vbem(X, qZ, weights, clusters, clusterprior, -1, sparse, verbose,
-                 wfactory=wfactory, trace=rtrace)
+                 wfactory=wfactory, trace=rtrace, cfactory=cfactory)
         if trace is not None:
             trace.append((len(clusters), rtrace))
         prune_clusters(qZ, weights, clusters, verbose)
         if verbose:
             print("<", end="", flush=True)
         issplit = split_gr(X, weights, clusters, qZ, tally, F, maxclusters,
-                           sparse, verbose, wfactory, events=events)
+                           sparse, verbose, wfactory, events=events, cfactory=cfactory)
         if verbose:
             print(">")
     if verbose:
@@ -639,6 +798,46 @@ def learnSGMC(X, clusterprior=PRIORVAL, maxclusters=-1, sparse=False,
     return F, qZ, w, clusters
 
 
+def _nonneg(Xl):
+    for x in Xl:
+        if (x < 0).any():
+            raise ValueError("X has to be in the range [0, inf)!")
+
+
+def learnDGMM(X, clusterprior=PRIORVAL, maxclusters=-1, verbose=False, trace=None):
+    """src/cluster.cpp:698-726 (Dirichlet weights, diagonal Gaussian clusters)."""
+    w, clusters = [Dirichlet()], []
+    F, qZ = cluster([np.asarray(X, dtype=np.float64)], w, clusters, clusterprior, maxclusters, False, verbose,
+                    Dirichlet, trace, None, NormGamma)
+    return F, qZ[0], w[0], clusters
+
+
+def learnBEMM(X, clusterprior=PRIORVAL, maxclusters=-1, verbose=False, trace=None):
+    """src/cluster.cpp:729-760 (Dirichlet weights, exponential clusters; X >= 0)."""
+    Xa = np.asarray(X, dtype=np.float64)
+    _nonneg([Xa])
+    w, clusters = [Dirichlet()], []
+    F, qZ = cluster([Xa], w, clusters, clusterprior, maxclusters, False, verbose, Dirichlet, trace, None, ExpGamma)
+    return F, qZ[0], w[0], clusters
+
+
+def learnDGMC(X, clusterprior=PRIORVAL, maxclusters=-1, sparse=False, verbose=False, trace=None):
+    """src/cluster.cpp:810-831 (GDirichlet per group, diagonal Gaussian clusters)."""
+    w, clusters = [], []
+    Xl = [np.asarray(x, dtype=np.float64) for x in X]
+    F, qZ = cluster(Xl, w, clusters, clusterprior, maxclusters, sparse, verbose, GDirichlet, trace, None, NormGamma)
+    return F, qZ, w, clusters
+
+
+def learnEGMC(X, clusterprior=PRIORVAL, maxclusters=-1, sparse=False, verbose=False, trace=None):
+    """src/cluster.cpp:834-859 (GDirichlet per group, exponential clusters; X >= 0)."""
+    Xl = [np.asarray(x, dtype=np.float64) for x in X]
+    _nonneg(Xl)
+    w, clusters = [], []
+    F, qZ = cluster(Xl, w, clusters, clusterprior, maxclusters, sparse, verbose, GDirichlet, trace, None, ExpGamma)
+    return F, qZ, w, clusters
+
+
 # ---------------------------------------------------------------------------
 # fixed-K harness (no reference entry point: vbem is file-static there,
 # cluster.cpp:177).  Used by parity tests and bench.py's cpu_baseline check.
@@ -652,7 +851,7 @@ def suffstats(X, qZ):
     return Nk, xs, xxs
 
 
-def vbem_fixed(X, qZ0, wfactory, clusterprior, iters, sparse=False):
+def vbem_fixed(X, qZ0, wfactory, clusterprior, iters, sparse=False, cfactory=None):
     """``iters`` VBEM iterations from the given qZ with the convergence test
     disabled (same body as vbem, cluster.cpp:198-234).  Returns
     (F trace, Fz trace, qZ list, weights, clusters)."""
@@ -661,7 +860,7 @@ def vbem_fixed(X, qZ0, wfactory, clusterprior, iters, sparse=False):
     D = X[0].shape[1]
     qZ = [q.copy() for q in qZ0]
     weights = [wfactory() for _ in range(J)]
-    clusters = [GaussWish(clusterprior, D) for _ in range(K)]
+    clusters = [(cfactory or GaussWish)(clusterprior, D) for _ in range(K)]
     Ftrace, Fztrace = [], []
     for _ in range(iters):
         for c in clusters:

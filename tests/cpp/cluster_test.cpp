@@ -39,6 +39,8 @@ int main() {
   }
   double Fgmc_ref, Fbgmm_ref, Fvdp_ref;
   REQUIRE(scanf("%lf %lf %lf", &Fgmc_ref, &Fbgmm_ref, &Fvdp_ref) == 3);
+  double Fdgmm_ref, Fdgmc_ref, Fbemm_ref, Fegmc_ref;
+  REQUIRE(scanf("%lf %lf %lf %lf", &Fdgmm_ref, &Fdgmc_ref, &Fbemm_ref, &Fegmc_ref) == 4);
 
   // GMC, exactly as test/cluster_test.cpp:45-66
   vector<GDirichlet> weights;
@@ -92,6 +94,65 @@ int main() {
   const lcmat::VectorXd ell = g.Eloglike(Xcat);
   REQUIRE(ell.size() == Xcat.rows() && std::isfinite(ell(0)) && ell(0) < 0);
   REQUIRE(g.splitobs(Xcat).size() == Xcat.rows());
+
+  // diagonal-Gaussian and exponential families (libcluster.h:262-315, 462-523)
+  {
+    Dirichlet w1;
+    vector<NormGamma> cd;
+    const double Fd = learnDGMM(Xcat, qZ, w1, cd);
+    REQUIRE(cd.size() == 3 && fabs(Fd - Fdgmm_ref) < 1e-7 * fabs(Fdgmm_ref));
+    vector<GDirichlet> wg;
+    vector<NormGamma> cg;
+    vMatrixXd qg;
+    const double Fg = learnDGMC(X, qg, wg, cg);
+    REQUIRE(cg.size() == 4 && fabs(Fg - Fdgmc_ref) < 1e-7 * fabs(Fdgmc_ref));
+    REQUIRE(qg.size() == (size_t)J && qg[0].cols() == 4 && wg.size() == (size_t)J);
+    // the NormGamma plugin interface on the GPU path: refit cluster 0 from its responsibilities
+    NormGamma ng(PRIORVAL, D);
+    for (int r = 0; r < Xcat.rows(); ++r) q(r) = qZ(r, 0);
+    ng.addobs(q, Xcat);
+    ng.update();
+    REQUIRE(fabs(ng.getN() - cd[0].getN()) < 1e-8);
+    REQUIRE(fabs(ng.getmean()(0) - cd[0].getmean()(0)) < 1e-6 && fabs(ng.getcov()(1) - cd[0].getcov()(1)) < 1e-6);
+    REQUIRE(fabs(ng.fenergy() - cd[0].fenergy()) < 1e-7);
+    const lcmat::VectorXd e1 = ng.Eloglike(Xcat), e2 = cd[0].Eloglike(Xcat);
+    REQUIRE(e1.size() == Xcat.rows() && fabs(e1(5) - e2(5)) < 1e-7 * fabs(e2(5)));
+    REQUIRE(ng.splitobs(Xcat).size() == Xcat.rows());
+
+    lcmat::MatrixXd Xpos(Xcat.rows(), D);
+    vMatrixXd Xp(J);
+    for (int j = 0; j < J; ++j) {
+      Xp[j].resize(n, D);
+      for (int r = 0; r < n; ++r)
+        for (int d = 0; d < D; ++d) Xpos(j * n + r, d) = Xp[j](r, d) = fabs(X[j](r, d)) + 0.1;
+    }
+    Dirichlet w2;
+    vector<ExpGamma> ce;
+    const double Fe = learnBEMM(Xpos, qZ, w2, ce);
+    REQUIRE(ce.size() == 2 && fabs(Fe - Fbemm_ref) < 1e-7 * fabs(Fbemm_ref));
+    vector<GDirichlet> wge;
+    vector<ExpGamma> cge;
+    const double Fge = learnEGMC(Xp, qg, wge, cge);
+    REQUIRE(cge.size() == 2 && fabs(Fge - Fegmc_ref) < 1e-7 * fabs(Fegmc_ref));
+    ExpGamma eg(PRIORVAL, D);
+    for (int r = 0; r < Xpos.rows(); ++r) q(r) = qZ(r, 1);
+    eg.addobs(q, Xpos);
+    eg.update();
+    REQUIRE(fabs(eg.getN() - ce[1].getN()) < 1e-8 && fabs(eg.getrate()(0) - ce[1].getrate()(0)) < 1e-7);
+    REQUIRE(fabs(eg.fenergy() - ce[1].fenergy()) < 1e-7);
+    const lcmat::VectorXd e3 = eg.Eloglike(Xpos), e4 = ce[1].Eloglike(Xpos);
+    REQUIRE(fabs(e3(7) - e4(7)) < 1e-7 * fabs(e4(7)));
+    REQUIRE(eg.splitobs(Xpos).size() == Xpos.rows());
+    bool neg = false;
+    try { learnBEMM(Xcat, qZ, w2, ce); } catch (const invalid_argument&) { neg = true; }
+    REQUIRE(neg);
+    neg = false;
+    try { learnEGMC(X, qg, wge, cge); } catch (const invalid_argument&) { neg = true; }
+    REQUIRE(neg);
+    neg = false;
+    try { NormGamma bad(0.0, 2); } catch (const invalid_argument&) { neg = true; }
+    REQUIRE(neg);
+  }
 
   // error behaviour (cluster.cpp:576-577, distributions.cpp:107-108/282-283)
   bool threw = false;

@@ -2,7 +2,8 @@
 oracle (oracle/lc_oracle.py) and cross-check them against scikit-learn.
 
 Run in the build container:   python tests/golden/make_golden.py
-Outputs (committed): tests/golden/estep_cases.json, tests/golden/xcat_traces.json
+Outputs (committed): tests/golden/estep_cases.json, tests/golden/xcat_traces.json,
+tests/golden/family_traces.json
 
 The reference itself cannot be built or imported here (no Eigen/Boost), so
 these vectors are restatement-derived ("parity unpinned", see oracle header);
@@ -171,7 +172,34 @@ def main():
     F, _, _, cl = o.learnVDP(Xcat, weights=o.StickBreak(2.5))
     out["learnVDP_conc2.5"] = {"F": F, "K": len(cl)}
     (HERE / "xcat_traces.json").write_text(json.dumps(out))
-    for f in ("estep_cases.json", "xcat_traces.json"):
+
+    # diagonal-Gaussian and exponential families (NormGamma / ExpGamma): the toy data, the toy data folded to
+    # [0.1, inf) for the exponential learners, and a 3-component exponential mixture in 4 dimensions
+    fam = {}
+    Xpos = [np.abs(g) + 0.1 for g in X]
+    rates = np.array([[0.2, 5.0, 1.0, 0.5], [4.0, 0.25, 2.0, 6.0], [1.0, 1.0, 8.0, 0.1]])
+    zz = rng.integers(0, 3, size=360)
+    Xexp = rng.exponential(1.0, size=(360, 4)) / rates[zz]
+    fam["Xexp"] = Xexp.tolist()
+    Xexp_g = [Xexp[:130], Xexp[130:250], Xexp[250:]]
+    for name, fn, arg in (("learnDGMM", o.learnDGMM, Xcat), ("learnDGMC", o.learnDGMC, X),
+                          ("learnBEMM", o.learnBEMM, np.vstack(Xpos)), ("learnEGMC", o.learnEGMC, Xpos),
+                          ("learnBEMM_exp", o.learnBEMM, Xexp), ("learnEGMC_exp", o.learnEGMC, Xexp_g)):
+        tr = []
+        F, qZ, w, cl = fn(arg, trace=tr)
+        wl = w if isinstance(w, list) else [w]
+        qs = qZ if isinstance(qZ, list) else [qZ]
+        rec = {"F": F, "K": len(cl), "rounds": [[k, t] for k, t in tr], "N": [c.getN() for c in cl],
+               "Elogweight": [x.Elogweight().tolist() for x in wl], "qZ": [q.tolist() for q in qs]}
+        if hasattr(cl[0], "getrate"):
+            rec["rates"] = [c.getrate().tolist() for c in cl]
+        else:
+            rec["means"] = [c.getmean().tolist() for c in cl]
+            rec["covs"] = [c.getcov().tolist() for c in cl]
+        fam[name] = rec
+        print(name, "F =", F, "K =", len(cl))
+    (HERE / "family_traces.json").write_text(json.dumps(fam))
+    for f in ("estep_cases.json", "xcat_traces.json", "family_traces.json"):
         print(f, (HERE / f).stat().st_size // 1024, "KiB")
 
 

@@ -1,6 +1,7 @@
 """The drop-in C++ headers (include/libcluster.h, include/distributions.h):
 they must compile with plain g++ against the C-ABI library (CPU check), and
 the reference's own test main, re-written with assertions, must pass on the GPU."""
+import json
 import subprocess
 from pathlib import Path
 
@@ -43,6 +44,8 @@ def test_reference_test_main_passes_on_gpu(lib, xcat, xcat_traces):
     for g in X:
         lines += [" ".join(repr(float(v)) for v in row) for row in g]
     lines.append(f"{xcat_traces['learnGMC']['F']!r} {xcat_traces['learnBGMM']['F']!r} {xcat_traces['learnVDP']['F']!r}")
+    fam = json.loads((ROOT / "tests" / "golden" / "family_traces.json").read_text())
+    lines.append(" ".join(repr(fam[k]["F"]) for k in ("learnDGMM", "learnDGMC", "learnBEMM", "learnEGMC")))
     r = subprocess.run([str(exe)], input="\n".join(lines) + "\n", capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "cluster_test OK" in r.stdout

@@ -91,3 +91,36 @@ def test_no_cpu_fallback(lib):
         capi.Context(0)
     with pytest.raises(capi.HipError):
         capi.learn(capi.ALGO_BGMM, np.zeros((4, 2)))
+
+
+def test_ng_and_eg_mstep_match_oracle(lib):
+    """NormGamma / ExpGamma update(), fenergy() and the Eloglike constant (distributions.cpp:441-464, 508-517,
+    545-552, 584-589) against the oracle, incl. odd D (the reference's integer D/2 in NormGamma::fenergy)."""
+    from scipy.special import digamma
+
+    rng = np.random.default_rng(3)
+    for D in (1, 2, 5, 16, 33):
+        n = 40
+        Xn = rng.normal(size=(n, D)) * 2 + 1
+        q = rng.uniform(0.05, 1.0, n)
+        for prior in (1.0, 0.3):
+            c = o.NormGamma(prior, D)
+            c.addobs(q, Xn)
+            c.update()
+            r = capi.ng_mstep(prior, q.sum(), q @ Xn, q @ (Xn * Xn))
+            assert abs(r["nu"] - c.nu) < 1e-12 and abs(r["beta"] - c.beta) < 1e-12
+            np.testing.assert_allclose(r["m"], c.m, rtol=1e-12, atol=1e-13)
+            np.testing.assert_allclose(r["L"], c.L, rtol=1e-11)
+            assert abs(r["logL"] - c.logL) < 1e-10
+            assert abs(r["fenergy"] - c.fenergy()) < 1e-9 * max(1, abs(c.fenergy()))
+            cst = 0.5 * (D * (digamma(c.nu) - np.log(2 * np.pi) - 1 / c.beta) - c.logL)
+            assert abs(r["eloglike_const"] - cst) < 1e-10
+            Xe = np.abs(Xn)
+            e = o.ExpGamma(prior, D)
+            e.addobs(q, Xe)
+            e.update()
+            r = capi.eg_mstep(prior, q.sum(), q @ Xe)
+            assert abs(r["a"] - e.a) < 1e-12 and abs(r["logb"] - e.logb) < 1e-11
+            np.testing.assert_allclose(r["ib"], e.ib, rtol=1e-12)
+            assert abs(r["fenergy"] - e.fenergy()) < 1e-9 * max(1, abs(e.fenergy()))
+            assert abs(r["eloglike_const"] - (D * digamma(e.a) - e.logb)) < 1e-10
