@@ -42,12 +42,22 @@ CONFIGS = {
     "5": dict(N=4_000_000, D=128, K=64, w="GDirichlet", seed=1005, J=8,
               label="BASELINE configs[4] per GPU: GMC, 8 groups x 500k rows, D=128 K=64 (64 groups on 8 GPUs)"),
     "tiny": dict(N=200_000, D=16, K=4, w="Dirichlet", seed=7, label="smoke: N=200k D=16 K=4"),
+    # the diagonal / exponential families at the north-star shape (HBM/VALU-bound kernels)
+    "dgmm": dict(N=10_000_000, D=64, K=32, w="Dirichlet", c="NormGamma", seed=1006,
+                 label="DGMM (diagonal Gaussians, NormGamma) N=10M/GPU D=64 K=32"),
+    "bemm": dict(N=10_000_000, D=64, K=32, w="Dirichlet", c="ExpGamma", seed=1007,
+                 label="BEMM (exponential clusters, ExpGamma) N=10M/GPU D=64 K=32"),
 }
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
-def mixture(D, K, seed):
-    """mu_k ~ N(0, 9 I), Sigma_k = B B^T / D + 0.5 I."""
+def mixture(D, K, seed, family="GaussWish"):
+    """mu_k ~ N(0, 9 I), Sigma_k = B B^T / D + 0.5 I.  Diagonal families: axis-aligned components
+    (ExpGamma needs x >= 0: means 20..60, unit-scale spread)."""
     rng = np.random.default_rng(seed)
+    if family != "GaussWish":
+        mu = rng.normal(0.0, 3.0, (K, D)) if family == "NormGamma" else rng.uniform(20.0, 60.0, (K, D))
+        return mu, np.stack([np.diag(rng.uniform(0.5, 1.5, D)) for _ in range(K)])
     mu = rng.normal(0.0, 3.0, (K, D))
     L = np.empty((K, D, D))
     for k in range(K):
@@ -59,6 +69,27 @@ def mixture(D, K, seed):
 def alg_flops(N, D, K):
     """Algorithmic (minimal, structure-exploiting) flops per launch, SURVEY 8(d)."""
     return {"estep": N * K * (D * D + 4 * D), "suffstat": N * K * (D * D + 3 * D + 1)}
+
+
+def cpu_baseline_family(ctx, cfg, sample_rows):
+    """Diagonal / exponential families: the numpy oracle's own VBEM iteration (updateSS + update + vbexpectation,
+    oracle/lc_oracle.py) on the first rows of the same stream, one thread."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import lc_oracle as o
+    from threadpoolctl import threadpool_limits
+
+    n = min(sample_rows, cfg["N"])
+    X = [ctx.get_rows(0, 0, n)]
+    q0 = [ctx.get_qz_rows(0, 0, n)]
+    cf = o.NormGamma if cfg["c"] == "NormGamma" else o.ExpGamma
+    with threadpool_limits(limits=1):
+        o.vbem_fixed(X, q0, o.Dirichlet, 1.0, 1, False, cf)
+        t0 = time.perf_counter()
+        o.vbem_fixed(X, q0, o.Dirichlet, 1.0, 2, False, cf)
+        dt = (time.perf_counter() - t0) / 2
+    return {"value": n / dt, "unit": "points/s", "cores": 1, "kind": "port",
+            "sample": f"first {n} rows of the same synthetic stream, one full VBEM iteration of oracle/lc_oracle.py "
+                      f"(numpy, 1 thread), mean of 2"}
 
 
 def cpu_baseline(ctx, model, cfg, wkind_name, sample_rows):
@@ -102,7 +133,7 @@ def group_mix(cfg, gids):
     return np.stack([np.random.default_rng([cfg["seed"], int(g)]).dirichlet(np.full(cfg["K"], 0.5)) for g in gids])
 
 
-def parity(capi, cfg, wkind, mu, L, device, rows=20000, iters=3):
+def parity(capi, cfg, wkind, mu, L, device, rows=20000, iters=3, ckind=0):
     """Free-energy / qZ delta of the GPU path vs the numpy oracle on identical inputs
     (the first `rows` rows of the Philox stream of every group, same initial qZ)."""
     sys.path.insert(0, str(ROOT / "oracle"))
@@ -117,11 +148,12 @@ def parity(capi, cfg, wkind, mu, L, device, rows=20000, iters=3):
             c2.synth_groups(nj, D, K, mu, L, cfg["seed"], mix=group_mix(cfg, range(J)), group_ids=list(range(J)))
         X = [c2.get_rows(j, 0, nj[j]) for j in range(J)]
         q0 = c2.get_qz(nj)
-        F, tr, m = c2.vbem(wkind, fixed_iters=iters, nthreads=8)
+        F, tr, m = c2.vbem(wkind, fixed_iters=iters, nthreads=8, ckind=ckind)
         q = c2.get_qz(nj)
         m.close()
     wf = {"Dirichlet": o.Dirichlet, "StickBreak": o.StickBreak, "GDirichlet": o.GDirichlet}[cfg["w"]]
-    Ftr, _, qT, _, _ = o.vbem_fixed(X, q0, wf, 1.0, iters)
+    cf = {"GaussWish": o.GaussWish, "NormGamma": o.NormGamma, "ExpGamma": o.ExpGamma}[cfg.get("c", "GaussWish")]
+    Ftr, _, qT, _, _ = o.vbem_fixed(X, q0, wf, 1.0, iters, False, cf)
     q, qT = np.vstack(q), np.vstack(qT)
     big = qT > 1e-12
     return {
@@ -176,7 +208,9 @@ def main():
     N, D, K = cfg["N"], cfg["D"], cfg["K"]
     wkind = {"Dirichlet": capi.W_DIRICHLET, "StickBreak": capi.W_STICKBREAK, "GDirichlet": capi.W_GDIRICHLET}[cfg["w"]]
     J = cfg.get("J", 1)
-    mu, L = mixture(D, K, cfg["seed"])
+    family = cfg.get("c", "GaussWish")
+    ckind = {"GaussWish": capi.C_GAUSSWISH, "NormGamma": capi.C_NORMGAMMA, "ExpGamma": capi.C_EXPGAMMA}[family]
+    mu, L = mixture(D, K, cfg["seed"], family)
     nthreads = max(1, min(32, (os.cpu_count() or 2) // max(1, world)))
 
     stream = torch.cuda.current_stream().cuda_stream
@@ -192,14 +226,14 @@ def main():
 
     model = None
     if args.warmup > 0:
-        _, _, model = ctx.vbem(wkind, fixed_iters=args.warmup, nthreads=nthreads)
+        _, _, model = ctx.vbem(wkind, fixed_iters=args.warmup, nthreads=nthreads, ckind=ckind)
     ctx.timing_enable(True)
     ctx.timing_reset()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    F, tr, model = ctx.vbem(wkind, fixed_iters=args.steps, nthreads=nthreads, model=model)
+    F, tr, model = ctx.vbem(wkind, fixed_iters=args.steps, nthreads=nthreads, model=model, ckind=ckind)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -251,10 +285,21 @@ def main():
                          "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
                          "alg_flops_per_launch": dom_fl, "avg_launch_ms": dom_ms},
         }
+        if family != "GaussWish":
+            # separable families: 8 (D + K) algorithmic bytes per row and launch (X read + q column written / read)
+            dom = "estep_diag_kernel" if est >= sst else "suffstat_diag_kernel"
+            gbs = 8.0 * N * (D + K) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+            line["config"]["clusters"] = family
+            line["kernels"].pop("both_kernels_alg_tflops")
+            line["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
+                                "alg_bytes_per_launch": 8.0 * N * (D + K), "avg_launch_ms": dom_ms}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(ctx, model, cfg, cfg["w"], args.cpu_sample_rows)
+            line["cpu_baseline"] = (cpu_baseline(ctx, model, cfg, cfg["w"], args.cpu_sample_rows)
+                                    if family == "GaussWish" else
+                                    cpu_baseline_family(ctx, cfg, min(args.cpu_sample_rows, 400_000)))
         if world == 1 and not args.no_parity:
-            line["parity"] = parity(capi, cfg, wkind, mu, L, local_rank)
+            line["parity"] = parity(capi, cfg, wkind, mu, L, local_rank, ckind=ckind)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -592,11 +592,16 @@ void Context::estep_diag(int K, const double* av, const double* w2, const double
   LC_HIP(hipSetDevice(device_));
   const int D = D_, DP = DP_;
   hpack_.assign((size_t)K * 3 * DP + (size_t)J_ * K, 0.0);
+  bool no_w1 = true, only_w1 = true;
   for (int k = 0; k < K; ++k) {
-    double* P = hpack_.data() + (size_t)k * 3 * DP;
+    double* P = hpack_.data() + (size_t)k * DP;
     std::copy(av + (size_t)k * D, av + (size_t)(k + 1) * D, P);
-    std::copy(w2 + (size_t)k * D, w2 + (size_t)(k + 1) * D, P + DP);
-    std::copy(w1 + (size_t)k * D, w1 + (size_t)(k + 1) * D, P + 2 * DP);
+    std::copy(w2 + (size_t)k * D, w2 + (size_t)(k + 1) * D, P + (size_t)K * DP);
+    std::copy(w1 + (size_t)k * D, w1 + (size_t)(k + 1) * D, P + (size_t)2 * K * DP);
+    for (int d = 0; d < D; ++d) {
+      no_w1 = no_w1 && w1[(size_t)k * D + d] == 0.0;
+      only_w1 = only_w1 && w2[(size_t)k * D + d] == 0.0;
+    }
   }
   std::memcpy(hpack_.data() + (size_t)K * 3 * DP, c, (size_t)J_ * K * sizeof(double));
   params_.reserve(hpack_.size());
@@ -615,13 +620,14 @@ void Context::estep_diag(int K, const double* av, const double* w2, const double
   a.rginfo = J_ > 1 ? rginfo_.p : nullptr;
   a.nrows = Nj_[0];
   a.params = params_.p;
-  a.ctab = params_.p + (size_t)K * 3 * DP;
+  a.ctab = params_.p + (size_t)K * 3 * DP;  // params: [3][K][DP]
   a.K = K;
   a.qZ = qz_[cur_].buf.p;
   a.ldq = NP_;
   a.fz_part = fzpart_.p;
   a.ll_part = LLk ? llpart_.p : nullptr;
   a.raw = raw ? 1 : 0;
+  a.mode = only_w1 ? 2 : no_w1 ? 1 : 0;  // same arithmetic with the identically-zero terms left out
   EvPair ev{};
   if (timing_) {
     LC_HIP(hipEventCreate(&ev.a));
@@ -662,10 +668,11 @@ void Context::suffstat_diag(const unsigned char* smask, double* Nk, double* xs, 
   ssout_.reserve(nout);
   double* njk_d = ssout_.p + (size_t)K * SS;
   if (NP_ > 0) {
-    // ~8 blocks per CU, whole 32-row tiles
-    int64_t want = std::min<int64_t>(2048, (NP_ + 255) / 256);
+    // one resident round of blocks (2 per CU: 64 KB of LDS each), whole 256-row tiles; few chunks keep the
+    // partial-record reduction (chunks x K x (1 + 2 DP) doubles) short
+    int64_t want = std::min<int64_t>(512, (NP_ + 255) / 256);
     if (want < 1) want = 1;
-    int64_t rows = ((NP_ + want - 1) / want + 31) / 32 * 32;
+    int64_t rows = ((NP_ + want - 1) / want + 255) / 256 * 256;
     const int nchunks = (int)((NP_ + rows - 1) / rows);
     sspart_.reserve((size_t)nchunks * K * SS);
     lck::DiagStatLaunch a;
@@ -686,6 +693,7 @@ void Context::suffstat_diag(const unsigned char* smask, double* Nk, double* xs, 
     a.partial = sspart_.p;
     a.nchunks = nchunks;
     a.chunk_rows = rows;
+    a.second = xxs ? 1 : 0;
     EvPair ev{};
     if (timing_) {
       LC_HIP(hipEventCreate(&ev.a));

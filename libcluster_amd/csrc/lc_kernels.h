@@ -75,7 +75,8 @@ struct DiagEstepLaunch {
   int64_t nrg;
   const int* rginfo;
   int64_t nrows;
-  const double* params;  // [K][3][DP]: a, w2, w1
+  const double* params;  // [3][K][DP]: a, w2, w1 (padding columns zero)
+  int mode = 0;          // 0: general, 1: w1 == 0 (NormGamma), 2: a == w2 == 0 (ExpGamma)
   const double* ctab;    // [J x K]
   int K;
   double* qZ;
@@ -98,8 +99,10 @@ struct DiagStatLaunch {
   const unsigned char* smask;
   double* partial;       // [nchunks x K x (1 + 2 DP)]
   int nchunks;
-  int64_t chunk_rows;    // multiple of 32
+  int64_t chunk_rows;    // multiple of 256
+  int second = 1;        // 0: skip the second moments (ExpGamma)
   int k0 = 0, k1 = 0;    // cluster range of one launch (filled in by launch_suffstat_diag)
+  int tile_rows = 0;     // ditto
 };
 hipError_t launch_suffstat_diag(const DiagStatLaunch& a, hipStream_t stream);
 

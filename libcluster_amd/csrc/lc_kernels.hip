@@ -693,20 +693,77 @@ hipError_t launch_suffstat(const SuffstatLaunch& a, hipStream_t stream) {
 // ===========================================================================
 // NormGamma::Eloglike (src/distributions.cpp:483-492) and ExpGamma::Eloglike (:568-572) inside the same
 // vbexpectation (cluster.cpp:91-138):  log q~[n,k] = c_jk + sum_d ( w2_kd (x_nd - a_kd)^2 + w1_kd x_nd ).
-// O(N K D) flops against 8(D+K) bytes per row: HBM/VALU-balanced, no matrix instruction needed.
-// A 256-thread block owns 64 rows staged in LDS (coalesced load, conflict-free column reads with an odd
-// row stride); lane = row, wave w takes the clusters k = w mod 4; parameters are wave-uniform loads.
-__global__ void __launch_bounds__(256) estep_diag_kernel(DiagEstepLaunch a) {
+// O(N K D) fp64 VALU operations against 8(D+K) bytes per row: at D = 64, K = 32 the two limits are about equal
+// (the fp64 vector rate equals the fp64 MFMA rate on this part, and the difference form (x - a)^2 is not
+// bilinear, so there is nothing for the matrix pipe to do here).  The design therefore minimises everything
+// that is not one of the 3 (NormGamma) / 1 (ExpGamma) operations per (row, cluster, dimension):
+//  * a 256-thread block owns 64 rows, staged once in LDS (coalesced load; odd row stride => conflict-free
+//    per-lane row reads); lane = row;
+//  * wave w owns the cluster tiles {w, w+4, ...} of KT clusters: the tile index is wave-uniform, so the
+//    parameters arrive through the scalar cache as SGPR operands (no vector loads, no LDS traffic), and one
+//    LDS read of x feeds 3*KT operations;
+//  * log q~ stays in registers up to K = 4*DIAG_MAXT*KT clusters; the row maximum and sum cross the four waves
+//    through 2 KB of LDS; beyond that the columns are re-read from L2.
+// MODE 0: general (a, w2, w1); 1: w1 == 0 (NormGamma); 2: a == w2 == 0 (ExpGamma).
+constexpr int DIAG_MAXT = 4;
+
+template <int MODE, int KT>
+__device__ __forceinline__ void diag_tile(const double* __restrict__ xr, const double* __restrict__ PA,
+                                          const double* __restrict__ PW2, const double* __restrict__ PW1, int k0,
+                                          int K, int DP, double (&acc)[KT]) {
+  const double* pa[KT];
+  const double* p2[KT];
+  const double* p1[KT];
+#pragma unroll
+  for (int j = 0; j < KT; ++j) {
+    const int k = k0 + j < K ? k0 + j : K - 1;  // clamped: the caller discards clusters >= K
+    pa[j] = PA + (int64_t)k * DP;
+    p2[j] = PW2 + (int64_t)k * DP;
+    p1[j] = PW1 + (int64_t)k * DP;
+    acc[j] = 0.0;
+  }
+  for (int d = 0; d < DP; d += 4) {
+    double x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) x[u] = xr[d + u];
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (MODE != 2) {
+          const double t = x[u] - pa[j][d + u];
+          acc[j] = fma(t * p2[j][d + u], t, acc[j]);
+        }
+        if (MODE != 1) acc[j] = fma(p1[j][d + u], x[u], acc[j]);
+      }
+    }
+  }
+}
+
+template <int MODE, int KT, bool REG>
+__global__ void __launch_bounds__(256)
+    estep_diag_kernel(const double* __restrict__ X, const double* __restrict__ PA, const double* __restrict__ PW2,
+                      const double* __restrict__ PW1, const double* __restrict__ ctab, const int* __restrict__ rginfo,
+                      double* __restrict__ qZ, double* __restrict__ fz_part, double* __restrict__ ll_part, int DP, int K,
+                      int64_t NP, int64_t nrows, int64_t ldq, int raw) {
   extern __shared__ double lds[];
-  const int DP = a.DP, D = a.D, K = a.K, LD = DP + 1;
-  double* xt = lds;                 // [64][LD]
-  double* red = lds + 64 * LD;      // [4][64]
-  double* llw = red + 256;          // [K]
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int64_t row0 = (int64_t)blockIdx.x * 64, NP = a.nrg * RG;
-  for (int idx = tid; idx < 64 * DP; idx += 256) {
-    const int r = idx / DP, d = idx % DP;
-    xt[r * LD + d] = row0 + r < NP ? a.X[(row0 + r) * DP + d] : 0.0;
+  const int LD = DP + 1;
+  double* xt = lds;             // [64][LD]
+  double* red = lds + 64 * LD;  // [4][64]
+  double* llw = red + 256;      // [K]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t row0 = (int64_t)blockIdx.x * 64;
+  {
+    const int c2 = DP >> 1, sh = __builtin_ctz(c2);  // double2 columns per row (DP is a power of two)
+    const double2* X2 = reinterpret_cast<const double2*>(X);
+    for (int idx = tid; idx < 64 * c2; idx += 256) {
+      const int r = idx >> sh, c = idx & (c2 - 1);
+      double2 v = make_double2(0.0, 0.0);
+      if (row0 + r < NP) v = X2[(row0 + r) * c2 + c];
+      xt[r * LD + 2 * c] = v.x;
+      xt[r * LD + 2 * c + 1] = v.y;
+    }
   }
   __syncthreads();
   const int64_t row = row0 + lane;
@@ -714,144 +771,323 @@ __global__ void __launch_bounds__(256) estep_diag_kernel(DiagEstepLaunch a) {
   int grp = 0;
   bool ok = false;
   if (inb) {
-    if (a.rginfo) {
-      const int info = a.rginfo[row >> 4];
+    if (rginfo) {
+      const int info = rginfo[row >> 4];
       grp = info >> 5;
       ok = (int)(row & 15) < (info & 31);
     } else {
-      ok = row < a.nrows;
+      ok = row < nrows;
     }
   }
   const double* xr = xt + lane * LD;
-  double mx = -INFINITY;
-  for (int k = w; k < K; k += 4) {
-    const double* pa = a.params + (int64_t)k * 3 * DP;
-    double acc = 0.0;
-    for (int d = 0; d < D; ++d) {
-      const double x = xr[d], t = x - pa[d];
-      acc = fma(pa[DP + d], t * t, acc);
-      acc = fma(pa[2 * DP + d], x, acc);
+  const double* crow = ctab + (int64_t)grp * K;
+  const int ntiles = (K + KT - 1) / KT;
+  const double NINF = -INFINITY;
+  double mx = NINF;
+  double lq[REG ? DIAG_MAXT : 1][KT], dt[REG ? DIAG_MAXT : 1][KT];
+
+  // ---- pass 1: log q~ for this wave's tiles ----
+  if (REG) {
+#pragma unroll
+    for (int i = 0; i < DIAG_MAXT; ++i) {
+      const int tile = w + 4 * i;
+#pragma unroll
+      for (int j = 0; j < KT; ++j) lq[i][j] = NINF, dt[i][j] = 0.0;
+      if (tile < ntiles) {
+        double acc[KT];
+        diag_tile<MODE, KT>(xr, PA, PW2, PW1, tile * KT, K, DP, acc);
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {
+          const int k = tile * KT + j;
+          if (k < K) {
+            const double v = crow[k] + acc[j];
+            lq[i][j] = v;
+            dt[i][j] = acc[j];
+            mx = fmax(mx, v);
+            if (raw && inb) qZ[(int64_t)k * ldq + row] = v;
+          }
+        }
+      }
     }
-    const double lq = a.ctab[(int64_t)grp * K + k] + acc;
-    mx = fmax(mx, lq);
-    if (inb) a.qZ[(int64_t)k * a.ldq + row] = lq;
+  } else {
+    for (int tile = w; tile < ntiles; tile += 4) {
+      double acc[KT];
+      diag_tile<MODE, KT>(xr, PA, PW2, PW1, tile * KT, K, DP, acc);
+#pragma unroll
+      for (int j = 0; j < KT; ++j) {
+        const int k = tile * KT + j;
+        if (k < K) {
+          const double v = crow[k] + acc[j];
+          mx = fmax(mx, v);
+          if (inb) qZ[(int64_t)k * ldq + row] = v;
+        }
+      }
+    }
   }
-  if (a.raw) return;
+  if (raw) return;
+
+  // ---- row maximum and sum of exponentials across the four waves (logsumexp, probutils.cpp:141-150) ----
   red[w * 64 + lane] = mx;
   __syncthreads();
   mx = fmax(fmax(red[lane], red[64 + lane]), fmax(red[128 + lane], red[192 + lane]));
   __syncthreads();
   double se = 0.0;
-  if (inb)
-    for (int k = w; k < K; k += 4) se += exp(a.qZ[(int64_t)k * a.ldq + row] - mx);
+  if (REG) {
+#pragma unroll
+    for (int i = 0; i < DIAG_MAXT; ++i)
+#pragma unroll
+      for (int j = 0; j < KT; ++j) {
+        lq[i][j] = exp(lq[i][j] - mx);  // exp(-inf) = 0 for the slots past K
+        se += lq[i][j];
+      }
+  } else if (inb) {
+    for (int tile = w; tile < ntiles; tile += 4)
+      for (int j = 0; j < KT; ++j) {
+        const int k = tile * KT + j;
+        if (k < K) se += exp(qZ[(int64_t)k * ldq + row] - mx);
+      }
+  }
   red[w * 64 + lane] = se;
   __syncthreads();
-  const double logZ = log(red[lane] + red[64 + lane] + red[128 + lane] + red[192 + lane]) + mx;
-  for (int k = w; k < K; k += 4) {
-    double ll = 0.0;
-    if (inb) {
-      double* qp = a.qZ + (int64_t)k * a.ldq + row;
-      const double lq = *qp;
-      const double q = ok ? exp(lq - logZ) : 0.0;
-      *qp = q;
-      if (a.ll_part && q > 0.0) ll = q * (lq - a.ctab[(int64_t)grp * K + k]);
+  se = red[lane] + red[64 + lane] + red[128 + lane] + red[192 + lane];
+  const double logZ = log(se) + mx;
+  const double inv = 1.0 / se;
+
+  // ---- pass 2: q = exp(log q~ - logZ), data term of the split ordering ----
+  if (REG) {
+#pragma unroll
+    for (int i = 0; i < DIAG_MAXT; ++i) {
+      const int tile = w + 4 * i;
+      if (tile < ntiles) {
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {
+          const int k = tile * KT + j;
+          if (k < K) {
+            const double q = ok ? lq[i][j] * inv : 0.0;
+            if (inb) qZ[(int64_t)k * ldq + row] = q;
+            if (ll_part) {
+              const double ll = wave_sum(q > 0.0 ? q * dt[i][j] : 0.0);
+              if (lane == 0) llw[k] = ll;
+            }
+          }
+        }
+      }
     }
-    if (a.ll_part) {
-      ll = wave_sum(ll);
-      if (lane == 0) llw[k] = ll;
-    }
+  } else {
+    for (int tile = w; tile < ntiles; tile += 4)
+      for (int j = 0; j < KT; ++j) {
+        const int k = tile * KT + j;
+        if (k < K) {
+          double ll = 0.0;
+          if (inb) {
+            double* qp = qZ + (int64_t)k * ldq + row;
+            const double v = *qp;
+            const double q = ok ? exp(v - mx) * inv : 0.0;
+            *qp = q;
+            if (ll_part && q > 0.0) ll = q * (v - crow[k]);
+          }
+          if (ll_part) {
+            ll = wave_sum(ll);
+            if (lane == 0) llw[k] = ll;
+          }
+        }
+      }
   }
   double fz = (w == 0 && ok) ? logZ : 0.0;
   fz = wave_sum(fz);
   __syncthreads();
-  if (tid == 0) a.fz_part[blockIdx.x] = -fz;
-  if (a.ll_part)
-    for (int k = tid; k < K; k += 256) a.ll_part[(int64_t)blockIdx.x * K + k] = llw[k];
+  if (tid == 0) fz_part[blockIdx.x] = -fz;
+  if (ll_part)
+    for (int k = tid; k < K; k += 256) ll_part[(int64_t)blockIdx.x * K + k] = llw[k];
+}
+
+template <int MODE, int KT, bool REG>
+static hipError_t launch_ed_t(const DiagEstepLaunch& a, int64_t grid, size_t shmem, hipStream_t stream) {
+  auto kern = estep_diag_kernel<MODE, KT, REG>;
+  static size_t attr_set = 0;
+  if (shmem > 64 * 1024 && shmem > attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)shmem);
+    if (e != hipSuccess) return e;
+    attr_set = shmem;
+  }
+  const double* PA = a.params;
+  const double* PW2 = PA + (int64_t)a.K * a.DP;
+  const double* PW1 = PW2 + (int64_t)a.K * a.DP;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), shmem, stream, a.X, PA, PW2, PW1, a.ctab, a.rginfo, a.qZ,
+                     a.fz_part, a.ll_part, a.DP, a.K, a.nrg * RG, a.nrows, a.ldq, a.raw);
+  return hipGetLastError();
+}
+
+template <int MODE>
+static hipError_t launch_ed_m(const DiagEstepLaunch& a, int64_t grid, size_t shmem, hipStream_t stream) {
+  // clusters per tile: every wave should have work (K >= 4*KT), registers hold 4*DIAG_MAXT*KT columns
+  if (a.K <= 4) return launch_ed_t<MODE, 1, true>(a, grid, shmem, stream);
+  if (a.K <= 8) return launch_ed_t<MODE, 2, true>(a, grid, shmem, stream);
+  if (a.K <= 4 * DIAG_MAXT * 4) return launch_ed_t<MODE, 4, true>(a, grid, shmem, stream);
+  return launch_ed_t<MODE, 4, false>(a, grid, shmem, stream);
 }
 
 hipError_t launch_estep_diag(const DiagEstepLaunch& a, hipStream_t stream) {
   const int64_t grid = (a.nrg * RG + 63) / 64;
   if (grid <= 0) return hipSuccess;
   const size_t shmem = (size_t)(64 * (a.DP + 1) + 256 + a.K) * sizeof(double);
-  static size_t attr_set = 0;
-  if (shmem > 64 * 1024 && shmem > attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(estep_diag_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    if (e != hipSuccess) return e;
-    attr_set = shmem;
+  switch (a.mode) {
+    case 1:
+      return launch_ed_m<1>(a, grid, shmem, stream);
+    case 2:
+      return launch_ed_m<2>(a, grid, shmem, stream);
+    default:
+      return launch_ed_m<0>(a, grid, shmem, stream);
   }
-  hipLaunchKernelGGL(estep_diag_kernel, dim3((unsigned)grid), dim3(256), shmem, stream, a);
-  return hipGetLastError();
 }
 
 // NormGamma::addobs (distributions.cpp:426-438) / ExpGamma::addobs (:533-542) for a range of clusters:
-// N_k = sum q, x_s = sum q x, xx_s = sum q x^2 (elementwise).  Thread = (cluster slot, dimension); a block
-// streams its row chunk through LDS in 32-row tiles and keeps up to DIAG_PMAX cluster passes in registers.
-constexpr int DIAG_PMAX = 16;
-__global__ void __launch_bounds__(256) suffstat_diag_kernel(DiagStatLaunch a) {
-  __shared__ double xt[32 * 128];
-  extern __shared__ double qt[];  // [kcount][32]
-  const int DP = a.DP, K = a.K;
-  const int slots = 256 / DP, s = threadIdx.x / DP, d = threadIdx.x % DP;
-  const int kcount = a.k1 - a.k0, passes = (kcount + slots - 1) / slots;
+// N_k = sum q, x_s = sum q x, xx_s = sum q x^2 (elementwise).  2 fp64 FMAs per (row, cluster, dimension)
+// against 8(D+K) bytes per row: about balanced at D = 64, K = 32, so the kernel is built to do nothing else
+// in the inner loop.  Thread = (cluster slot s, dimension d); a block streams its row chunk through LDS in
+// tiles of TR rows (X tile and the q columns, both coalesced; the next tile is in flight in registers while
+// this one is consumed); each thread keeps P clusters (s, s+slots, ...) in registers so one LDS read of x
+// (and one multiply for x^2) serves 2P FMAs, and q is a slot-uniform (broadcast) LDS read.  N_k is summed
+// on the way into LDS by the loading threads, not in the inner loop.
+template <int P, bool SECOND>
+__global__ void __launch_bounds__(256, 2) suffstat_diag_kernel(DiagStatLaunch a) {
+  extern __shared__ double lds[];
+  const int DP = a.DP, K = a.K, TR = a.tile_rows;
+  const int dsh = __builtin_ctz(DP), tsh = __builtin_ctz(TR);
+  const int slots = 256 >> dsh, nq = P * slots;
+  double* xt = lds;            // [TR][DP]
+  double* qt = lds + TR * DP;  // [nq][TR], rows >= kcount stay zero
+  const int tid = threadIdx.x, s = tid >> dsh, d = tid & (DP - 1);
+  const int kcount = a.k1 - a.k0;
   const int64_t r0 = (int64_t)blockIdx.x * a.chunk_rows;
   const int64_t r1 = (r0 + a.chunk_rows) < a.NP ? (r0 + a.chunk_rows) : a.NP;
-  double n[DIAG_PMAX], xs[DIAG_PMAX], xx[DIAG_PMAX];
+  const int nx2 = (TR * DP) >> 9;   // double2 loads of X per thread and tile (<= 8)
+  const int nqe = (nq * TR + 255) >> 8;  // q elements per thread and tile (<= 16)
+  const double2* X2 = reinterpret_cast<const double2*>(a.X);
+  double2 xreg[8];
+  double qreg[16], nacc[16];
+  double xs[P], xx[P];
 #pragma unroll
-  for (int p = 0; p < DIAG_PMAX; ++p) n[p] = xs[p] = xx[p] = 0.0;
-  for (int64_t b0 = r0; b0 < r1; b0 += 32) {
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < 32 * DP; idx += 256) {
-      const int r = idx / DP;
-      xt[idx] = b0 + r < r1 ? a.X[(b0 + r) * DP + idx % DP] : 0.0;
-    }
-    for (int idx = threadIdx.x; idx < 32 * kcount; idx += 256) {
-      const int k = a.k0 + idx / 32, r = idx % 32;
-      double q = 0.0;
-      if (b0 + r < r1) {
-        q = a.qZ[(int64_t)k * a.ldq + b0 + r];
-        if (a.smask && !a.smask[(int64_t)(a.rginfo[(b0 + r) >> 4] >> 5) * K + k]) q = 0.0;
+  for (int p = 0; p < P; ++p) xs[p] = xx[p] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) nacc[i] = 0.0;
+
+  auto fetch = [&](int64_t b0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      xreg[i] = make_double2(0.0, 0.0);
+      if (i < nx2) {
+        const int idx = tid + (i << 8);                // double2 index inside the tile
+        const int64_t row = b0 + (idx >> (dsh - 1));
+        if (row < r1) xreg[i] = X2[(b0 << (dsh - 1)) + idx];
       }
-      qt[idx] = q;
     }
-    __syncthreads();
 #pragma unroll
-    for (int p = 0; p < DIAG_PMAX; ++p) {
-      const int kk = p * slots + s;
-      if (p < passes && kk < kcount) {
-        for (int r = 0; r < 32; ++r) {
-          const double q = qt[kk * 32 + r], x = xt[r * DP + d];
-          const double qx = q * x;
-          n[p] += q;
-          xs[p] += qx;
-          xx[p] = fma(qx, x, xx[p]);
+    for (int i = 0; i < 16; ++i) {
+      qreg[i] = 0.0;
+      if (i < nqe) {
+        const int idx = tid + (i << 8);
+        const int kk = idx >> tsh;
+        const int64_t row = b0 + (idx & (TR - 1));
+        if (kk < kcount && row < r1) {
+          const int k = a.k0 + kk;
+          double q = a.qZ[(int64_t)k * a.ldq + row];
+          if (a.smask && !a.smask[(int64_t)(a.rginfo[row >> 4] >> 5) * K + k]) q = 0.0;
+          qreg[i] = q;
+        }
+      }
+    }
+  };
+
+  if (r0 < r1) fetch(r0);
+  for (int64_t b0 = r0; b0 < r1; b0 += TR) {
+    __syncthreads();  // the previous tile has been consumed
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i < nx2) reinterpret_cast<double2*>(xt)[tid + (i << 8)] = xreg[i];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (i < nqe) {
+        const int idx = tid + (i << 8);
+        if (idx < nq * TR) qt[idx] = qreg[i];
+        nacc[i] += qreg[i];
+      }
+    __syncthreads();
+    if (b0 + TR < r1) fetch(b0 + TR);
+    const double* qs = qt + s * TR;
+    constexpr int U = P >= 8 ? 1 : P == 4 ? 2 : 4;  // rows in flight: bounded by the register budget
+    for (int rb = 0; rb < TR; rb += U) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int r = rb + u;
+        const double x = xt[(r << dsh) + d];
+        const double x2 = x * x;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          const double q = qs[((p * slots) << tsh) + r];
+          xs[p] = fma(q, x, xs[p]);
+          if (SECOND) xx[p] = fma(q, x2, xx[p]);
         }
       }
     }
   }
-  const int64_t SS = 1 + 2 * (int64_t)DP;
+
+  // N_k: the loading threads hold per-(cluster, row-in-tile) partial sums; fold the TR of a cluster in order
+  __syncthreads();
 #pragma unroll
-  for (int p = 0; p < DIAG_PMAX; ++p) {
+  for (int i = 0; i < 16; ++i)
+    if (i < nqe) {
+      const int idx = tid + (i << 8);
+      if (idx < nq * TR) qt[idx] = nacc[i];
+    }
+  __syncthreads();
+  const int64_t SS = 1 + 2 * (int64_t)DP;
+  double* outb = a.partial + ((int64_t)blockIdx.x * K + a.k0) * SS;
+  for (int kk = tid; kk < kcount; kk += 256) {
+    double n = 0.0;
+    for (int r = 0; r < TR; ++r) n += qt[(kk << tsh) + r];
+    outb[(int64_t)kk * SS] = n;
+  }
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
     const int kk = p * slots + s;
-    if (p < passes && kk < kcount) {
-      double* out = a.partial + ((int64_t)blockIdx.x * K + a.k0 + kk) * SS;
-      if (d == 0) out[0] = n[p];
+    if (kk < kcount) {
+      double* out = outb + (int64_t)kk * SS;
       out[1 + d] = xs[p];
-      out[1 + DP + d] = xx[p];
+      out[1 + DP + d] = SECOND ? xx[p] : 0.0;
     }
   }
 }
 
+template <int P>
+static hipError_t launch_sd_t(const DiagStatLaunch& a, size_t shmem, hipStream_t stream) {
+  if (a.second)
+    hipLaunchKernelGGL((suffstat_diag_kernel<P, true>), dim3((unsigned)a.nchunks), dim3(256), shmem, stream, a);
+  else
+    hipLaunchKernelGGL((suffstat_diag_kernel<P, false>), dim3((unsigned)a.nchunks), dim3(256), shmem, stream, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_suffstat_diag(const DiagStatLaunch& a0, hipStream_t stream) {
   if (a0.K <= 0 || a0.nchunks <= 0) return hipSuccess;
-  const int slots = 256 / a0.DP, kmax = DIAG_PMAX * slots;
+  if (a0.chunk_rows % 256) return hipErrorInvalidValue;
+  const int slots = 256 / a0.DP, kmax = 16 * slots;
   for (int k0 = 0; k0 < a0.K; k0 += kmax) {
     DiagStatLaunch a = a0;
     a.k0 = k0;
     a.k1 = k0 + kmax < a0.K ? k0 + kmax : a0.K;
-    const size_t shmem = (size_t)32 * (a.k1 - a.k0) * sizeof(double);
-    hipLaunchKernelGGL(suffstat_diag_kernel, dim3((unsigned)a.nchunks), dim3(256), shmem, stream, a);
-    hipError_t e = hipGetLastError();
+    const int need = (a.k1 - a.k0 + slots - 1) / slots;
+    const int P = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : need <= 8 ? 8 : 16;
+    int TR = 256;  // tile rows: X tile and q tile of at most 4096 doubles each
+    while (TR > 16 && (TR * a.DP > 4096 || TR * P * slots > 4096)) TR >>= 1;
+    a.tile_rows = TR;
+    const size_t shmem = (size_t)(TR * a.DP + TR * P * slots) * sizeof(double);
+    hipError_t e = P == 1   ? launch_sd_t<1>(a, shmem, stream)
+                   : P == 2 ? launch_sd_t<2>(a, shmem, stream)
+                   : P == 4 ? launch_sd_t<4>(a, shmem, stream)
+                   : P == 8 ? launch_sd_t<8>(a, shmem, stream)
+                            : launch_sd_t<16>(a, shmem, stream);
     if (e != hipSuccess) return e;
   }
   return hipSuccess;
