@@ -246,6 +246,15 @@ class GaussWish : public ClusterDist {
     m_.assign(m, m + D);
     iW_.assign(iW, iW + (size_t)D * D);
   }
+  /* additive: cluster idx (level 0: bottom, 1: top) of a learnt two-level model (learnSCM / learnMCM) */
+  static GaussWish from_tmodel_(lc_tmodel* mdl, int level, int idx, double clusterprior, unsigned D) {
+    std::vector<double> m(D), iW((size_t)D * D);
+    double N, nu, beta, logdW, F;
+    detail::check(lc_tmodel_cluster(mdl, level, idx, &N, m.data(), 0, &nu, &beta, iW.data(), &logdW, &F));
+    GaussWish c(clusterprior, D);
+    c.set_posterior_(N, nu, beta, m.data(), iW.data(), logdW, F);
+    return c;
+  }
   /* additive: cluster k of a learnt model (used by libcluster.h's learners) */
   static GaussWish from_model_(lc_model* mdl, int k, double clusterprior, unsigned D, double Fk) {
     std::vector<double> m(D), iW((size_t)D * D);

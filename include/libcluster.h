@@ -190,5 +190,130 @@ inline double learnEGMC(const vMatrixXd& X, vMatrixXd& qZ, std::vector<distribut
                      nthreads);
 }
 
+namespace detail {
+struct TModelGuard {
+  lc_tmodel* m;
+  TModelGuard() : m(0) {}
+  ~TModelGuard() { if (m) lc_tmodel_free(m); }
+};
+/* learnSCM / learnMCM over lc_learn_topic: W == 0 selects the SCM */
+inline double run_topic(const vMatrixXd* W, const vvMatrixXd& X, vMatrixXd& qY, vvMatrixXd& qZ,
+                        std::vector<distributions::GDirichlet>& weights_j,
+                        std::vector<distributions::Dirichlet>& weights_t,
+                        std::vector<distributions::GaussWish>* clusters_t,
+                        std::vector<distributions::GaussWish>& clusters_k, double prior_t, double prior_k,
+                        unsigned maxT, int maxK, bool verbose, unsigned nthreads) {
+  using distributions::detail::check;
+  const int J = (int)X.size();
+  if (W) { /* mcluster.cpp:548-556 */
+    if (W->size() != X.size()) throw std::invalid_argument("W and X need to have the same number of groups!");
+    for (int j = 0; j < J; ++j)
+      if ((size_t)(*W)[j].rows() != X[j].size())
+        throw std::invalid_argument("W and X need to have the same number of 'docs'!");
+  }
+  if (J < 1) throw std::invalid_argument("need at least one group of observations");
+  std::vector<int> Ij(J);
+  std::vector<std::vector<double> > docs; /* row-major copies: documents rarely share strides */
+  std::vector<const double*> ptr;
+  std::vector<int64_t> n;
+  int D = -1;
+  for (int j = 0; j < J; ++j) {
+    Ij[j] = (int)X[j].size();
+    for (size_t i = 0; i < X[j].size(); ++i) {
+      const lcmat::MatrixXd& x = X[j][i];
+      if (D < 0) D = (int)x.cols();
+      if ((int)x.cols() != D) throw std::invalid_argument("X dimensions are inconsistent between groups!");
+      docs.push_back(std::vector<double>((size_t)x.rows() * D));
+      for (std::ptrdiff_t r = 0; r < x.rows(); ++r)
+        for (int d = 0; d < D; ++d) docs.back()[(size_t)r * D + d] = x(r, d);
+      n.push_back((int64_t)x.rows());
+    }
+  }
+  if (D < 0) throw std::invalid_argument("need at least one document");
+  for (size_t i = 0; i < docs.size(); ++i) ptr.push_back(docs[i].data());
+  std::vector<std::vector<double> > wrow;
+  std::vector<const double*> wptr;
+  int Dt = 0;
+  if (W) {
+    Dt = (int)(*W)[0].cols();
+    wrow.resize(J);
+    for (int j = 0; j < J; ++j) {
+      const lcmat::MatrixXd& w = (*W)[j];
+      if ((int)w.cols() != Dt) throw std::invalid_argument("W dimensions are inconsistent between groups!");
+      wrow[j].resize((size_t)w.rows() * Dt);
+      for (std::ptrdiff_t r = 0; r < w.rows(); ++r)
+        for (int d = 0; d < Dt; ++d) wrow[j][(size_t)r * Dt + d] = w(r, d);
+      wptr.push_back(wrow[j].data());
+    }
+  }
+  TModelGuard g;
+  double F = 0.0;
+  check(lc_learn_topic(J, Ij.data(), ptr.data(), n.data(), D, D, 1, W ? wptr.data() : 0, Dt, 0, prior_t, prior_k, maxT,
+                       maxK, verbose ? 1 : 0, nthreads, 0, &g.m, &F));
+  int T = 0, K = 0;
+  check(lc_tmodel_dims(g.m, 0, 0, &T, &K, 0, 0));
+  qY.resize(J);
+  qZ.resize(J);
+  weights_j.assign(J, distributions::GDirichlet());
+  weights_t.assign(T, W ? distributions::Dirichlet() : distributions::Dirichlet(prior_t));
+  std::vector<double> buf;
+  int doc = 0;
+  for (int j = 0; j < J; ++j) {
+    buf.resize((size_t)Ij[j] * T);
+    if (Ij[j] > 0) check(lc_tmodel_get_qy(g.m, j, buf.data()));
+    qY[j].resize(Ij[j], T);
+    for (int i = 0; i < Ij[j]; ++i)
+      for (int t = 0; t < T; ++t) qY[j](i, t) = buf[(size_t)i * T + t];
+    qZ[j].resize(Ij[j]);
+    for (int i = 0; i < Ij[j]; ++i, ++doc) {
+      qZ[j][i].resize(X[j][i].rows(), K);
+      int64_t r, c;
+      lcmat::strides(qZ[j][i], r, c);
+      if (X[j][i].rows() > 0) check(lc_tmodel_get_qz(g.m, doc, qZ[j][i].data(), r, c));
+    }
+    lcmat::ArrayXd Nk(T);
+    check(lc_tmodel_weights(g.m, 0, j, 0, Nk.data()));
+    weights_j[j].update(Nk); /* same arithmetic as inside the learner */
+  }
+  for (int t = 0; t < T; ++t) {
+    lcmat::ArrayXd Nk(K);
+    check(lc_tmodel_weights(g.m, 1, t, 0, Nk.data()));
+    weights_t[t].update(Nk);
+  }
+  clusters_k.clear();
+  for (int k = 0; k < K; ++k)
+    clusters_k.push_back(distributions::GaussWish::from_tmodel_(g.m, 0, k, prior_k, (unsigned)D));
+  if (clusters_t) {
+    clusters_t->clear();
+    for (int t = 0; t < T; ++t)
+      clusters_t->push_back(distributions::GaussWish::from_tmodel_(g.m, 1, t, prior_t, (unsigned)Dt));
+  }
+  return F;
+}
+}  // namespace detail
+
+/* include/libcluster.h:583-596, src/scluster.cpp:578-605.  qY starts from std::rand() like the reference. */
+inline double learnSCM(const vvMatrixXd& X, vMatrixXd& qY, vvMatrixXd& qZ,
+                       std::vector<distributions::GDirichlet>& weights_j,
+                       std::vector<distributions::Dirichlet>& weights_t,
+                       std::vector<distributions::GaussWish>& clusters, const double dirprior = PRIORVAL,
+                       const double gausprior = PRIORVAL, const unsigned int maxT = TRUNC, const int maxK = -1,
+                       const bool verbose = false, const unsigned int nthreads = detail::default_threads()) {
+  return detail::run_topic(0, X, qY, qZ, weights_j, weights_t, 0, clusters, dirprior, gausprior, maxT, maxK, verbose,
+                           nthreads);
+}
+
+/* include/libcluster.h:661-676, src/mcluster.cpp:613-642 */
+inline double learnMCM(const vMatrixXd& W, const vvMatrixXd& X, vMatrixXd& qY, vvMatrixXd& qZ,
+                       std::vector<distributions::GDirichlet>& weights_j,
+                       std::vector<distributions::Dirichlet>& weights_t,
+                       std::vector<distributions::GaussWish>& clusters_t,
+                       std::vector<distributions::GaussWish>& clusters_k, const double prior_t = PRIORVAL,
+                       const double prior_k = PRIORVAL, const unsigned int maxT = TRUNC, const int maxK = -1,
+                       const bool verbose = false, const unsigned int nthreads = detail::default_threads()) {
+  return detail::run_topic(&W, X, qY, qZ, weights_j, weights_t, &clusters_t, clusters_k, prior_t, prior_k, maxT, maxK,
+                           verbose, nthreads);
+}
+
 }  // namespace libcluster
 #endif /* LIBCLUSTER_H */

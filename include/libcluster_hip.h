@@ -47,6 +47,7 @@ typedef enum { LC_C_GAUSSWISH = 0, LC_C_NORMGAMMA = 1, LC_C_EXPGAMMA = 2 } lc_ck
 
 typedef struct lc_ctx lc_ctx;     /* device-resident data set + qZ + workspaces */
 typedef struct lc_model lc_model; /* weights + clusters (+ the context that holds qZ) */
+typedef struct lc_tmodel lc_tmodel; /* two-level (SCM / MCM) model: qY, qZ, weights_j, weights_t, clusters(_t) */
 
 const char* lc_last_error(void);
 int lc_version(void);
@@ -207,6 +208,40 @@ int lc_model_kinds(lc_model* m, int* wkind, int* ckind);
 int lc_model_cluster(lc_model* m, int k, double* N, double* mean, double* cov, double* nu, double* beta, double* iW,
                      double* logdW);
 int lc_model_fenergy(lc_model* m, double* Fw /*[J]*/, double* Fc /*[K]*/);
+
+/* ======================================================================== *
+ * Two-level models: learnSCM (libcluster.h:583-596, scluster.cpp:578-605) and
+ * learnMCM (libcluster.h:661-676, mcluster.cpp:613-642).
+ * X[j][i]: J groups with Ij[j] "documents" each; Xji holds the sum(Ij) document
+ * matrices group-major, document d is Nji[d] x D with the given strides.  Every
+ * document is one group of an internal context, so vbeZ (scluster.cpp:93-124 /
+ * mcluster.cpp:100-135) is the E-step kernel and the bottom-level M-step is the
+ * suff-stat kernel; qY and W (document level, small) stay on the host.
+ * Wj: NULL selects the SCM (GDirichlet / Dirichlet(prior_t) / GaussWish(prior_k));
+ *     else J pointers to (Ij[j] x Dt) row-major document observations: the MCM
+ *     (GDirichlet / Dirichlet() / GaussWish(prior_t, Dt) / GaussWish(prior_k, D)).
+ * qY0: NULL = the reference's random start, |U(-1,1)| rows normalised, drawn with
+ *     std::rand() (Eigen's Random(), scluster.cpp:519-521); else J pointers to
+ *     (Ij[j] x maxT) row-major initial assignments (additive: reproducible runs).
+ * Errors: LC_EINVAL for nthreads < 1, and for the SCM maxT > number of documents
+ * ("maxT must be less than the number of documents ofX!", scluster.cpp:531-533);
+ * LC_ERUNTIME "Free energy increase!" (scluster.cpp:248-249).
+ * ======================================================================== */
+int lc_learn_topic(int J, const int* Ij, const double* const* Xji, const int64_t* Nji, int D, int64_t row_stride,
+                   int64_t col_stride, const double* const* Wj, int Dt, const double* const* qY0, double prior_t,
+                   double prior_k, unsigned maxT, int maxK, int verbose, unsigned nthreads, int device,
+                   lc_tmodel** out, double* F);
+int lc_tmodel_free(lc_tmodel* m);
+int lc_tmodel_dims(lc_tmodel* m, int* J, int* Itot, int* T, int* K, int* D, int* Dt);
+int lc_tmodel_get_qy(lc_tmodel* m, int j, double* qY /* Ij[j] x T row-major */);
+int lc_tmodel_get_qz(lc_tmodel* m, int doc, double* q, int64_t row_stride, int64_t col_stride); /* Nji[doc] x K */
+/* level 0: weights_j[idx] (T values each); level 1: weights_t[idx] (K values each) */
+int lc_tmodel_weights(lc_tmodel* m, int level, int idx, double* Elogweight, double* Nk);
+/* level 0: bottom-level clusters[idx] (D); level 1: top-level clusters_t[idx] (Dt, MCM only) */
+int lc_tmodel_cluster(lc_tmodel* m, int level, int idx, double* N, double* mean, double* cov, double* nu, double* beta,
+                      double* iW, double* logdW, double* fenergy);
+int lc_tmodel_rounds(lc_tmodel* m, int* nrounds);
+int lc_tmodel_round(lc_tmodel* m, int r, int* T, int* K, int* niter, double* F, int nF);
 
 /* ======================================================================== *
  * Host-only pieces of the path (no GPU needed; used by the C++ facade classes

@@ -9,5 +9,5 @@ learnGMC with the reference Python binding's return shape) and `dist`
 a CPU implementation of the data path.
 """
 from . import capi  # noqa: F401
-from .api import (learnBEMM, learnBGMM, learnDGMC, learnDGMM, learnEGMC, learnGMC, learnSGMC,  # noqa: F401
-                  learnVDP)
+from .api import (learnBEMM, learnBGMM, learnDGMC, learnDGMM, learnEGMC, learnGMC, learnMCM,  # noqa: F401
+                  learnSCM, learnSGMC, learnVDP)

@@ -80,3 +80,36 @@ def learnEGMC(X, prior=1.0, maxclusters=-1, sparse=False, verbose=False, nthread
     F, m, rows = capi.learn(capi.ALGO_EGMC, [np.asarray(x, dtype=np.float64) for x in X], 1.0, prior, maxclusters,
                             sparse, verbose, nthreads, device)
     return _result(F, m, rows, True)
+
+
+def _topic_result(F, m, mcm):
+    d = m.dims()
+    qY, qZ = m.qY(), m.qZ()
+    wj = [np.exp(m.weights(0, j)[0]) for j in range(d["J"])]
+    wt = [np.exp(m.weights(1, t)[0]) for t in range(d["T"])]
+    ck = [m.cluster(0, k) for k in range(d["K"])]
+    ct = [m.cluster(1, t) for t in range(d["T"])] if mcm else []
+    info = {"T": d["T"], "K": d["K"], "rounds": m.rounds(), "clusters_k": ck, "clusters_t": ct,
+            "Elogweight_j": [m.weights(0, j)[0] for j in range(d["J"])],
+            "Elogweight_t": [m.weights(1, t)[0] for t in range(d["T"])]}
+    m.close()
+    if mcm:  # python/libclusterpy.cpp:305-307
+        return (F, qY, qZ, wj, wt, [c["mean"] for c in ct], [c["mean"] for c in ck], [c["cov"] for c in ct],
+                [c["cov"] for c in ck], info)
+    return F, qY, qZ, wj, wt, [c["mean"] for c in ck], [c["cov"] for c in ck], info  # libclusterpy.cpp:270-271
+
+
+def learnSCM(X, dirprior=1.0, gausprior=1.0, trunc=100, maxclusters=-1, verbose=False, nthreads=1, qY0=None, device=0):
+    """include/libcluster.h:583-596, python/libclusterpy.cpp:244-272.  X: list (groups) of lists (documents) of
+    (N_ji, D) arrays.  Returns (F, qY, qZ, weights_j, weights_t, means, covs, info).  qY0 (additive): initial
+    (I_j, trunc) top-level assignments instead of the reference's std::rand() start."""
+    F, m = capi.learn_topic(X, None, qY0, dirprior, gausprior, trunc, maxclusters, verbose, nthreads, device)
+    return _topic_result(F, m, False)
+
+
+def learnMCM(W, X, gausprior_t=1.0, gausprior_k=1.0, trunc=100, maxclusters=-1, verbose=False, nthreads=1, qY0=None,
+             device=0):
+    """include/libcluster.h:661-676, python/libclusterpy.cpp:276-308.  W: list of (I_j, Dt) document observations.
+    Returns (F, qY, qZ, weights_j, weights_t, means_t, means_k, covs_t, covs_k, info)."""
+    F, m = capi.learn_topic(X, W, qY0, gausprior_t, gausprior_k, trunc, maxclusters, verbose, nthreads, device)
+    return _topic_result(F, m, True)

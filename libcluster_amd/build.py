@@ -19,8 +19,8 @@ OBJ = PKG / "lib" / "obj"
 LIB = PKG / "lib" / "libcluster_hip.so"
 ARCH = "gfx950"
 
-SOURCES = ["lc_kernels.hip", "lc_ctx.cpp", "lc_engine.cpp", "lc_capi.cpp"]
-HEADERS = ["lc_kernels.h", "lc_ctx.hpp", "lc_engine.hpp", "lc_host.hpp", "../../include/libcluster_hip.h"]
+SOURCES = ["lc_kernels.hip", "lc_ctx.cpp", "lc_engine.cpp", "lc_topic.cpp", "lc_capi.cpp"]
+HEADERS = ["lc_kernels.h", "lc_ctx.hpp", "lc_engine.hpp", "lc_topic.hpp", "lc_host.hpp", "../../include/libcluster_hip.h"]
 
 
 def _hipcc() -> str:

@@ -116,6 +116,18 @@ def lib() -> C.CDLL:
     L.lc_weights_update.argtypes = [C.c_int, C.c_double, c_double_p, C.c_int, c_double_p, c_double_p]
     L.lc_gw_mstep.argtypes = [C.c_double, C.c_int, C.c_double, c_double_p, c_double_p, c_double_p, c_double_p,
                               c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]
+    L.lc_learn_topic.argtypes = [C.c_int, c_int_p, C.POINTER(c_double_p), c_int64_p, C.c_int, C.c_int64, C.c_int64,
+                                 C.POINTER(c_double_p), C.c_int, C.POINTER(c_double_p), C.c_double, C.c_double,
+                                 C.c_uint, C.c_int, C.c_int, C.c_uint, C.c_int, C.POINTER(C.c_void_p), c_double_p]
+    L.lc_tmodel_free.argtypes = [C.c_void_p]
+    L.lc_tmodel_dims.argtypes = [C.c_void_p, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p]
+    L.lc_tmodel_get_qy.argtypes = [C.c_void_p, C.c_int, c_double_p]
+    L.lc_tmodel_get_qz.argtypes = [C.c_void_p, C.c_int, c_double_p, C.c_int64, C.c_int64]
+    L.lc_tmodel_weights.argtypes = [C.c_void_p, C.c_int, C.c_int, c_double_p, c_double_p]
+    L.lc_tmodel_cluster.argtypes = [C.c_void_p, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p,
+                                    c_double_p, c_double_p, c_double_p, c_double_p]
+    L.lc_tmodel_rounds.argtypes = [C.c_void_p, c_int_p]
+    L.lc_tmodel_round.argtypes = [C.c_void_p, C.c_int, c_int_p, c_int_p, c_int_p, c_double_p, C.c_int]
     L.lc_ng_mstep.argtypes = [C.c_double, C.c_int, C.c_double, c_double_p, c_double_p, c_double_p, c_double_p,
                               c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]
     L.lc_eg_mstep.argtypes = [C.c_double, C.c_int, C.c_double, c_double_p, c_double_p, c_double_p, c_double_p,
@@ -515,3 +527,119 @@ def eg_mstep(obsmag, Ns, xs):
     ib = np.zeros(D)
     check(lib().lc_eg_mstep(obsmag, D, Ns, dptr(xs), C.byref(a), dptr(ib), C.byref(logb), C.byref(fe), C.byref(cst)))
     return {"a": a.value, "ib": ib, "logb": logb.value, "fenergy": fe.value, "eloglike_const": cst.value}
+
+
+class TopicModel:
+    """lc_tmodel: the result of learnSCM / learnMCM."""
+
+    def __init__(self, handle, Ij, Nji):
+        self._h = handle
+        self.Ij = list(Ij)
+        self.Nji = list(Nji)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().lc_tmodel_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def dims(self):
+        v = [C.c_int() for _ in range(6)]
+        check(lib().lc_tmodel_dims(self._h, *[C.byref(x) for x in v]))
+        return dict(zip(("J", "Itot", "T", "K", "D", "Dt"), (x.value for x in v)))
+
+    def qY(self):
+        d = self.dims()
+        out = []
+        for j, I in enumerate(self.Ij):
+            q = np.zeros((I, d["T"]))
+            check(lib().lc_tmodel_get_qy(self._h, j, dptr(q)))
+            out.append(q)
+        return out
+
+    def qZ(self):
+        K = self.dims()["K"]
+        out, doc = [], 0
+        for I in self.Ij:
+            g = []
+            for _ in range(I):
+                q = np.zeros((self.Nji[doc], K))
+                if self.Nji[doc]:
+                    check(lib().lc_tmodel_get_qz(self._h, doc, dptr(q), K, 1))
+                g.append(q)
+                doc += 1
+            out.append(g)
+        return out
+
+    def weights(self, level, idx):
+        d = self.dims()
+        n = d["T"] if level == 0 else d["K"]
+        e, nk = np.zeros(n), np.zeros(n)
+        check(lib().lc_tmodel_weights(self._h, level, idx, dptr(e), dptr(nk)))
+        return e, nk
+
+    def cluster(self, level, idx):
+        d = self.dims()
+        D = d["D"] if level == 0 else d["Dt"]
+        N, nu, beta, logdW, fe = (C.c_double() for _ in range(5))
+        mean, cov, iW = np.zeros(D), np.zeros((D, D)), np.zeros((D, D))
+        check(lib().lc_tmodel_cluster(self._h, level, idx, C.byref(N), dptr(mean), dptr(cov), C.byref(nu),
+                                      C.byref(beta), dptr(iW), C.byref(logdW), C.byref(fe)))
+        return {"N": N.value, "mean": mean, "cov": cov, "nu": nu.value, "beta": beta.value, "iW": iW,
+                "logdW": logdW.value, "fenergy": fe.value}
+
+    def rounds(self):
+        n = C.c_int()
+        check(lib().lc_tmodel_rounds(self._h, C.byref(n)))
+        out = []
+        for r in range(n.value):
+            T, K, ni = C.c_int(), C.c_int(), C.c_int()
+            check(lib().lc_tmodel_round(self._h, r, C.byref(T), C.byref(K), C.byref(ni), None, 0))
+            F = np.zeros(ni.value)
+            check(lib().lc_tmodel_round(self._h, r, None, None, None, dptr(F), ni.value))
+            out.append((T.value, K.value, F.tolist()))
+        return out
+
+
+def learn_topic(X, W=None, qY0=None, prior_t=1.0, prior_k=1.0, maxT=100, maxK=-1, verbose=False, nthreads=1,
+                device=0):
+    """lc_learn_topic: X is a list (groups) of lists (documents) of (N_ji, D) arrays; W (MCM) a list of (I_j, Dt)
+    arrays; qY0 an optional list of (I_j, maxT) initial assignments.  Returns (F, TopicModel)."""
+    Xs = [[np.ascontiguousarray(x, dtype=np.float64) for x in Xj] for Xj in X]
+    J = len(Xs)
+    docs = [x for Xj in Xs for x in Xj]
+    if not docs:
+        raise ValueError("need at least one document")
+    D = docs[0].shape[1]
+    for x in docs:
+        if x.ndim != 2 or x.shape[1] != D:
+            raise ValueError("X dimensions are inconsistent between documents!")
+    Ij = (C.c_int * J)(*[len(Xj) for Xj in Xs])
+    ptrs = (c_double_p * len(docs))(*[dptr(x) for x in docs])
+    Nji = (C.c_int64 * len(docs))(*[x.shape[0] for x in docs])
+    Wp, Dt, Ws = None, 0, None
+    if W is not None:
+        Ws = [np.ascontiguousarray(w, dtype=np.float64) for w in W]
+        if len(Ws) != J:  # mcluster.cpp:548-549
+            raise ValueError("W and X need to have the same number of groups!")
+        for j in range(J):
+            if Ws[j].shape[0] != len(Xs[j]):  # mcluster.cpp:553-555
+                raise ValueError("W and X need to have the same number of 'docs'!")
+        Dt = Ws[0].shape[1]
+        Wp = (c_double_p * J)(*[dptr(w) for w in Ws])
+    Qp, Qs = None, None
+    if qY0 is not None:
+        Qs = [np.ascontiguousarray(q, dtype=np.float64) for q in qY0]
+        for j in range(J):
+            if Qs[j].shape != (len(Xs[j]), maxT):
+                raise ValueError("qY0[j] must be (I_j, maxT)")
+        Qp = (c_double_p * J)(*[dptr(q) for q in Qs])
+    mh, F = C.c_void_p(), C.c_double()
+    check(lib().lc_learn_topic(J, Ij, ptrs, Nji, D, D, 1, Wp, Dt, Qp, prior_t, prior_k, maxT, maxK, int(verbose),
+                               nthreads, device, C.byref(mh), C.byref(F)))
+    return F.value, TopicModel(mh, [len(Xj) for Xj in Xs], [x.shape[0] for x in docs])

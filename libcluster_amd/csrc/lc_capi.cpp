@@ -10,6 +10,7 @@
 #include "../../include/libcluster_hip.h"
 #include "lc_ctx.hpp"
 #include "lc_engine.hpp"
+#include "lc_topic.hpp"
 #include "lc_host.hpp"
 
 struct lc_ctx {
@@ -22,6 +23,16 @@ struct lc_model {
   lc_ctx* ctx = nullptr;              // context holding qZ (owned or borrowed)
   lce::Model model;
   std::vector<std::pair<int, std::vector<double>>> rounds;
+  int D = 0;
+};
+
+struct lc_tmodel {
+  std::unique_ptr<lc_ctx> ctx;  // one group per document; holds qZ
+  lce::TopicData data;
+  lce::TopicModel model;
+  std::vector<double> W;        // I_tot x Dt (MCM)
+  std::vector<lce::TopicRound> rounds;
+  std::vector<int> doc0;        // first document of every group (J + 1)
   int D = 0;
 };
 
@@ -663,6 +674,173 @@ int lc_eg_mstep(double obsmag, int D, double Ns, const double* xs, double* a, do
     if (logb) *logb = g.logb;
     if (fenergy) *fenergy = g.fenergy();
     if (eloglike_const) *eloglike_const = g.eloglike_const();
+  });
+}
+
+// ---------------------------------------------------------------------------
+// learnSCM / learnMCM
+// ---------------------------------------------------------------------------
+int lc_learn_topic(int J, const int* Ij, const double* const* Xji, const int64_t* Nji, int D, int64_t rs, int64_t cs,
+                   const double* const* Wj, int Dt, const double* const* qY0, double prior_t, double prior_k,
+                   unsigned maxT, int maxK, int verbose, unsigned nthreads, int device, lc_tmodel** out, double* F) {
+  return guarded([&] {
+    need(Ij, "Ij");
+    need(Xji, "Xji");
+    need(Nji, "Nji");
+    need(out, "out");
+    if (nthreads < 1) throw std::invalid_argument("Must specify at least one thread for execution!");
+    if (J < 1) throw std::invalid_argument("need at least one group of observations");
+    if (maxT < 1) throw std::invalid_argument("maxT must be at least 1");
+    const bool mcm = Wj != nullptr;
+    std::unique_ptr<lc_tmodel> m(new lc_tmodel());
+    lce::TopicData& d = m->data;
+    d.J = J;
+    d.Ij.assign(Ij, Ij + J);
+    m->doc0.assign(1, 0);
+    for (int j = 0; j < J; ++j) {
+      if (Ij[j] < 0) throw std::invalid_argument("negative document count");
+      for (int i = 0; i < Ij[j]; ++i) d.doc_group.push_back(j);
+      m->doc0.push_back(m->doc0.back() + Ij[j]);
+    }
+    d.Itot = (int)d.doc_group.size();
+    if (d.Itot < 1) throw std::invalid_argument("need at least one document");
+    if (mcm) {  // mcluster.cpp:548-556 checks W.size() / W[j].rows() against X: here they are implied by Ij
+      if (Dt < 1) throw std::invalid_argument("W needs at least one column");
+      m->W.resize((size_t)d.Itot * Dt);
+      for (int j = 0; j < J; ++j) {
+        if (Ij[j] > 0) need(Wj[j], "Wj[j]");
+        if (Ij[j] > 0) std::copy(Wj[j], Wj[j] + (size_t)Ij[j] * Dt, m->W.begin() + (size_t)m->doc0[j] * Dt);
+      }
+      d.W = m->W.data();
+      d.Dt = Dt;
+    }
+    if (verbose) std::cout << (mcm ? "Learning MCM..." : "Learning SCM...") << std::endl;  // scluster.cpp:595-596
+    // qY: |U(-1,1)| rows, normalised (scluster.cpp:519-521 / mcluster.cpp:559-561).  The reference draws from Eigen's
+    // Random(), i.e. std::rand() per coefficient in column-major order; the same sequence is consumed here.
+    m->model.T = (int)maxT;
+    m->model.qY.assign((size_t)d.Itot * maxT, 0.0);
+    for (int j = 0; j < J; ++j) {
+      const int I = Ij[j];
+      double* q = m->model.qY.data() + (size_t)m->doc0[j] * maxT;
+      if (qY0) {
+        if (I > 0) need(qY0[j], "qY0[j]");
+        std::copy(qY0[j], qY0[j] + (size_t)I * maxT, q);
+      } else {
+        for (unsigned t = 0; t < maxT; ++t)
+          for (int i = 0; i < I; ++i)
+            q[(size_t)i * maxT + t] = std::abs(-1.0 + 2.0 * (double)std::rand() / (double)RAND_MAX);
+        for (int i = 0; i < I; ++i) {
+          double nrm = 0.0;
+          for (unsigned t = 0; t < maxT; ++t) nrm += q[(size_t)i * maxT + t];
+          for (unsigned t = 0; t < maxT; ++t)
+            q[(size_t)i * maxT + t] = std::exp(std::log(q[(size_t)i * maxT + t]) - std::log(nrm));
+        }
+      }
+    }
+    if (!mcm && maxT > (unsigned)d.Itot)  // scluster.cpp:531-533 (sic: no space before X)
+      throw std::invalid_argument("maxT must be less than the number of documents ofX!");
+    m->ctx.reset(new lc_ctx(device, nullptr));
+    m->D = D;
+    m->ctx->impl.set_data(d.Itot, Xji, Nji, D, rs, cs);
+    lce::TopicOptions o;
+    o.prior_t = prior_t;
+    o.prior_k = prior_k;
+    o.maxK = maxK;
+    o.verbose = verbose != 0;
+    o.nthreads = nthreads;
+    const double f = lce::topic_cluster(m->ctx->impl, d, m->model, o, &m->rounds);
+    if (F) *F = f;
+    *out = m.release();
+  });
+}
+
+int lc_tmodel_free(lc_tmodel* m) {
+  return guarded([&] { delete m; });
+}
+
+int lc_tmodel_dims(lc_tmodel* m, int* J, int* Itot, int* T, int* K, int* D, int* Dt) {
+  return guarded([&] {
+    need(m, "model");
+    if (J) *J = m->data.J;
+    if (Itot) *Itot = m->data.Itot;
+    if (T) *T = m->model.T;
+    if (K) *K = (int)m->model.clusters.size();
+    if (D) *D = m->D;
+    if (Dt) *Dt = m->data.Dt;
+  });
+}
+
+int lc_tmodel_get_qy(lc_tmodel* m, int j, double* qY) {
+  return guarded([&] {
+    need(m, "model");
+    need(qY, "qY");
+    if (j < 0 || j >= m->data.J) throw std::invalid_argument("group index out of range");
+    const int T = m->model.T;
+    std::copy(m->model.qY.begin() + (size_t)m->doc0[(size_t)j] * T, m->model.qY.begin() + (size_t)m->doc0[(size_t)j + 1] * T,
+              qY);
+  });
+}
+
+int lc_tmodel_get_qz(lc_tmodel* m, int doc, double* q, int64_t rs, int64_t cs) {
+  return guarded([&] {
+    need(m, "model");
+    need(q, "q");
+    m->ctx->impl.qz_get(doc, q, rs, cs);
+  });
+}
+
+int lc_tmodel_weights(lc_tmodel* m, int level, int idx, double* Elogweight, double* Nk) {
+  return guarded([&] {
+    need(m, "model");
+    const std::vector<lch::WeightState>& v = level == 0 ? m->model.weights_j : m->model.weights_t;
+    if (level < 0 || level > 1) throw std::invalid_argument("level must be 0 (groups) or 1 (top-level clusters)");
+    if (idx < 0 || idx >= (int)v.size()) throw std::invalid_argument("weight index out of range");
+    const lch::WeightState& w = v[(size_t)idx];
+    if (Elogweight) std::copy(w.Elogpi.begin(), w.Elogpi.end(), Elogweight);
+    if (Nk) std::copy(w.Nk.begin(), w.Nk.end(), Nk);
+  });
+}
+
+int lc_tmodel_cluster(lc_tmodel* m, int level, int idx, double* N, double* mean, double* cov, double* nu, double* beta,
+                      double* iW, double* logdW, double* fenergy) {
+  return guarded([&] {
+    need(m, "model");
+    if (level < 0 || level > 1) throw std::invalid_argument("level must be 0 (bottom) or 1 (top-level clusters)");
+    const std::vector<lch::GaussWishState>& v = level == 0 ? m->model.clusters : m->model.clusters_t;
+    if (idx < 0 || idx >= (int)v.size()) throw std::invalid_argument("cluster index out of range");
+    const lch::GaussWishState& c = v[(size_t)idx];
+    if (N) *N = c.N;
+    if (mean) std::copy(c.m.begin(), c.m.end(), mean);
+    if (cov) {
+      const std::vector<double> cv = c.getcov();
+      std::copy(cv.begin(), cv.end(), cov);
+    }
+    if (nu) *nu = c.nu;
+    if (beta) *beta = c.beta;
+    if (iW) std::copy(c.iW.begin(), c.iW.end(), iW);
+    if (logdW) *logdW = c.logdW;
+    if (fenergy) *fenergy = c.fenergy();
+  });
+}
+
+int lc_tmodel_rounds(lc_tmodel* m, int* nrounds) {
+  return guarded([&] {
+    need(m, "model");
+    need(nrounds, "nrounds");
+    *nrounds = (int)m->rounds.size();
+  });
+}
+
+int lc_tmodel_round(lc_tmodel* m, int r, int* T, int* K, int* niter, double* F, int nF) {
+  return guarded([&] {
+    need(m, "model");
+    if (r < 0 || r >= (int)m->rounds.size()) throw std::invalid_argument("round index out of range");
+    const lce::TopicRound& rd = m->rounds[(size_t)r];
+    if (T) *T = rd.T;
+    if (K) *K = rd.K;
+    if (niter) *niter = (int)rd.F.size();
+    if (F)
+      for (int i = 0; i < nF && i < (int)rd.F.size(); ++i) F[i] = rd.F[(size_t)i];
   });
 }
 

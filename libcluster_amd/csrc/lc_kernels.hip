@@ -1147,10 +1147,28 @@ __global__ void __launch_bounds__(256) group_colsum_kernel(const double* qZ, int
   if (threadIdx.x == 0) out[(int64_t)j * K + k] = sh[0];
 }
 
+// many small groups (the documents of learnSCM / learnMCM): one block per group, wave w sums the columns
+// w, w+4, ... with a fixed-shape reduction => deterministic
+__global__ void __launch_bounds__(256) group_colsum_small_kernel(const double* qZ, int64_t ldq, int K,
+                                                                 const int64_t* goff, double* out) {
+  const int j = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t b = goff[j], e = goff[j + 1];
+  for (int k = w; k < K; k += 4) {
+    double s = 0.0;
+    for (int64_t r = b + lane; r < e; r += 64) s += qZ[(int64_t)k * ldq + r];
+    s = wave_sum(s);
+    if (lane == 0) out[(int64_t)j * K + k] = s;
+  }
+}
+
 hipError_t launch_group_colsum(const double* qZ, int64_t ldq, int K, const int64_t* goff, int J, double* out,
                                hipStream_t stream) {
   if (K <= 0 || J <= 0) return hipSuccess;
-  hipLaunchKernelGGL(group_colsum_kernel, dim3((unsigned)K, (unsigned)J), dim3(256), 0, stream, qZ, ldq, K, goff, out);
+  if (J > 1024)
+    hipLaunchKernelGGL(group_colsum_small_kernel, dim3((unsigned)J), dim3(256), 0, stream, qZ, ldq, K, goff, out);
+  else
+    hipLaunchKernelGGL(group_colsum_kernel, dim3((unsigned)K, (unsigned)J), dim3(256), 0, stream, qZ, ldq, K, goff,
+                       out);
   return hipGetLastError();
 }
 

@@ -839,6 +839,285 @@ def learnEGMC(X, clusterprior=PRIORVAL, maxclusters=-1, sparse=False, verbose=Fa
 
 
 # ---------------------------------------------------------------------------
+# Simultaneous / multiple-source clustering models: src/scluster.cpp (learnSCM) and src/mcluster.cpp (learnMCM).
+# X[j][i] is the (N_ji x D) matrix of "document" i of group j; qY[j] is (I_j x T); qZ[j][i] is (N_ji x K);
+# W[j] (MCM only) is the (I_j x Dt) matrix of document-level observations.  One restatement serves both: the MCM
+# is the SCM plus the top-level Gaussian clusters over W (mcluster.cpp differs from scluster.cpp only there, in
+# the default-constructed weights_t, and in its guards for empty documents).
+# ---------------------------------------------------------------------------
+
+def random_qY(I, maxT, rng):
+    """scluster.cpp:519-521 / mcluster.cpp:559-561: |U(-1,1)| rows, normalised.  The reference draws from Eigen's
+    Random() (std::rand); here the generator is the caller's numpy Generator -- the learners take an explicit qY0
+    for reproducible parity."""
+    r = np.abs(rng.uniform(-1.0, 1.0, (I, maxT)))
+    return np.exp(np.log(r) - np.log(r.sum(axis=1))[:, None])
+
+
+def vbeY(qZj, weightsj, weights_t, qYshape, Wj=None, clusters_t=None):
+    """scluster.cpp:50-85 / mcluster.cpp:49-92 -> (qYj, Fyz_j)."""
+    T = len(weights_t)
+    Ij = len(qZj)
+    if Ij == 0:  # mcluster.cpp:64-65
+        return np.zeros((0, T)), 0.0
+    E_logwj = weightsj.Elogweight()
+    Njik = np.stack([q.sum(axis=0) for q in qZj])
+    like = np.empty((Ij, T))
+    logq = np.empty((Ij, T))
+    for t in range(T):
+        like[:, t] = Njik @ weights_t[t].Elogweight()
+        if clusters_t is None:
+            logq[:, t] = E_logwj[t] + like[:, t]
+        else:
+            logq[:, t] = like[:, t] + E_logwj[t] + clusters_t[t].Eloglike(Wj)
+    logZ = logsumexp(logq)
+    qY = np.exp(logq - logZ[:, None])
+    return qY, float(((qY * like).sum(axis=1) - logZ).sum())
+
+
+def vbeZ(Xji, qYji, weights_t, clusters):
+    """scluster.cpp:93-124 / mcluster.cpp:100-135 -> (qZji, Fz_ji)."""
+    K = len(clusters)
+    if Xji.shape[0] == 0:
+        return np.zeros((0, K)), 0.0
+    E = np.zeros(K)
+    for t in range(len(weights_t)):
+        E = E + qYji[t] * weights_t[t].Elogweight()
+    logq = np.empty((Xji.shape[0], K))
+    for k in range(K):
+        logq[:, k] = E[k] + clusters[k].Eloglike(Xji)
+    logZ = logsumexp(logq)
+    return np.exp(logq - logZ[:, None]), float(-logZ.sum())
+
+
+def _resize(lst, n, factory):
+    del lst[n:]
+    while len(lst) < n:
+        lst.append(factory())
+
+
+def tvbem(X, qZ, qY, weights_j, weights_t, clusters, prior_t, prior_k, maxit=-1, verbose=False, W=None,
+          clusters_t=None, trace=None, fixed_iters=-1):
+    """scluster.cpp:172-260 / mcluster.cpp:186-287.  qZ and qY are updated in place; returns F."""
+    J = len(X)
+    K = qZ[0][0].shape[1]
+    T = qY[0].shape[1]
+    D = X[0][0].shape[1]
+    mcm = W is not None
+    _resize(weights_j, J, GDirichlet)
+    _resize(weights_t, T, (lambda: Dirichlet()) if mcm else (lambda: Dirichlet(prior_t)))
+    if mcm:
+        _resize(clusters_t, T, lambda: GaussWish(prior_t, W[0].shape[1]))
+    _resize(clusters, K, lambda: GaussWish(prior_k, D))
+    it = 0
+    F = np.finfo(np.float64).max
+    while True:
+        Fold = F
+        Ntk = np.zeros((T, K))
+        for j in range(J):
+            for i in range(len(X[j])):
+                Ntk += np.outer(qY[j][i], qZ[j][i].sum(axis=0))
+            weights_j[j].update(qY[j].sum(axis=0))
+        for t in range(T):
+            if mcm:
+                clusters_t[t].clearobs()
+                for j in range(J):
+                    clusters_t[t].addobs(qY[j][:, t], W[j])
+            weights_t[t].update(Ntk[t])
+            if mcm:
+                clusters_t[t].update()
+        for k in range(K):
+            clusters[k].clearobs()
+            for j in range(J):
+                for i in range(len(X[j])):
+                    clusters[k].addobs(qZ[j][i][:, k], X[j][i])
+            clusters[k].update()
+        Fz = Fyz = 0.0
+        for j in range(J):
+            qY[j], f = vbeY(qZ[j], weights_j[j], weights_t, None, W[j] if mcm else None, clusters_t if mcm else None)
+            Fyz += f
+        for j in range(J):
+            for i in range(len(X[j])):
+                qZ[j][i], f = vbeZ(X[j][i], qY[j][i], weights_t, clusters)
+                Fz += f
+        F = (sum(w.fenergy() for w in weights_j) + sum(w.fenergy() for w in weights_t)
+             + (sum(c.fenergy() for c in clusters_t) if mcm else 0.0) + sum(c.fenergy() for c in clusters) + Fyz + Fz)
+        if trace is not None:
+            trace.append(F)
+        if fixed_iters >= 0:
+            it += 1
+            if it >= fixed_iters:
+                return F
+            continue
+        if (F - Fold) / abs(Fold) > FENGYDEL:
+            raise RuntimeError("Free energy increase!")
+        if verbose:
+            print("-", end="", flush=True)
+        if not abs((Fold - F) / Fold) > CONVERGE:
+            return F
+        it += 1
+        if not (it < maxit or maxit < 0):
+            return F
+
+
+def tsplit(X, clusters, prior_t, qY, qZ, tally, F, maxK, verbose, W=None, clusters_t=None, events=None):
+    """scluster.cpp:280-428 (split_gr) / mcluster.cpp:309-455 (ssplit)."""
+    J = len(X)
+    K = len(clusters)
+    mcm = W is not None
+    if maxK >= 0 and K >= maxK:
+        return False
+    while len(tally) < K:
+        tally.append(0)
+    del tally[K:]
+    Fk = np.array([c.fenergy() for c in clusters])
+    for j in range(J):
+        for i in range(len(X[j])):
+            for k in range(K):
+                if X[j][i].shape[0]:
+                    Fk[k] -= float(qZ[j][i][:, k] @ clusters[k].Eloglike(X[j][i]))
+    order = sorted(range(K), key=lambda k: (tally[k], -Fk[k]))
+    if events is not None:
+        events.append(("order", list(order), Fk.tolist()))
+    for k in order:
+        tally[k] += 1
+        if clusters[k].getN() < 4:
+            continue
+        scount = Mtot = 0
+        mapidx = [[None] * len(X[j]) for j in range(J)]
+        Xk = [[None] * len(X[j]) for j in range(J)]
+        qZref = [[None] * len(X[j]) for j in range(J)]
+        for j in range(J):
+            for i in range(len(X[j])):
+                mapidx[j][i], Xk[j][i] = partobs(X[j][i], qZ[j][i][:, k] > 0.5)
+                n = Xk[j][i].shape[0]
+                Mtot += n
+                splitk = clusters[k].splitobs(Xk[j][i]) if n else np.zeros(0, dtype=bool)
+                q = np.zeros((n, 2))
+                q[:, 0] = splitk.astype(np.float64)
+                q[:, 1] = (~splitk).astype(np.float64)
+                qZref[j][i] = q
+                scount += int(splitk.sum())
+        if scount < 2 or scount > Mtot - 2:
+            continue
+        wspl, lspl, cspl, ctspl = [], [], [], []
+        if mcm:  # mcluster.cpp:414-416: refined with the current qY and W
+            qYref = [q.copy() for q in qY]
+            tvbem(Xk, qZref, qYref, wspl, lspl, cspl, clusters_t[0].getprior(), clusters[0].getprior(), SPLITITER,
+                  W=W, clusters_t=ctspl)
+        else:    # scluster.cpp:363, 385-386: one top-level cluster
+            qYref = [np.ones((len(X[j]), 1)) for j in range(J)]
+            tvbem(Xk, qZref, qYref, wspl, lspl, cspl, prior_t, clusters[0].getprior(), SPLITITER)
+        if anyempty(cspl):
+            continue
+        qZaug = [[auglabels(k, mapidx[j][i], qZref[j][i][:, 1] > 0.5, qZ[j][i]) for i in range(len(X[j]))]
+                 for j in range(J)]
+        qYaug = [q.copy() for q in qY]
+        if mcm:
+            Fs = tvbem(X, qZaug, qYaug, wspl, lspl, cspl, clusters_t[0].getprior(), clusters[0].getprior(), 1,
+                       W=W, clusters_t=ctspl)
+        else:
+            Fs = tvbem(X, qZaug, qYaug, wspl, lspl, cspl, prior_t, clusters[0].getprior(), 1)
+        if anyempty(cspl):
+            continue
+        if verbose:
+            print("=", end="", flush=True)
+        if events is not None:
+            events.append(("candidate", int(k), float(Fs)))
+        if Fs < F and abs((F - Fs) / F) > CONVERGE:
+            for j in range(J):
+                qY[j] = qYaug[j]
+                qZ[j] = qZaug[j]
+            tally[k] = 0
+            return True
+    return False
+
+
+def prune_clusters_t(qY, weights_t, clusters_t=None, verbose=False):
+    """scluster.cpp:437-481 / mcluster.cpp:465-511: drop top-level clusters with fewer than one observation."""
+    Nt = np.array([w.getNk().sum() for w in weights_t])
+    empty = Nt < 1
+    if not empty.any():
+        return False
+    if verbose:
+        print("*", end="", flush=True)
+    keep = np.flatnonzero(~empty)
+    for t in sorted(np.flatnonzero(empty), reverse=True):
+        del weights_t[t]
+        if clusters_t is not None:
+            del clusters_t[t]
+    for j in range(len(qY)):
+        qY[j] = qY[j][:, keep].copy()
+    return True
+
+
+def tcluster(X, prior_t, prior_k, maxT, maxK, verbose, W=None, qY0=None, rng=None, trace=None, events=None):
+    """scluster.cpp:493-570 (scluster) / mcluster.cpp:525-605 (mcluster)
+    -> (F, qY, qZ, weights_j, weights_t, clusters_t, clusters)."""
+    J = len(X)
+    mcm = W is not None
+    if mcm:
+        if len(W) != J:
+            raise ValueError("W and X need to have the same number of groups!")
+        for j in range(J):
+            if W[j].shape[0] != len(X[j]):
+                raise ValueError("W and X need to have the same number of 'docs'!")
+    if qY0 is not None:
+        qY = [np.array(q, dtype=np.float64) for q in qY0]
+    else:
+        rng = rng or np.random.default_rng(0)
+        qY = [random_qY(len(X[j]), maxT, rng) for j in range(J)]
+    qZ = [[np.ones((x.shape[0], 1)) for x in X[j]] for j in range(J)]
+    Itot = sum(len(x) for x in X)
+    if not mcm and maxT > Itot:
+        raise ValueError("maxT must be less than the number of documents ofX!")
+    weights_j, weights_t, clusters_t, clusters = [], [], [], []
+    issplit = emptyclasses = True
+    F = 0.0
+    tally = []
+    while issplit or emptyclasses:
+        rtrace = [] if trace is not None else None
+        F = tvbem(X, qZ, qY, weights_j, weights_t, clusters, prior_t, prior_k, -1, verbose, W,
+                  clusters_t if mcm else None, rtrace)
+        if trace is not None:
+            trace.append((len(weights_t), len(clusters), rtrace))
+        if verbose:
+            print("<", end="", flush=True)
+        if not issplit:
+            emptyclasses = prune_clusters_t(qY, weights_t, clusters_t if mcm else None, verbose)
+        else:
+            issplit = tsplit(X, clusters, prior_t, qY, qZ, tally, F, maxK, verbose, W, clusters_t if mcm else None,
+                             events)
+        if verbose:
+            print(">")
+    if verbose:
+        print("Finished!")
+        print("Number of top level clusters = %d, and bottom level clusters = %d" % (len(weights_t), len(clusters)))
+        print("Free energy =", F)
+    return F, qY, qZ, weights_j, weights_t, clusters_t, clusters
+
+
+def learnSCM(X, dirprior=PRIORVAL, gausprior=PRIORVAL, maxT=TRUNC, maxK=-1, verbose=False, qY0=None, rng=None,
+             trace=None, events=None):
+    """src/scluster.cpp:578-605 -> (F, qY, qZ, weights_j, weights_t, clusters)."""
+    Xl = [[np.asarray(x, dtype=np.float64) for x in Xj] for Xj in X]
+    if verbose:
+        print("Learning SCM...")
+    F, qY, qZ, wj, wt, _, cl = tcluster(Xl, dirprior, gausprior, maxT, maxK, verbose, None, qY0, rng, trace, events)
+    return F, qY, qZ, wj, wt, cl
+
+
+def learnMCM(W, X, prior_t=PRIORVAL, prior_k=PRIORVAL, maxT=TRUNC, maxK=-1, verbose=False, qY0=None, rng=None,
+             trace=None, events=None):
+    """src/mcluster.cpp:613-642 -> (F, qY, qZ, weights_j, weights_t, clusters_t, clusters_k)."""
+    Xl = [[np.asarray(x, dtype=np.float64) for x in Xj] for Xj in X]
+    Wl = [np.asarray(w, dtype=np.float64) for w in W]
+    if verbose:
+        print("Learning MCM...")
+    return tcluster(Xl, prior_t, prior_k, maxT, maxK, verbose, Wl, qY0, rng, trace, events)
+
+
+# ---------------------------------------------------------------------------
 # fixed-K harness (no reference entry point: vbem is file-static there,
 # cluster.cpp:177).  Used by parity tests and bench.py's cpu_baseline check.
 # ---------------------------------------------------------------------------

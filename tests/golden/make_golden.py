@@ -3,7 +3,7 @@ oracle (oracle/lc_oracle.py) and cross-check them against scikit-learn.
 
 Run in the build container:   python tests/golden/make_golden.py
 Outputs (committed): tests/golden/estep_cases.json, tests/golden/xcat_traces.json,
-tests/golden/family_traces.json
+tests/golden/family_traces.json, tests/golden/topic_traces.json
 
 The reference itself cannot be built or imported here (no Eigen/Boost), so
 these vectors are restatement-derived ("parity unpinned", see oracle header);
@@ -199,7 +199,33 @@ def main():
         fam[name] = rec
         print(name, "F =", F, "K =", len(cl))
     (HERE / "family_traces.json").write_text(json.dumps(fam))
-    for f in ("estep_cases.json", "xcat_traces.json", "family_traces.json"):
+
+    # two-level models on the reference's own test set-up (test/scluster_test.cpp:44-68: the 12 groups of
+    # testdata.h as 2 groups x 6 documents, maxT = 4; test/mcluster_test.cpp:44-70: + the O data, maxT = 10).
+    # The reference's start is std::rand(); the start used is stored with the trace.
+    top = {}
+    Xv = [X[:6], X[6:]]
+    Wd = [np.array(g) for g in d["O"]]
+    for name, maxT, Wx in (("learnSCM", 4, None), ("learnMCM", 10, Wd)):
+        qY0 = [o.random_qY(6, maxT, rng) for _ in range(2)]
+        tr = []
+        if Wx is None:
+            F, qY, qZ, wj, wt, cl = o.learnSCM(Xv, maxT=maxT, qY0=qY0, trace=tr)
+            ct = []
+        else:
+            F, qY, qZ, wj, wt, ct, cl = o.learnMCM(Wx, Xv, maxT=maxT, qY0=qY0, trace=tr)
+        top[name] = {
+            "qY0": [q.tolist() for q in qY0], "maxT": maxT, "F": F, "T": len(wt), "K": len(cl),
+            "rounds": [[t, k, f] for t, k, f in tr], "qY": [q.tolist() for q in qY],
+            "qZ": [[q.tolist() for q in qj] for qj in qZ],
+            "Elogweight_j": [w.Elogweight().tolist() for w in wj],
+            "Elogweight_t": [w.Elogweight().tolist() for w in wt],
+            "means_k": [c.getmean().tolist() for c in cl], "covs_k": [c.getcov().tolist() for c in cl],
+            "means_t": [c.getmean().tolist() for c in ct], "covs_t": [c.getcov().tolist() for c in ct],
+        }
+        print(name, "F =", F, "T =", len(wt), "K =", len(cl))
+    (HERE / "topic_traces.json").write_text(json.dumps(top))
+    for f in ("estep_cases.json", "xcat_traces.json", "family_traces.json", "topic_traces.json"):
         print(f, (HERE / f).stat().st_size // 1024, "KiB")
 
 

@@ -46,8 +46,13 @@ def test_reference_test_main_passes_on_gpu(lib, xcat, xcat_traces):
     lines.append(f"{xcat_traces['learnGMC']['F']!r} {xcat_traces['learnBGMM']['F']!r} {xcat_traces['learnVDP']['F']!r}")
     fam = json.loads((ROOT / "tests" / "golden" / "family_traces.json").read_text())
     lines.append(" ".join(repr(fam[k]["F"]) for k in ("learnDGMM", "learnDGMC", "learnBEMM", "learnEGMC")))
+    lines.append(str(len(X)))  # the O data of testdata.h (document observations of mcluster_test.cpp)
+    for g in xcat["O"]:
+        lines += [" ".join(repr(float(v)) for v in row) for row in g]
     r = subprocess.run([str(exe)], input="\n".join(lines) + "\n", capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "cluster_test OK" in r.stdout
     # the reference's verbose progress glyphs (README.md:355-376, cluster.cpp:232-233, 605-617)
     assert "Learning GMC..." in r.stdout and "<" in r.stdout and ">" in r.stdout and "Finished!" in r.stdout
+    assert "Learning SCM..." in r.stdout and "Learning MCM..." in r.stdout
+    assert "Number of top level clusters = " in r.stdout and ", and bottom level clusters = " in r.stdout
