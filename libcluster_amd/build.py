@@ -42,6 +42,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     hipcc = _hipcc()
     hdrs = [CSRC / h for h in HEADERS]
     common = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", f"-I{PKG.parent / 'include'}"]
+    common += os.environ.get("LC_EXTRA_CXXFLAGS", "").split()  # kernel tuning experiments (-DLC_SS_UNROLL=2 ...)
     objs = []
     for src in SOURCES:
         s = CSRC / src

@@ -641,6 +641,18 @@ int suffstat_plan(int DP, int64_t NP, int K, int64_t* chunk_rows) {
   const int kwaves = (K + cpw - 1) / cpw;  // waves needed to cover the clusters
   // aim for ~8 waves per CU on 256 CUs, at least 256 rows per chunk
   int64_t want = (256 * 8 + kwaves - 1) / kwaves;
+  // four blocks per resident slot: the hardware back-fills slots as blocks retire, which evens out the
+  // per-CU / per-XCD speed differences (measured 25.7 -> 24.9 ms at N=10M, D=64, K=32), while the partial
+  // records (chunks x K x (1 + DP + DP^2) doubles) stay below 1 GiB
+  int rounds = 4;
+  if (const char* e = getenv("LC_SS_ROUNDS")) {  // tuning knob
+    const int v = atoi(e);
+    if (v >= 1 && v <= 16) rounds = v;
+  }
+  const int64_t rec = (int64_t)K * (1 + DP + (int64_t)DP * DP) * 8;
+  const int64_t cap = ((int64_t)1 << 30) / rec;
+  if (want * rounds <= cap) want *= rounds;
+  else if (want < cap) want = cap;
   int64_t maxchunks = (NP + 255) / 256;
   if (want > maxchunks) want = maxchunks;
   if (want < 1) want = 1;
