@@ -668,13 +668,15 @@ void Context::suffstat_diag(const unsigned char* smask, double* Nk, double* xs, 
   ssout_.reserve(nout);
   double* njk_d = ssout_.p + (size_t)K * SS;
   if (NP_ > 0) {
-    // one resident round of blocks (2 per CU: 64 KB of LDS each), whole 256-row tiles; few chunks keep the
-    // partial-record reduction (chunks x K x (1 + 2 DP) doubles) short
-    int64_t want = std::min<int64_t>(512, (NP_ + 255) / 256);
+    // about four blocks per resident slot (2 blocks per CU), whole 32-row batches; the partial records
+    // (chunks x row classes x K x (1 + 2 DP) doubles) stay small next to the data
+    const int rs = lck::suffstat_diag_rsplit(K), nslice = (K + 63) / 64;
+    int64_t want = std::min<int64_t>(std::max<int64_t>(2048 / nslice, 1), (NP_ + 255) / 256);
     if (want < 1) want = 1;
-    int64_t rows = ((NP_ + want - 1) / want + 255) / 256 * 256;
+    int64_t rows = ((NP_ + want - 1) / want + 31) / 32 * 32;
     const int nchunks = (int)((NP_ + rows - 1) / rows);
-    sspart_.reserve((size_t)nchunks * K * SS);
+    const int nparts = nchunks * rs;
+    sspart_.reserve((size_t)nparts * K * SS);
     lck::DiagStatLaunch a;
     a.DP = DP;
     a.X = X_.p;
@@ -706,7 +708,7 @@ void Context::suffstat_diag(const unsigned char* smask, double* Nk, double* xs, 
       LC_HIP(hipEventRecord(ev.b, stream_));
       pending_.push_back(ev);
     }
-    LC_HIP(lck::launch_reduce_partials(sspart_.p, nchunks, (int64_t)K * SS, ssout_.p, stream_));
+    LC_HIP(lck::launch_reduce_partials(sspart_.p, nparts, (int64_t)K * SS, ssout_.p, stream_));
     if (J_ > 1) LC_HIP(lck::launch_group_colsum(qz_[cur_].buf.p, NP_, K, goff_d_.p, J_, njk_d, stream_));
     else LC_HIP(hipMemsetAsync(njk_d, 0, (size_t)K * sizeof(double), stream_));
   } else {

@@ -97,13 +97,13 @@ struct DiagStatLaunch {
   int K;
   const int* rginfo;
   const unsigned char* smask;
-  double* partial;       // [nchunks x K x (1 + 2 DP)]
+  double* partial;       // [nchunks * rsplit x K x (1 + 2 DP)], rsplit = suffstat_diag_rsplit(K)
   int nchunks;
-  int64_t chunk_rows;    // multiple of 256
+  int64_t chunk_rows;    // multiple of 32
   int second = 1;        // 0: skip the second moments (ExpGamma)
-  int k0 = 0, k1 = 0;    // cluster range of one launch (filled in by launch_suffstat_diag)
-  int tile_rows = 0;     // ditto
+  int nslice = 0, rsplit = 0;  // filled in by launch_suffstat_diag
 };
+int suffstat_diag_rsplit(int K);
 hipError_t launch_suffstat_diag(const DiagStatLaunch& a, hipStream_t stream);
 
 // ---- split-search data passes (partobs / splitobs / auglabels on the device) ----
