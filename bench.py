@@ -251,6 +251,8 @@ def main():
         est = kt["estep_ms"] / max(1, kt["estep_calls"])
         sst = kt["suffstat_ms"] / max(1, kt["suffstat_calls"])
         dom = "estep_kernel" if est >= sst else "suffstat_kernel"
+        if family != "GaussWish":
+            dom = dom.replace("_kernel", "_diag_kernel")
         dom_ms = max(est, sst)
         dom_fl = fl["estep"] if est >= sst else fl["suffstat"]
         achieved = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
@@ -287,7 +289,6 @@ def main():
         }
         if family != "GaussWish":
             # separable families: 8 (D + K) algorithmic bytes per row and launch (X read + q column written / read)
-            dom = "estep_diag_kernel" if est >= sst else "suffstat_diag_kernel"
             gbs = 8.0 * N * (D + K) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
             line["config"]["clusters"] = family
             line["kernels"].pop("both_kernels_alg_tflops")

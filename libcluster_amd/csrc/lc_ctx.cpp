@@ -470,8 +470,9 @@ void Context::estep(int K, const double* A, const double* m, const double* c, do
     return;
   }
   if (grid > 0) {
-    LC_HIP(lck::launch_reduce_partials(fzpart_.p, (int)grid, 1, red_.p, stream_));
-    if (LLk) LC_HIP(lck::launch_reduce_partials(llpart_.p, (int)grid, K, red_.p + 1, stream_));
+    redtmp_.reserve((size_t)lck::REDUCE_TMP_ELEMS * 64);
+    LC_HIP(lck::launch_reduce_partials(fzpart_.p, (int)grid, 1, red_.p, stream_, redtmp_.p));
+    if (LLk) LC_HIP(lck::launch_reduce_partials(llpart_.p, (int)grid, K, red_.p + 1, stream_, redtmp_.p));
     else LC_HIP(hipMemsetAsync(red_.p + 1, 0, (size_t)K * sizeof(double), stream_));
   } else {
     LC_HIP(hipMemsetAsync(red_.p, 0, (size_t)(1 + K) * sizeof(double), stream_));
@@ -645,8 +646,9 @@ void Context::estep_diag(int K, const double* av, const double* w2, const double
     return;
   }
   if (grid > 0) {
-    LC_HIP(lck::launch_reduce_partials(fzpart_.p, (int)grid, 1, red_.p, stream_));
-    if (LLk) LC_HIP(lck::launch_reduce_partials(llpart_.p, (int)grid, K, red_.p + 1, stream_));
+    redtmp_.reserve((size_t)lck::REDUCE_TMP_ELEMS * 64);
+    LC_HIP(lck::launch_reduce_partials(fzpart_.p, (int)grid, 1, red_.p, stream_, redtmp_.p));
+    if (LLk) LC_HIP(lck::launch_reduce_partials(llpart_.p, (int)grid, K, red_.p + 1, stream_, redtmp_.p));
     else LC_HIP(hipMemsetAsync(red_.p + 1, 0, (size_t)K * sizeof(double), stream_));
   } else {
     LC_HIP(hipMemsetAsync(red_.p, 0, (size_t)(1 + K) * sizeof(double), stream_));

@@ -61,7 +61,10 @@ int suffstat_plan(int DP, int64_t NP, int K, int64_t* chunk_rows);
 hipError_t launch_suffstat(const SuffstatLaunch& a, hipStream_t stream);
 
 // out[e] = sum_c partial[c*n + e]  (fixed order => deterministic)
-hipError_t launch_reduce_partials(const double* partial, int nparts, int64_t n, double* out, hipStream_t stream);
+// tmp (optional): REDUCE_TMP_ELEMS * 64 doubles of scratch, enables the two-stage path for very many records
+constexpr int REDUCE_TMP_ELEMS = 512;
+hipError_t launch_reduce_partials(const double* partial, int nparts, int64_t n, double* out, hipStream_t stream,
+                                  double* tmp = nullptr);
 // out[j*K+k] = sum over rows of group j of qZ[k*ldq + row]; goff = padded row offsets [J+1]
 hipError_t launch_group_colsum(const double* qZ, int64_t ldq, int K, const int64_t* goff, int J, double* out,
                                hipStream_t stream);

@@ -1187,13 +1187,43 @@ __global__ void __launch_bounds__(256) reduce_cols_kernel(const double* partial,
   if (threadIdx.x == 0) out[e] = sh[0];
 }
 
-hipError_t launch_reduce_partials(const double* partial, int nparts, int64_t n, double* out, hipStream_t stream) {
+// very many records of a few elements (the per-block F_z / LL_k partials of an E-step over 10^7 rows): 64 blocks
+// per element sum contiguous record ranges into tmp[e][64] (each with the fixed-shape tree above), a second
+// launch folds the 64.  Same summation order for a given (nparts, n) => deterministic.
+__global__ void __launch_bounds__(256) reduce_cols_stage1_kernel(const double* partial, int nparts, int64_t n,
+                                                                 double* tmp) {
+  __shared__ double sh[256];
+  const int64_t e = blockIdx.y;
+  const int per = (nparts + 63) / 64, c0 = blockIdx.x * per;
+  const int c1 = c0 + per < nparts ? c0 + per : nparts;
+  double s = 0.0;
+  for (int c = c0 + threadIdx.x; c < c1; c += 256) s += partial[(int64_t)c * n + e];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) tmp[e * 64 + blockIdx.x] = sh[0];
+}
+__global__ void __launch_bounds__(64) reduce_cols_stage2_kernel(const double* tmp, double* out) {
+  double v = tmp[(int64_t)blockIdx.x * 64 + threadIdx.x];
+  v = wave_sum(v);
+  if (threadIdx.x == 0) out[blockIdx.x] = v;
+}
+
+hipError_t launch_reduce_partials(const double* partial, int nparts, int64_t n, double* out, hipStream_t stream,
+                                  double* tmp) {
   if (n <= 0) return hipSuccess;
-  if (nparts > 512 && n <= 4096)
+  if (tmp && nparts > 8192 && n <= REDUCE_TMP_ELEMS) {
+    hipLaunchKernelGGL(reduce_cols_stage1_kernel, dim3(64, (unsigned)n), dim3(256), 0, stream, partial, nparts, n, tmp);
+    hipLaunchKernelGGL(reduce_cols_stage2_kernel, dim3((unsigned)n), dim3(64), 0, stream, tmp, out);
+  } else if (nparts > 512 && n <= 4096) {
     hipLaunchKernelGGL(reduce_cols_kernel, dim3((unsigned)n), dim3(256), 0, stream, partial, nparts, n, out);
-  else
+  } else {
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, stream, partial,
                        nparts, n, out);
+  }
   return hipGetLastError();
 }
 

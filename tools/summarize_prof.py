@@ -24,7 +24,10 @@ if log.exists():
 
 
 def short(n):
-    return "estep_kernel" if "estep_kernel" in n else "suffstat_kernel" if "suffstat_kernel" in n else None
+    for k in ("estep_diag_kernel", "suffstat_diag_kernel", "estep_kernel", "suffstat_kernel"):
+        if k in n:
+            return k
+    return None
 
 
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
