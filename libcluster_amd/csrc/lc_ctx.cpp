@@ -338,21 +338,30 @@ void Context::qz_init_split(const double* m, const double* v) {
 void Context::qz_init_split_mean(const double* v) {
   ensure_qz(qz_[cur_], 2, false);
   qz_[cur_].K = 2;
-  if (NP_ == 0) return;
+  // rows of one group may be spread over ranks (row sharding): the group means are global quantities, so every
+  // rank takes part in the exchange, also one that holds no selected row
+  const bool global_mean = distributed() && !group_sharded_;
   std::vector<double> mv((size_t)2 * DP_, 0.0);
   std::copy(v, v + D_, mv.begin() + DP_);
-  mv_.reserve(mv.size() + (size_t)J_);
-  LC_HIP(hipMemcpyAsync(mv_.p, mv.data(), mv.size() * sizeof(double), hipMemcpyHostToDevice, stream_));
+  std::vector<double> sc((size_t)J_ * 2, 0.0);  // [sum of projections | row count] per group
   const int* rgi = J_ > 1 ? rginfo_.p : nullptr;
-  // pass 1: the projections x.v land in column 0; their per-group sums give the means
-  LC_HIP(lck::launch_split_init(X_.p, DP_, D_, NP_, rgi, Nj_[0], mv_.p, qz_[cur_].buf.p, NP_, 1, nullptr, stream_));
-  std::vector<double> sums((size_t)J_ * 2);
-  red_.reserve((size_t)J_ * 2);
-  LC_HIP(lck::launch_group_colsum(qz_[cur_].buf.p, NP_, 2, goff_d_.p, J_, red_.p, stream_));
-  LC_HIP(hipMemcpyAsync(sums.data(), red_.p, sums.size() * sizeof(double), hipMemcpyDeviceToHost, stream_));
-  LC_HIP(hipStreamSynchronize(stream_));
+  if (NP_ > 0) {
+    mv_.reserve(mv.size() + (size_t)J_);
+    LC_HIP(hipMemcpyAsync(mv_.p, mv.data(), mv.size() * sizeof(double), hipMemcpyHostToDevice, stream_));
+    // pass 1: the projections x.v land in column 0; their per-group sums give the means
+    LC_HIP(lck::launch_split_init(X_.p, DP_, D_, NP_, rgi, Nj_[0], mv_.p, qz_[cur_].buf.p, NP_, 1, nullptr, stream_));
+    std::vector<double> sums((size_t)J_ * 2);
+    red_.reserve((size_t)J_ * 2);
+    LC_HIP(lck::launch_group_colsum(qz_[cur_].buf.p, NP_, 2, goff_d_.p, J_, red_.p, stream_));
+    LC_HIP(hipMemcpyAsync(sums.data(), red_.p, sums.size() * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    LC_HIP(hipStreamSynchronize(stream_));
+    for (int j = 0; j < J_; ++j) sc[(size_t)j] = sums[(size_t)j * 2];
+  }
+  for (int j = 0; j < J_; ++j) sc[(size_t)J_ + j] = (double)Nj_[j];
+  if (global_mean) allreduce_values(sc.data(), 2 * J_);
+  if (NP_ == 0) return;
   std::vector<double> thr((size_t)J_);
-  for (int j = 0; j < J_; ++j) thr[(size_t)j] = Nj_[j] > 0 ? sums[(size_t)j * 2] / (double)Nj_[j] : 0.0;  // XdotL.sum()/size
+  for (int j = 0; j < J_; ++j) thr[(size_t)j] = sc[(size_t)J_ + j] > 0 ? sc[(size_t)j] / sc[(size_t)J_ + j] : 0.0;  // XdotL.sum()/size
   double* thr_d = mv_.p + mv.size();
   LC_HIP(hipMemcpyAsync(thr_d, thr.data(), thr.size() * sizeof(double), hipMemcpyHostToDevice, stream_));
   LC_HIP(lck::launch_split_init(X_.p, DP_, D_, NP_, rgi, Nj_[0], mv_.p, qz_[cur_].buf.p, NP_, 2, thr_d, stream_));

@@ -23,22 +23,24 @@ def _run(cmd, env=None):
     return json.loads(line[len("RESULT "):])
 
 
-@pytest.mark.parametrize("mode", ["rows", "groups"])
-def test_two_rank_cluster_equals_single_rank(lib, mode):
+@pytest.mark.parametrize("mode,family", [("rows", "GaussWish"), ("groups", "GaussWish"), ("rows", "NormGamma"),
+                                         ("groups", "ExpGamma"), ("rows", "ExpGamma")])
+def test_two_rank_cluster_equals_single_rank(lib, mode, family):
     """cluster() (VBEM + prune + split search) sharded over two ranks -- by row blocks (BGMM) or by whole
     groups (GMC: per-group counts and weights stay local) -- with all-reduced statistics, Fz, LL_k and
-    decision counts takes the same decisions and reaches the same F as one rank."""
+    decision counts takes the same decisions and reaches the same F as one rank.  Also for the diagonal and the
+    exponential family (whose split threshold is a global per-group mean in row-sharded runs)."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     script = str(ROOT / "tools" / "dist_cluster_check.py")
-    args = ["30000", "6", "5", mode]
+    args = ["30000", "6", "5", mode, family]
     one = _run([sys.executable, script, *args])
     two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                 "--master-addr", "127.0.0.1", "--master-port", str(port), script, *args],
                {"LC_DIST_BACKEND": "gloo", "LC_ALL_RANKS_ON_GPU0": "1"})
     assert two["world"] == 2 and one["world"] == 1
-    assert one["K"] == two["K"] and one["K"] >= 5
+    assert one["K"] == two["K"] and one["K"] >= (5 if family != "ExpGamma" else 2)
     assert [k for k, _ in one["rounds"]] == [k for k, _ in two["rounds"]]
     for (_, a), (_, b) in zip(one["rounds"], two["rounds"]):
         np.testing.assert_allclose(a, b, rtol=1e-10)

@@ -23,6 +23,8 @@ from libcluster_amd import dist as lcd  # noqa: E402
 
 N, D, Kt = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 MODE = sys.argv[4] if len(sys.argv) > 4 else "rows"  # "rows": BGMM, row blocks; "groups": GMC, whole groups per rank
+FAMILY = sys.argv[5] if len(sys.argv) > 5 else "GaussWish"  # cluster family: GaussWish | NormGamma | ExpGamma
+CK = {"GaussWish": capi.C_GAUSSWISH, "NormGamma": capi.C_NORMGAMMA, "ExpGamma": capi.C_EXPGAMMA}[FAMILY]
 rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 dev = 0 if os.environ.get("LC_ALL_RANKS_ON_GPU0") else int(os.environ.get("LOCAL_RANK", "0"))
 torch.cuda.set_device(dev)
@@ -37,6 +39,12 @@ if world > 1:
 rng = np.random.default_rng(3)
 mu = rng.normal(0, 5.0, (Kt, D))
 L = np.stack([np.linalg.cholesky((lambda B: B @ B.T / D + 0.5 * np.eye(D))(rng.normal(size=(D, D)))) for _ in range(Kt)])
+if FAMILY != "GaussWish":  # axis-aligned components; the exponential family needs x >= 0
+    L = np.stack([np.diag(rng.uniform(0.5, 1.5, D)) for _ in range(Kt)])
+    if FAMILY == "ExpGamma":  # components that differ in magnitude (what an exponential mixture can tell apart)
+        scale = 9.0 ** np.arange(Kt)
+        mu = scale[:, None] * rng.uniform(0.8, 1.2, (Kt, D))
+        L = np.stack([np.diag(0.1 * scale[k] * rng.uniform(0.5, 1.5, D)) for k in range(Kt)])
 with capi.Context(dev, torch.cuda.current_stream().cuda_stream) as ctx:
     if MODE == "rows":
         lo, hi = lcd.shard_rows(N, world, rank)
@@ -52,7 +60,7 @@ with capi.Context(dev, torch.cuda.current_stream().cuda_stream) as ctx:
         wkind = capi.W_GDIRICHLET
     if world > 1:
         ctx.set_allreduce(lcd.make_device_hook(dev))
-    F, model = ctx.cluster(wkind, nthreads=4)
+    F, model = ctx.cluster(wkind, nthreads=4, ckind=CK)
     out = {"world": world, "F": F, "K": model.dims()[1], "rounds": model.rounds(),
            "N": [model.cluster(k)["N"] for k in range(model.dims()[1])]}
     model.close()
