@@ -27,6 +27,23 @@ void DevBuf<T>::reserve(size_t n) {
   p = static_cast<T*>(q);
   cap = n;
 }
+void PinnedBuf::resize(size_t count) {
+  if (count > cap) {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    void* q = nullptr;
+    const size_t want = count < 1024 ? 1024 : count + count / 2;
+    hipError_t e = hipHostMalloc(&q, want * sizeof(double), hipHostMallocDefault);
+    if (e != hipSuccess)
+      throw HipFailure(std::string("HIP error: hipHostMalloc of ") + std::to_string(want * sizeof(double)) +
+                       " bytes failed: " + hipGetErrorString(e));
+    p = static_cast<double*>(q);
+    cap = want;
+  }
+  n = count;
+}
+
 template struct DevBuf<double>;
 template struct DevBuf<int>;
 template struct DevBuf<int64_t>;

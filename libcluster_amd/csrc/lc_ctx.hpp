@@ -36,6 +36,31 @@ struct DevBuf {
   void reserve(size_t n);
 };
 
+// page-locked host staging buffer (grow-only): asynchronous copies to / from it do not bounce through the
+// driver's own pinned pool, which is what a pageable std::vector costs on every small per-iteration transfer
+struct PinnedBuf {
+  double* p = nullptr;
+  size_t cap = 0, n = 0;
+  ~PinnedBuf() {
+    if (p) (void)hipHostFree(p);
+  }
+  PinnedBuf() = default;
+  PinnedBuf(const PinnedBuf&) = delete;
+  PinnedBuf& operator=(const PinnedBuf&) = delete;
+  void resize(size_t count);  // contents NOT preserved when it grows
+  void assign(size_t count, double v) {
+    resize(count);
+    for (size_t i = 0; i < count; ++i) p[i] = v;
+  }
+  double* data() { return p; }
+  const double* data() const { return p; }
+  size_t size() const { return n; }
+  double& operator[](size_t i) { return p[i]; }
+  const double& operator[](size_t i) const { return p[i]; }
+  double* begin() { return p; }
+  double* end() { return p + n; }
+};
+
 // an ordered set of (padded, global) row indices of one context, kept on the device
 struct RowSelection {
   DevBuf<int64_t> idx;          // [M] ascending
@@ -175,7 +200,7 @@ class Context {
   DevBuf<int> selcnt_;
   DevBuf<int64_t> seloff_;
   DevBuf<double> mv_;
-  std::vector<double> hpack_, hred_, hss_;
+  PinnedBuf hpack_, hred_, hss_;
 
   bool timing_ = false;
   struct EvPair {
