@@ -340,10 +340,16 @@ static bool split_gr(lcc::Context& ctx, Model& model, std::vector<int>& tally, d
   std::vector<double> njs;
   std::vector<double> eigv;
 
+  static const bool trace_phases = std::getenv("LC_TRACE_PHASES") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto msec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+    return std::chrono::duration<double, std::milli>(b - a).count();
+  };
   for (const GreedOrder& o : ord) {
     const int k = o.k;
     ++tally[k];
     if (model.clusters[k].N() < 4) continue;  // :432
+    const auto t0 = now();
 
     // partobs + splitobs per group (:438-453), on the device: ordered compaction of the rows with
     // q_k > 0.5, device-to-device gather into a fresh context, projection on the principal axis
@@ -369,6 +375,7 @@ static bool split_gr(lcc::Context& ctx, Model& model, std::vector<int>& tally, d
         sub.qz_init_split_mean(eigv.data());
       }
     }
+    const auto t1 = now();
     njs.assign((size_t)J * 2, 0.0);
     sub.colsums(njs.data());
     double sc = 0.0;
@@ -390,11 +397,13 @@ static bool split_gr(lcc::Context& ctx, Model& model, std::vector<int>& tally, d
       vbem(sub, ms, vo);
       if (anyempty(ms.clusters)) continue;  // :464
     }
+    const auto t2 = now();
 
     // auglabels (:468-470, comutils.cpp:75-104) on a copy of qZ
     ctx.qz_clone_to_alt();
     ctx.qz_swap_alt();
     ctx.qz_split_from(sub, sel, k);
+    const auto t3 = now();
 
     // free energy of the split with all data (:473)
     VbemOptions vo;
@@ -414,6 +423,10 @@ static bool split_gr(lcc::Context& ctx, Model& model, std::vector<int>& tally, d
       continue;
     }
     if (opt.verbose) std::cout << '=' << std::flush;
+    if (trace_phases)
+      std::cerr << "[split k=" << k << " M=" << sel.M << "] select+gather+init " << msec(t0, t1) << " ms, refine "
+                << msec(t1, t2) << " ms, clone+auglabels " << msec(t2, t3) << " ms, full-data iteration " << msec(t3, now())
+                << " ms" << std::endl;
     if ((Fsplit < F) && (std::abs((F - Fsplit) / F) > lch::CONVERGE)) {  // :484-489
       tally[k] = 0;
       return true;  // the augmented qZ is now the current one
@@ -445,10 +458,18 @@ double cluster(lcc::Context& ctx, Model& model, const ClusterOptions& opt) {
     if (opt.trace) opt.trace->emplace_back((int)model.clusters.size(), tr);
     int nkeep = 0;
     for (const auto& cl : model.clusters) nkeep += !(cl.N() < lch::ZEROCUTOFF);
+    static const bool trace_phases = std::getenv("LC_TRACE_PHASES") != nullptr;
+    const auto c0 = std::chrono::steady_clock::now();
     if (!(nkeep >= opt.maxclusters && opt.maxclusters >= 0)) data_loglik(ctx, model);  // split_gr will need it
     prune_clusters(ctx, model, opt.verbose);
+    const auto c1 = std::chrono::steady_clock::now();
     if (opt.verbose) std::cout << '<' << std::flush;
     issplit = split_gr(ctx, model, tally, F, opt);
+    if (trace_phases)
+      std::cerr << "[cluster K=" << model.clusters.size() << "] data_loglik+prune "
+                << std::chrono::duration<double, std::milli>(c1 - c0).count() << " ms, split search "
+                << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c1).count() << " ms"
+                << std::endl;
     if (opt.verbose) std::cout << '>' << std::endl;
   }
   if (opt.verbose) {
