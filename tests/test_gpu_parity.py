@@ -292,3 +292,43 @@ def test_random_shapes_sweep():
         np.testing.assert_allclose(Ng, [c.getN() for c in clT], rtol=1e-10, atol=1e-12, err_msg=msg)
         for j in range(J):
             assert_q_close(q[j], qT[j], rtol=1e-8)
+
+
+def test_many_clusters_and_many_small_groups():
+    """K well above the register-resident paths (K = 150: cluster slices, re-read normalisation) and J = 1500 tiny
+    ragged groups (block-per-group column sums, per-group constant tables), all three cluster families."""
+    rng = np.random.default_rng(77)
+    # (a) many clusters
+    N, D, K = 3000, 6, 150
+    X = [rng.normal(size=(N, D)) * 2 + rng.integers(0, 12, (N, 1))]
+    q0 = [rng.dirichlet(np.ones(K) * 0.2, N)]
+    for cf, ck in ((o.GaussWish, capi.C_GAUSSWISH), (o.NormGamma, capi.C_NORMGAMMA), (o.ExpGamma, capi.C_EXPGAMMA)):
+        Xs = [np.abs(X[0]) + 0.05] if cf is o.ExpGamma else X
+        tro, _, qo, _, clo = o.vbem_fixed(Xs, q0, o.StickBreak, 1.0, 2, False, cf)
+        with capi.Context(0) as ctx:
+            ctx.set_data(Xs)
+            ctx.set_qz(q0)
+            F, tr, model = ctx.vbem(capi.W_STICKBREAK, fixed_iters=2, ckind=ck, nthreads=4)
+            q = ctx.get_qz([N])
+            model.close()
+        np.testing.assert_allclose(tr, tro, rtol=1e-9, err_msg=cf.__name__)
+        assert_q_close(q[0], qo[0], rtol=1e-7)
+    # (b) many small groups
+    J, K = 1500, 5
+    sizes = rng.integers(1, 40, J)
+    sizes[7] = 0
+    Xg = [rng.normal(size=(int(n), 3)) + rng.integers(0, K, (int(n), 1)) * 3.0 for n in sizes]
+    qg = [rng.dirichlet(np.ones(K) * 0.5, int(n)) for n in sizes]
+    for cf, ck in ((o.GaussWish, capi.C_GAUSSWISH), (o.NormGamma, capi.C_NORMGAMMA)):
+        tro, _, qo, wo, _ = o.vbem_fixed(Xg, qg, o.GDirichlet, 1.0, 2, False, cf)
+        with capi.Context(0) as ctx:
+            ctx.set_data(Xg)
+            ctx.set_qz(qg)
+            F, tr, model = ctx.vbem(capi.W_GDIRICHLET, fixed_iters=2, ckind=ck)
+            q = ctx.get_qz([int(n) for n in sizes])
+            el = np.stack([model.weights(j)[0] for j in (0, 7, 733, J - 1)])
+            model.close()
+        np.testing.assert_allclose(tr, tro, rtol=1e-9, err_msg=cf.__name__)
+        np.testing.assert_allclose(el, np.stack([wo[j].Elogweight() for j in (0, 7, 733, J - 1)]), rtol=1e-9)
+        for j in range(0, J, 97):
+            assert_q_close(q[j], qo[j], rtol=1e-7)
