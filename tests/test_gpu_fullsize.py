@@ -91,3 +91,73 @@ def test_full_size_properties(N, D, K, seed):
     np.testing.assert_allclose(tot_stats[1], xs, rtol=1e-9, atol=1e-6)
     np.testing.assert_allclose(tot_stats[2], xxs, rtol=1e-9, atol=1e-5)
     assert abs(tot_Fz - Fz) <= 1e-11 * abs(Fz)
+
+
+@pytest.mark.parametrize("family", ["NormGamma", "ExpGamma"])
+def test_full_size_properties_diagonal_families(family):
+    """The same size-independent properties for the separable families at N = 10M, D = 64, K = 32 (bench --config
+    dgmm / bemm): unit row sums, prefix rows bit-identical to a stand-alone run and equal to the oracle, shard
+    additivity of the MFMA statistics and of F_z, non-increasing F."""
+    N, D, K, seed = 10_000_000, 64, 32, 1006
+    eg = family == "ExpGamma"
+    rng = np.random.default_rng(seed)
+    mu = rng.uniform(20.0, 60.0, (K, D)) if eg else rng.normal(0.0, 3.0, (K, D))
+    L = np.stack([np.diag(rng.uniform(0.5, 1.5, D)) for _ in range(K)])
+    ck = capi.C_EXPGAMMA if eg else capi.C_NORMGAMMA
+    P = 4096
+    with capi.Context(0) as ctx:
+        ctx.synth(N, D, K, mu, L, seed, 0, 0.9)
+        Xp = ctx.get_rows(0, 0, P)
+        Nk, xs, xxs, Njk = ctx.suffstat_diag(second=not eg)
+        assert abs(Nk.sum() - N) <= 1e-9 * N
+        if not eg:
+            assert np.all(xxs > 0)
+        if eg:
+            post = [capi.eg_mstep(1.0, Nk[k], xs[k]) for k in range(K)]
+            a, w2 = np.zeros((K, D)), np.zeros((K, D))
+            w1 = np.stack([-p["a"] * p["ib"] for p in post])
+        else:
+            post = [capi.ng_mstep(1.0, Nk[k], xs[k], xxs[k]) for k in range(K)]
+            a = np.stack([p["m"] for p in post])
+            w2 = np.stack([-0.5 * p["nu"] / p["L"] for p in post])
+            w1 = np.zeros((K, D))
+        elog, _ = capi.weights_update(capi.W_DIRICHLET, Nk)
+        c = (elog + np.array([p["eloglike_const"] for p in post]))[None, :]
+        Fz, _ = ctx.estep_diag(a, w2, w1, c)
+        qp = ctx.get_qz_rows(0, 0, P)
+        qmid = ctx.get_qz_rows(0, N // 2 - 7, 1001)
+        colsum = ctx.colsums()[0]
+        F, tr, m = ctx.vbem(capi.W_DIRICHLET, fixed_iters=3, nthreads=8, ckind=ck)
+        m.close()
+    assert abs(colsum.sum() - N) <= 1e-9 * N
+    np.testing.assert_allclose(qp.sum(axis=1), 1.0, rtol=1e-12)
+    np.testing.assert_allclose(qmid.sum(axis=1), 1.0, rtol=1e-12)
+    assert np.all(np.diff(tr) <= 1e-9 * abs(tr[0]))
+
+    with capi.Context(0) as c2:
+        c2.set_data(Xp)
+        Fzp, _ = c2.estep_diag(a, w2, w1, c)
+        qp2 = c2.get_qz([P])[0]
+    np.testing.assert_array_equal(qp, qp2)
+    logq = c + np.einsum("kd,nkd->nk", w2, (Xp[:, None, :] - a[None]) ** 2) + Xp @ w1.T
+    logZ = o.logsumexp(logq)
+    qref = np.exp(logq - logZ[:, None])
+    big = qref > 1e-12
+    assert np.max(np.abs(qp[big] - qref[big]) / qref[big]) < 1e-9
+    assert abs(Fzp + logZ.sum()) <= 1e-10 * abs(logZ.sum())
+
+    half = N // 2
+    tot, tot_Fz = None, 0.0
+    for r in range(2):
+        with capi.Context(0) as cs:
+            cs.synth(half, D, K, mu, L, seed, r * half, 0.9)
+            st = cs.suffstat_diag(second=not eg)
+            fz, _ = cs.estep_diag(a, w2, w1, c)
+        tot_Fz += fz
+        st = [x for x in st if x is not None]
+        tot = st if tot is None else [p + q for p, q in zip(tot, st)]
+    np.testing.assert_allclose(tot[0], Nk, rtol=1e-12)
+    np.testing.assert_allclose(tot[1], xs, rtol=1e-9, atol=1e-6)
+    if not eg:
+        np.testing.assert_allclose(tot[2], xxs, rtol=1e-9, atol=1e-5)
+    assert abs(tot_Fz - Fz) <= 1e-11 * abs(Fz)
