@@ -3,7 +3,7 @@ oracle (oracle/lc_oracle.py) and cross-check them against scikit-learn.
 
 Run in the build container:   python tests/golden/make_golden.py
 Outputs (committed): tests/golden/estep_cases.json, tests/golden/xcat_traces.json,
-tests/golden/family_traces.json, tests/golden/topic_traces.json
+tests/golden/family_traces.json, tests/golden/topic_traces.json, tests/golden/scott25_traces.json
 
 The reference itself cannot be built or imported here (no Eigen/Boost), so
 these vectors are restatement-derived ("parity unpinned", see oracle header);
@@ -225,7 +225,37 @@ def main():
         }
         print(name, "F =", F, "T =", len(wt), "K =", len(cl))
     (HERE / "topic_traces.json").write_text(json.dumps(top))
-    for f in ("estep_cases.json", "xcat_traces.json", "family_traces.json", "topic_traces.json"):
+
+    # scott25.dat: the 9815 x 23 data file the reference keeps next to its tests (test/scott25.dat; committed
+    # here as a data fixture).  Flat learners on all rows, grouped learners on five consecutive blocks, the
+    # two-level learner on 2 groups x 5 documents of ~980 rows.
+    S = np.loadtxt(HERE / "scott25.dat", skiprows=2)
+    cuts = [0, 1500, 3800, 5200, 7900, S.shape[0]]
+    Sg = [S[cuts[i]:cuts[i + 1]] for i in range(5)]
+    sc = {}
+    for name, fn, arg in (("learnBGMM", o.learnBGMM, S), ("learnVDP", o.learnVDP, S), ("learnDGMM", o.learnDGMM, S),
+                          ("learnBEMM", o.learnBEMM, S), ("learnGMC", o.learnGMC, Sg), ("learnDGMC", o.learnDGMC, Sg)):
+        tr = []
+        F, qZ, w, cl = fn(arg, trace=tr)
+        wl = w if isinstance(w, list) else [w]
+        sc[name] = {"F": F, "K": len(cl), "rounds": [[k, t] for k, t in tr], "N": [c.getN() for c in cl],
+                    "Elogweight": [x.Elogweight().tolist() for x in wl]}
+        if hasattr(cl[0], "getrate"):
+            sc[name]["rates"] = [c.getrate().tolist() for c in cl]
+        else:
+            sc[name]["means"] = [c.getmean().tolist() for c in cl]
+        print("scott25", name, "F =", F, "K =", len(cl))
+    docs = np.array_split(S, 10)
+    Xd = [docs[:5], docs[5:]]
+    qY0 = [o.random_qY(5, 4, rng) for _ in range(2)]
+    tr = []
+    F, qY, qZ, wj, wt, cl = o.learnSCM(Xd, maxT=4, qY0=qY0, trace=tr)
+    sc["learnSCM"] = {"qY0": [q.tolist() for q in qY0], "F": F, "T": len(wt), "K": len(cl),
+                      "rounds": [[t, k, f] for t, k, f in tr], "qY": [q.tolist() for q in qY],
+                      "means": [c.getmean().tolist() for c in cl]}
+    print("scott25 learnSCM F =", F, "T =", len(wt), "K =", len(cl))
+    (HERE / "scott25_traces.json").write_text(json.dumps(sc))
+    for f in ("estep_cases.json", "xcat_traces.json", "family_traces.json", "topic_traces.json", "scott25_traces.json"):
         print(f, (HERE / f).stat().st_size // 1024, "KiB")
 
 
