@@ -153,11 +153,11 @@ def _check(res, ref):
         np.testing.assert_allclose(tr, rtr, rtol=1e-8)
     np.testing.assert_allclose(info["N"], ref["N"], rtol=1e-7)
     if "rates" in ref:
-        np.testing.assert_allclose(np.array(means), np.array(ref["rates"]), rtol=1e-7)
+        np.testing.assert_allclose(np.vstack(means), np.array(ref["rates"]), rtol=1e-7)
         assert all(c is None for c in covs)
     else:
-        np.testing.assert_allclose(np.array(means), np.array(ref["means"]), rtol=1e-7, atol=1e-9)
-        np.testing.assert_allclose(np.array(covs), np.array(ref["covs"]), rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(np.vstack(means), np.array(ref["means"]), rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(np.vstack(covs), np.array(ref["covs"]), rtol=1e-7, atol=1e-9)
     qs = qZ if isinstance(qZ, list) else [qZ]
     for a, b in zip(qs, ref["qZ"]):
         assert_q_close(a, np.array(b), rtol=1e-6)
@@ -167,19 +167,19 @@ def _check(res, ref):
 def test_learnDGMM_and_DGMC_on_reference_test_data(xcat, fam):
     import libcluster_amd as lc
 
-    _check(lc.learnDGMM(xcat["Xcat"]), fam["learnDGMM"])
-    _check(lc.learnDGMC(xcat["X"]), fam["learnDGMC"])
+    _check(lc.learnDGMM(xcat["Xcat"], return_info=True), fam["learnDGMM"])
+    _check(lc.learnDGMC(xcat["X"], return_info=True), fam["learnDGMC"])
 
 
 def test_learnBEMM_and_EGMC(xcat, fam):
     import libcluster_amd as lc
 
     Xpos = [np.abs(g) + 0.1 for g in xcat["X"]]
-    _check(lc.learnBEMM(np.vstack(Xpos)), fam["learnBEMM"])
-    _check(lc.learnEGMC(Xpos), fam["learnEGMC"])
+    _check(lc.learnBEMM(np.vstack(Xpos), return_info=True), fam["learnBEMM"])
+    _check(lc.learnEGMC(Xpos, return_info=True), fam["learnEGMC"])
     Xexp = np.array(fam["Xexp"])
-    _check(lc.learnBEMM(Xexp), fam["learnBEMM_exp"])
-    _check(lc.learnEGMC([Xexp[:130], Xexp[130:250], Xexp[250:]]), fam["learnEGMC_exp"])
+    _check(lc.learnBEMM(Xexp, return_info=True), fam["learnBEMM_exp"])
+    _check(lc.learnEGMC([Xexp[:130], Xexp[130:250], Xexp[250:]], return_info=True), fam["learnEGMC_exp"])
 
 
 def test_exponential_learners_reject_negative_observations(xcat):

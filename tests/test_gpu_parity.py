@@ -166,8 +166,9 @@ def _check_learn(res, ref, rows):
     for (k, tr), (_, rtr) in zip(info["rounds"], ref["rounds"]):
         np.testing.assert_allclose(tr, rtr, rtol=1e-8)
     np.testing.assert_allclose(info["N"], ref["N"], rtol=1e-7)
-    np.testing.assert_allclose(np.array(means), np.array(ref["means"]), rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(np.vstack(means), np.array(ref["means"]), rtol=1e-7, atol=1e-9)
     np.testing.assert_allclose(np.array(covs), np.array(ref["covs"]), rtol=1e-7, atol=1e-9)
+    assert means[0].shape == (1, len(ref["means"][0])) and np.asarray(w[0] if isinstance(w, list) else w).shape[1] == 1
     qs = qZ if isinstance(qZ, list) else [qZ]
     for a, b in zip(qs, ref["qZ"]):
         assert_q_close(a, np.array(b), rtol=1e-6)
@@ -179,16 +180,16 @@ def test_learnBGMM_on_reference_test_data(xcat, xcat_traces):
     """BASELINE config 1: learnBGMM on test/testdata.h Xcat."""
     import libcluster_amd as lc
 
-    _check_learn(lc.learnBGMM(xcat["Xcat"]), xcat_traces["learnBGMM"], [120])
-    F, *_, info = lc.learnBGMM(xcat["Xcat"], maxclusters=1)
+    _check_learn(lc.learnBGMM(xcat["Xcat"], return_info=True), xcat_traces["learnBGMM"], [120])
+    F, *_, info = lc.learnBGMM(xcat["Xcat"], maxclusters=1, return_info=True)
     assert info["K"] == 1 and abs(F - xcat_traces["learnBGMM_max1"]["F"]) < 1e-8
 
 
 def test_learnVDP_on_reference_test_data(xcat, xcat_traces):
     import libcluster_amd as lc
 
-    _check_learn(lc.learnVDP(xcat["Xcat"]), xcat_traces["learnVDP"], [120])
-    F, *_, info = lc.learnVDP(xcat["Xcat"], concentration=2.5)
+    _check_learn(lc.learnVDP(xcat["Xcat"], return_info=True), xcat_traces["learnVDP"], [120])
+    F, *_, info = lc.learnVDP(xcat["Xcat"], concentration=2.5, return_info=True)
     assert info["K"] == xcat_traces["learnVDP_conc2.5"]["K"]
     assert abs(F - xcat_traces["learnVDP_conc2.5"]["F"]) < 1e-7
 
@@ -197,7 +198,7 @@ def test_learnGMC_on_reference_test_data(xcat, xcat_traces):
     """The reference's own test main: test/cluster_test.cpp:38-69."""
     import libcluster_amd as lc
 
-    _check_learn(lc.learnGMC(xcat["X"]), xcat_traces["learnGMC"], [10] * 12)
+    _check_learn(lc.learnGMC(xcat["X"], return_info=True), xcat_traces["learnGMC"], [10] * 12)
     ref = xcat_traces["learnGMC_sparse"]
     if ref["throws"]:
         with pytest.raises(RuntimeError, match="Free energy increase"):
@@ -237,7 +238,7 @@ def test_learnSGMC_on_reference_test_data(xcat, xcat_traces):
     """learnSGMC (include/libcluster.h:409-419): Dirichlet weights per group, same kernels."""
     import libcluster_amd as lc
 
-    _check_learn(lc.learnSGMC(xcat["X"]), xcat_traces["learnSGMC"], [10] * 12)
+    _check_learn(lc.learnSGMC(xcat["X"], return_info=True), xcat_traces["learnSGMC"], [10] * 12)
 
 
 def test_cluster_on_device_resident_data_matches_oracle():

@@ -39,16 +39,16 @@ def test_learnSCM_on_reference_test_setup(xcat, top):
 
     ref = top["learnSCM"]
     X = xcat["X"]
-    F, qY, qZ, wj, wt, means, covs, info = lc.learnSCM([X[:6], X[6:]], trunc=ref["maxT"], qY0=ref["qY0"])
+    F, qY, qZ, wj, wt, means, covs, info = lc.learnSCM([X[:6], X[6:]], trunc=ref["maxT"], qY0=ref["qY0"], return_info=True)
     assert (info["T"], info["K"]) == (ref["T"], ref["K"])
     assert abs(F - ref["F"]) <= 1e-8 * abs(ref["F"])
     _check_rounds(info["rounds"], ref["rounds"])
     _check_q(qY, qZ, ref["qY"], ref["qZ"])
-    np.testing.assert_allclose(np.array(means), np.array(ref["means_k"]), rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(np.vstack(means), np.array(ref["means_k"]), rtol=1e-7, atol=1e-9)
     np.testing.assert_allclose(np.array(covs), np.array(ref["covs_k"]), rtol=1e-7, atol=1e-9)
     np.testing.assert_allclose(np.array(info["Elogweight_j"]), np.array(ref["Elogweight_j"]), rtol=1e-8)
     np.testing.assert_allclose(np.array(info["Elogweight_t"]), np.array(ref["Elogweight_t"]), rtol=1e-8)
-    np.testing.assert_allclose(np.array(wj), np.exp(np.array(ref["Elogweight_j"])), rtol=1e-8)
+    np.testing.assert_allclose(np.hstack(wj).T, np.exp(np.array(ref["Elogweight_j"])), rtol=1e-8)
 
 
 def test_learnMCM_on_reference_test_setup(xcat, top):
@@ -58,14 +58,14 @@ def test_learnMCM_on_reference_test_setup(xcat, top):
     ref = top["learnMCM"]
     X = xcat["X"]
     F, qY, qZ, wj, wt, mt, mk, ct, ck, info = lc.learnMCM(xcat["O"], [X[:6], X[6:]], trunc=ref["maxT"],
-                                                         qY0=ref["qY0"])
+                                                         qY0=ref["qY0"], return_info=True)
     assert (info["T"], info["K"]) == (ref["T"], ref["K"])
     assert abs(F - ref["F"]) <= 1e-8 * abs(ref["F"])
     _check_rounds(info["rounds"], ref["rounds"])
     _check_q(qY, qZ, ref["qY"], ref["qZ"])
-    np.testing.assert_allclose(np.array(mk), np.array(ref["means_k"]), rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(np.vstack(mk), np.array(ref["means_k"]), rtol=1e-7, atol=1e-9)
     np.testing.assert_allclose(np.array(ck), np.array(ref["covs_k"]), rtol=1e-7, atol=1e-9)
-    np.testing.assert_allclose(np.array(mt), np.array(ref["means_t"]), rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(np.vstack(mt), np.array(ref["means_t"]), rtol=1e-7, atol=1e-9)
     np.testing.assert_allclose(np.array(ct), np.array(ref["covs_t"]), rtol=1e-7, atol=1e-9)
     np.testing.assert_allclose(np.array(info["Elogweight_t"]), np.array(ref["Elogweight_t"]), rtol=1e-8)
 
@@ -101,16 +101,16 @@ def test_topic_models_match_oracle_on_synthetic_documents(mcm):
     tr = []
     if mcm:
         Fo, qYo, qZo, wjo, wto, cto, clo = o.learnMCM(W, X, maxT=maxT, qY0=qY0, trace=tr)
-        F, qY, qZ, wj, wt, mt, mk, ct, ck, info = lc.learnMCM(W, X, trunc=maxT, qY0=qY0, nthreads=2)
-        np.testing.assert_allclose(np.array(mt), np.array([c.getmean() for c in cto]), rtol=1e-7, atol=1e-9)
+        F, qY, qZ, wj, wt, mt, mk, ct, ck, info = lc.learnMCM(W, X, trunc=maxT, qY0=qY0, nthreads=2, return_info=True)
+        np.testing.assert_allclose(np.vstack(mt), np.array([c.getmean() for c in cto]), rtol=1e-7, atol=1e-9)
     else:
         Fo, qYo, qZo, wjo, wto, clo = o.learnSCM(X, maxT=maxT, qY0=qY0, trace=tr)
-        F, qY, qZ, wj, wt, mk, ck, info = lc.learnSCM(X, trunc=maxT, qY0=qY0, nthreads=2)
+        F, qY, qZ, wj, wt, mk, ck, info = lc.learnSCM(X, trunc=maxT, qY0=qY0, nthreads=2, return_info=True)
     assert (info["T"], info["K"]) == (len(wto), len(clo))
     _check_rounds(info["rounds"], tr)
     assert abs(F - Fo) <= 1e-8 * abs(Fo)
     _check_q(qY, qZ, qYo, qZo)
-    np.testing.assert_allclose(np.array(mk), np.array([c.getmean() for c in clo]), rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(np.vstack(mk), np.array([c.getmean() for c in clo]), rtol=1e-7, atol=1e-9)
     np.testing.assert_allclose(np.array(ck), np.array([c.getcov() for c in clo]), rtol=1e-7, atol=1e-8)
 
 
@@ -128,7 +128,8 @@ def test_topic_argument_errors_and_random_start(xcat):
     with pytest.raises(ValueError, match="at least one thread"):
         lc.learnSCM(Xv, trunc=4, nthreads=0)
     # the reference's own start (std::rand): a valid model comes back
-    F, qY, qZ, wj, wt, means, covs, info = lc.learnSCM(Xv, trunc=4)
+    F, qY, qZ, wj, wt, means, covs = lc.learnSCM(Xv, trunc=4)  # the reference tuple (libclusterpy.cpp:270)
+    info = {"T": qY[0].shape[1], "K": len(means)}
     assert np.isfinite(F) and 1 <= info["T"] <= 4 and info["K"] >= 1
     for q in qY:
         np.testing.assert_allclose(q.sum(axis=1), 1.0, rtol=1e-9)
