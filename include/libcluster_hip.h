@@ -152,6 +152,10 @@ int lc_ctx_set_allreduce(lc_ctx* ctx, lc_allreduce_fn fn, void* user);
  * weights' free energy are summed, the per-group counts N_jk and the group weights stay local. */
 int lc_ctx_set_sharding(lc_ctx* ctx, int whole_groups);
 
+/* Device and page-locked blocks released by contexts are cached for re-use (the split search builds a context per
+ * attempt); this returns all of them to the driver. */
+int lc_trim_cache(void);
+
 /* ---- kernel timing (hipEvents on the context's stream) ------------------ */
 int lc_ctx_timing_enable(lc_ctx* ctx, int on);
 int lc_ctx_timing_reset(lc_ctx* ctx);

@@ -489,6 +489,11 @@ def learn(algo, X, wprior=1.0, clusterprior=1.0, maxclusters=-1, sparse=False, v
     return F.value, Model(mh), [x.shape[0] for x in Xs]
 
 
+def trim_cache():
+    """Return every cached device / page-locked block to the driver."""
+    check(lib().lc_trim_cache())
+
+
 def weights_update(wkind, Nk, wprior=1.0):
     Nk = np.ascontiguousarray(Nk, dtype=np.float64)
     e, f = np.zeros(Nk.size), C.c_double()

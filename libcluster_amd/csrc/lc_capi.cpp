@@ -322,6 +322,10 @@ int lc_ctx_set_allreduce(lc_ctx* ctx, lc_allreduce_fn fn, void* user) {
   });
 }
 
+int lc_trim_cache(void) {
+  return guarded([&] { lcc::trim_cache(); });
+}
+
 int lc_ctx_timing_enable(lc_ctx* ctx, int on) {
   return guarded([&] {
     need(ctx, "ctx");

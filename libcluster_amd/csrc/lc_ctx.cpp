@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 
 namespace lcc {
 
@@ -15,31 +16,129 @@ namespace lcc {
                        std::to_string(__LINE__) + ")");                                                \
   } while (0)
 
+// Freed device / page-locked blocks are kept for re-use: the split search builds and tears down a sub-context per
+// attempt, and hipFree / hipHostFree (50-340 us each, the former also a device-wide synchronisation) were 6 % of a
+// model-selection run.  Blocks are matched best-fit within 2x; the device cache is capped at 16 GiB per process
+// (lc_trim_cache() empties it).  Nothing is returned to the driver at process exit (the runtime may be gone).
+namespace {
+struct BlockCache {
+  struct Block {
+    void* p;
+    size_t bytes;
+    int device;
+  };
+  std::mutex m;
+  std::vector<Block> dev, pinned;
+  size_t dev_bytes = 0;
+  static BlockCache& get() {
+    static BlockCache* c = new BlockCache();  // intentionally leaked
+    return *c;
+  }
+  void* take(std::vector<Block>& v, size_t need, int device, size_t* got) {
+    std::lock_guard<std::mutex> g(m);
+    int best = -1;
+    for (int i = 0; i < (int)v.size(); ++i)
+      if (v[i].device == device && v[i].bytes >= need && v[i].bytes <= 2 * need + 4096 &&
+          (best < 0 || v[i].bytes < v[best].bytes))
+        best = i;
+    if (best < 0) return nullptr;
+    void* p = v[best].p;
+    *got = v[best].bytes;
+    if (&v == &dev) dev_bytes -= v[best].bytes;
+    v[best] = v.back();
+    v.pop_back();
+    return p;
+  }
+};
+constexpr size_t DEV_CACHE_LIMIT = (size_t)16 << 30, DEV_BLOCK_LIMIT = (size_t)8 << 30;
+int current_device() {
+  int d = 0;
+  (void)hipGetDevice(&d);
+  return d;
+}
+}  // namespace
+
+void trim_cache() {
+  BlockCache& c = BlockCache::get();
+  std::lock_guard<std::mutex> g(c.m);
+  for (auto& b : c.dev) (void)hipFree(b.p);
+  for (auto& b : c.pinned) (void)hipHostFree(b.p);
+  c.dev.clear();
+  c.pinned.clear();
+  c.dev_bytes = 0;
+}
+
+template <typename T>
+void DevBuf<T>::release() {
+  if (p) {
+    BlockCache& c = BlockCache::get();
+    const size_t bytes = cap * sizeof(T);
+    bool kept = false;
+    if (bytes <= DEV_BLOCK_LIMIT) {
+      std::lock_guard<std::mutex> g(c.m);
+      if (c.dev_bytes + bytes <= DEV_CACHE_LIMIT && c.dev.size() < 4096) {
+        c.dev.push_back({p, bytes, current_device()});
+        c.dev_bytes += bytes;
+        kept = true;
+      }
+    }
+    if (!kept) (void)hipFree(p);
+  }
+  p = nullptr;
+  cap = 0;
+}
+
 template <typename T>
 void DevBuf<T>::reserve(size_t n) {
   if (n <= cap) return;
   release();
-  void* q = nullptr;
-  hipError_t e = hipMalloc(&q, n * sizeof(T));
-  if (e != hipSuccess)
-    throw HipFailure(std::string("HIP error: hipMalloc of ") + std::to_string(n * sizeof(T)) +
-                     " bytes failed: " + hipGetErrorString(e));
+  BlockCache& c = BlockCache::get();
+  size_t got = 0;
+  void* q = c.take(c.dev, n * sizeof(T), current_device(), &got);
+  if (!q) {
+    hipError_t e = hipMalloc(&q, n * sizeof(T));
+    if (e != hipSuccess) {  // make room and retry once
+      trim_cache();
+      e = hipMalloc(&q, n * sizeof(T));
+    }
+    if (e != hipSuccess)
+      throw HipFailure(std::string("HIP error: hipMalloc of ") + std::to_string(n * sizeof(T)) +
+                       " bytes failed: " + hipGetErrorString(e));
+    got = n * sizeof(T);
+  }
   p = static_cast<T*>(q);
-  cap = n;
+  cap = got / sizeof(T);
 }
+
+PinnedBuf::~PinnedBuf() {
+  if (!p) return;
+  BlockCache& c = BlockCache::get();
+  std::lock_guard<std::mutex> g(c.m);
+  if (c.pinned.size() < 256) c.pinned.push_back({p, cap * sizeof(double), 0});
+  else (void)hipHostFree(p);
+}
+
 void PinnedBuf::resize(size_t count) {
   if (count > cap) {
-    if (p) (void)hipHostFree(p);
+    BlockCache& c = BlockCache::get();
+    if (p) {
+      std::lock_guard<std::mutex> g(c.m);
+      c.pinned.push_back({p, cap * sizeof(double), 0});
+    }
     p = nullptr;
     cap = 0;
-    void* q = nullptr;
     const size_t want = count < 1024 ? 1024 : count + count / 2;
-    hipError_t e = hipHostMalloc(&q, want * sizeof(double), hipHostMallocDefault);
-    if (e != hipSuccess)
-      throw HipFailure(std::string("HIP error: hipHostMalloc of ") + std::to_string(want * sizeof(double)) +
-                       " bytes failed: " + hipGetErrorString(e));
+    size_t got = 0;
+    void* q = c.take(c.pinned, want * sizeof(double), 0, &got);
+    if (!q) {
+      hipError_t e = hipHostMalloc(&q, want * sizeof(double), hipHostMallocDefault);
+      if (e != hipSuccess)
+        throw HipFailure(std::string("HIP error: hipHostMalloc of ") + std::to_string(want * sizeof(double)) +
+                         " bytes failed: " + hipGetErrorString(e));
+      got = want * sizeof(double);
+    }
     p = static_cast<double*>(q);
-    cap = want;
+    cap = got / sizeof(double);
   }
   n = count;
 }
@@ -50,8 +149,9 @@ template struct DevBuf<int64_t>;
 template struct DevBuf<unsigned char>;
 
 Context::Context(int device, hipStream_t stream) : device_(device), stream_(stream) {
-  int n = 0;
-  hipError_t e = hipGetDeviceCount(&n);
+  // hipGetDeviceCount costs ~2.5 ms per call; the split search builds a context per attempt
+  static int n = 0;
+  static hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n <= 0)
     throw HipFailure("libcluster_amd: no HIP device available (the E-step has no CPU fallback): " +
                      std::string(e != hipSuccess ? hipGetErrorString(e) : "device count is 0"));
@@ -60,6 +160,9 @@ Context::Context(int device, hipStream_t stream) : device_(device), stream_(stre
 }
 
 Context::~Context() {
+  // the buffers go back to the block cache (no implicit device synchronisation like hipFree): make sure nothing
+  // enqueued by this context still uses them
+  if (X_.p || qz_[0].buf.p || qz_[1].buf.p) (void)hipStreamSynchronize(stream_);
   for (auto& p : pending_) {
     (void)hipEventDestroy(p.a);
     (void)hipEventDestroy(p.b);

@@ -27,11 +27,7 @@ struct DevBuf {
   T* p = nullptr;
   size_t cap = 0;  // elements
   ~DevBuf() { release(); }
-  void release() {
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    cap = 0;
-  }
+  void release();  // back to the block cache (lc_ctx.cpp), not to the driver
   // grow (contents NOT preserved)
   void reserve(size_t n);
 };
@@ -41,9 +37,7 @@ struct DevBuf {
 struct PinnedBuf {
   double* p = nullptr;
   size_t cap = 0, n = 0;
-  ~PinnedBuf() {
-    if (p) (void)hipHostFree(p);
-  }
+  ~PinnedBuf();
   PinnedBuf() = default;
   PinnedBuf(const PinnedBuf&) = delete;
   PinnedBuf& operator=(const PinnedBuf&) = delete;
@@ -68,6 +62,9 @@ struct RowSelection {
   std::vector<int64_t> starts;  // host copy
   int64_t M = 0;
 };
+
+// return every cached device / page-locked block to the driver
+void trim_cache();
 
 struct KernelTimes {
   double estep_ms = 0, suffstat_ms = 0;
