@@ -151,6 +151,11 @@ int lc_ctx_set_allreduce(lc_ctx* ctx, lc_allreduce_fn fn, void* user);
  * 1: every rank holds WHOLE, different groups (GMC) -- cluster statistics, Fz, LL_k and the
  * weights' free energy are summed, the per-group counts N_jk and the group weights stay local. */
 int lc_ctx_set_sharding(lc_ctx* ctx, int whole_groups);
+/* Statistics pass: skip every (4-row step, cluster) pair whose responsibilities are all exactly 0.0.  Their
+ * contribution is exactly zero, so results are bit-identical; it pays off once qZ is mostly hard (late EM
+ * iterations on separated data).  Off by default (the dense kernel has no test in its inner loop); always on in the
+ * reference's `sparse` mode, whose point is to leave massless (group, cluster) pairs out (cluster.cpp:67-79). */
+int lc_ctx_set_skip_zero(lc_ctx* ctx, int on);
 
 /* Device and page-locked blocks released by contexts are cached for re-use (the split search builds a context per
  * attempt); this returns all of them to the driver. */

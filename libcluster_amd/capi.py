@@ -78,6 +78,7 @@ def lib() -> C.CDLL:
     L.lc_ctx_synth_groups.argtypes = [C.c_void_p, C.c_int, c_int64_p, C.c_int, C.c_int, c_double_p, c_double_p,
                                       c_double_p, C.c_uint64, c_int64_p, C.c_double]
     L.lc_ctx_set_sharding.argtypes = [C.c_void_p, C.c_int]
+    L.lc_ctx_set_skip_zero.argtypes = [C.c_void_p, C.c_int]
     L.lc_ctx_get_rows.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, c_double_p]
     L.lc_ctx_set_qz.argtypes = [C.c_void_p, C.c_int, c_double_p, C.c_int, C.c_int64, C.c_int64]
     L.lc_ctx_get_qz.argtypes = [C.c_void_p, C.c_int, c_double_p, C.c_int64, C.c_int64]
@@ -227,6 +228,10 @@ class Context:
         gid = None if group_ids is None else np.ascontiguousarray(group_ids, dtype=np.int64)
         check(lib().lc_ctx_synth_groups(self._h, J, Nj.ctypes.data_as(c_int64_p), D, K, dptr(mu), dptr(L), dptr(cdf),
                                         seed, None if gid is None else gid.ctypes.data_as(c_int64_p), hard))
+
+    def set_skip_zero(self, on: bool = True):
+        """Exact: leave out (4-row step, cluster) pairs with all-zero responsibilities in the statistics pass."""
+        check(lib().lc_ctx_set_skip_zero(self._h, int(on)))
 
     def set_sharding(self, whole_groups: bool):
         check(lib().lc_ctx_set_sharding(self._h, int(whole_groups)))

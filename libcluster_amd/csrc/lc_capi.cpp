@@ -158,6 +158,13 @@ int lc_ctx_set_sharding(lc_ctx* ctx, int whole_groups) {
   });
 }
 
+int lc_ctx_set_skip_zero(lc_ctx* ctx, int on) {
+  return guarded([&] {
+    need(ctx, "ctx");
+    ctx->impl.set_skip_zero(on != 0);
+  });
+}
+
 int lc_ctx_get_rows(lc_ctx* ctx, int j, int64_t row0, int64_t n, double* out) {
   return guarded([&] {
     need(ctx, "ctx");

@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <limits>
 #include <mutex>
 
 namespace lcc {
@@ -582,6 +583,8 @@ void Context::estep(int K, const double* A, const double* m, const double* c, do
   a.fz_part = fzpart_.p;
   a.ll_part = LLk ? llpart_.p : nullptr;
   a.raw = raw ? 1 : 0;
+  for (size_t t = 0; t < (size_t)J_ * K && !a.sparse; ++t)
+    if (c[t] == -std::numeric_limits<double>::infinity()) a.sparse = 1;
   EvPair ev{};
   if (timing_) {
     LC_HIP(hipEventCreate(&ev.a));
@@ -642,6 +645,18 @@ void Context::suffstat(const unsigned char* smask, double* Nk, double* xs, doubl
       a.smask = smask_.p;
     } else if (smask) {
       // single group: a masked cluster simply receives nothing (handled on the host below)
+    }
+    a.skip_zero = skip_zero_ ? 1 : 0;
+    if (a.smask && !skip_zero_) {
+      // the skipping variant costs ~10 % when nothing can be skipped: use it when the mask removes most
+      // of the (row, cluster) pairs, otherwise the dense variant (masked q are staged as zeros either way)
+      double off = 0.0, tot = 0.0;
+      for (int j2 = 0; j2 < J_; ++j2)
+        for (int k2 = 0; k2 < K; ++k2) {
+          tot += (double)Nj_[j2];
+          if (!smask[(size_t)j2 * K + k2]) off += (double)Nj_[j2];
+        }
+      a.skip_zero = off > 0.6 * tot ? 1 : -1;
     }
     a.partial = sspart_.p;
     a.nchunks = nchunks;

@@ -115,12 +115,16 @@ class Context {
   // row blocks): counts are summed; true = every rank holds WHOLE, different groups (GMC): the per-group
   // counts stay local, only cluster statistics and scalars are summed.
   void set_group_sharded(bool on) { group_sharded_ = on; }
+  // statistics pass: skip (4-row step, cluster) pairs whose responsibilities are all exactly 0.0 (bit-identical
+  // results; pays off once qZ is mostly hard).  Always on in sparse mode.
+  void set_skip_zero(bool on) { skip_zero_ = on; }
   bool group_sharded() const { return group_sharded_ && ar_fn_ != nullptr; }
   // a context for a sub-problem of this one: same device, stream and all-reduce hook
   void inherit_comm(const Context& parent) {
     ar_fn_ = parent.ar_fn_;
     ar_user_ = parent.ar_user_;
     group_sharded_ = parent.group_sharded_;
+    skip_zero_ = parent.skip_zero_;
   }
 
   // ---- qZ -----------------------------------------------------------------
@@ -182,6 +186,7 @@ class Context {
   allreduce_fn ar_fn_ = nullptr;
   void* ar_user_ = nullptr;
   bool group_sharded_ = false;
+  bool skip_zero_ = false;
 
   int J_ = 0, D_ = 0, DP_ = 0;
   std::vector<int64_t> Nj_, goff_;  // goff_: padded row offsets, size J+1

@@ -37,6 +37,7 @@ struct EstepLaunch {
   double* fz_part;       // [estep_grid(...)]
   double* ll_part;       // [estep_grid(...) x K], or nullptr: skip the split-ordering data term
   int raw = 0;           // 1: stop after writing log q~ (no log-sum-exp, fz/ll untouched)
+  int sparse = 0;        // 1: ctab holds -inf entries; waves skip clusters inactive for all their rows
 };
 int estep_rows_per_block(int DP);
 int64_t estep_grid(int DP, int64_t nrg);
@@ -55,6 +56,7 @@ struct SuffstatLaunch {
   int nchunks;
   int64_t chunk_rows;       // multiple of 4
   int nslice = 1;           // filled in by launch_suffstat
+  int skip_zero = 0;        // 1: use the variant that skips (4-row step, cluster) pairs with all-zero q (exact)
 };
 // choose a chunking for (NP, K); returns nchunks and sets chunk_rows
 int suffstat_plan(int DP, int64_t NP, int K, int64_t* chunk_rows);

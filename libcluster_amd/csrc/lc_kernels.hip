@@ -178,6 +178,16 @@ __global__ void __launch_bounds__(WAVES * 64, 2) estep_kernel(EstepLaunch a) {
     double d2[R], acc[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) d2[r] = 0.0;
+    // sparse mode (cluster.cpp:109-112): a cluster that is inactive (c_jk = -inf) for the groups of ALL of this
+    // wave's row groups needs no Mahalanobis term -- its log q~ is -inf whatever the distance
+    bool wave_active = true;
+    if (a.sparse) {
+      wave_active = false;
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        wave_active = wave_active || (rgok[r] && a.ctab[(int64_t)grp[r] * K + k] != -INFINITY);
+    }
+    if (wave_active)
     static_for<NREAD>([&](auto nc) {
       constexpr int n = nc;
       constexpr RdInfo ri = rd_info(n);
@@ -362,7 +372,10 @@ struct SSAcc { static constexpr int N = NB * 3 + NB * (NB - 1) / 2 * 4; };
 
 constexpr int SS_BR = 32;  // rows staged per batch
 
-template <int DP, int CPW>
+// SKIP: a (4-row step, cluster) pair whose four responsibilities are all exactly 0.0 contributes exactly nothing;
+// the sparse mode (cluster.cpp:67-79: groups without mass in a cluster are left out) launches this variant so that
+// "sparse" saves the work it saves in the reference.  The dense variant carries no test in its inner loop.
+template <int DP, int CPW, bool SKIP>
 __global__ void __launch_bounds__(256, (DP <= 64 ? 2 : 1)) suffstat_kernel(SuffstatLaunch a) {
   constexpr int NB = DP / 16;
   constexpr int NACC = SSAcc<NB>::N;
@@ -501,6 +514,7 @@ __global__ void __launch_bounds__(256, (DP <= 64 ? 2 : 1)) suffstat_kernel(Suffs
           for (int c = 0; c < CPW; ++c) qn[c] = qb[c * BR + (st + 1) * 4];
 #pragma unroll
           for (int c = 0; c < CPW; ++c) {
+            if (SKIP && __builtin_amdgcn_ballot_w64(q[c] != 0.0) == 0) continue;
             double qx[NB];
 #pragma unroll
             for (int jb = 0; jb < NB; ++jb) {
@@ -533,6 +547,12 @@ __global__ void __launch_bounds__(256, (DP <= 64 ? 2 : 1)) suffstat_kernel(Suffs
       } else {
         const int nstep = (int)(((r1 - b0) < BR ? (r1 - b0) : BR) / 4);
         for (int st = 0; st < nstep; ++st) {
+          if (SKIP) {  // nothing to do for any of this wave's clusters: do not even fetch the fragments
+            bool any = false;
+#pragma unroll
+            for (int c = 0; c < CPW; ++c) any = any || qb[c * BR + st * 4] != 0.0;
+            if (__builtin_amdgcn_ballot_w64(any) == 0) continue;
+          }
           // fragments: xr[jb][s] = x[row 4*st+hi][16*jb + 4*((blk+s)&3) + lo2]
           double xr[NB][4];
   #pragma unroll
@@ -542,6 +562,7 @@ __global__ void __launch_bounds__(256, (DP <= 64 ? 2 : 1)) suffstat_kernel(Suffs
   #pragma unroll
           for (int c = 0; c < CPW; ++c) {
             const double q = qb[c * BR + st * 4];
+            if (SKIP && __builtin_amdgcn_ballot_w64(q != 0.0) == 0) continue;
             double qx[NB];
   #pragma unroll
             for (int jb = 0; jb < NB; ++jb) {
@@ -662,15 +683,15 @@ int suffstat_plan(int DP, int64_t NP, int K, int64_t* chunk_rows) {
   return (int)((NP + rows - 1) / rows);
 }
 
-template <int DP, int CPW>
-static hipError_t launch_ss_t(const SuffstatLaunch& a, hipStream_t stream) {
+template <int DP, int CPW, bool SKIP>
+static hipError_t launch_ss_s(const SuffstatLaunch& a, hipStream_t stream) {
   const int kwaves = (a.K + CPW - 1) / CPW;
   const int wpb = 4;
   const int nslice = (kwaves + wpb - 1) / wpb;
   SuffstatLaunch b = a;
   b.nslice = nslice;
   const size_t shmem = (size_t)(2 * SS_BR * (DP + 16) + 2 * wpb * CPW * SS_BR) * sizeof(double);
-  auto kern = suffstat_kernel<DP, CPW>;
+  auto kern = suffstat_kernel<DP, CPW, SKIP>;
   static bool attr_set = false;
   if (shmem > 64 * 1024 && !attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -680,6 +701,13 @@ static hipError_t launch_ss_t(const SuffstatLaunch& a, hipStream_t stream) {
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.nchunks * nslice)), dim3(wpb * 64), shmem, stream, b);
   return hipGetLastError();
+}
+
+template <int DP, int CPW>
+static hipError_t launch_ss_t(const SuffstatLaunch& a, hipStream_t stream) {
+  // skip_zero: 1 = skipping variant, -1 = dense even with a mask, 0 = skipping iff a mask is given
+  const bool skip = a.skip_zero > 0 || (a.skip_zero == 0 && a.smask);
+  return skip ? launch_ss_s<DP, CPW, true>(a, stream) : launch_ss_s<DP, CPW, false>(a, stream);
 }
 
 hipError_t launch_suffstat(const SuffstatLaunch& a, hipStream_t stream) {

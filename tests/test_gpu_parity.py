@@ -333,3 +333,35 @@ def test_many_clusters_and_many_small_groups():
         np.testing.assert_allclose(el, np.stack([wo[j].Elogweight() for j in (0, 7, 733, J - 1)]), rtol=1e-9)
         for j in range(0, J, 97):
             assert_q_close(q[j], qo[j], rtol=1e-7)
+
+
+def test_sparse_mode_and_zero_skipping_are_exact():
+    """Grouped data where every group uses a few of the clusters: the sparse variants (waves skip clusters that are
+    inactive for all their rows; statistics skip all-zero steps) give the oracle's sparse results, and the
+    zero-skipping statistics pass equals the dense one bit for bit."""
+    rng = np.random.default_rng(5)
+    J, K, D = 6, 8, 5
+    X, q0 = [], []
+    for j in range(J):
+        n = 900 + 64 * j
+        use = rng.choice(K, 2, replace=False)
+        z = rng.choice(use, n)
+        X.append(rng.normal(size=(n, D)) + 9.0 * np.eye(K, D)[z] * 1.0 + z[:, None])
+        q = np.zeros((n, K))
+        q[np.arange(n), z] = 1.0  # hard start: most responsibilities are exactly zero
+        q0.append(q)
+    tro, _, qo, wo, clo = o.vbem_fixed(X, q0, o.GDirichlet, 1.0, 3, True)
+    with capi.Context(0) as ctx:
+        ctx.set_data(X)
+        ctx.set_qz(q0)
+        dense = ctx.suffstat()
+        ctx.set_skip_zero(True)
+        skipped = ctx.suffstat()
+        for a, b in zip(dense, skipped):
+            np.testing.assert_array_equal(a, b)
+        F, tr, model = ctx.vbem(capi.W_GDIRICHLET, sparse=True, fixed_iters=3)
+        q = ctx.get_qz([x.shape[0] for x in X])
+        model.close()
+    np.testing.assert_allclose(tr, tro, rtol=1e-10)
+    for j in range(J):
+        assert_q_close(q[j], qo[j], rtol=1e-8)
