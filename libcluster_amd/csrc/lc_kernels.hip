@@ -89,7 +89,7 @@ __device__ __forceinline__ void static_for(F&& f) {
   static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
 }
 
-template <int DP, int R, int WAVES>
+template <int DP, int R, int WAVES, bool SPARSE>
 __global__ void __launch_bounds__(WAVES * 64, 2) estep_kernel(EstepLaunch a) {
   constexpr int NT = DP / 4;
   constexpr int NTILES = NT * (NT + 1) / 2;
@@ -103,6 +103,9 @@ __global__ void __launch_bounds__(WAVES * 64, 2) estep_kernel(EstepLaunch a) {
   double* pbuf = lds;              // [2][PS]
   double* llw = lds + 2 * PS;      // [WAVES][K]
   double* fzw = llw + WAVES * a.K; // [WAVES]
+  int* klist = reinterpret_cast<int*>(fzw + WAVES);  // sparse mode: [K] active clusters of this block, [K] flags,
+  int* kflag = klist + a.K;                          // [WAVES*R] groups of the block's row groups, [1] count
+  int* bgrp = kflag + a.K;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lo4 = lane & 15, hi = lane >> 4;
@@ -153,17 +156,53 @@ __global__ void __launch_bounds__(WAVES * 64, 2) estep_kernel(EstepLaunch a) {
     }                                                                                         \
   }
 
-  LC_GLOAD(0);
-  LC_LSTORE(0);
+  // Sparse mode (cluster.cpp:109-112, 134-135): the block walks only the clusters that are active (c_jk > -inf)
+  // for at least one of its row groups -- no parameter staging, barrier or MFMA for the others; their columns
+  // get log q~ = -inf directly.  Waves whose own row groups are all inactive for a listed cluster skip it too.
+  int nact = K;
+  if constexpr (SPARSE) {
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) bgrp[wave * R + r] = rgok[r] ? grp[r] : -1;
+    }
+    __syncthreads();
+    for (int k = tid; k < K; k += NTHR) {
+      int f = 0;
+      for (int g = 0; g < WAVES * R; ++g)
+        if (bgrp[g] >= 0 && a.ctab[(int64_t)bgrp[g] * K + k] != -INFINITY) f = 1;
+      kflag[k] = f;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int n = 0;
+      for (int k = 0; k < K; ++k)
+        if (kflag[k]) klist[n++] = k;
+      bgrp[WAVES * R] = n;
+    }
+    __syncthreads();
+    nact = bgrp[WAVES * R];
+    for (int k = 0; k < K; ++k) {
+      if (kflag[k]) continue;
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (rgok[r] && hi == (k & 3)) a.qZ[(int64_t)k * a.ldq + (rg0 + r) * RG + lo4] = -INFINITY;
+    }
+  }
+
+  if (nact > 0) {
+    LC_GLOAD(SPARSE ? klist[0] : 0);
+    LC_LSTORE(0);
+  }
   __syncthreads();
 
   double mx[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) mx[r] = -INFINITY;
 
-  for (int k = 0; k < K; ++k) {
-    const int buf = k & 1;
-    if (k + 1 < K) LC_GLOAD(k + 1);
+  for (int ii = 0; ii < nact; ++ii) {
+    const int k = SPARSE ? klist[ii] : ii;
+    const int buf = ii & 1;
+    if (ii + 1 < nact) LC_GLOAD(SPARSE ? klist[ii + 1] : ii + 1);
     const double* P = pbuf + buf * PS;
     const double* Pt = P + (lane & 3) + 4 * hi;  // this lane's element of every 4x4 tile
     const double* Pb = P + NTILES * 16 + hi;     // this lane's element of every 4-vector of -b
@@ -181,7 +220,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) estep_kernel(EstepLaunch a) {
     // sparse mode (cluster.cpp:109-112): a cluster that is inactive (c_jk = -inf) for the groups of ALL of this
     // wave's row groups needs no Mahalanobis term -- its log q~ is -inf whatever the distance
     bool wave_active = true;
-    if (a.sparse) {
+    if constexpr (SPARSE) {
       wave_active = false;
 #pragma unroll
       for (int r = 0; r < R; ++r)
@@ -222,7 +261,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) estep_kernel(EstepLaunch a) {
       mx[r] = fmax(mx[r], lq);
       if (rgok[r] && hi == (k & 3)) a.qZ[(int64_t)k * a.ldq + (rg0 + r) * RG + lo4] = lq;
     }
-    if (k + 1 < K) LC_LSTORE(buf ^ 1);
+    if (ii + 1 < nact) LC_LSTORE(buf ^ 1);
     __syncthreads();
   }
 
@@ -314,11 +353,12 @@ int64_t estep_grid(int DP, int64_t nrg) {
   return (nrg + rgpb - 1) / rgpb;
 }
 
-template <int DP>
-static hipError_t launch_estep_t(const EstepLaunch& a, hipStream_t stream) {
+template <int DP, bool SPARSE>
+static hipError_t launch_estep_s(const EstepLaunch& a, hipStream_t stream) {
   constexpr int R = EstepCfg<DP>::R, WAVES = EstepCfg<DP>::WAVES;
-  const size_t shmem = (size_t)(2 * pstride(DP) + WAVES * a.K + WAVES) * sizeof(double);
-  auto kern = estep_kernel<DP, R, WAVES>;
+  const size_t shmem = (size_t)(2 * pstride(DP) + WAVES * a.K + WAVES) * sizeof(double) +
+                       (size_t)(2 * a.K + WAVES * R + 2) * sizeof(int);
+  auto kern = estep_kernel<DP, R, WAVES, SPARSE>;
   static size_t attr_set = 0;  // largest dynamic-LDS size already granted
   if (shmem > 64 * 1024 && shmem > attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -330,6 +370,11 @@ static hipError_t launch_estep_t(const EstepLaunch& a, hipStream_t stream) {
   if (grid <= 0) return hipSuccess;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVES * 64), shmem, stream, a);
   return hipGetLastError();
+}
+
+template <int DP>
+static hipError_t launch_estep_t(const EstepLaunch& a, hipStream_t stream) {
+  return a.sparse ? launch_estep_s<DP, true>(a, stream) : launch_estep_s<DP, false>(a, stream);
 }
 
 hipError_t launch_estep(const EstepLaunch& a, hipStream_t stream) {
