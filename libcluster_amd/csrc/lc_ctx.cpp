@@ -647,16 +647,84 @@ void Context::suffstat(const unsigned char* smask, double* Nk, double* xs, doubl
       // single group: a masked cluster simply receives nothing (handled on the host below)
     }
     a.skip_zero = skip_zero_ ? 1 : 0;
-    if (a.smask && !skip_zero_) {
-      // the skipping variant costs ~10 % when nothing can be skipped: use it when the mask removes most
-      // of the (row, cluster) pairs, otherwise the dense variant (masked q are staged as zeros either way)
+    bool listed = false;  // sparse work list instead of the dense (chunk, slice) grid
+    int nrec = 0;
+    if (a.smask) {
       double off = 0.0, tot = 0.0;
       for (int j2 = 0; j2 < J_; ++j2)
         for (int k2 = 0; k2 < K; ++k2) {
           tot += (double)Nj_[j2];
           if (!smask[(size_t)j2 * K + k2]) off += (double)Nj_[j2];
         }
-      a.skip_zero = off > 0.6 * tot ? 1 : -1;
+      // Sparse mode (cluster.cpp:67-79).  When the mask removes a fair share of the (row, cluster) pairs the pass
+      // runs over a work list -- (row range of one group) x (slice of that group's ACTIVE clusters) -- so the
+      // work is proportional to sum_j N_j * K_active(j); otherwise the dense grid with masked q staged as zeros.
+      if (off > 0.3 * tot) {
+        listed = true;
+        const int cpb = lck::suffstat_clusters_per_block(DP, K);
+        std::vector<int> klist, kofs((size_t)J_ + 1, 0);
+        for (int j2 = 0; j2 < J_; ++j2) {
+          for (int k2 = 0; k2 < K; ++k2)
+            if (smask[(size_t)j2 * K + k2]) klist.push_back(k2);
+          kofs[(size_t)j2 + 1] = (int)klist.size();
+        }
+        // row chunks: whole 32-row batches inside one group, about 2048 blocks in total
+        double blocks_per_row = 0.0;
+        for (int j2 = 0; j2 < J_; ++j2)
+          blocks_per_row += (double)(goff_[(size_t)j2 + 1] - goff_[(size_t)j2]) *
+                            (double)((kofs[(size_t)j2 + 1] - kofs[(size_t)j2] + cpb - 1) / cpb);
+        int64_t rows = (int64_t)(blocks_per_row / 2048.0);
+        rows = std::max<int64_t>(256, (rows + 31) / 32 * 32);
+        std::vector<lck::SSItem> items;
+        std::vector<std::vector<int>> recs((size_t)K);
+        for (int j2 = 0; j2 < J_; ++j2) {
+          const int na = kofs[(size_t)j2 + 1] - kofs[(size_t)j2];
+          if (na == 0) continue;
+          for (int64_t b0 = goff_[(size_t)j2]; b0 < goff_[(size_t)j2 + 1]; b0 += rows) {
+            const int64_t b1 = std::min<int64_t>(b0 + rows, goff_[(size_t)j2 + 1]);
+            for (int s0 = 0; s0 < na; s0 += cpb) {
+              lck::SSItem it;
+              it.r0 = b0;
+              it.r1 = b1;
+              it.kofs = kofs[(size_t)j2] + s0;
+              it.kcnt = std::min(cpb, na - s0);
+              it.rec0 = nrec;
+              for (int t = 0; t < it.kcnt; ++t) recs[(size_t)klist[(size_t)it.kofs + t]].push_back(nrec + t);
+              nrec += it.kcnt;
+              items.push_back(it);
+            }
+          }
+        }
+        std::vector<int> kptr((size_t)K + 1, 0), krec;
+        krec.reserve((size_t)nrec);
+        for (int k2 = 0; k2 < K; ++k2) {
+          krec.insert(krec.end(), recs[(size_t)k2].begin(), recs[(size_t)k2].end());
+          kptr[(size_t)k2 + 1] = (int)krec.size();
+        }
+        ssitems_.reserve(items.size() * sizeof(lck::SSItem));
+        ssints_.reserve(klist.size() + kptr.size() + krec.size() + 1);
+        int* klist_d = ssints_.p;
+        int* kptr_d = klist_d + klist.size();
+        int* krec_d = kptr_d + kptr.size();
+        if (!items.empty()) {
+          LC_HIP(hipMemcpyAsync(ssitems_.p, items.data(), items.size() * sizeof(lck::SSItem), hipMemcpyHostToDevice,
+                                stream_));
+          LC_HIP(hipMemcpyAsync(klist_d, klist.data(), klist.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
+          LC_HIP(hipMemcpyAsync(krec_d, krec.data(), krec.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
+        }
+        LC_HIP(hipMemcpyAsync(kptr_d, kptr.data(), kptr.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
+        LC_HIP(hipStreamSynchronize(stream_));  // the host vectors go out of scope
+        a.items = reinterpret_cast<const lck::SSItem*>(ssitems_.p);
+        a.klist = klist_d;
+        a.nitems = (int)items.size();
+        a.smask = nullptr;  // only active clusters are listed
+        a.rginfo = nullptr;
+        sskptr_ = kptr_d;
+        sskrec_ = krec_d;
+        sspart_.reserve((size_t)std::max(nrec, 1) * SS);
+      } else if (!skip_zero_) {
+        a.skip_zero = -1;  // dense variant; masked q are staged as zeros
+      }
     }
     a.partial = sspart_.p;
     a.nchunks = nchunks;
@@ -673,7 +741,10 @@ void Context::suffstat(const unsigned char* smask, double* Nk, double* xs, doubl
       LC_HIP(hipEventRecord(ev.b, stream_));
       pending_.push_back(ev);
     }
-    LC_HIP(lck::launch_reduce_partials(sspart_.p, nchunks, (int64_t)K * SS, ssout_.p, stream_));
+    if (listed)
+      LC_HIP(lck::launch_reduce_records(sspart_.p, SS, K, sskptr_, sskrec_, ssout_.p, stream_));
+    else
+      LC_HIP(lck::launch_reduce_partials(sspart_.p, nchunks, (int64_t)K * SS, ssout_.p, stream_));
     // per-group counts N_jk: with one group they are the N_k just reduced (filled in on the host below)
     if (J_ > 1) LC_HIP(lck::launch_group_colsum(qz_[cur_].buf.p, NP_, K, goff_d_.p, J_, njk_d, stream_));
     else LC_HIP(hipMemsetAsync(njk_d, 0, (size_t)K * sizeof(double), stream_));

@@ -194,6 +194,10 @@ class Context {
   DevBuf<double> X_;
   DevBuf<int> rginfo_;      // only when J > 1
   DevBuf<int64_t> goff_d_;  // J+1
+  DevBuf<unsigned char> ssitems_;  // sparse statistics: work items, and [klist | kptr | krec]
+  DevBuf<int> ssints_;
+  const int* sskptr_ = nullptr;
+  const int* sskrec_ = nullptr;
   QZ qz_[2];
   int cur_ = 0;
 

@@ -43,6 +43,12 @@ int estep_rows_per_block(int DP);
 int64_t estep_grid(int DP, int64_t nrg);
 hipError_t launch_estep(const EstepLaunch& a, hipStream_t stream);
 
+// sparse work item of suffstat_kernel: rows [r0, r1) of one group x clusters klist[kofs .. kofs + kcnt)
+struct SSItem {
+  int64_t r0, r1;
+  int kofs, kcnt;
+  int64_t rec0;  // partial record of the item's first cluster
+};
 struct SuffstatLaunch {
   int DP;
   const double* X;
@@ -57,10 +63,16 @@ struct SuffstatLaunch {
   int64_t chunk_rows;       // multiple of 4
   int nslice = 1;           // filled in by launch_suffstat
   int skip_zero = 0;        // 1: use the variant that skips (4-row step, cluster) pairs with all-zero q (exact)
+  const SSItem* items = nullptr;  // sparse work list (device) or nullptr: dense (chunk, slice) grid
+  const int* klist = nullptr;     // active cluster lists the items point into
+  int nitems = 0;
 };
 // choose a chunking for (NP, K); returns nchunks and sets chunk_rows
 int suffstat_plan(int DP, int64_t NP, int K, int64_t* chunk_rows);
 hipError_t launch_suffstat(const SuffstatLaunch& a, hipStream_t stream);
+int suffstat_clusters_per_block(int DP, int K);  // 4 waves x clusters per wave
+hipError_t launch_reduce_records(const double* partial, int64_t n, int K, const int* kptr, const int* krec, double* out,
+                                 hipStream_t stream);
 
 // out[e] = sum_c partial[c*n + e]  (fixed order => deterministic)
 // tmp (optional): REDUCE_TMP_ELEMS * 64 doubles of scratch, enables the two-stage path for very many records

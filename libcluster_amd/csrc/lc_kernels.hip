@@ -455,9 +455,30 @@ __global__ void __launch_bounds__(256, (DP <= 64 ? 2 : 1)) suffstat_kernel(Suffs
     }
   }
   const int kbase = (slice * nwaves + wave) * CPW;   // may be >= K: the wave still helps staging
-  const int nk = kbase >= K ? 0 : ((K - kbase) < CPW ? (K - kbase) : CPW);
-  const int64_t r0 = (int64_t)chunk * a.chunk_rows;
-  const int64_t r1 = (r0 + a.chunk_rows) < a.NP ? (r0 + a.chunk_rows) : a.NP;
+  int nk = kbase >= K ? 0 : ((K - kbase) < CPW ? (K - kbase) : CPW);
+  int64_t r0 = (int64_t)chunk * a.chunk_rows;
+  int64_t r1 = (r0 + a.chunk_rows) < a.NP ? (r0 + a.chunk_rows) : a.NP;
+  int kidx[CPW];      // cluster of accumulator set c
+  int64_t recidx[CPW];  // its partial record
+#pragma unroll
+  for (int c = 0; c < CPW; ++c) {
+    kidx[c] = kbase + c;
+    recidx[c] = (int64_t)chunk * K + kbase + c;
+  }
+  if (a.items) {
+    // sparse work list: one block = (row range inside ONE group, up to 4*CPW clusters of that group's active
+    // list); work is proportional to the active (row, cluster) pairs, records exist only for those pairs
+    const SSItem it = a.items[blockIdx.x];
+    r0 = it.r0;
+    r1 = it.r1;
+    const int first = wave * CPW;
+    nk = first >= it.kcnt ? 0 : ((it.kcnt - first) < CPW ? (it.kcnt - first) : CPW);
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+      kidx[c] = c < nk ? a.klist[it.kofs + first + c] : 0;
+      recidx[c] = it.rec0 + first + c;
+    }
+  }
 
   double acc[CPW][NACC];
   double sacc[CPW][NB];
@@ -496,8 +517,8 @@ __global__ void __launch_bounds__(256, (DP <= 64 ? 2 : 1)) suffstat_kernel(Suffs
     for (int c = 0; c < CPW; ++c) {
       double q = 0.0;
       if (c < nk && qok) {
-        q = a.qZ[(int64_t)(kbase + c) * a.ldq + qrow];
-        if (a.smask && !a.smask[(int64_t)g * K + kbase + c]) q = 0.0;
+        q = a.qZ[(int64_t)kidx[c] * a.ldq + qrow];
+        if (a.smask && !a.smask[(int64_t)g * K + kidx[c]]) q = 0.0;
       }
       qpre[c] = q;
     }
@@ -642,7 +663,7 @@ __global__ void __launch_bounds__(256, (DP <= 64 ? 2 : 1)) suffstat_kernel(Suffs
 #pragma unroll
   for (int c = 0; c < CPW; ++c) {
     if (c < nk) {
-      double* out = a.partial + ((int64_t)chunk * K + kbase + c) * SS;
+      double* out = a.partial + recidx[c] * SS;
       const double nsum = sum_over_hi(nacc[c]);
       if (lane == 0) out[0] = nsum;
 #pragma unroll
@@ -702,6 +723,8 @@ static int ss_cpw(int DP, int K) {
   return cpw;
 }
 
+int suffstat_clusters_per_block(int DP, int K) { return 4 * ss_cpw(DP, K); }
+
 int suffstat_plan(int DP, int64_t NP, int K, int64_t* chunk_rows) {
   const int cpw = ss_cpw(DP, K);
   const int kwaves = (K + cpw - 1) / cpw;  // waves needed to cover the clusters
@@ -744,7 +767,9 @@ static hipError_t launch_ss_s(const SuffstatLaunch& a, hipStream_t stream) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)(a.nchunks * nslice)), dim3(wpb * 64), shmem, stream, b);
+  const unsigned grid = a.items ? (unsigned)a.nitems : (unsigned)(a.nchunks * nslice);
+  if (grid == 0) return hipSuccess;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(wpb * 64), shmem, stream, b);
   return hipGetLastError();
 }
 
@@ -1258,6 +1283,41 @@ __global__ void __launch_bounds__(256) reduce_cols_kernel(const double* partial,
     __syncthreads();
   }
   if (threadIdx.x == 0) out[e] = sh[0];
+}
+
+// Sparse statistics: records exist only for (row chunk, active cluster) pairs; cluster k sums the records listed in
+// krec[kptr[k] .. kptr[k+1]) in list order (fixed => deterministic).  Same 16 x 16 tile as reduce_partials_kernel.
+__global__ void __launch_bounds__(256) reduce_records_kernel(const double* __restrict__ partial, int64_t n,
+                                                             const int* __restrict__ kptr, const int* __restrict__ krec,
+                                                             double* __restrict__ out) {
+  __shared__ double sh[16][17];
+  const int ex = threadIdx.x & 15, py = threadIdx.x >> 4, k = blockIdx.y;
+  const int64_t e = (int64_t)blockIdx.x * 16 + ex;
+  const int b = kptr[k], en = kptr[k + 1];
+  double s0 = 0.0, s1 = 0.0;
+  if (e < n) {
+    int c = b + py;
+    for (; c + 16 < en; c += 32) {
+      s0 += partial[(int64_t)krec[c] * n + e];
+      s1 += partial[(int64_t)krec[c + 16] * n + e];
+    }
+    for (; c < en; c += 16) s0 += partial[(int64_t)krec[c] * n + e];
+  }
+  sh[py][ex] = s0 + s1;
+  __syncthreads();
+  for (int w = 8; w > 0; w >>= 1) {
+    if (py < w) sh[py][ex] += sh[py + w][ex];
+    __syncthreads();
+  }
+  if (py == 0 && e < n) out[(int64_t)k * n + e] = sh[0][ex];
+}
+
+hipError_t launch_reduce_records(const double* partial, int64_t n, int K, const int* kptr, const int* krec, double* out,
+                                 hipStream_t stream) {
+  if (n <= 0 || K <= 0) return hipSuccess;
+  hipLaunchKernelGGL(reduce_records_kernel, dim3((unsigned)((n + 15) / 16), (unsigned)K), dim3(256), 0, stream, partial,
+                     n, kptr, krec, out);
+  return hipGetLastError();
 }
 
 // very many records of a few elements (the per-block F_z / LL_k partials of an E-step over 10^7 rows): 64 blocks

@@ -365,3 +365,30 @@ def test_sparse_mode_and_zero_skipping_are_exact():
     np.testing.assert_allclose(tr, tro, rtol=1e-10)
     for j in range(J):
         assert_q_close(q[j], qo[j], rtol=1e-8)
+
+    # the work-list path with several cluster slices per group, an empty group, a one-row group and a group that uses
+    # most clusters: statistics with a mask equal the masked dense sums
+    J, K, D = 7, 40, 9
+    sizes = [700, 0, 1, 333, 2048, 90, 1500]
+    X = [rng.normal(size=(n, D)) * 2 for n in sizes]
+    qz = [rng.dirichlet(np.ones(K) * 0.3, n) if n else np.zeros((0, K)) for n in sizes]
+    mask = (rng.random((J, K)) < 0.2).astype(np.uint8)
+    mask[4] = 1
+    mask[4, ::7] = 0
+    mask[5] = 0
+    with capi.Context(0) as ctx:
+        ctx.set_data(X)
+        ctx.set_qz(qz)
+        Nk, xs, xxs, Njk = ctx.suffstat(mask)
+    Nr, xr, xxr = np.zeros(K), np.zeros((K, D)), np.zeros((K, D, D))
+    for j in range(J):
+        for k in range(K):
+            if mask[j, k] and sizes[j]:
+                w = qz[j][:, k]
+                Nr[k] += w.sum()
+                xr[k] += w @ X[j]
+                xxr[k] += (X[j] * w[:, None]).T @ X[j]
+    np.testing.assert_allclose(Nk, Nr, rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(xs, xr, rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(xxs, xxr, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(Njk, np.stack([q.sum(axis=0) for q in qz]), rtol=1e-11, atol=1e-13)
