@@ -24,8 +24,9 @@ ARCH = "gfx950"
 # north-star shape, other kernels unchanged (measured; max-ilp / iterative-ilp / max-memory-clause are slower).
 DEVICE_FLAGS = ["-mllvm", "-amdgpu-use-amdgpu-trackers=1", "-mllvm", "-amdgpu-disable-unclustered-high-rp-reschedule=1"]
 
-SOURCES = ["lc_kernels.hip", "lc_ctx.cpp", "lc_engine.cpp", "lc_topic.cpp", "lc_capi.cpp"]
-HEADERS = ["lc_kernels.h", "lc_ctx.hpp", "lc_engine.hpp", "lc_topic.hpp", "lc_host.hpp", "../../include/libcluster_hip.h"]
+SOURCES = ["lc_kernels_estep.hip", "lc_kernels_suffstat.hip", "lc_kernels_diag.hip", "lc_kernels_aux.hip", "lc_ctx.cpp",
+           "lc_engine.cpp", "lc_topic.cpp", "lc_capi.cpp"]
+HEADERS = ["lc_kernels.h", "lc_device.hpp", "lc_ctx.hpp", "lc_engine.hpp", "lc_topic.hpp", "lc_host.hpp", "../../include/libcluster_hip.h"]
 
 
 def _hipcc() -> str:
@@ -48,7 +49,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     hdrs = [CSRC / h for h in HEADERS]
     common = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", f"-I{PKG.parent / 'include'}"]
     common += os.environ.get("LC_EXTRA_CXXFLAGS", "").split()  # kernel tuning experiments (-DLC_SS_UNROLL=2 ...)
-    objs = []
+    objs, jobs = [], []
     for src in SOURCES:
         s = CSRC / src
         o = OBJ / (Path(src).stem + ".o")
@@ -57,9 +58,17 @@ def build(force: bool = False, verbose: bool = False) -> Path:
             cmd = [hipcc, *common, "-c", str(s), "-o", str(o)]
             if src.endswith(".hip"):
                 cmd[1:1] = [f"--offload-arch={ARCH}", *DEVICE_FLAGS]
+            jobs.append(cmd)
+    if jobs:  # the translation units are independent: compile them side by side
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
             if verbose:
                 print(" ".join(cmd))
             subprocess.run(cmd, check=True)
+
+        with ThreadPoolExecutor(max_workers=min(len(jobs), max(1, (os.cpu_count() or 2) // 2))) as ex:
+            list(ex.map(run, jobs))
     if force or _newer(LIB, objs):
         cmd = [hipcc, "-shared", "-o", str(LIB), *map(str, objs), "-lpthread"]
         if verbose:

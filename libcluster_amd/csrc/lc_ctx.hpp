@@ -1,6 +1,6 @@
 // Device context: owns the device-resident copy of one data set (all groups,
 // padded), the responsibility matrix qZ and every workspace of the hot path,
-// and drives the kernels of lc_kernels.hip.  One context per learn*() call
+// and drives the kernels of lc_kernels_*.hip.  One context per learn*() call
 // (and one per split sub-problem); contexts are independent.
 #pragma once
 #include <hip/hip_runtime.h>

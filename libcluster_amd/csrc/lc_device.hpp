@@ -1,0 +1,45 @@
+// Device-side helpers shared by the kernel translation units.
+//
+// Matrix instruction: v_mfma_f64_4x4x4_4b_f64 (four independent 4x4x4 blocks, 512 flop, 16 cycles/SIMD = 32
+// flop/clk/SIMD; measured 73-77 TFLOP/s on MI355X, vs 47-49 for v_mfma_f64_16x16x4_f64 --
+// profiles/r01_mfma_f64_probe.log).  Lane layout (probed, tools/mfma_f64_4x4_layout.hip),
+// lane = lo2 + 4*blk + 16*hi:
+//   A[i][k] of block blk : i = lo2, k = hi
+//   B[k][j] of block blk : j = lo2, k = hi
+//   D[i][j] of block blk : j = lo2, i = hi
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdlib>
+#include <type_traits>
+#include <utility>
+
+#include "lc_kernels.h"
+
+namespace lck {
+
+__device__ __forceinline__ double mfma4(double a, double b, double c) {
+  return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
+}
+
+// sum over the 4 lanes {l, l^16, l^32, l^48}
+__device__ __forceinline__ double sum_over_hi(double v) {
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+// sum over the 16 lanes of a DPP row (same hi)
+__device__ __forceinline__ double sum_over_lo4(double v) {
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 8);
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+  v = sum_over_lo4(v);
+  return sum_over_hi(v);
+}
+
+}  // namespace lck

@@ -1,0 +1,495 @@
+// Reductions, column sums, fills; the split-search data passes (partobs / splitobs / auglabels); the synthetic mixture generator
+// (one translation unit per kernel family; the file header of lc_kernels_estep.hip maps kernels to the reference)
+#include "lc_device.hpp"
+
+namespace lck {
+
+// ===========================================================================
+// small helpers
+// ===========================================================================
+// out[e] = sum_c partial[c][e] in a fixed order.  Block = 16 consecutive elements x 16 part lanes: a part lane
+// adds every 16th record with four independent accumulators, then the lanes are folded by a tree in LDS.
+// (One thread per element walking all records serially was latency-bound: 1.5 ms for 4096 records.)
+__global__ void __launch_bounds__(256) reduce_partials_kernel(const double* __restrict__ partial, int nparts, int64_t n,
+                                                              double* __restrict__ out) {
+  __shared__ double sh[16][17];
+  const int ex = threadIdx.x & 15, py = threadIdx.x >> 4;
+  const int64_t e = (int64_t)blockIdx.x * 16 + ex;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  if (e < n) {
+    const double* p = partial + e;
+    int c = py;
+    for (; c + 48 < nparts; c += 64) {
+      s0 += p[(int64_t)c * n];
+      s1 += p[(int64_t)(c + 16) * n];
+      s2 += p[(int64_t)(c + 32) * n];
+      s3 += p[(int64_t)(c + 48) * n];
+    }
+    for (; c < nparts; c += 16) s0 += p[(int64_t)c * n];
+  }
+  sh[py][ex] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  for (int w = 8; w > 0; w >>= 1) {
+    if (py < w) sh[py][ex] += sh[py + w][ex];
+    __syncthreads();
+  }
+  if (py == 0 && e < n) out[e] = sh[0][ex];
+}
+
+// few elements, many parts: one block per element, fixed-shape strided sum + tree
+__global__ void __launch_bounds__(256) reduce_cols_kernel(const double* partial, int nparts, int64_t n, double* out) {
+  __shared__ double sh[256];
+  const int64_t e = blockIdx.x;
+  double s = 0.0;
+  for (int c = threadIdx.x; c < nparts; c += 256) s += partial[(int64_t)c * n + e];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[e] = sh[0];
+}
+
+// Sparse statistics: records exist only for (row chunk, active cluster) pairs; cluster k sums the records listed in
+// krec[kptr[k] .. kptr[k+1]) in list order (fixed => deterministic).  Same 16 x 16 tile as reduce_partials_kernel.
+__global__ void __launch_bounds__(256) reduce_records_kernel(const double* __restrict__ partial, int64_t n,
+                                                             const int* __restrict__ kptr, const int* __restrict__ krec,
+                                                             double* __restrict__ out) {
+  __shared__ double sh[16][17];
+  const int ex = threadIdx.x & 15, py = threadIdx.x >> 4, k = blockIdx.y;
+  const int64_t e = (int64_t)blockIdx.x * 16 + ex;
+  const int b = kptr[k], en = kptr[k + 1];
+  double s0 = 0.0, s1 = 0.0;
+  if (e < n) {
+    int c = b + py;
+    for (; c + 16 < en; c += 32) {
+      s0 += partial[(int64_t)krec[c] * n + e];
+      s1 += partial[(int64_t)krec[c + 16] * n + e];
+    }
+    for (; c < en; c += 16) s0 += partial[(int64_t)krec[c] * n + e];
+  }
+  sh[py][ex] = s0 + s1;
+  __syncthreads();
+  for (int w = 8; w > 0; w >>= 1) {
+    if (py < w) sh[py][ex] += sh[py + w][ex];
+    __syncthreads();
+  }
+  if (py == 0 && e < n) out[(int64_t)k * n + e] = sh[0][ex];
+}
+
+hipError_t launch_reduce_records(const double* partial, int64_t n, int K, const int* kptr, const int* krec, double* out,
+                                 hipStream_t stream) {
+  if (n <= 0 || K <= 0) return hipSuccess;
+  hipLaunchKernelGGL(reduce_records_kernel, dim3((unsigned)((n + 15) / 16), (unsigned)K), dim3(256), 0, stream, partial,
+                     n, kptr, krec, out);
+  return hipGetLastError();
+}
+
+// very many records of a few elements (the per-block F_z / LL_k partials of an E-step over 10^7 rows): 64 blocks
+// per element sum contiguous record ranges into tmp[e][64] (each with the fixed-shape tree above), a second
+// launch folds the 64.  Same summation order for a given (nparts, n) => deterministic.
+__global__ void __launch_bounds__(256) reduce_cols_stage1_kernel(const double* partial, int nparts, int64_t n,
+                                                                 double* tmp) {
+  __shared__ double sh[256];
+  const int64_t e = blockIdx.y;
+  const int per = (nparts + 63) / 64, c0 = blockIdx.x * per;
+  const int c1 = c0 + per < nparts ? c0 + per : nparts;
+  double s = 0.0;
+  for (int c = c0 + threadIdx.x; c < c1; c += 256) s += partial[(int64_t)c * n + e];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) tmp[e * 64 + blockIdx.x] = sh[0];
+}
+__global__ void __launch_bounds__(64) reduce_cols_stage2_kernel(const double* tmp, double* out) {
+  double v = tmp[(int64_t)blockIdx.x * 64 + threadIdx.x];
+  v = wave_sum(v);
+  if (threadIdx.x == 0) out[blockIdx.x] = v;
+}
+
+hipError_t launch_reduce_partials(const double* partial, int nparts, int64_t n, double* out, hipStream_t stream,
+                                  double* tmp) {
+  if (n <= 0) return hipSuccess;
+  if (tmp && nparts > 8192 && n <= REDUCE_TMP_ELEMS) {
+    hipLaunchKernelGGL(reduce_cols_stage1_kernel, dim3(64, (unsigned)n), dim3(256), 0, stream, partial, nparts, n, tmp);
+    hipLaunchKernelGGL(reduce_cols_stage2_kernel, dim3((unsigned)n), dim3(64), 0, stream, tmp, out);
+  } else if (nparts > 512 && n <= 4096) {
+    hipLaunchKernelGGL(reduce_cols_kernel, dim3((unsigned)n), dim3(256), 0, stream, partial, nparts, n, out);
+  } else {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, stream, partial,
+                       nparts, n, out);
+  }
+  return hipGetLastError();
+}
+
+// one block per (k, j): fixed-shape tree => deterministic
+__global__ void __launch_bounds__(256) group_colsum_kernel(const double* qZ, int64_t ldq, int K, const int64_t* goff,
+                                                           double* out) {
+  __shared__ double sh[256];
+  const int k = blockIdx.x, j = blockIdx.y;
+  const int64_t b = goff[j], e = goff[j + 1];
+  double s = 0.0;
+  for (int64_t r = b + threadIdx.x; r < e; r += 256) s += qZ[(int64_t)k * ldq + r];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[(int64_t)j * K + k] = sh[0];
+}
+
+// many small groups (the documents of learnSCM / learnMCM): one block per group, wave w sums the columns
+// w, w+4, ... with a fixed-shape reduction => deterministic
+__global__ void __launch_bounds__(256) group_colsum_small_kernel(const double* qZ, int64_t ldq, int K,
+                                                                 const int64_t* goff, double* out) {
+  const int j = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t b = goff[j], e = goff[j + 1];
+  for (int k = w; k < K; k += 4) {
+    double s = 0.0;
+    for (int64_t r = b + lane; r < e; r += 64) s += qZ[(int64_t)k * ldq + r];
+    s = wave_sum(s);
+    if (lane == 0) out[(int64_t)j * K + k] = s;
+  }
+}
+
+hipError_t launch_group_colsum(const double* qZ, int64_t ldq, int K, const int64_t* goff, int J, double* out,
+                               hipStream_t stream) {
+  if (K <= 0 || J <= 0) return hipSuccess;
+  if (J > 1024)
+    hipLaunchKernelGGL(group_colsum_small_kernel, dim3((unsigned)J), dim3(256), 0, stream, qZ, ldq, K, goff, out);
+  else
+    hipLaunchKernelGGL(group_colsum_kernel, dim3((unsigned)K, (unsigned)J), dim3(256), 0, stream, qZ, ldq, K, goff,
+                       out);
+  return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) fill_qz_kernel(double* qZ, int64_t ldq, int K, const int* rginfo,
+                                                      int64_t nrows, int64_t NP, double value) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= NP) return;
+  bool ok;
+  if (rginfo)
+    ok = (row & 15) < (rginfo[row >> 4] & 31);
+  else
+    ok = row < nrows;
+  const double v = ok ? value : 0.0;
+  for (int k = 0; k < K; ++k) qZ[(int64_t)k * ldq + row] = v;
+}
+
+hipError_t launch_fill_qz(double* qZ, int64_t ldq, int K, const int* rginfo, int64_t nrows, int64_t nrg, double value,
+                          hipStream_t stream) {
+  const int64_t NP = nrg * RG;
+  if (NP <= 0 || K <= 0) return hipSuccess;
+  hipLaunchKernelGGL(fill_qz_kernel, dim3((unsigned)((NP + 255) / 256)), dim3(256), 0, stream, qZ, ldq, K, rginfo,
+                     nrows, NP, value);
+  return hipGetLastError();
+}
+
+
+// ===========================================================================
+// split-search data passes: partobs / splitobs / auglabels
+// ===========================================================================
+// partobs (src/comutils.cpp:56-72) selects the rows with q_k > 0.5 in order.  Two passes over the
+// column: per-block counts, then (after the host scans the ~N/1024 counts) an ordered compaction.
+constexpr int SEL_ROWS = 1024;  // rows per 256-thread block, 4 consecutive rows per thread
+
+__global__ void __launch_bounds__(256) select_count_kernel(const double* qcol, int64_t NP, double thresh,
+                                                           int* counts) {
+  __shared__ int sh[256];
+  const int64_t r0 = (int64_t)blockIdx.x * SEL_ROWS + threadIdx.x * 4;
+  int c = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (r0 + i < NP && qcol[r0 + i] > thresh) ++c;
+  sh[threadIdx.x] = c;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) counts[blockIdx.x] = sh[0];
+}
+
+__global__ void __launch_bounds__(256) select_compact_kernel(const double* qcol, int64_t NP, double thresh,
+                                                             const int64_t* offsets, int64_t* idx) {
+  __shared__ int sh[256];
+  const int64_t r0 = (int64_t)blockIdx.x * SEL_ROWS + threadIdx.x * 4;
+  bool f[4];
+  int c = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[i] = r0 + i < NP && qcol[r0 + i] > thresh;
+    c += f[i] ? 1 : 0;
+  }
+  sh[threadIdx.x] = c;
+  __syncthreads();
+  // inclusive Hillis-Steele scan over the 256 per-thread counts
+  for (int d = 1; d < 256; d <<= 1) {
+    const int v = (int)threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
+    __syncthreads();
+    sh[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int64_t pos = offsets[blockIdx.x] + sh[threadIdx.x] - c;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (f[i]) idx[pos++] = r0 + i;
+}
+
+hipError_t launch_select_count(const double* qcol, int64_t NP, double thresh, int* counts, hipStream_t stream) {
+  if (NP <= 0) return hipSuccess;
+  const unsigned nb = (unsigned)((NP + SEL_ROWS - 1) / SEL_ROWS);
+  hipLaunchKernelGGL(select_count_kernel, dim3(nb), dim3(256), 0, stream, qcol, NP, thresh, counts);
+  return hipGetLastError();
+}
+
+hipError_t launch_select_compact(const double* qcol, int64_t NP, double thresh, const int64_t* offsets, int64_t* idx,
+                                 hipStream_t stream) {
+  if (NP <= 0) return hipSuccess;
+  const unsigned nb = (unsigned)((NP + SEL_ROWS - 1) / SEL_ROWS);
+  hipLaunchKernelGGL(select_compact_kernel, dim3(nb), dim3(256), 0, stream, qcol, NP, thresh, offsets, idx);
+  return hipGetLastError();
+}
+int select_blocks(int64_t NP) { return (int)((NP + SEL_ROWS - 1) / SEL_ROWS); }
+
+// starts[j] = first position p with idx[p] >= goff[j]  (idx ascending), j = 0..J
+__global__ void group_starts_kernel(const int64_t* idx, int64_t M, const int64_t* goff, int J, int64_t* starts) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j > J) return;
+  const int64_t key = goff[j];
+  int64_t lo = 0, hi = M;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (idx[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  starts[j] = lo;
+}
+
+hipError_t launch_group_starts(const int64_t* idx, int64_t M, const int64_t* goff, int J, int64_t* starts,
+                               hipStream_t stream) {
+  hipLaunchKernelGGL(group_starts_kernel, dim3((unsigned)((J + 1 + 63) / 64)), dim3(64), 0, stream, idx, M, goff, J,
+                     starts);
+  return hipGetLastError();
+}
+
+// position p of the selection -> (group j, destination row in the gathered, re-padded layout)
+__device__ __forceinline__ int64_t sel_dst_row(int64_t p, const int64_t* starts, const int64_t* goff_sub, int J) {
+  int lo = 0, hi = J;  // largest j with starts[j] <= p
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (starts[mid] <= p) lo = mid; else hi = mid;
+  }
+  return goff_sub[lo] + (p - starts[lo]);
+}
+
+// Xk = X(rows idx): partobs' copy, device to device; one thread per (selected row, double2)
+__global__ void __launch_bounds__(256) gather_rows_kernel(const double* X, int DP, const int64_t* idx, int64_t M,
+                                                          const int64_t* starts, const int64_t* goff_sub, int J,
+                                                          double* Xdst) {
+  const int per = DP / 2;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= M * per) return;
+  const int64_t p = t / per;
+  const int c2 = (int)(t % per);
+  const int64_t dst = sel_dst_row(p, starts, goff_sub, J);
+  reinterpret_cast<double2*>(Xdst + dst * DP)[c2] = reinterpret_cast<const double2*>(X + idx[p] * DP)[c2];
+}
+
+hipError_t launch_gather_rows(const double* X, int DP, const int64_t* idx, int64_t M, const int64_t* starts,
+                              const int64_t* goff_sub, int J, double* Xdst, hipStream_t stream) {
+  if (M <= 0) return hipSuccess;
+  const int64_t n = M * (DP / 2);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, X, DP, idx, M, starts,
+                     goff_sub, J, Xdst);
+  return hipGetLastError();
+}
+
+// splitobs + the initial split responsibilities (cluster.cpp:446-449).  mode 0 (GaussWish
+// distributions.cpp:373-385, NormGamma :495-505): q0 = (sum_d (x_d - m_d) v_d >= 0); mode 1 (first pass of
+// ExpGamma :575-581): q0 = sum_d x_d v_d (the projection itself, for the per-group mean); mode 2 (second
+// pass): q0 = (q0 > thr[group]).  q1 = 1 - q0 in modes 0 and 2; pad rows 0.  mv = [m(DP), v(DP)].
+__global__ void __launch_bounds__(256) split_init_kernel(const double* X, int DP, int D, int64_t NP, const int* rginfo,
+                                                         int64_t nrows, const double* mv, double* q, int64_t ldq,
+                                                         int mode, const double* thr) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= NP) return;
+  int grp = 0;
+  bool ok;
+  if (rginfo) {
+    const int info = rginfo[row >> 4];
+    grp = info >> 5;
+    ok = (int)(row & 15) < (info & 31);
+  } else {
+    ok = row < nrows;
+  }
+  double q0 = 0.0, q1 = 0.0;
+  if (ok) {
+    if (mode == 2) {
+      q0 = q[row] > thr[grp] ? 1.0 : 0.0;
+      q1 = 1.0 - q0;
+    } else {
+      double s = 0.0;
+      if (mode == 0) {
+        for (int d = 0; d < D; ++d) s += (X[row * DP + d] - mv[d]) * mv[DP + d];
+        q0 = s >= 0.0 ? 1.0 : 0.0;
+        q1 = 1.0 - q0;
+      } else {
+        for (int d = 0; d < D; ++d) s += X[row * DP + d] * mv[DP + d];
+        q0 = s;
+      }
+    }
+  }
+  q[row] = q0;
+  q[ldq + row] = q1;
+}
+
+hipError_t launch_split_init(const double* X, int DP, int D, int64_t NP, const int* rginfo, int64_t nrows,
+                             const double* mv, double* q, int64_t ldq, int mode, const double* thr,
+                             hipStream_t stream) {
+  if (NP <= 0) return hipSuccess;
+  hipLaunchKernelGGL(split_init_kernel, dim3((unsigned)((NP + 255) / 256)), dim3(256), 0, stream, X, DP, D, NP, rginfo,
+                     nrows, mv, q, ldq, mode, thr);
+  return hipGetLastError();
+}
+
+// auglabels (src/comutils.cpp:75-104) straight from the refined sub-problem: every selected row whose
+// second refined responsibility exceeds 0.5 moves its column-k mass to the new column K
+__global__ void __launch_bounds__(256) aug_from_sub_kernel(double* q, int64_t ldq, int k, int K, const int64_t* idx,
+                                                           int64_t M, const int64_t* starts, const int64_t* goff_sub,
+                                                           int J, const double* qsub1) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= M) return;
+  const int64_t sub = sel_dst_row(p, starts, goff_sub, J);
+  if (qsub1[sub] > 0.5) {
+    const int64_t r = idx[p];
+    q[(int64_t)K * ldq + r] = q[(int64_t)k * ldq + r];
+    q[(int64_t)k * ldq + r] = 0.0;
+  }
+}
+
+hipError_t launch_aug_from_sub(double* q, int64_t ldq, int k, int K, const int64_t* idx, int64_t M,
+                               const int64_t* starts, const int64_t* goff_sub, int J, const double* qsub1,
+                               hipStream_t stream) {
+  if (M <= 0) return hipSuccess;
+  hipLaunchKernelGGL(aug_from_sub_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, stream, q, ldq, k, K, idx, M,
+                     starts, goff_sub, J, qsub1);
+  return hipGetLastError();
+}
+
+
+// ===========================================================================
+// synthetic mixture (bench workload)
+// ===========================================================================
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t out[4]) {
+  constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+    const uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += W0; k1 += W1;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ double u01(uint32_t a, uint32_t b) {
+  // 53-bit uniform in (0,1)
+  const uint64_t v = (((uint64_t)a << 32) | b) >> 11;
+  return ((double)v + 0.5) * (1.0 / 9007199254740992.0);
+}
+
+// 16 rows (one row-group => one group of observations) per 256-thread block; eps staged in LDS.
+// Philox counter = (group id << 40) + row inside the group (+ row_offset), so any shard of any group can
+// be regenerated independently.  Labels: uniform, or by inverse CDF of the group's mixing proportions.
+__global__ void __launch_bounds__(256) synth_kernel(SynthLaunch a) {
+  extern __shared__ double eps[];  // [16][DP]
+  __shared__ int zlab[16];
+  const int DP = a.DP, D = a.D, K = a.K;
+  const int64_t row0 = (int64_t)blockIdx.x * 16;
+  int grp = 0, nvalid;
+  if (a.rginfo) {
+    const int info = a.rginfo[blockIdx.x];
+    grp = info >> 5;
+    nvalid = info & 31;
+  } else {
+    const int64_t rem = a.nrows - row0;
+    nvalid = rem >= 16 ? 16 : (rem > 0 ? (int)rem : 0);
+  }
+  const int64_t ingrp0 = row0 - (a.goff ? a.goff[grp] : 0);  // row inside its group
+  const uint64_t gid = a.gids ? (uint64_t)a.gids[grp] : (uint64_t)(a.group_base + grp);
+  const uint64_t gbase = (gid << 40) + (uint64_t)(a.row_offset + ingrp0);
+  const uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32);
+  const int npair = (D + 1) / 2;
+  for (int t = threadIdx.x; t < 16 * npair; t += 256) {
+    const int r = t / npair, p = t % npair;
+    const uint64_t g = gbase + (uint64_t)r;
+    uint32_t o[4];
+    philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)p, 1u, k0, k1, o);
+    const double u1 = u01(o[0], o[1]), u2 = u01(o[2], o[3]);
+    const double rad = sqrt(-2.0 * log(u1));
+    double sn, cs;
+    sincos(6.283185307179586476925 * u2, &sn, &cs);
+    eps[r * DP + 2 * p] = rad * cs;
+    if (2 * p + 1 < D) eps[r * DP + 2 * p + 1] = rad * sn;
+  }
+  if (threadIdx.x < 16) {
+    const uint64_t g = gbase + (uint64_t)threadIdx.x;
+    uint32_t o[4];
+    philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), 0u, 2u, k0, k1, o);
+    int z;
+    if (a.cdf) {
+      const double u = u01(o[0], o[1]);
+      const double* c = a.cdf + (int64_t)grp * K;
+      z = K - 1;
+      for (int k = 0; k < K - 1; ++k)
+        if (u < c[k]) {
+          z = k;
+          break;
+        }
+    } else {
+      z = (int)(o[0] % (uint32_t)K);
+    }
+    zlab[threadIdx.x] = z;
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < 16 * DP; t += 256) {
+    const int r = t / DP, i = t % DP;
+    const int64_t row = row0 + r;
+    if (row >= a.NP) continue;
+    double v = 0.0;
+    if (r < nvalid && i < D) {
+      const int z = zlab[r];
+      const double* Lz = a.L + ((int64_t)z * D + i) * D;
+      v = a.mu[(int64_t)z * D + i];
+      for (int j = 0; j <= i; ++j) v += Lz[j] * eps[r * DP + j];
+    }
+    a.X[row * DP + i] = v;
+  }
+  if (a.qZ) {
+    for (int t = threadIdx.x; t < 16 * K; t += 256) {
+      const int k = t / 16, r = t % 16;
+      const int64_t row = row0 + r;
+      if (row >= a.NP) continue;
+      double q = 0.0;
+      if (r < nvalid) q = K == 1 ? 1.0 : (k == zlab[r] ? a.hard : (1.0 - a.hard) / (K - 1));
+      a.qZ[(int64_t)k * a.ldq + row] = q;
+    }
+  }
+}
+
+hipError_t launch_synth(const SynthLaunch& a, hipStream_t stream) {
+  if (a.NP <= 0) return hipSuccess;
+  const size_t shmem = (size_t)16 * a.DP * sizeof(double);
+  hipLaunchKernelGGL(synth_kernel, dim3((unsigned)((a.NP + 15) / 16)), dim3(256), shmem, stream, a);
+  return hipGetLastError();
+}
+
+
+}  // namespace lck

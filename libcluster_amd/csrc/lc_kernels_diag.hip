@@ -1,0 +1,448 @@
+// E-step and statistics of the diagonal (NormGamma) and exponential (ExpGamma) cluster families (src/distributions.cpp:418-590)
+// (one translation unit per kernel family; the file header of lc_kernels_estep.hip maps kernels to the reference)
+#include "lc_device.hpp"
+
+namespace lck {
+
+// ===========================================================================
+// Diagonal / exponential cluster families
+// ===========================================================================
+// NormGamma::Eloglike (src/distributions.cpp:483-492) and ExpGamma::Eloglike (:568-572) inside the same
+// vbexpectation (cluster.cpp:91-138):  log q~[n,k] = c_jk + sum_d ( w2_kd (x_nd - a_kd)^2 + w1_kd x_nd ).
+// O(N K D) fp64 VALU operations against 8(D+K) bytes per row: at D = 64, K = 32 the two limits are about equal
+// (the fp64 vector rate equals the fp64 MFMA rate on this part, and the difference form (x - a)^2 is not
+// bilinear, so there is nothing for the matrix pipe to do here).  The design therefore minimises everything
+// that is not one of the 3 (NormGamma) / 1 (ExpGamma) operations per (row, cluster, dimension):
+//  * a 256-thread block owns 64 rows, staged once in LDS (coalesced load; odd row stride => conflict-free
+//    per-lane row reads); lane = row;
+//  * wave w owns the cluster tiles {w, w+4, ...} of KT clusters: the tile index is wave-uniform, so the
+//    parameters arrive through the scalar cache as SGPR operands (no vector loads, no LDS traffic), and one
+//    LDS read of x feeds 3*KT operations;
+//  * log q~ stays in registers up to K = 4*DIAG_MAXT*KT clusters; the row maximum and sum cross the four waves
+//    through 2 KB of LDS; beyond that the columns are re-read from L2.
+// MODE 0: general (a, w2, w1); 1: w1 == 0 (NormGamma); 2: a == w2 == 0 (ExpGamma).
+constexpr int DIAG_MAXT = 4;
+
+template <int MODE, int KT>
+__device__ __forceinline__ void diag_tile(const double* __restrict__ xr, const double* __restrict__ PA,
+                                          const double* __restrict__ PW2, const double* __restrict__ PW1, int k0,
+                                          int K, int DP, double (&acc)[KT]) {
+  const double* pa[KT];
+  const double* p2[KT];
+  const double* p1[KT];
+#pragma unroll
+  for (int j = 0; j < KT; ++j) {
+    const int k = k0 + j < K ? k0 + j : K - 1;  // clamped: the caller discards clusters >= K
+    pa[j] = PA + (int64_t)k * DP;
+    p2[j] = PW2 + (int64_t)k * DP;
+    p1[j] = PW1 + (int64_t)k * DP;
+    acc[j] = 0.0;
+  }
+  for (int d = 0; d < DP; d += 4) {
+    double x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) x[u] = xr[d + u];
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (MODE != 2) {
+          const double t = x[u] - pa[j][d + u];
+          acc[j] = fma(t * p2[j][d + u], t, acc[j]);
+        }
+        if (MODE != 1) acc[j] = fma(p1[j][d + u], x[u], acc[j]);
+      }
+    }
+  }
+}
+
+template <int MODE, int KT, bool REG>
+__global__ void __launch_bounds__(256)
+    estep_diag_kernel(const double* __restrict__ X, const double* __restrict__ PA, const double* __restrict__ PW2,
+                      const double* __restrict__ PW1, const double* __restrict__ ctab, const int* __restrict__ rginfo,
+                      double* __restrict__ qZ, double* __restrict__ fz_part, double* __restrict__ ll_part, int DP, int K,
+                      int64_t NP, int64_t nrows, int64_t ldq, int raw) {
+  extern __shared__ double lds[];
+  const int LD = DP + 1;
+  double* xt = lds;             // [64][LD]
+  double* red = lds + 64 * LD;  // [4][64]
+  double* llw = red + 256;      // [K]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t row0 = (int64_t)blockIdx.x * 64;
+  {
+    const int c2 = DP >> 1, sh = __builtin_ctz(c2);  // double2 columns per row (DP is a power of two)
+    const double2* X2 = reinterpret_cast<const double2*>(X);
+    for (int idx = tid; idx < 64 * c2; idx += 256) {
+      const int r = idx >> sh, c = idx & (c2 - 1);
+      double2 v = make_double2(0.0, 0.0);
+      if (row0 + r < NP) v = X2[(row0 + r) * c2 + c];
+      xt[r * LD + 2 * c] = v.x;
+      xt[r * LD + 2 * c + 1] = v.y;
+    }
+  }
+  __syncthreads();
+  const int64_t row = row0 + lane;
+  const bool inb = row < NP;
+  int grp = 0;
+  bool ok = false;
+  if (inb) {
+    if (rginfo) {
+      const int info = rginfo[row >> 4];
+      grp = info >> 5;
+      ok = (int)(row & 15) < (info & 31);
+    } else {
+      ok = row < nrows;
+    }
+  }
+  const double* xr = xt + lane * LD;
+  const double* crow = ctab + (int64_t)grp * K;
+  const int ntiles = (K + KT - 1) / KT;
+  const double NINF = -INFINITY;
+  double mx = NINF;
+  double lq[REG ? DIAG_MAXT : 1][KT], dt[REG ? DIAG_MAXT : 1][KT];
+
+  // ---- pass 1: log q~ for this wave's tiles ----
+  if (REG) {
+#pragma unroll
+    for (int i = 0; i < DIAG_MAXT; ++i) {
+      const int tile = w + 4 * i;
+#pragma unroll
+      for (int j = 0; j < KT; ++j) lq[i][j] = NINF, dt[i][j] = 0.0;
+      if (tile < ntiles) {
+        double acc[KT];
+        diag_tile<MODE, KT>(xr, PA, PW2, PW1, tile * KT, K, DP, acc);
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {
+          const int k = tile * KT + j;
+          if (k < K) {
+            const double v = crow[k] + acc[j];
+            lq[i][j] = v;
+            dt[i][j] = acc[j];
+            mx = fmax(mx, v);
+            if (raw && inb) qZ[(int64_t)k * ldq + row] = v;
+          }
+        }
+      }
+    }
+  } else {
+    for (int tile = w; tile < ntiles; tile += 4) {
+      double acc[KT];
+      diag_tile<MODE, KT>(xr, PA, PW2, PW1, tile * KT, K, DP, acc);
+#pragma unroll
+      for (int j = 0; j < KT; ++j) {
+        const int k = tile * KT + j;
+        if (k < K) {
+          const double v = crow[k] + acc[j];
+          mx = fmax(mx, v);
+          if (inb) qZ[(int64_t)k * ldq + row] = v;
+        }
+      }
+    }
+  }
+  if (raw) return;
+
+  // ---- row maximum and sum of exponentials across the four waves (logsumexp, probutils.cpp:141-150) ----
+  red[w * 64 + lane] = mx;
+  __syncthreads();
+  mx = fmax(fmax(red[lane], red[64 + lane]), fmax(red[128 + lane], red[192 + lane]));
+  __syncthreads();
+  double se = 0.0;
+  if (REG) {
+#pragma unroll
+    for (int i = 0; i < DIAG_MAXT; ++i)
+#pragma unroll
+      for (int j = 0; j < KT; ++j) {
+        lq[i][j] = exp(lq[i][j] - mx);  // exp(-inf) = 0 for the slots past K
+        se += lq[i][j];
+      }
+  } else if (inb) {
+    for (int tile = w; tile < ntiles; tile += 4)
+      for (int j = 0; j < KT; ++j) {
+        const int k = tile * KT + j;
+        if (k < K) se += exp(qZ[(int64_t)k * ldq + row] - mx);
+      }
+  }
+  red[w * 64 + lane] = se;
+  __syncthreads();
+  se = red[lane] + red[64 + lane] + red[128 + lane] + red[192 + lane];
+  const double logZ = log(se) + mx;
+  const double inv = 1.0 / se;
+
+  // ---- pass 2: q = exp(log q~ - logZ), data term of the split ordering ----
+  if (REG) {
+#pragma unroll
+    for (int i = 0; i < DIAG_MAXT; ++i) {
+      const int tile = w + 4 * i;
+      if (tile < ntiles) {
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {
+          const int k = tile * KT + j;
+          if (k < K) {
+            const double q = ok ? lq[i][j] * inv : 0.0;
+            if (inb) qZ[(int64_t)k * ldq + row] = q;
+            if (ll_part) {
+              const double ll = wave_sum(q > 0.0 ? q * dt[i][j] : 0.0);
+              if (lane == 0) llw[k] = ll;
+            }
+          }
+        }
+      }
+    }
+  } else {
+    for (int tile = w; tile < ntiles; tile += 4)
+      for (int j = 0; j < KT; ++j) {
+        const int k = tile * KT + j;
+        if (k < K) {
+          double ll = 0.0;
+          if (inb) {
+            double* qp = qZ + (int64_t)k * ldq + row;
+            const double v = *qp;
+            const double q = ok ? exp(v - mx) * inv : 0.0;
+            *qp = q;
+            if (ll_part && q > 0.0) ll = q * (v - crow[k]);
+          }
+          if (ll_part) {
+            ll = wave_sum(ll);
+            if (lane == 0) llw[k] = ll;
+          }
+        }
+      }
+  }
+  double fz = (w == 0 && ok) ? logZ : 0.0;
+  fz = wave_sum(fz);
+  __syncthreads();
+  if (tid == 0) fz_part[blockIdx.x] = -fz;
+  if (ll_part)
+    for (int k = tid; k < K; k += 256) ll_part[(int64_t)blockIdx.x * K + k] = llw[k];
+}
+
+template <int MODE, int KT, bool REG>
+static hipError_t launch_ed_t(const DiagEstepLaunch& a, int64_t grid, size_t shmem, hipStream_t stream) {
+  auto kern = estep_diag_kernel<MODE, KT, REG>;
+  static size_t attr_set = 0;
+  if (shmem > 64 * 1024 && shmem > attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)shmem);
+    if (e != hipSuccess) return e;
+    attr_set = shmem;
+  }
+  const double* PA = a.params;
+  const double* PW2 = PA + (int64_t)a.K * a.DP;
+  const double* PW1 = PW2 + (int64_t)a.K * a.DP;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), shmem, stream, a.X, PA, PW2, PW1, a.ctab, a.rginfo, a.qZ,
+                     a.fz_part, a.ll_part, a.DP, a.K, a.nrg * RG, a.nrows, a.ldq, a.raw);
+  return hipGetLastError();
+}
+
+template <int MODE>
+static hipError_t launch_ed_m(const DiagEstepLaunch& a, int64_t grid, size_t shmem, hipStream_t stream) {
+  // clusters per tile: every wave should have work (K >= 4*KT), registers hold 4*DIAG_MAXT*KT columns
+  if (a.K <= 4) return launch_ed_t<MODE, 1, true>(a, grid, shmem, stream);
+  if (a.K <= 8) return launch_ed_t<MODE, 2, true>(a, grid, shmem, stream);
+  if (a.K <= 4 * DIAG_MAXT * 4) return launch_ed_t<MODE, 4, true>(a, grid, shmem, stream);
+  return launch_ed_t<MODE, 4, false>(a, grid, shmem, stream);
+}
+
+hipError_t launch_estep_diag(const DiagEstepLaunch& a, hipStream_t stream) {
+  const int64_t grid = (a.nrg * RG + 63) / 64;
+  if (grid <= 0) return hipSuccess;
+  const size_t shmem = (size_t)(64 * (a.DP + 1) + 256 + a.K) * sizeof(double);
+  switch (a.mode) {
+    case 1:
+      return launch_ed_m<1>(a, grid, shmem, stream);
+    case 2:
+      return launch_ed_m<2>(a, grid, shmem, stream);
+    default:
+      return launch_ed_m<0>(a, grid, shmem, stream);
+  }
+}
+
+// NormGamma::addobs (distributions.cpp:426-438) / ExpGamma::addobs (:533-542):
+//   N_k = sum_n q_nk,  x_s[k][d] = sum_n q_nk x_nd,  xx_s[k][d] = sum_n q_nk x_nd^2.
+// These are plain GEMMs  Q^T X  and  Q^T X.^2  (reduction over rows; bilinear, so the matrix pipe applies
+// without any cancellation concern), 2 N K D MACs against 8(D+K) bytes per row.  A VALU formulation is
+// LDS-issue-bound (every FMA pair needs a broadcast q operand from LDS); v_mfma_f64_4x4x4_4b shares each
+// operand fragment over 4 x 4 outputs, so one ds_read feeds 16 MACs per lane instead of 1.
+//   One MFMA: A[i][k] = q[row k][cluster i] (the same fragment in all four blocks),
+//             B_b[k][j] = x[row k][dim 16 jb + 4 b + j]  (b = MFMA block) -> 4 clusters x 16 dims x 4 rows.
+//   A wave owns 16 clusters (CT = 4 cluster tiles) x all DP dims x {x, x^2}: CT*NB*2 accumulators.
+//   A block = 4 waves = up to 64 clusters ("slice"); with fewer than 3 cluster groups of 16 the waves also
+//   split the 4-row steps of a batch (RS = 2 or 4 row classes, each writing its own partial record).
+// X batches (BR rows) and the slice's q columns are staged through LDS, next batch in flight in registers,
+// the same scheme as suffstat_kernel.
+constexpr int SD_QMAX = 64;  // clusters per block
+template <int DP, bool SECOND>
+__global__ void __launch_bounds__(256, 2) suffstat_diag_kernel(DiagStatLaunch a) {
+  constexpr int NB = DP / 16, CT = 4;
+  constexpr int BR = DP <= 64 ? 32 : 16;
+  constexpr int LD = DP + 16, XBUF = BR * LD;
+  constexpr int NV2 = BR * DP / 2, NPRE = (NV2 + 255) / 256;   // double2 per thread and batch
+  constexpr int NQ = SD_QMAX * BR / 256;                       // q elements per thread and batch
+  constexpr int QLD = BR + 4;                                  // padded q column stride: conflict-free A fragments
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* xbuf = lds;                // [2][BR][LD]
+  double* qbuf = lds + 2 * XBUF;     // [2][SD_QMAX][QLD]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lo2 = lane & 3, blk = (lane >> 2) & 3, hi = lane >> 4, lo4 = lane & 15;
+  const int K = a.K, RS = a.rsplit;
+  const int chunk = blockIdx.x / a.nslice, slice = blockIdx.x % a.nslice;
+  const int kb0 = slice * SD_QMAX;
+  const int kc = (K - kb0) < SD_QMAX ? (K - kb0) : SD_QMAX;     // clusters of this block
+  const int group = RS == 1 ? wave : RS == 2 ? (wave & 1) : 0;  // 16-cluster group of this wave
+  const int rcls = RS == 1 ? 0 : RS == 2 ? (wave >> 1) : wave;  // row class (steps st = rcls mod RS)
+  const bool active = group * 16 < kc;
+  const int64_t r0 = (int64_t)chunk * a.chunk_rows;
+  const int64_t r1 = (r0 + a.chunk_rows) < a.NP ? (r0 + a.chunk_rows) : a.NP;
+
+  double acc1[CT][NB], acc2[CT][NB], nacc[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) {
+    nacc[c] = 0.0;
+#pragma unroll
+    for (int jb = 0; jb < NB; ++jb) acc1[c][jb] = acc2[c][jb] = 0.0;
+  }
+
+  double pre[NPRE][2], qpre[NQ];
+  auto gload = [&](int64_t b0) {
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) {
+      const int idx = tid + i * 256;  // double2 index inside the batch, row-major [BR][DP/2]
+      const int row = idx / (DP / 2), c2 = idx % (DP / 2);
+      double2 v = make_double2(0.0, 0.0);
+      if (idx < NV2 && b0 + row < r1) v = *reinterpret_cast<const double2*>(a.X + (b0 + row) * DP + 2 * c2);
+      pre[i][0] = v.x;
+      pre[i][1] = v.y;
+    }
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int idx = tid + i * 256;  // [SD_QMAX][BR]
+      const int kk = idx / BR, r = idx % BR;
+      double q = 0.0;
+      if (kk < kc && b0 + r < r1) {
+        q = a.qZ[(int64_t)(kb0 + kk) * a.ldq + b0 + r];
+        if (a.smask && !a.smask[(int64_t)(a.rginfo[(b0 + r) >> 4] >> 5) * K + kb0 + kk]) q = 0.0;
+      }
+      qpre[i] = q;
+    }
+  };
+  auto lstore = [&](int buf) {
+    double* xb = xbuf + buf * XBUF;
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx / (DP / 2), c2 = idx % (DP / 2);
+      if (idx < NV2) *reinterpret_cast<double2*>(xb + row * LD + 2 * c2) = make_double2(pre[i][0], pre[i][1]);
+    }
+    double* qb = qbuf + buf * SD_QMAX * QLD;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int idx = tid + i * 256;
+      qb[(idx / BR) * QLD + idx % BR] = qpre[i];
+    }
+  };
+
+  if (r0 < r1) {
+    gload(r0);
+    lstore(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int64_t b0 = r0; b0 < r1; b0 += BR, buf ^= 1) {
+    const bool more = b0 + BR < r1;
+    if (more) gload(b0 + BR);
+    if (active) {
+      const double* xb = xbuf + buf * XBUF + hi * LD + 4 * blk + lo2;
+      const double* qb = qbuf + buf * SD_QMAX * QLD + (group * 16 + lo2) * QLD + hi;
+      // rows past the chunk end were staged as zeros with q = 0, so every step runs
+      for (int st = rcls; st < BR / 4; st += RS) {
+        double xf[NB], x2[NB];
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb) {
+          xf[jb] = xb[st * 4 * LD + 16 * jb];
+          if (SECOND) x2[jb] = xf[jb] * xf[jb];
+        }
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+          const double q = qb[4 * c * QLD + st * 4];
+          nacc[c] += q;
+#pragma unroll
+          for (int jb = 0; jb < NB; ++jb) {
+            acc1[c][jb] = mfma4(q, xf[jb], acc1[c][jb]);
+            if (SECOND) acc2[c][jb] = mfma4(q, x2[jb], acc2[c][jb]);
+          }
+        }
+      }
+    }
+    if (more) lstore(buf ^ 1);
+    __syncthreads();
+  }
+  if (!active) return;
+
+  // output lane (lo2, blk, hi) of accumulator (c, jb): cluster 4 c + hi, dimension 16 jb + 4 blk + lo2
+  const int64_t SS = 1 + 2 * (int64_t)DP;
+  double* rec = a.partial + ((int64_t)(chunk * RS + rcls) * K + kb0 + group * 16) * SS;
+#pragma unroll
+  for (int c = 0; c < CT; ++c) {
+    // N_k: this lane summed q[row class hi][cluster 4 c + lo2] (replicated over blk)
+    const double n = sum_over_hi(nacc[c]);
+    if (hi == 0 && blk == 0 && group * 16 + 4 * c + lo2 < kc) rec[(int64_t)(4 * c + lo2) * SS] = n;
+    if (group * 16 + 4 * c + hi < kc) {
+      double* out = rec + (int64_t)(4 * c + hi) * SS;
+#pragma unroll
+      for (int jb = 0; jb < NB; ++jb) {
+        out[1 + 16 * jb + lo4] = acc1[c][jb];
+        out[1 + DP + 16 * jb + lo4] = SECOND ? acc2[c][jb] : 0.0;
+      }
+    }
+  }
+}
+
+int suffstat_diag_rsplit(int K) {  // row classes per block: waves left over by the cluster groups split the rows
+  const int groups = ((K < SD_QMAX ? K : SD_QMAX) + 15) / 16;
+  return groups >= 3 ? 1 : groups == 2 ? 2 : 4;
+}
+
+template <int DP>
+static hipError_t launch_sd_t(const DiagStatLaunch& a, hipStream_t stream) {
+  constexpr int BR = DP <= 64 ? 32 : 16;
+  const size_t shmem = (size_t)(2 * BR * (DP + 16) + 2 * SD_QMAX * (BR + 4)) * sizeof(double);
+  static bool attr_set = false;
+  if (shmem > 64 * 1024 && !attr_set) {
+    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(suffstat_diag_kernel<DP, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(suffstat_diag_kernel<DP, false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e1 != hipSuccess) return e1;
+    if (e2 != hipSuccess) return e2;
+    attr_set = true;
+  }
+  const dim3 grid((unsigned)(a.nchunks * a.nslice));
+  if (a.second)
+    hipLaunchKernelGGL((suffstat_diag_kernel<DP, true>), grid, dim3(256), shmem, stream, a);
+  else
+    hipLaunchKernelGGL((suffstat_diag_kernel<DP, false>), grid, dim3(256), shmem, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_suffstat_diag(const DiagStatLaunch& a0, hipStream_t stream) {
+  if (a0.K <= 0 || a0.nchunks <= 0) return hipSuccess;
+  if (a0.chunk_rows % 32) return hipErrorInvalidValue;
+  DiagStatLaunch a = a0;
+  a.nslice = (a.K + SD_QMAX - 1) / SD_QMAX;
+  a.rsplit = suffstat_diag_rsplit(a.K);
+  switch (a.DP) {
+    case 16:
+      return launch_sd_t<16>(a, stream);
+    case 32:
+      return launch_sd_t<32>(a, stream);
+    case 64:
+      return launch_sd_t<64>(a, stream);
+    case 128:
+      return launch_sd_t<128>(a, stream);
+  }
+  return hipErrorInvalidValue;
+}
+
+
+}  // namespace lck

@@ -1,0 +1,363 @@
+// gfx950 (MI355X / CDNA4) kernels for the libcluster variational E-step and
+// sufficient-statistic accumulation.  fp64 throughout.
+//
+// What they replace in the reference (dsteinberg/libcluster):
+//   estep_kernel     vbexpectation            src/cluster.cpp:91-138
+//                    -> GaussWish::Eloglike   src/distributions.cpp:356-370
+//                    -> probutils::mahaldist  src/probutils.cpp:113-138
+//                    -> probutils::logsumexp  src/probutils.cpp:141-150
+//   suffstat_kernel  updateSS                 src/cluster.cpp:53-82
+//                    -> GaussWish::addobs     src/distributions.cpp:301-313
+//
+// Matrix instruction: v_mfma_f64_4x4x4_4b_f64 (four independent 4x4x4 blocks,
+// 512 flop, 16 cycles/SIMD = 32 flop/clk/SIMD; measured 73-74 TFLOP/s on
+// MI355X, vs 47-49 for v_mfma_f64_16x16x4_f64 -- profiles/r01_mfma_f64_probe.log).
+// Lane layout (probed, tools/mfma_f64_4x4_layout.hip), lane = lo2 + 4*blk + 16*hi:
+//   A[i][k] of block blk : i = lo2, k = hi
+//   B[k][j] of block blk : j = lo2, k = hi
+//   D[i][j] of block blk : j = lo2, i = hi
+#include "lc_device.hpp"
+
+namespace lck {
+
+// ===========================================================================
+// E-step
+// ===========================================================================
+// One wave owns R row-groups of 16 rows and keeps their X fragments in
+// registers for the whole cluster loop (X is read from HBM exactly once).
+// Per cluster k the host supplies A_k = sqrt(nu_k) * chol(iW_k)^-1 (lower
+// triangular), b_k = A_k m_k and c_jk, so that
+//     log q~[n,k] = c_jk - 0.5 * || A_k x_n - b_k ||^2
+// which equals E_logZ(k) + Eloglike_k(x_n) of cluster.cpp:120-121.
+// A_k arrives as 4x4 tiles in consumption order (only tiles on or below the
+// diagonal), staged through LDS with register double-buffering; one tile read
+// feeds R MFMAs.  MFMA block b <-> rows 4b..4b+3 of the row-group, so
+//   A operand = tile A_k[4it+lo2][4jt+hi]   (same for all 4 blocks)
+//   B operand = x[row = lane&15][4jt + hi]
+//   D         = y[4it+hi][row = lane&15]
+// log q~ is written to the qZ buffer as scratch, then normalised in place in
+// the same arithmetic order as the reference: max, sum exp(x-max), log+max,
+// exp(x - logZ).
+// n-th read of a cluster's parameter stream (for it: -b[it], tile(it,0), ..., tile(it,it)):
+// .jt < 0: element of the -b vector (offset in doubles from Pb), else of tile (it,jt) (from Pt)
+struct RdInfo {
+  int it, jt, off;
+};
+__host__ __device__ constexpr RdInfo rd_info(int n) {
+  int it = 0;
+  while (n >= it + 2) {
+    n -= it + 2;
+    ++it;
+  }
+  return n == 0 ? RdInfo{it, -1, 4 * it} : RdInfo{it, n - 1, (it * (it + 1) / 2 + (n - 1)) * 16};
+}
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(<N-1>)
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+template <int DP, int R, int WAVES, bool SPARSE>
+__global__ void __launch_bounds__(WAVES * 64, 2) estep_kernel(EstepLaunch a) {
+  constexpr int NT = DP / 4;
+  constexpr int NTILES = NT * (NT + 1) / 2;
+  constexpr int NREAD = NTILES + NT;  // LDS reads per cluster
+  constexpr int PF = 6;               // reads in flight ahead of their use
+  constexpr int PS = NTILES * 16 + DP;
+  constexpr int NTHR = WAVES * 64;
+  constexpr int NV2 = PS / 2;
+  constexpr int NPRE = (NV2 + NTHR - 1) / NTHR;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* pbuf = lds;              // [2][PS]
+  double* llw = lds + 2 * PS;      // [WAVES][K]
+  double* fzw = llw + WAVES * a.K; // [WAVES]
+  int* klist = reinterpret_cast<int*>(fzw + WAVES);  // sparse mode: [K] active clusters of this block, [K] flags,
+  int* kflag = klist + a.K;                          // [WAVES*R] groups of the block's row groups, [1] count
+  int* bgrp = kflag + a.K;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lo4 = lane & 15, hi = lane >> 4;
+  const int K = a.K;
+  const int64_t rg0 = ((int64_t)blockIdx.x * WAVES + wave) * R;
+
+  double xf[R][NT];
+  int grp[R];
+  bool rowok[R], rgok[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int64_t rg = rg0 + r;
+    rgok[r] = rg < a.nrg;
+    int info = 0;
+    if (rgok[r]) {
+      if (a.rginfo) {
+        info = a.rginfo[rg];
+      } else {
+        const int64_t rem = a.nrows - rg * RG;
+        info = rem >= RG ? RG : (rem > 0 ? (int)rem : 0);
+      }
+    }
+    grp[r] = info >> 5;
+    rowok[r] = lo4 < (info & 31);
+    const double* xr = a.X + ((rgok[r] ? rg : 0) * RG + lo4) * DP + hi;
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) xf[r][jt] = xr[4 * jt];
+  }
+
+  // register double-buffer for the next cluster's parameter record
+  double pre[NPRE][2];
+#define LC_GLOAD(kk)                                                                          \
+  {                                                                                           \
+    const double2* src_ = reinterpret_cast<const double2*>(a.params + (int64_t)(kk) * PS);   \
+    _Pragma("unroll") for (int i_ = 0; i_ < NPRE; ++i_) {                                     \
+      const int idx_ = tid + i_ * NTHR;                                                       \
+      const double2 v_ = src_[idx_ < NV2 ? idx_ : NV2 - 1];                                   \
+      pre[i_][0] = v_.x;                                                                      \
+      pre[i_][1] = v_.y;                                                                      \
+    }                                                                                         \
+  }
+#define LC_LSTORE(bb)                                                                         \
+  {                                                                                           \
+    double2* dst_ = reinterpret_cast<double2*>(pbuf + (bb) * PS);                             \
+    _Pragma("unroll") for (int i_ = 0; i_ < NPRE; ++i_) {                                     \
+      const int idx_ = tid + i_ * NTHR;                                                       \
+      if (idx_ < NV2) dst_[idx_] = make_double2(pre[i_][0], pre[i_][1]);                      \
+    }                                                                                         \
+  }
+
+  // Sparse mode (cluster.cpp:109-112, 134-135): the block walks only the clusters that are active (c_jk > -inf)
+  // for at least one of its row groups -- no parameter staging, barrier or MFMA for the others; their columns
+  // get log q~ = -inf directly.  Waves whose own row groups are all inactive for a listed cluster skip it too.
+  int nact = K;
+  if constexpr (SPARSE) {
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) bgrp[wave * R + r] = rgok[r] ? grp[r] : -1;
+    }
+    __syncthreads();
+    for (int k = tid; k < K; k += NTHR) {
+      int f = 0;
+      for (int g = 0; g < WAVES * R; ++g)
+        if (bgrp[g] >= 0 && a.ctab[(int64_t)bgrp[g] * K + k] != -INFINITY) f = 1;
+      kflag[k] = f;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int n = 0;
+      for (int k = 0; k < K; ++k)
+        if (kflag[k]) klist[n++] = k;
+      bgrp[WAVES * R] = n;
+    }
+    __syncthreads();
+    nact = bgrp[WAVES * R];
+    for (int k = 0; k < K; ++k) {
+      if (kflag[k]) continue;
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (rgok[r] && hi == (k & 3)) a.qZ[(int64_t)k * a.ldq + (rg0 + r) * RG + lo4] = -INFINITY;
+    }
+  }
+
+  if (nact > 0) {
+    LC_GLOAD(SPARSE ? klist[0] : 0);
+    LC_LSTORE(0);
+  }
+  __syncthreads();
+
+  double mx[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) mx[r] = -INFINITY;
+
+  for (int ii = 0; ii < nact; ++ii) {
+    const int k = SPARSE ? klist[ii] : ii;
+    const int buf = ii & 1;
+    if (ii + 1 < nact) LC_GLOAD(SPARSE ? klist[ii + 1] : ii + 1);
+    const double* P = pbuf + buf * PS;
+    const double* Pt = P + (lane & 3) + 4 * hi;  // this lane's element of every 4x4 tile
+    const double* Pb = P + NTILES * 16 + hi;     // this lane's element of every 4-vector of -b
+    // The cluster's parameters are consumed as one linear stream of LDS reads
+    // (for it: -b[it], tile(it,0..it)), software-pipelined PF reads ahead so no
+    // MFMA ever waits on the read issued just before it.
+    double ring[PF];
+    static_for<PF>([&](auto ic) {
+      constexpr RdInfo ri = rd_info(ic);
+      ring[ic] = ri.jt < 0 ? Pb[ri.off] : Pt[ri.off];
+    });
+    double d2[R], acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) d2[r] = 0.0;
+    // sparse mode (cluster.cpp:109-112): a cluster that is inactive (c_jk = -inf) for the groups of ALL of this
+    // wave's row groups needs no Mahalanobis term -- its log q~ is -inf whatever the distance
+    bool wave_active = true;
+    if constexpr (SPARSE) {
+      wave_active = false;
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        wave_active = wave_active || (rgok[r] && a.ctab[(int64_t)grp[r] * K + k] != -INFINITY);
+    }
+    if (wave_active)
+    static_for<NREAD>([&](auto nc) {
+      constexpr int n = nc;
+      constexpr RdInfo ri = rd_info(n);
+      const double v = ring[n % PF];
+      if constexpr (n + PF < NREAD) {
+        constexpr RdInfo rn = rd_info(n + PF);
+        ring[n % PF] = rn.jt < 0 ? Pb[rn.off] : Pt[rn.off];
+      }
+      if constexpr (ri.jt < 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = v;
+      } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = mfma4(v, xf[r][ri.jt], acc[r]);
+        if constexpr (ri.jt == ri.it) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            d2[r] = fma(acc[r], acc[r], d2[r]);
+            // pin the running sum here: otherwise LLVM sinks the whole fma chain below the
+            // MFMA stream and keeps every row's accumulator alive (96 extra VGPRs, spills)
+            asm volatile("" : "+v"(d2[r]));
+          }
+        }
+      }
+    });
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      // sum over the four hi lanes on the matrix pipe: D[i][j] = sum_k 1 * B[k][j] leaves the
+      // total in every lane (B[k=hi][j=row] is exactly where the partial sums live)
+      const double dd = mfma4(1.0, d2[r], 0.0);
+      const double lq = a.ctab[(int64_t)grp[r] * K + k] - 0.5 * dd;
+      mx[r] = fmax(mx[r], lq);
+      if (rgok[r] && hi == (k & 3)) a.qZ[(int64_t)k * a.ldq + (rg0 + r) * RG + lo4] = lq;
+    }
+    if (ii + 1 < nact) LC_LSTORE(buf ^ 1);
+    __syncthreads();
+  }
+
+#undef LC_GLOAD
+#undef LC_LSTORE
+
+  if (a.raw) return;  // GaussWish::Eloglike: leave c_k - 0.5 d^2 in qZ, no normalisation
+
+  // ---- normalise (probutils.cpp:141-150, cluster.cpp:124-131) -------------
+  double logZ[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    double s = 0.0;
+    if (rgok[r]) {
+      const double* qp = a.qZ + (rg0 + r) * RG + lo4;
+#pragma unroll 8
+      for (int k = hi; k < K; k += 4) s += exp(qp[(int64_t)k * a.ldq] - mx[r]);
+    }
+    s = sum_over_hi(s);
+    logZ[r] = log(s) + mx[r];
+  }
+  for (int kb = 0; kb < K; kb += 4) {
+    const int k = kb + hi;
+    double ll = 0.0;
+    if (k < K) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (rgok[r]) {
+          double* qp = a.qZ + (int64_t)k * a.ldq + (rg0 + r) * RG + lo4;
+          const double lq = *qp;
+          double q = exp(lq - logZ[r]);
+          if (!rowok[r]) q = 0.0;
+          *qp = q;
+          if (a.ll_part && q > 0.0) ll += q * (lq - a.ctab[(int64_t)grp[r] * K + k]);
+        }
+      }
+    }
+    if (a.ll_part) {  // wave-uniform
+      ll = sum_over_lo4(ll);
+      if (k < K && lo4 == 0) llw[wave * K + k] = ll;
+    }
+  }
+  double fz = 0.0;
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    if (rgok[r] && rowok[r] && hi == 0) fz += logZ[r];
+  fz = wave_sum(fz);
+  if (lane == 0) fzw[wave] = fz;
+  __syncthreads();
+  if (a.ll_part)
+    for (int k = tid; k < K; k += NTHR) {
+      double s = 0.0;
+      for (int w = 0; w < WAVES; ++w) s += llw[w * K + k];
+      a.ll_part[(int64_t)blockIdx.x * K + k] = s;
+    }
+  if (tid == 0) {
+    double s = 0.0;
+    for (int w = 0; w < WAVES; ++w) s += fzw[w];
+    a.fz_part[blockIdx.x] = -s;  // cluster.cpp:137 returns -sum(logZ)
+  }
+}
+
+template <int DP>
+struct EstepCfg;
+template <>
+struct EstepCfg<16> { static constexpr int R = 4, WAVES = 4; };
+template <>
+struct EstepCfg<32> { static constexpr int R = 4, WAVES = 4; };
+template <>
+struct EstepCfg<64> { static constexpr int R = 4, WAVES = 4; };
+template <>
+struct EstepCfg<128> { static constexpr int R = 2, WAVES = 8; };
+
+template <int DP>
+static int rows_per_block_t() { return EstepCfg<DP>::R * EstepCfg<DP>::WAVES * RG; }
+
+int estep_rows_per_block(int DP) {
+  switch (DP) {
+    case 16: return rows_per_block_t<16>();
+    case 32: return rows_per_block_t<32>();
+    case 64: return rows_per_block_t<64>();
+    case 128: return rows_per_block_t<128>();
+  }
+  return -1;
+}
+
+int64_t estep_grid(int DP, int64_t nrg) {
+  const int64_t rgpb = estep_rows_per_block(DP) / RG;
+  return (nrg + rgpb - 1) / rgpb;
+}
+
+template <int DP, bool SPARSE>
+static hipError_t launch_estep_s(const EstepLaunch& a, hipStream_t stream) {
+  constexpr int R = EstepCfg<DP>::R, WAVES = EstepCfg<DP>::WAVES;
+  const size_t shmem = (size_t)(2 * pstride(DP) + WAVES * a.K + WAVES) * sizeof(double) +
+                       (size_t)(2 * a.K + WAVES * R + 2) * sizeof(int);
+  auto kern = estep_kernel<DP, R, WAVES, SPARSE>;
+  static size_t attr_set = 0;  // largest dynamic-LDS size already granted
+  if (shmem > 64 * 1024 && shmem > attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e != hipSuccess) return e;
+    attr_set = shmem;
+  }
+  const int64_t grid = estep_grid(DP, a.nrg);
+  if (grid <= 0) return hipSuccess;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVES * 64), shmem, stream, a);
+  return hipGetLastError();
+}
+
+template <int DP>
+static hipError_t launch_estep_t(const EstepLaunch& a, hipStream_t stream) {
+  return a.sparse ? launch_estep_s<DP, true>(a, stream) : launch_estep_s<DP, false>(a, stream);
+}
+
+hipError_t launch_estep(const EstepLaunch& a, hipStream_t stream) {
+  switch (a.DP) {
+    case 16: return launch_estep_t<16>(a, stream);
+    case 32: return launch_estep_t<32>(a, stream);
+    case 64: return launch_estep_t<64>(a, stream);
+    case 128: return launch_estep_t<128>(a, stream);
+  }
+  return hipErrorInvalidValue;
+}
+
+
+}  // namespace lck

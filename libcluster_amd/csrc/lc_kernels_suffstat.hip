@@ -1,0 +1,419 @@
+// Sufficient statistics of the Gauss-Wishart clusters: updateSS (src/cluster.cpp:53-82) -> GaussWish::addobs (src/distributions.cpp:301-313)
+// (one translation unit per kernel family; the file header of lc_kernels_estep.hip maps kernels to the reference)
+#include "lc_device.hpp"
+
+namespace lck {
+
+// ===========================================================================
+// Sufficient statistics
+// ===========================================================================
+// S_k = sum_n q_nk x_n x_n^T is a GEMM whose reduction dimension is the data
+// rows.  One wave owns CPW clusters and streams over a chunk of rows, four
+// rows per step, with the (symmetric, lower-triangular 16x16-blocked)
+// accumulators in registers for the whole chunk.  For every needed pair of
+// 16-wide feature blocks (JBp >= JB) and every rotation s of the four 4-wide
+// sub-blocks inside JBp the wave issues
+//     D += A(x[., 16*JBp + 4*((blk+s)&3) + lo2]) * B(q_k * x[., 16*JB + 4*blk + lo2])
+// so that MFMA block blk computes the 4x4 tile (i-tile (blk+s)&3, j-tile blk).
+// Off-diagonal 16x16 blocks need s=0..3, diagonal ones s=0..2 (symmetry).
+//
+// fp64 VALU and fp64 MFMA share the issue pipe on gfx950 (a VALU block between
+// MFMA streams is not hidden by the other resident wave:
+// tools/mfma_issue_probe.hip, 97% -> 81% of peak), so the rotated operands are
+// NOT formed with DPP moves: the workgroup stages BR rows of X in LDS (every
+// wave of the group needs the same rows) and each wave reads all four
+// rotations of a fragment straight from LDS with rotated addresses (LGKM
+// path).  Row stride DP+16 doubles keeps the two rows a ds_read_b64 half-wave
+// touches on disjoint banks.  q columns are staged per wave the same way.
+// What remains on the VALU per cluster and step: NB multiplies (q*x), NB adds
+// (s_k) and one add (N_k) against NACC MFMAs.
+// Each (chunk, cluster) writes one partial record; launch_reduce_partials sums
+// chunks in fixed order.
+template <int NB>
+struct SSAcc { static constexpr int N = NB * 3 + NB * (NB - 1) / 2 * 4; };
+
+constexpr int SS_BR = 32;  // rows staged per batch
+
+// SKIP: a (4-row step, cluster) pair whose four responsibilities are all exactly 0.0 contributes exactly nothing;
+// the sparse mode (cluster.cpp:67-79: groups without mass in a cluster are left out) launches this variant so that
+// "sparse" saves the work it saves in the reference.  The dense variant carries no test in its inner loop.
+template <int DP, int CPW, bool SKIP>
+__global__ void __launch_bounds__(256, (DP <= 64 ? 2 : 1)) suffstat_kernel(SuffstatLaunch a) {
+  constexpr int NB = DP / 16;
+  constexpr int NACC = SSAcc<NB>::N;
+  constexpr int BR = SS_BR;
+  constexpr int LD = DP + 16;            // padded LDS row stride (doubles)
+  constexpr int XBUF = BR * LD;          // doubles per X buffer
+  constexpr int NV2 = BR * DP / 2;       // double2 elements per staged batch
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  constexpr int nwaves = 4, nthr = 256;  // always launched with 4 waves; surplus waves only help staging
+  double* xbuf = lds;                              // [2][BR][LD]
+  double* qbuf = lds + 2 * XBUF;                   // [2][nwaves][CPW][BR]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lo4 = lane & 15, hi = lane >> 4, blk = (lane >> 2) & 3, lo2 = lane & 3;
+  const int K = a.K;
+  // Workgroup -> (row chunk, cluster slice).  Every slice of a chunk re-reads the
+  // same X rows, so the slices of one chunk are placed back-to-back on ONE XCD
+  // (block b runs on XCD b % 8, each XCD has its own L2): seq = b / 8 walks
+  // (chunk-in-XCD, slice) with the slice fastest.  Pure speed; any placement is correct.
+  int chunk, slice;
+  {
+    const int nslice = a.nslice, nchunks = a.nchunks;
+    const int b = blockIdx.x;
+    const int full = (nchunks / 8) * 8;
+    if (b < full * nslice) {
+      const int xcd = b & 7, seq = b >> 3;
+      chunk = (seq / nslice) * 8 + xcd;
+      slice = seq % nslice;
+    } else {
+      const int t = b - full * nslice;
+      chunk = full + t / nslice;
+      slice = t % nslice;
+    }
+  }
+  const int kbase = (slice * nwaves + wave) * CPW;   // may be >= K: the wave still helps staging
+  int nk = kbase >= K ? 0 : ((K - kbase) < CPW ? (K - kbase) : CPW);
+  int64_t r0 = (int64_t)chunk * a.chunk_rows;
+  int64_t r1 = (r0 + a.chunk_rows) < a.NP ? (r0 + a.chunk_rows) : a.NP;
+  int kidx[CPW];      // cluster of accumulator set c
+  int64_t recidx[CPW];  // its partial record
+#pragma unroll
+  for (int c = 0; c < CPW; ++c) {
+    kidx[c] = kbase + c;
+    recidx[c] = (int64_t)chunk * K + kbase + c;
+  }
+  if (a.items) {
+    // sparse work list: one block = (row range inside ONE group, up to 4*CPW clusters of that group's active
+    // list); work is proportional to the active (row, cluster) pairs, records exist only for those pairs
+    const SSItem it = a.items[blockIdx.x];
+    r0 = it.r0;
+    r1 = it.r1;
+    const int first = wave * CPW;
+    nk = first >= it.kcnt ? 0 : ((it.kcnt - first) < CPW ? (it.kcnt - first) : CPW);
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+      kidx[c] = c < nk ? a.klist[it.kofs + first + c] : 0;
+      recidx[c] = it.rec0 + first + c;
+    }
+  }
+
+  double acc[CPW][NACC];
+  double sacc[CPW][NB];
+  double nacc[CPW];
+#pragma unroll
+  for (int c = 0; c < CPW; ++c) {
+    nacc[c] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[c][i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) sacc[c][i] = 0.0;
+  }
+
+  // ---- staging: registers hold the next batch while the current one is consumed
+  constexpr int NPRE_MAX = (NV2 + nthr - 1) / nthr, npre = NPRE_MAX;
+  double pre[NPRE_MAX][2];
+  double qpre[CPW];
+  auto gload = [&](int64_t b0) {
+#pragma unroll
+    for (int i = 0; i < NPRE_MAX; ++i) {
+      if (i < npre) {
+        const int idx = tid + i * nthr;          // double2 index inside the batch: row-major [BR][DP/2]
+        const int row = idx / (DP / 2), c2 = idx % (DP / 2);
+        double2 v = make_double2(0.0, 0.0);
+        if (idx < NV2 && b0 + row < r1) v = *reinterpret_cast<const double2*>(a.X + (b0 + row) * DP + 2 * c2);
+        pre[i][0] = v.x;
+        pre[i][1] = v.y;
+      }
+    }
+    // q: lanes 0..BR-1 of each wave fetch that wave's CPW columns (coalesced)
+    int g = 0;
+    const int64_t qrow = b0 + lane;
+    const bool qok = lane < BR && qrow < r1;
+    if (a.smask && qok) g = a.rginfo[qrow >> 4] >> 5;
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+      double q = 0.0;
+      if (c < nk && qok) {
+        q = a.qZ[(int64_t)kidx[c] * a.ldq + qrow];
+        if (a.smask && !a.smask[(int64_t)g * K + kidx[c]]) q = 0.0;
+      }
+      qpre[c] = q;
+    }
+  };
+  auto lstore = [&](int buf) {
+    double* xb = xbuf + buf * XBUF;
+#pragma unroll
+    for (int i = 0; i < NPRE_MAX; ++i) {
+      if (i < npre) {
+        const int idx = tid + i * nthr;
+        const int row = idx / (DP / 2), c2 = idx % (DP / 2);
+        if (idx < NV2) *reinterpret_cast<double2*>(xb + row * LD + 2 * c2) = make_double2(pre[i][0], pre[i][1]);
+      }
+    }
+    if (lane < BR) {
+      double* qb = qbuf + ((buf * nwaves + wave) * CPW) * BR;
+#pragma unroll
+      for (int c = 0; c < CPW; ++c) qb[c * BR + lane] = qpre[c];
+    }
+  };
+
+  if (r0 < r1) {
+    gload(r0);
+    lstore(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int64_t b0 = r0; b0 < r1; b0 += BR, buf ^= 1) {
+    const bool more = b0 + BR < r1;
+    if (more) gload(b0 + BR);
+    if (nk > 0) {
+      const double* xb = xbuf + buf * XBUF + hi * LD + lo2;
+      const double* qb = qbuf + ((buf * nwaves + wave) * CPW) * BR + hi;
+      if constexpr (DP > 64) {
+        // One wave per SIMD (the accumulators need > 256 registers): nothing else hides the LDS
+        // latency, so the step loop is software-pipelined by hand, unrolled by two with two register
+        // sets (unrotated fragments + q of a step) that swap roles -- no copies.  A step fetches its
+        // rotated fragments at the top (first needed after the unrotated MFMAs) and the unrotated
+        // fragments and q of the NEXT step; only the first step of a batch waits on LDS.  All BR/4
+        // steps run (rows past the chunk end were staged as zeros with q = 0); the last step's prefetch
+        // reads one step past the tile: inside the LDS allocation, never used.
+        double xA[NB], qA[CPW], xB[NB], qB[CPW];
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb) xA[jb] = xb[16 * jb + 4 * blk];
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) qA[c] = qb[c * BR];
+        auto step = [&](int st, const double (&x0)[NB], const double (&q)[CPW], double (&x0n)[NB],
+                        double (&qn)[CPW]) {
+          double xr[NB][4];
+#pragma unroll
+          for (int jb = 0; jb < NB; ++jb) {
+            xr[jb][0] = x0[jb];
+#pragma unroll
+            for (int s2 = 1; s2 < 4; ++s2) xr[jb][s2] = xb[st * 4 * LD + 16 * jb + 4 * ((blk + s2) & 3)];
+          }
+#pragma unroll
+          for (int jb = 0; jb < NB; ++jb) x0n[jb] = xb[(st + 1) * 4 * LD + 16 * jb + 4 * blk];
+#pragma unroll
+          for (int c = 0; c < CPW; ++c) qn[c] = qb[c * BR + (st + 1) * 4];
+#pragma unroll
+          for (int c = 0; c < CPW; ++c) {
+            if (SKIP && __builtin_amdgcn_ballot_w64(q[c] != 0.0) == 0) continue;
+            double qx[NB];
+#pragma unroll
+            for (int jb = 0; jb < NB; ++jb) {
+              qx[jb] = q[c] * xr[jb][0];
+              sacc[c][jb] += qx[jb];
+            }
+            nacc[c] += q[c];
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {  // unrotated operands first
+              int idx = 0;
+#pragma unroll
+              for (int jbp = 0; jbp < NB; ++jbp)
+#pragma unroll
+                for (int jb = 0; jb <= jbp; ++jb)
+#pragma unroll
+                  for (int s2 = 0; s2 < 4; ++s2)
+                    if (s2 < 3 || jb < jbp) {
+                      if ((pass == 0) == (s2 == 0)) acc[c][idx] = mfma4(xr[jbp][s2], qx[jb], acc[c][idx]);
+                      ++idx;
+                    }
+            }
+          }
+        };
+        static_assert((BR / 4) % 2 == 0, "step loop is unrolled by two");
+#pragma unroll 1
+        for (int st = 0; st < BR / 4; st += 2) {
+          step(st, xA, qA, xB, qB);
+          step(st + 1, xB, qB, xA, qA);
+        }
+      } else {
+        const int nstep = (int)(((r1 - b0) < BR ? (r1 - b0) : BR) / 4);
+        for (int st = 0; st < nstep; ++st) {
+          if (SKIP) {  // nothing to do for any of this wave's clusters: do not even fetch the fragments
+            bool any = false;
+#pragma unroll
+            for (int c = 0; c < CPW; ++c) any = any || qb[c * BR + st * 4] != 0.0;
+            if (__builtin_amdgcn_ballot_w64(any) == 0) continue;
+          }
+          // fragments: xr[jb][s] = x[row 4*st+hi][16*jb + 4*((blk+s)&3) + lo2]
+          double xr[NB][4];
+  #pragma unroll
+          for (int jb = 0; jb < NB; ++jb)
+  #pragma unroll
+            for (int s = 0; s < 4; ++s) xr[jb][s] = xb[st * 4 * LD + 16 * jb + 4 * ((blk + s) & 3)];
+  #pragma unroll
+          for (int c = 0; c < CPW; ++c) {
+            const double q = qb[c * BR + st * 4];
+            if (SKIP && __builtin_amdgcn_ballot_w64(q != 0.0) == 0) continue;
+            double qx[NB];
+  #pragma unroll
+            for (int jb = 0; jb < NB; ++jb) {
+              qx[jb] = q * xr[jb][0];
+              sacc[c][jb] += qx[jb];
+            }
+            nacc[c] += q;
+            int idx = 0;
+  #pragma unroll
+            for (int jbp = 0; jbp < NB; ++jbp) {
+  #pragma unroll
+              for (int jb = 0; jb <= jbp; ++jb) {
+  #pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                  if (s < 3 || jb < jbp) {
+                    acc[c][idx] = mfma4(xr[jbp][s], qx[jb], acc[c][idx]);
+                    ++idx;
+                  }
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+    if (more) lstore(buf ^ 1);
+    __syncthreads();
+  }
+  if (nk == 0) return;
+
+  const int64_t SS = 1 + (int64_t)DP + (int64_t)DP * DP;
+#pragma unroll
+  for (int c = 0; c < CPW; ++c) {
+    if (c < nk) {
+      double* out = a.partial + recidx[c] * SS;
+      const double nsum = sum_over_hi(nacc[c]);
+      if (lane == 0) out[0] = nsum;
+#pragma unroll
+      for (int jb = 0; jb < NB; ++jb) {
+        const double s = sum_over_hi(sacc[c][jb]);
+        if (hi == 0) out[1 + 16 * jb + lo4] = s;
+      }
+      double* S = out + 1 + DP;
+      int idx = 0;
+#pragma unroll
+      for (int jbp = 0; jbp < NB; ++jbp) {
+#pragma unroll
+        for (int jb = 0; jb <= jbp; ++jb) {
+          const int ns = jb < jbp ? 4 : 3;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            if (s < ns) {
+              const int ti = (blk + s) & 3, tj = blk;
+              const int gi = 16 * jbp + 4 * ti + hi, gj = 16 * jb + 4 * tj + lo2;
+              const bool diag = jb == jbp;
+              // diagonal 16x16 blocks: s=0 gives the diagonal tiles, s=1 every pair {t,t+1 mod 4}
+              // once, s=2 the pairs {0,2},{1,3} twice (keep the lower copy); s=3 is never issued
+              const bool wr = !diag || ti == tj || s == 1 || ti > tj;
+              const double v = acc[c][idx];
+              if (wr) {
+                S[(int64_t)gi * DP + gj] = v;
+                if (!diag || ti != tj) S[(int64_t)gj * DP + gi] = v;
+              }
+              ++idx;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int DP>
+struct SSCfg;
+template <>
+struct SSCfg<16> { static constexpr int CPW = 4; };
+template <>
+struct SSCfg<32> { static constexpr int CPW = 4; };
+template <>
+struct SSCfg<64> { static constexpr int CPW = 2; };
+template <>
+struct SSCfg<128> { static constexpr int CPW = 1; };
+
+static int ss_cpw(int DP, int K) {
+  if (const char* e = getenv("LC_SS_CPW")) {  // tuning knob
+    const int v = atoi(e);
+    if (v == 1 || (v == 2 && DP <= 64) || (v == 4 && DP <= 32)) return v;
+  }
+  int cpw = DP == 16 ? SSCfg<16>::CPW : DP == 32 ? SSCfg<32>::CPW : DP == 64 ? SSCfg<64>::CPW : SSCfg<128>::CPW;
+  // few clusters: spread them over more waves instead of stacking them in one
+  while (cpw > 1 && (K + cpw - 1) / cpw < 4 && (K + cpw / 2 - 1) / (cpw / 2) <= 4) cpw /= 2;
+  return cpw;
+}
+
+int suffstat_clusters_per_block(int DP, int K) { return 4 * ss_cpw(DP, K); }
+
+int suffstat_plan(int DP, int64_t NP, int K, int64_t* chunk_rows) {
+  const int cpw = ss_cpw(DP, K);
+  const int kwaves = (K + cpw - 1) / cpw;  // waves needed to cover the clusters
+  // aim for ~8 waves per CU on 256 CUs, at least 256 rows per chunk
+  int64_t want = (256 * 8 + kwaves - 1) / kwaves;
+  // four blocks per resident slot: the hardware back-fills slots as blocks retire, which evens out the
+  // per-CU / per-XCD speed differences (measured 25.7 -> 24.9 ms at N=10M, D=64, K=32), while the partial
+  // records (chunks x K x (1 + DP + DP^2) doubles) stay below 1 GiB
+  int rounds = 4;
+  if (const char* e = getenv("LC_SS_ROUNDS")) {  // tuning knob
+    const int v = atoi(e);
+    if (v >= 1 && v <= 16) rounds = v;
+  }
+  const int64_t rec = (int64_t)K * (1 + DP + (int64_t)DP * DP) * 8;
+  const int64_t cap = ((int64_t)1 << 30) / rec;
+  if (want * rounds <= cap) want *= rounds;
+  else if (want < cap) want = cap;
+  int64_t maxchunks = (NP + 255) / 256;
+  if (want > maxchunks) want = maxchunks;
+  if (want < 1) want = 1;
+  int64_t rows = (NP + want - 1) / want;
+  rows = (rows + SS_BR - 1) / SS_BR * SS_BR;  // whole staging batches
+  *chunk_rows = rows;
+  return (int)((NP + rows - 1) / rows);
+}
+
+template <int DP, int CPW, bool SKIP>
+static hipError_t launch_ss_s(const SuffstatLaunch& a, hipStream_t stream) {
+  const int kwaves = (a.K + CPW - 1) / CPW;
+  const int wpb = 4;
+  const int nslice = (kwaves + wpb - 1) / wpb;
+  SuffstatLaunch b = a;
+  b.nslice = nslice;
+  const size_t shmem = (size_t)(2 * SS_BR * (DP + 16) + 2 * wpb * CPW * SS_BR) * sizeof(double);
+  auto kern = suffstat_kernel<DP, CPW, SKIP>;
+  static bool attr_set = false;
+  if (shmem > 64 * 1024 && !attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(96 * 1024));
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const unsigned grid = a.items ? (unsigned)a.nitems : (unsigned)(a.nchunks * nslice);
+  if (grid == 0) return hipSuccess;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(wpb * 64), shmem, stream, b);
+  return hipGetLastError();
+}
+
+template <int DP, int CPW>
+static hipError_t launch_ss_t(const SuffstatLaunch& a, hipStream_t stream) {
+  // skip_zero: 1 = skipping variant, -1 = dense even with a mask, 0 = skipping iff a mask is given
+  const bool skip = a.skip_zero > 0 || (a.skip_zero == 0 && a.smask);
+  return skip ? launch_ss_s<DP, CPW, true>(a, stream) : launch_ss_s<DP, CPW, false>(a, stream);
+}
+
+hipError_t launch_suffstat(const SuffstatLaunch& a, hipStream_t stream) {
+  if (a.K <= 0 || a.nchunks <= 0) return hipSuccess;
+  const int cpw = ss_cpw(a.DP, a.K);
+  switch (a.DP) {
+    case 16:
+      return cpw == 4 ? launch_ss_t<16, 4>(a, stream) : cpw == 2 ? launch_ss_t<16, 2>(a, stream)
+                                                                : launch_ss_t<16, 1>(a, stream);
+    case 32:
+      return cpw == 4 ? launch_ss_t<32, 4>(a, stream) : cpw == 2 ? launch_ss_t<32, 2>(a, stream)
+                                                                : launch_ss_t<32, 1>(a, stream);
+    case 64:
+      return cpw == 2 ? launch_ss_t<64, 2>(a, stream) : launch_ss_t<64, 1>(a, stream);
+    case 128:
+      return launch_ss_t<128, 1>(a, stream);
+  }
+  return hipErrorInvalidValue;
+}
+
+
+}  // namespace lck
