@@ -37,8 +37,15 @@ constexpr int SS_BR = 32;  // rows staged per batch
 // SKIP: a (4-row step, cluster) pair whose four responsibilities are all exactly 0.0 contributes exactly nothing;
 // the sparse mode (cluster.cpp:67-79: groups without mass in a cluster are left out) launches this variant so that
 // "sparse" saves the work it saves in the reference.  The dense variant carries no test in its inner loop.
-template <int DP, int CPW, bool SKIP>
-__global__ void __launch_bounds__(256, (DP <= 64 ? 2 : 1)) suffstat_kernel(SuffstatLaunch a) {
+// HALF: 0 = the whole tile triangle in one launch; 1 / 2 = the first / second half of the 16x16 block pairs (balanced by
+// MFMA count).  At D = 128 the 136 accumulators per cluster of the full triangle leave room for ONE wave per SIMD, and
+// a lone wave cannot hide its own LDS latency; two half launches (68 / 69 accumulators, both re-read X, which the
+// MFMA-bound kernel can afford) run two waves per SIMD with the simple step loop.  N_k and s_k ride with half 1.
+__host__ __device__ constexpr bool ss_in_half(int half, int jbp, int jb) {
+  return half == 0 || ((jbp < 5 || (jbp == 5 && jb < 3)) == (half == 1));
+}
+template <int DP, int CPW, bool SKIP, int HALF>
+__global__ void __launch_bounds__(256, ((DP <= 64 || HALF != 0) ? 2 : 1)) suffstat_kernel(SuffstatLaunch a) {
   constexpr int NB = DP / 16;
   constexpr int NACC = SSAcc<NB>::N;
   constexpr int BR = SS_BR;
@@ -169,7 +176,7 @@ __global__ void __launch_bounds__(256, (DP <= 64 ? 2 : 1)) suffstat_kernel(Suffs
     if (nk > 0) {
       const double* xb = xbuf + buf * XBUF + hi * LD + lo2;
       const double* qb = qbuf + ((buf * nwaves + wave) * CPW) * BR + hi;
-      if constexpr (DP > 64) {
+      if constexpr (DP > 64 && HALF == 0) {
         // One wave per SIMD (the accumulators need > 256 registers): nothing else hides the LDS
         // latency, so the step loop is software-pipelined by hand, unrolled by two with two register
         // sets (unrotated fragments + q of a step) that swap roles -- no copies.  A step fetches its
@@ -250,9 +257,9 @@ __global__ void __launch_bounds__(256, (DP <= 64 ? 2 : 1)) suffstat_kernel(Suffs
   #pragma unroll
             for (int jb = 0; jb < NB; ++jb) {
               qx[jb] = q * xr[jb][0];
-              sacc[c][jb] += qx[jb];
+              if (HALF != 2) sacc[c][jb] += qx[jb];
             }
-            nacc[c] += q;
+            if (HALF != 2) nacc[c] += q;
             int idx = 0;
   #pragma unroll
             for (int jbp = 0; jbp < NB; ++jbp) {
@@ -261,7 +268,7 @@ __global__ void __launch_bounds__(256, (DP <= 64 ? 2 : 1)) suffstat_kernel(Suffs
   #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                   if (s < 3 || jb < jbp) {
-                    acc[c][idx] = mfma4(xr[jbp][s], qx[jb], acc[c][idx]);
+                    if (ss_in_half(HALF, jbp, jb)) acc[c][idx] = mfma4(xr[jbp][s], qx[jb], acc[c][idx]);
                     ++idx;
                   }
                 }
@@ -281,12 +288,14 @@ __global__ void __launch_bounds__(256, (DP <= 64 ? 2 : 1)) suffstat_kernel(Suffs
   for (int c = 0; c < CPW; ++c) {
     if (c < nk) {
       double* out = a.partial + recidx[c] * SS;
-      const double nsum = sum_over_hi(nacc[c]);
-      if (lane == 0) out[0] = nsum;
+      if (HALF != 2) {
+        const double nsum = sum_over_hi(nacc[c]);
+        if (lane == 0) out[0] = nsum;
 #pragma unroll
-      for (int jb = 0; jb < NB; ++jb) {
-        const double s = sum_over_hi(sacc[c][jb]);
-        if (hi == 0) out[1 + 16 * jb + lo4] = s;
+        for (int jb = 0; jb < NB; ++jb) {
+          const double s = sum_over_hi(sacc[c][jb]);
+          if (hi == 0) out[1 + 16 * jb + lo4] = s;
+        }
       }
       double* S = out + 1 + DP;
       int idx = 0;
@@ -303,7 +312,7 @@ __global__ void __launch_bounds__(256, (DP <= 64 ? 2 : 1)) suffstat_kernel(Suffs
               const bool diag = jb == jbp;
               // diagonal 16x16 blocks: s=0 gives the diagonal tiles, s=1 every pair {t,t+1 mod 4}
               // once, s=2 the pairs {0,2},{1,3} twice (keep the lower copy); s=3 is never issued
-              const bool wr = !diag || ti == tj || s == 1 || ti > tj;
+              const bool wr = (!diag || ti == tj || s == 1 || ti > tj) && ss_in_half(HALF, jbp, jb);
               const double v = acc[c][idx];
               if (wr) {
                 S[(int64_t)gi * DP + gj] = v;
@@ -368,15 +377,15 @@ int suffstat_plan(int DP, int64_t NP, int K, int64_t* chunk_rows) {
   return (int)((NP + rows - 1) / rows);
 }
 
-template <int DP, int CPW, bool SKIP>
-static hipError_t launch_ss_s(const SuffstatLaunch& a, hipStream_t stream) {
+template <int DP, int CPW, bool SKIP, int HALF>
+static hipError_t launch_ss_h(const SuffstatLaunch& a, hipStream_t stream) {
   const int kwaves = (a.K + CPW - 1) / CPW;
   const int wpb = 4;
   const int nslice = (kwaves + wpb - 1) / wpb;
   SuffstatLaunch b = a;
   b.nslice = nslice;
   const size_t shmem = (size_t)(2 * SS_BR * (DP + 16) + 2 * wpb * CPW * SS_BR) * sizeof(double);
-  auto kern = suffstat_kernel<DP, CPW, SKIP>;
+  auto kern = suffstat_kernel<DP, CPW, SKIP, HALF>;
   static bool attr_set = false;
   if (shmem > 64 * 1024 && !attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -388,6 +397,19 @@ static hipError_t launch_ss_s(const SuffstatLaunch& a, hipStream_t stream) {
   if (grid == 0) return hipSuccess;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(wpb * 64), shmem, stream, b);
   return hipGetLastError();
+}
+
+template <int DP, int CPW, bool SKIP>
+static hipError_t launch_ss_s(const SuffstatLaunch& a, hipStream_t stream) {
+  if constexpr (DP > 64) {
+    static const bool whole = getenv("LC_SS_WHOLE") != nullptr;  // tuning knob: one launch, one wave per SIMD
+    if (!whole) {
+      hipError_t e = launch_ss_h<DP, CPW, SKIP, 1>(a, stream);
+      if (e != hipSuccess) return e;
+      return launch_ss_h<DP, CPW, SKIP, 2>(a, stream);
+    }
+  }
+  return launch_ss_h<DP, CPW, SKIP, 0>(a, stream);
 }
 
 template <int DP, int CPW>
