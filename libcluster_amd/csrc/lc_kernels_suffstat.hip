@@ -41,11 +41,15 @@ constexpr int SS_BR = 32;  // rows staged per batch
 // MFMA count).  At D = 128 the 136 accumulators per cluster of the full triangle leave room for ONE wave per SIMD, and
 // a lone wave cannot hide its own LDS latency; two half launches (68 / 69 accumulators, both re-read X, which the
 // MFMA-bound kernel can afford) run two waves per SIMD with the simple step loop.  N_k and s_k ride with half 1.
+template <int NB>
 __host__ __device__ constexpr bool ss_in_half(int half, int jbp, int jb) {
-  return half == 0 || ((jbp < 5 || (jbp == 5 && jb < 3)) == (half == 1));
+  if (half == 0) return true;
+  const bool first = NB == 8 ? (jbp < 5 || (jbp == 5 && jb < 3)) : (jbp == 1 || jbp == 2);  // 67|69 resp. 18|18 MFMAs
+  return first == (half == 1);
 }
 template <int DP, int CPW, bool SKIP, int HALF>
-__global__ void __launch_bounds__(256, ((DP <= 64 || HALF != 0) ? 2 : 1)) suffstat_kernel(SuffstatLaunch a) {
+__global__ void __launch_bounds__(256, (DP <= 64 ? (HALF != 0 ? 3 : 2) : (HALF != 0 ? 2 : 1)))
+    suffstat_kernel(SuffstatLaunch a) {
   constexpr int NB = DP / 16;
   constexpr int NACC = SSAcc<NB>::N;
   constexpr int BR = SS_BR;
@@ -268,7 +272,7 @@ __global__ void __launch_bounds__(256, ((DP <= 64 || HALF != 0) ? 2 : 1)) suffst
   #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                   if (s < 3 || jb < jbp) {
-                    if (ss_in_half(HALF, jbp, jb)) acc[c][idx] = mfma4(xr[jbp][s], qx[jb], acc[c][idx]);
+                    if (ss_in_half<NB>(HALF, jbp, jb)) acc[c][idx] = mfma4(xr[jbp][s], qx[jb], acc[c][idx]);
                     ++idx;
                   }
                 }
@@ -312,7 +316,7 @@ __global__ void __launch_bounds__(256, ((DP <= 64 || HALF != 0) ? 2 : 1)) suffst
               const bool diag = jb == jbp;
               // diagonal 16x16 blocks: s=0 gives the diagonal tiles, s=1 every pair {t,t+1 mod 4}
               // once, s=2 the pairs {0,2},{1,3} twice (keep the lower copy); s=3 is never issued
-              const bool wr = (!diag || ti == tj || s == 1 || ti > tj) && ss_in_half(HALF, jbp, jb);
+              const bool wr = (!diag || ti == tj || s == 1 || ti > tj) && ss_in_half<NB>(HALF, jbp, jb);
               const double v = acc[c][idx];
               if (wr) {
                 S[(int64_t)gi * DP + gj] = v;
@@ -401,7 +405,7 @@ static hipError_t launch_ss_h(const SuffstatLaunch& a, hipStream_t stream) {
 
 template <int DP, int CPW, bool SKIP>
 static hipError_t launch_ss_s(const SuffstatLaunch& a, hipStream_t stream) {
-  if constexpr (DP > 64) {
+  if constexpr (DP > 64) {  // (at D = 64 the two-half variant is slower: 26.0 vs 23.6 ms)
     static const bool whole = getenv("LC_SS_WHOLE") != nullptr;  // tuning knob: one launch, one wave per SIMD
     if (!whole) {
       hipError_t e = launch_ss_h<DP, CPW, SKIP, 1>(a, stream);
