@@ -240,6 +240,14 @@ int lc_learn_topic(int J, const int* Ij, const double* const* Xji, const int64_t
                    int64_t col_stride, const double* const* Wj, int Dt, const double* const* qY0, double prior_t,
                    double prior_k, unsigned maxT, int maxK, int verbose, unsigned nthreads, int device,
                    lc_tmodel** out, double* F);
+/* The same on one process per GPU: every rank passes WHOLE groups (with all their documents); fn (see
+ * lc_ctx_set_allreduce) sums the cluster statistics, N_tk, the document-level Gaussian statistics, Fyz / Fz and the
+ * decision counts of the split search, so all ranks take the same decisions.  qY0 (if given) holds this rank's
+ * documents.  stream: the HIP stream the context works on (the hook's collectives must be ordered with it). */
+int lc_learn_topic_dist(int J, const int* Ij, const double* const* Xji, const int64_t* Nji, int D, int64_t row_stride,
+                        int64_t col_stride, const double* const* Wj, int Dt, const double* const* qY0, double prior_t,
+                        double prior_k, unsigned maxT, int maxK, int verbose, unsigned nthreads, int device,
+                        void* stream, lc_allreduce_fn fn, void* user, lc_tmodel** out, double* F);
 int lc_tmodel_free(lc_tmodel* m);
 int lc_tmodel_dims(lc_tmodel* m, int* J, int* Itot, int* T, int* K, int* D, int* Dt);
 int lc_tmodel_get_qy(lc_tmodel* m, int j, double* qY /* Ij[j] x T row-major */);

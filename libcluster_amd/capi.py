@@ -120,6 +120,10 @@ def lib() -> C.CDLL:
     L.lc_learn_topic.argtypes = [C.c_int, c_int_p, C.POINTER(c_double_p), c_int64_p, C.c_int, C.c_int64, C.c_int64,
                                  C.POINTER(c_double_p), C.c_int, C.POINTER(c_double_p), C.c_double, C.c_double,
                                  C.c_uint, C.c_int, C.c_int, C.c_uint, C.c_int, C.POINTER(C.c_void_p), c_double_p]
+    L.lc_learn_topic_dist.argtypes = [C.c_int, c_int_p, C.POINTER(c_double_p), c_int64_p, C.c_int, C.c_int64, C.c_int64,
+                                      C.POINTER(c_double_p), C.c_int, C.POINTER(c_double_p), C.c_double, C.c_double,
+                                      C.c_uint, C.c_int, C.c_int, C.c_uint, C.c_int, C.c_void_p, ALLREDUCE_FN,
+                                      C.c_void_p, C.POINTER(C.c_void_p), c_double_p]
     L.lc_tmodel_free.argtypes = [C.c_void_p]
     L.lc_tmodel_dims.argtypes = [C.c_void_p, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p]
     L.lc_tmodel_get_qy.argtypes = [C.c_void_p, C.c_int, c_double_p]
@@ -617,9 +621,11 @@ class TopicModel:
 
 
 def learn_topic(X, W=None, qY0=None, prior_t=1.0, prior_k=1.0, maxT=100, maxK=-1, verbose=False, nthreads=1,
-                device=0):
+                device=0, allreduce=None, stream=None):
     """lc_learn_topic: X is a list (groups) of lists (documents) of (N_ji, D) arrays; W (MCM) a list of (I_j, Dt)
-    arrays; qY0 an optional list of (I_j, maxT) initial assignments.  Returns (F, TopicModel)."""
+    arrays; qY0 an optional list of (I_j, maxT) initial assignments.  Returns (F, TopicModel).
+    allreduce (one process per GPU, whole groups per rank): fn(device_ptr, count, stream) summing in place across
+    ranks, e.g. libcluster_amd.dist.make_device_hook(device); stream: the HIP stream to work on."""
     Xs = [[np.ascontiguousarray(x, dtype=np.float64) for x in Xj] for Xj in X]
     J = len(Xs)
     docs = [x for Xj in Xs for x in Xj]
@@ -650,6 +656,19 @@ def learn_topic(X, W=None, qY0=None, prior_t=1.0, prior_k=1.0, maxT=100, maxK=-1
                 raise ValueError("qY0[j] must be (I_j, maxT)")
         Qp = (c_double_p * J)(*[dptr(q) for q in Qs])
     mh, F = C.c_void_p(), C.c_double()
-    check(lib().lc_learn_topic(J, Ij, ptrs, Nji, D, D, 1, Wp, Dt, Qp, prior_t, prior_k, maxT, maxK, int(verbose),
-                               nthreads, device, C.byref(mh), C.byref(F)))
+    cb = C.cast(None, ALLREDUCE_FN)
+    if allreduce is not None:
+        def tramp(user, buf, count, strm):
+            try:
+                allreduce(buf or 0, count, strm or 0)
+                return 0
+            except Exception:  # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        cb = ALLREDUCE_FN(tramp)
+    check(lib().lc_learn_topic_dist(J, Ij, ptrs, Nji, D, D, 1, Wp, Dt, Qp, prior_t, prior_k, maxT, maxK, int(verbose),
+                                    nthreads, device, C.c_void_p(stream) if stream else None, cb, None, C.byref(mh),
+                                    C.byref(F)))
     return F.value, TopicModel(mh, [len(Xj) for Xj in Xs], [x.shape[0] for x in docs])

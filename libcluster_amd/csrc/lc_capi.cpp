@@ -694,6 +694,14 @@ int lc_eg_mstep(double obsmag, int D, double Ns, const double* xs, double* a, do
 int lc_learn_topic(int J, const int* Ij, const double* const* Xji, const int64_t* Nji, int D, int64_t rs, int64_t cs,
                    const double* const* Wj, int Dt, const double* const* qY0, double prior_t, double prior_k,
                    unsigned maxT, int maxK, int verbose, unsigned nthreads, int device, lc_tmodel** out, double* F) {
+  return lc_learn_topic_dist(J, Ij, Xji, Nji, D, rs, cs, Wj, Dt, qY0, prior_t, prior_k, maxT, maxK, verbose, nthreads,
+                             device, nullptr, nullptr, nullptr, out, F);
+}
+
+int lc_learn_topic_dist(int J, const int* Ij, const double* const* Xji, const int64_t* Nji, int D, int64_t rs,
+                        int64_t cs, const double* const* Wj, int Dt, const double* const* qY0, double prior_t,
+                        double prior_k, unsigned maxT, int maxK, int verbose, unsigned nthreads, int device,
+                        void* stream, lc_allreduce_fn fn, void* user, lc_tmodel** out, double* F) {
   return guarded([&] {
     need(Ij, "Ij");
     need(Xji, "Xji");
@@ -748,10 +756,15 @@ int lc_learn_topic(int J, const int* Ij, const double* const* Xji, const int64_t
         }
       }
     }
-    if (!mcm && maxT > (unsigned)d.Itot)  // scluster.cpp:531-533 (sic: no space before X)
-      throw std::invalid_argument("maxT must be less than the number of documents ofX!");
-    m->ctx.reset(new lc_ctx(device, nullptr));
+    m->ctx.reset(new lc_ctx(device, static_cast<hipStream_t>(stream)));
     m->D = D;
+    if (fn) {  // whole groups (with all their documents) per rank: cluster statistics, N_tk, Fyz, Fz are summed
+      m->ctx->impl.set_allreduce(fn, user);
+      m->ctx->impl.set_group_sharded(true);
+    }
+    const double docs = m->ctx->impl.allreduce_value((double)d.Itot);
+    if (!mcm && (double)maxT > docs)  // scluster.cpp:531-533 (sic: no space before X)
+      throw std::invalid_argument("maxT must be less than the number of documents ofX!");
     m->ctx->impl.set_data(d.Itot, Xji, Nji, D, rs, cs);
     lce::TopicOptions o;
     o.prior_t = prior_t;

@@ -46,3 +46,24 @@ def test_two_rank_cluster_equals_single_rank(lib, mode, family):
         np.testing.assert_allclose(a, b, rtol=1e-10)
     assert abs(one["F"] - two["F"]) <= 1e-10 * abs(one["F"])
     np.testing.assert_allclose(one["N"], two["N"], rtol=1e-9)
+
+
+@pytest.mark.parametrize("model", ["scm", "mcm"])
+def test_two_rank_topic_model_equals_single_rank(lib, model):
+    """learnSCM / learnMCM with whole groups (and their documents) per rank: all-reduced cluster statistics, N_tk,
+    document-level Gaussian statistics, Fyz / Fz and split-search counts reproduce the single-rank rounds and F."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = str(ROOT / "tools" / "dist_topic_check.py")
+    one = _run([sys.executable, script, model])
+    two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                "--master-addr", "127.0.0.1", "--master-port", str(port), script, model],
+               {"LC_DIST_BACKEND": "gloo", "LC_ALL_RANKS_ON_GPU0": "1"})
+    assert two["world"] == 2 and one["world"] == 1
+    assert (one["T"], one["K"]) == (two["T"], two["K"]) and one["K"] >= 3
+    assert [(t, k) for t, k, _ in one["rounds"]] == [(t, k) for t, k, _ in two["rounds"]]
+    for (_, _, a), (_, _, b) in zip(one["rounds"], two["rounds"]):
+        np.testing.assert_allclose(a, b, rtol=1e-10)
+    assert abs(one["F"] - two["F"]) <= 1e-10 * abs(one["F"])
+    np.testing.assert_allclose(one["N"], two["N"], rtol=1e-9)
