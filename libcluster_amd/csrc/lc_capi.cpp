@@ -9,6 +9,12 @@
 
 #include "../../include/libcluster_hip.h"
 #include "lc_ctx.hpp"
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+
+#include <cstdlib>
+
 #include "lc_engine.hpp"
 #include "lc_topic.hpp"
 #include "lc_host.hpp"
@@ -37,6 +43,25 @@ struct lc_tmodel {
 };
 
 namespace {
+// LC_BACKTRACE=1: print the native call stack on SIGSEGV / SIGABRT (debugging aid; symbols need -rdynamic or addr2line)
+void segv_handler(int sig) {
+  void* frames[64];
+  const int n = backtrace(frames, 64);
+  const char msg[] = "libcluster_hip: fatal signal, native backtrace:\n";
+  (void)!write(2, msg, sizeof(msg) - 1);
+  backtrace_symbols_fd(frames, n, 2);
+  signal(sig, SIG_DFL);
+  raise(sig);
+}
+struct BacktraceInstaller {
+  BacktraceInstaller() {
+    if (std::getenv("LC_BACKTRACE")) {
+      signal(SIGSEGV, segv_handler);
+      signal(SIGABRT, segv_handler);
+    }
+  }
+} g_backtrace_installer;
+
 thread_local std::string g_err;
 
 int fail(int code, const std::string& msg) {
@@ -619,7 +644,13 @@ int lc_model_fenergy(lc_model* m, double* Fw, double* Fc) {
 }
 
 // ---------------------------------------------------------------------------
-double lc_digamma(double x) { return lch::digamma(x); }
+double lc_digamma(double x) {  // poles (0, -1, -2, ...) give NaN here; inside the learners they raise LC_EDOMAIN
+  try {
+    return lch::digamma(x);
+  } catch (...) {
+    return std::numeric_limits<double>::quiet_NaN();
+  }
+}
 
 int lc_weights_update(int wkind, double wprior, const double* Nk, int K, double* Elogweight, double* fenergy) {
   return guarded([&] {

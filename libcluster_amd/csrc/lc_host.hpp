@@ -36,8 +36,10 @@ constexpr double PI = 3.14159265358979323846264338327950288;
 // (error < 1e-16 relative at x = 10 with 7 Bernoulli terms).  Near the root
 // x0 = 1.4616... the absolute error stays ~1e-16.
 inline double digamma(double x) {
+  if (x != x) return x;  // NaN in, NaN out (boost::math::digamma does the same; no recursion on NaN)
   if (!(x > 0.0)) {
-    if (x == 0.0) return -std::numeric_limits<double>::infinity();
+    // poles at 0, -1, -2, ...: boost's default policy throws std::domain_error there (probutils.cpp:213)
+    if (x == std::floor(x)) throw std::domain_error("digamma: evaluation at a pole");
     // reflection for completeness (never reached by the algorithms: all arguments are > 0)
     return digamma(1.0 - x) - PI / std::tan(PI * x);
   }

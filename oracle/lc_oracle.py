@@ -114,6 +114,86 @@ def eigpower(A):
     return eigval, eigvec
 
 
+def std_sort(items, less):
+    """``std::sort(first, last, comp)`` as libstdc++ implements it (bits/stl_algo.h: introsort = median-of-three
+    quicksort down to ranges of 16, then one insertion sort; GCC 4 ... 14 are identical here).  The reference sorts
+    the stick-breaking order (distributions.cpp:146) and the split candidates (cluster.cpp:418, scluster.cpp:331,
+    mcluster.cpp:360) with it; std::sort is not stable, so with TIES and more than 16 elements the resulting order --
+    and with it E[log pi] of the tied clusters -- depends on this exact algorithm.  ``less(a, b)`` is the comparator.
+    libstdc++ is a dependency outside /root/reference; its published algorithm is restated here."""
+    a = list(items)
+    n = len(a)
+    if n == 0:
+        return a
+
+    def unguarded_linear_insert(last):
+        val = a[last]
+        nxt = last - 1
+        while less(val, a[nxt]):
+            a[last] = a[nxt]
+            last = nxt
+            nxt -= 1
+        a[last] = val
+
+    def insertion_sort(first, last):
+        for i in range(first + 1, last):
+            if less(a[i], a[first]):
+                val = a[i]
+                a[first + 1:i + 1] = a[first:i]
+                a[first] = val
+            else:
+                unguarded_linear_insert(i)
+
+    def move_median_to_first(result, ia, ib, ic):
+        if less(a[ia], a[ib]):
+            if less(a[ib], a[ic]):
+                pick = ib
+            elif less(a[ia], a[ic]):
+                pick = ic
+            else:
+                pick = ia
+        elif less(a[ia], a[ic]):
+            pick = ia
+        elif less(a[ib], a[ic]):
+            pick = ic
+        else:
+            pick = ib
+        a[result], a[pick] = a[pick], a[result]
+
+    def unguarded_partition(first, last, pivot):
+        while True:
+            while less(a[first], a[pivot]):
+                first += 1
+            last -= 1
+            while less(a[pivot], a[last]):
+                last -= 1
+            if not first < last:
+                return first
+            a[first], a[last] = a[last], a[first]
+            first += 1
+
+    def introsort_loop(first, last, depth):
+        while last - first > 16:
+            if depth == 0:
+                raise NotImplementedError("std::sort fell back to heapsort (depth limit); not restated")
+            depth -= 1
+            mid = first + (last - first) // 2
+            move_median_to_first(first, first + 1, mid, last - 1)
+            cut = unguarded_partition(first + 1, last, first)
+            introsort_loop(cut, last, depth)
+            last = cut
+
+    introsort_loop(0, n, 2 * (n.bit_length() - 1))
+    if n > 16:
+        insertion_sort(0, 16)
+        for i in range(16, n):
+            unguarded_linear_insert(i)
+    else:
+        insertion_sort(0, n)
+    return a
+
+
+
 def enumdims(D):
     """1..D -- src/distributions.cpp:66-76."""
     return np.arange(1, D + 1, dtype=np.float64) if D > 1 else np.ones(1)
@@ -187,9 +267,8 @@ class StickBreak:
         self.E_logv = np.empty(K)
         self.E_lognv = np.empty(K)
         self.E_logpi = np.empty(K)
-        # descending by size (:141-146).  std::sort is unstable in the
-        # reference; a stable sort is used here, ties keep index order.
-        self.order = sorted(range(K), key=lambda k: -Nk[k])
+        # descending by size (:141-146) with std::sort's own (unstable) tie order, see std_sort
+        self.order = std_sort(range(K), lambda i, j: Nk[i] > Nk[j])
         N = Nk.sum()
         cumNk = 0.0
         cumE_lognv = 0.0
@@ -684,7 +763,7 @@ def split_gr(X, weights, clusters, qZ, tally, F, maxclusters, sparse, verbose,
             LL = float(qZ[j][:, k] @ (logpi[k] + clusters[k].Eloglike(X[j])))
             Fk[k] -= LL
     # greedcomp: tally ascending, then Fk descending (src/comutils.h:60-68)
-    order = sorted(range(K), key=lambda k: (tally[k], -Fk[k]))
+    order = std_sort(range(K), lambda i, j: Fk[i] > Fk[j] if tally[i] == tally[j] else tally[i] < tally[j])
     if events is not None:
         events.append(("order", list(order), Fk.tolist()))
 
@@ -976,7 +1055,7 @@ def tsplit(X, clusters, prior_t, qY, qZ, tally, F, maxK, verbose, W=None, cluste
             for k in range(K):
                 if X[j][i].shape[0]:
                     Fk[k] -= float(qZ[j][i][:, k] @ clusters[k].Eloglike(X[j][i]))
-    order = sorted(range(K), key=lambda k: (tally[k], -Fk[k]))
+    order = std_sort(range(K), lambda i, j: Fk[i] > Fk[j] if tally[i] == tally[j] else tally[i] < tally[j])
     if events is not None:
         events.append(("order", list(order), Fk.tolist()))
     for k in order:

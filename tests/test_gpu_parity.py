@@ -392,3 +392,17 @@ def test_sparse_mode_and_zero_skipping_are_exact():
     np.testing.assert_allclose(xs, xr, rtol=1e-9, atol=1e-10)
     np.testing.assert_allclose(xxs, xxr, rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(Njk, np.stack([q.sum(axis=0) for q in qz]), rtol=1e-11, atol=1e-13)
+
+
+def test_randomised_parity_fuzz():
+    """tools/fuzz_parity.py: random shapes, group structures, weight kinds, cluster families, sparse on/off, hard and
+    soft starts (hard starts produce tied counts, which exercise std::sort's tie order for K > 16)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    r = subprocess.run([sys.executable, str(root / "tools" / "fuzz_parity.py"), "80", "7"], capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "80 cases" in r.stdout and " 0 failures" in r.stdout

@@ -29,6 +29,13 @@ def test_digamma_matches_scipy(lib):
     got = np.array([lib.lc_digamma(float(v)) for v in x])
     ref = digamma(x)
     assert np.max(np.abs(got - ref) / np.maximum(1.0, np.abs(ref))) < 5e-15
+    # NaN in, NaN out (an all-inactive group in sparse mode produces NaN counts; this used to recurse forever);
+    # negative non-integers through the reflection formula; poles give NaN at this C entry point
+    assert np.isnan(lib.lc_digamma(float("nan")))
+    for v in (-0.5, -1.25, -7.75):
+        assert abs(lib.lc_digamma(v) - digamma(v)) < 1e-12 * max(1.0, abs(digamma(v)))
+    assert np.isnan(lib.lc_digamma(0.0)) and np.isnan(lib.lc_digamma(-3.0))
+    assert lib.lc_digamma(float("inf")) == float("inf")
 
 
 @pytest.mark.parametrize("kind,cls", [(capi.W_DIRICHLET, o.Dirichlet), (capi.W_STICKBREAK, o.StickBreak),

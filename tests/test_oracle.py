@@ -125,3 +125,41 @@ def test_errors():
         o.Dirichlet(0.0)
     with pytest.raises(ValueError):
         o.StickBreak(-1.0)
+
+
+def test_std_sort_restatement_matches_libstdcxx(tmp_path):
+    """The oracle restates libstdc++'s std::sort (unstable; the reference sorts the stick-breaking order and the
+    split candidates with it).  Compiled here against the real thing on tie-heavy inputs of 1 ... 300 elements."""
+    import random
+    import subprocess
+
+    src = tmp_path / "s.cpp"
+    src.write_text(r'''
+#include <algorithm>
+#include <cstdio>
+#include <utility>
+#include <vector>
+int main() {
+  int n;
+  while (scanf("%d", &n) == 1) {
+    std::vector<std::pair<int, double> > v(n);
+    for (int i = 0; i < n; ++i) { v[i].first = i; if (scanf("%lf", &v[i].second) != 1) return 1; }
+    std::sort(v.begin(), v.end(),
+              [](const std::pair<int, double>& a, const std::pair<int, double>& b) { return a.second > b.second; });
+    for (int i = 0; i < n; ++i) printf("%d ", v[i].first);
+    printf("\n");
+  }
+  return 0;
+}
+''')
+    exe = tmp_path / "s"
+    subprocess.run(["g++", "-O2", "-o", str(exe), str(src)], check=True)
+    rnd = random.Random(3)
+    cases = []
+    for _ in range(300):
+        n = rnd.choice([1, 2, 5, 16, 17, 18, 31, 33, 40, 65, 100, 300])
+        cases.append([float(rnd.randint(0, max(1, n // 3))) for _ in range(n)])
+    inp = "\n".join(f"{len(v)} " + " ".join(map(str, v)) for v in cases) + "\n"
+    out = subprocess.run([str(exe)], input=inp, capture_output=True, text=True, check=True).stdout.strip().split("\n")
+    for vals, line in zip(cases, out):
+        assert o.std_sort(range(len(vals)), lambda i, j: vals[i] > vals[j]) == [int(x) for x in line.split()]
