@@ -406,3 +406,17 @@ def test_randomised_parity_fuzz():
                        text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "80 cases" in r.stdout and " 0 failures" in r.stdout
+
+
+def test_randomised_learner_fuzz():
+    """tools/fuzz_learn.py: full model selection (all ten learners, random data / priors / maxclusters / sparse /
+    document structures) -- every round's K and free energies and the final K, T and F against the oracle."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    r = subprocess.run([sys.executable, str(root / "tools" / "fuzz_learn.py"), "150", "11"], capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "150 cases" in r.stdout and " 0 failures" in r.stdout
