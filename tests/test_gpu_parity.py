@@ -420,3 +420,17 @@ def test_randomised_learner_fuzz():
                        text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "150 cases" in r.stdout and " 0 failures" in r.stdout
+
+
+def test_randomised_kernel_fuzz():
+    """tools/fuzz_kernels.py: statistics and E-step of the three families at mid sizes (up to 400k rows, D to 128, K to
+    100, 1-31 ragged groups) against numpy / the oracle on row subsets: chunk, slice, batch and row-group edges."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    r = subprocess.run([sys.executable, str(root / "tools" / "fuzz_kernels.py"), "60", "21"], capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "60 cases" in r.stdout and " 0 failures" in r.stdout
