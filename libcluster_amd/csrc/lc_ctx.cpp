@@ -617,6 +617,77 @@ void Context::estep(int K, const double* A, const double* m, const double* c, do
   if (LLk) std::copy(hred_.begin() + 1, hred_.end(), LLk);
 }
 
+// Sparse statistics (cluster.cpp:67-79): turn the J x K activity mask into a work list of
+// (32-row-aligned row range inside ONE group) x (slice of that group's ACTIVE clusters), upload it with the active
+// cluster lists and the per-cluster record lists, and point the launch at it.  Returns the number of partial records
+// (one per listed (row range, cluster) pair).
+int Context::build_sparse_worklist(const unsigned char* smask, int K, int64_t SS, lck::SuffstatLaunch& a) {
+  const int DP = DP_;
+  int nrec = 0;
+  const int cpb = lck::suffstat_clusters_per_block(DP, K);
+  std::vector<int> klist, kofs((size_t)J_ + 1, 0);
+  for (int j2 = 0; j2 < J_; ++j2) {
+    for (int k2 = 0; k2 < K; ++k2)
+      if (smask[(size_t)j2 * K + k2]) klist.push_back(k2);
+    kofs[(size_t)j2 + 1] = (int)klist.size();
+  }
+  // row chunks: whole 32-row batches inside one group, about 2048 blocks in total (units = rows x slices)
+  double units = 0.0;
+  for (int j2 = 0; j2 < J_; ++j2)
+    units += (double)(goff_[(size_t)j2 + 1] - goff_[(size_t)j2]) *
+                      (double)((kofs[(size_t)j2 + 1] - kofs[(size_t)j2] + cpb - 1) / cpb);
+  int64_t rows = (int64_t)(units / 2048.0);
+  rows = std::max<int64_t>(256, (rows + 31) / 32 * 32);
+  std::vector<lck::SSItem> items;
+  std::vector<std::vector<int>> recs((size_t)K);
+  for (int j2 = 0; j2 < J_; ++j2) {
+    const int na = kofs[(size_t)j2 + 1] - kofs[(size_t)j2];
+    if (na == 0) continue;
+    for (int64_t b0 = goff_[(size_t)j2]; b0 < goff_[(size_t)j2 + 1]; b0 += rows) {
+      const int64_t b1 = std::min<int64_t>(b0 + rows, goff_[(size_t)j2 + 1]);
+      for (int s0 = 0; s0 < na; s0 += cpb) {
+        lck::SSItem it;
+        it.r0 = b0;
+        it.r1 = b1;
+        it.kofs = kofs[(size_t)j2] + s0;
+        it.kcnt = std::min(cpb, na - s0);
+        it.rec0 = nrec;
+        for (int t = 0; t < it.kcnt; ++t) recs[(size_t)klist[(size_t)it.kofs + t]].push_back(nrec + t);
+        nrec += it.kcnt;
+        items.push_back(it);
+      }
+    }
+  }
+  std::vector<int> kptr((size_t)K + 1, 0), krec;
+  krec.reserve((size_t)nrec);
+  for (int k2 = 0; k2 < K; ++k2) {
+    krec.insert(krec.end(), recs[(size_t)k2].begin(), recs[(size_t)k2].end());
+    kptr[(size_t)k2 + 1] = (int)krec.size();
+  }
+  ssitems_.reserve(items.size() * sizeof(lck::SSItem));
+  ssints_.reserve(klist.size() + kptr.size() + krec.size() + 1);
+  int* klist_d = ssints_.p;
+  int* kptr_d = klist_d + klist.size();
+  int* krec_d = kptr_d + kptr.size();
+  if (!items.empty()) {
+    LC_HIP(hipMemcpyAsync(ssitems_.p, items.data(), items.size() * sizeof(lck::SSItem), hipMemcpyHostToDevice,
+                          stream_));
+    LC_HIP(hipMemcpyAsync(klist_d, klist.data(), klist.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
+    LC_HIP(hipMemcpyAsync(krec_d, krec.data(), krec.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
+  }
+  LC_HIP(hipMemcpyAsync(kptr_d, kptr.data(), kptr.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
+  LC_HIP(hipStreamSynchronize(stream_));  // the host vectors go out of scope
+  a.items = reinterpret_cast<const lck::SSItem*>(ssitems_.p);
+  a.klist = klist_d;
+  a.nitems = (int)items.size();
+  a.smask = nullptr;  // only active clusters are listed
+  a.rginfo = nullptr;
+  sskptr_ = kptr_d;
+  sskrec_ = krec_d;
+  sspart_.reserve((size_t)std::max(nrec, 1) * SS);
+  return nrec;
+}
+
 void Context::suffstat(const unsigned char* smask, double* Nk, double* xs, double* xxs, double* Njk) {
   const int K = qz_[cur_].K, D = D_, DP = DP_;
   if (K < 1) throw std::invalid_argument("qZ has not been set");
@@ -661,67 +732,7 @@ void Context::suffstat(const unsigned char* smask, double* Nk, double* xs, doubl
       // work is proportional to sum_j N_j * K_active(j); otherwise the dense grid with masked q staged as zeros.
       if (off > 0.3 * tot) {
         listed = true;
-        const int cpb = lck::suffstat_clusters_per_block(DP, K);
-        std::vector<int> klist, kofs((size_t)J_ + 1, 0);
-        for (int j2 = 0; j2 < J_; ++j2) {
-          for (int k2 = 0; k2 < K; ++k2)
-            if (smask[(size_t)j2 * K + k2]) klist.push_back(k2);
-          kofs[(size_t)j2 + 1] = (int)klist.size();
-        }
-        // row chunks: whole 32-row batches inside one group, about 2048 blocks in total
-        double blocks_per_row = 0.0;
-        for (int j2 = 0; j2 < J_; ++j2)
-          blocks_per_row += (double)(goff_[(size_t)j2 + 1] - goff_[(size_t)j2]) *
-                            (double)((kofs[(size_t)j2 + 1] - kofs[(size_t)j2] + cpb - 1) / cpb);
-        int64_t rows = (int64_t)(blocks_per_row / 2048.0);
-        rows = std::max<int64_t>(256, (rows + 31) / 32 * 32);
-        std::vector<lck::SSItem> items;
-        std::vector<std::vector<int>> recs((size_t)K);
-        for (int j2 = 0; j2 < J_; ++j2) {
-          const int na = kofs[(size_t)j2 + 1] - kofs[(size_t)j2];
-          if (na == 0) continue;
-          for (int64_t b0 = goff_[(size_t)j2]; b0 < goff_[(size_t)j2 + 1]; b0 += rows) {
-            const int64_t b1 = std::min<int64_t>(b0 + rows, goff_[(size_t)j2 + 1]);
-            for (int s0 = 0; s0 < na; s0 += cpb) {
-              lck::SSItem it;
-              it.r0 = b0;
-              it.r1 = b1;
-              it.kofs = kofs[(size_t)j2] + s0;
-              it.kcnt = std::min(cpb, na - s0);
-              it.rec0 = nrec;
-              for (int t = 0; t < it.kcnt; ++t) recs[(size_t)klist[(size_t)it.kofs + t]].push_back(nrec + t);
-              nrec += it.kcnt;
-              items.push_back(it);
-            }
-          }
-        }
-        std::vector<int> kptr((size_t)K + 1, 0), krec;
-        krec.reserve((size_t)nrec);
-        for (int k2 = 0; k2 < K; ++k2) {
-          krec.insert(krec.end(), recs[(size_t)k2].begin(), recs[(size_t)k2].end());
-          kptr[(size_t)k2 + 1] = (int)krec.size();
-        }
-        ssitems_.reserve(items.size() * sizeof(lck::SSItem));
-        ssints_.reserve(klist.size() + kptr.size() + krec.size() + 1);
-        int* klist_d = ssints_.p;
-        int* kptr_d = klist_d + klist.size();
-        int* krec_d = kptr_d + kptr.size();
-        if (!items.empty()) {
-          LC_HIP(hipMemcpyAsync(ssitems_.p, items.data(), items.size() * sizeof(lck::SSItem), hipMemcpyHostToDevice,
-                                stream_));
-          LC_HIP(hipMemcpyAsync(klist_d, klist.data(), klist.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
-          LC_HIP(hipMemcpyAsync(krec_d, krec.data(), krec.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
-        }
-        LC_HIP(hipMemcpyAsync(kptr_d, kptr.data(), kptr.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
-        LC_HIP(hipStreamSynchronize(stream_));  // the host vectors go out of scope
-        a.items = reinterpret_cast<const lck::SSItem*>(ssitems_.p);
-        a.klist = klist_d;
-        a.nitems = (int)items.size();
-        a.smask = nullptr;  // only active clusters are listed
-        a.rginfo = nullptr;
-        sskptr_ = kptr_d;
-        sskrec_ = krec_d;
-        sspart_.reserve((size_t)std::max(nrec, 1) * SS);
+        nrec = build_sparse_worklist(smask, K, SS, a);
       } else if (!skip_zero_) {
         a.skip_zero = -1;  // dense variant; masked q are staged as zeros
       }
