@@ -88,6 +88,7 @@ __global__ void __launch_bounds__(WAVES * 64, EstepOcc<DP>::BLOCKS) estep_kernel
   const int lo4 = lane & 15, hi = lane >> 4;
   const int K = a.K;
   const int64_t rg0 = ((int64_t)blockIdx.x * WAVES + wave) * R;
+  constexpr bool ROWLANES = R == 4;  // four row groups per wave: lane (lo4, hi) can own row group hi outright
 
   double xf[R][NT];
   int grp[R];
@@ -111,6 +112,10 @@ __global__ void __launch_bounds__(WAVES * 64, EstepOcc<DP>::BLOCKS) estep_kernel
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt) xf[r][jt] = xr[4 * jt];
   }
+  bool myok = false;  // ROWLANES: this lane's row group exists
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    if (hi == r) myok = rgok[r];
 
   // register double-buffer for the next cluster's parameter record
   double pre[NPRE][2];
@@ -160,9 +165,13 @@ __global__ void __launch_bounds__(WAVES * 64, EstepOcc<DP>::BLOCKS) estep_kernel
     nact = bgrp[WAVES * R];
     for (int k = 0; k < K; ++k) {
       if (kflag[k]) continue;
+      if constexpr (ROWLANES) {
+        if (myok) a.qZ[(int64_t)k * a.ldq + (rg0 + hi) * RG + lo4] = -INFINITY;
+      } else {
 #pragma unroll
-      for (int r = 0; r < R; ++r)
-        if (rgok[r] && hi == (k & 3)) a.qZ[(int64_t)k * a.ldq + (rg0 + r) * RG + lo4] = -INFINITY;
+        for (int r = 0; r < R; ++r)
+          if (rgok[r] && hi == (k & 3)) a.qZ[(int64_t)k * a.ldq + (rg0 + r) * RG + lo4] = -INFINITY;
+      }
     }
   }
 
@@ -229,6 +238,7 @@ __global__ void __launch_bounds__(WAVES * 64, EstepOcc<DP>::BLOCKS) estep_kernel
         }
       }
     });
+    double lqsel = 0.0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       // sum over the four hi lanes on the matrix pipe: D[i][j] = sum_k 1 * B[k][j] leaves the
@@ -236,7 +246,16 @@ __global__ void __launch_bounds__(WAVES * 64, EstepOcc<DP>::BLOCKS) estep_kernel
       const double dd = mfma4(1.0, d2[r], 0.0);
       const double lq = a.ctab[(int64_t)grp[r] * K + k] - 0.5 * dd;
       mx[r] = fmax(mx[r], lq);
-      if (rgok[r] && hi == (k & 3)) a.qZ[(int64_t)k * a.ldq + (rg0 + r) * RG + lo4] = lq;
+      if constexpr (ROWLANES) {
+        if (hi == r) lqsel = lq;
+      } else {
+        if (rgok[r] && hi == (k & 3)) a.qZ[(int64_t)k * a.ldq + (rg0 + r) * RG + lo4] = lq;
+      }
+    }
+    // R == 4: lane (lo4, hi) keeps row group hi -- ONE 512-byte store per cluster column instead of four
+    // 128-byte ones, and the normalisation below needs no cross-lane sums
+    if constexpr (ROWLANES) {
+      if (myok) a.qZ[(int64_t)k * a.ldq + (rg0 + hi) * RG + lo4] = lqsel;
     }
     if (ii + 1 < nact) LC_LSTORE(buf ^ 1);
     __syncthreads();
@@ -248,6 +267,38 @@ __global__ void __launch_bounds__(WAVES * 64, EstepOcc<DP>::BLOCKS) estep_kernel
   if (a.raw) return;  // GaussWish::Eloglike: leave c_k - 0.5 d^2 in qZ, no normalisation
 
   // ---- normalise (probutils.cpp:141-150, cluster.cpp:124-131) -------------
+  double fz = 0.0;
+  if constexpr (ROWLANES) {
+    // every lane owns one row (row group hi, row lo4) and walks all K columns it wrote itself
+    double mymx = mx[0];
+    int mygrp = grp[0];
+    bool myrow = rowok[0];
+#pragma unroll
+    for (int r = 1; r < R; ++r)
+      if (hi == r) mymx = mx[r], mygrp = grp[r], myrow = rowok[r];
+    double* qp = a.qZ + (rg0 + hi) * RG + lo4;
+    double s = 0.0;
+    if (myok) {
+#pragma unroll 8
+      for (int k = 0; k < K; ++k) s += exp(qp[(int64_t)k * a.ldq] - mymx);
+    }
+    const double logZ = log(s) + mymx;
+    for (int k = 0; k < K; ++k) {
+      double ll = 0.0;
+      if (myok) {
+        const double lq = qp[(int64_t)k * a.ldq];
+        double q = exp(lq - logZ);
+        if (!myrow) q = 0.0;
+        qp[(int64_t)k * a.ldq] = q;
+        if (a.ll_part && q > 0.0) ll = q * (lq - a.ctab[(int64_t)mygrp * K + k]);
+      }
+      if (a.ll_part) {  // wave-uniform
+        ll = wave_sum(ll);
+        if (lane == 0) llw[wave * K + k] = ll;
+      }
+    }
+    fz = (myok && myrow) ? logZ : 0.0;
+  } else {
   double logZ[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -281,10 +332,10 @@ __global__ void __launch_bounds__(WAVES * 64, EstepOcc<DP>::BLOCKS) estep_kernel
       if (k < K && lo4 == 0) llw[wave * K + k] = ll;
     }
   }
-  double fz = 0.0;
 #pragma unroll
   for (int r = 0; r < R; ++r)
     if (rgok[r] && rowok[r] && hi == 0) fz += logZ[r];
+  }
   fz = wave_sum(fz);
   if (lane == 0) fzw[wave] = fz;
   __syncthreads();
