@@ -94,6 +94,8 @@ int lc_ctx_set_qz(lc_ctx* ctx, int j, const double* q, int K, int64_t row_stride
 int lc_ctx_get_qz(lc_ctx* ctx, int j, double* q, int64_t row_stride, int64_t col_stride);
 /* rows [row0,row0+n) of group j only (qZ[j].block(row0,0,n,K)) */
 int lc_ctx_get_qz_rows(lc_ctx* ctx, int j, int64_t row0, int64_t n, double* q, int64_t row_stride, int64_t col_stride);
+/* every group at once: q is [sum_j N_j x K] row-major, the groups' rows concatenated (one transfer) */
+int lc_ctx_get_qz_all(lc_ctx* ctx, double* q);
 int lc_ctx_fill_qz(lc_ctx* ctx, int K, double value); /* qZ[j].setOnes(N,1): cluster.cpp:583-585 */
 
 /* ---- the hot path ------------------------------------------------------ */
@@ -205,6 +207,7 @@ int lc_model_dims(lc_model* m, int* J, int* K, int* D);
 int lc_model_rounds(lc_model* m, int* nrounds);                       /* vbem rounds of cluster() */
 int lc_model_round(lc_model* m, int r, int* K, int* niter, double* F, int nF); /* F trace of round r */
 int lc_model_get_qz(lc_model* m, int j, double* q, int64_t row_stride, int64_t col_stride);
+int lc_model_get_qz_all(lc_model* m, double* q); /* all groups, [sum_j N_j x K] row-major */
 /* WeightDist::Elogweight() / getNk() of group j (K values each; may be NULL) */
 int lc_model_weights(lc_model* m, int j, double* Elogweight, double* Nk);
 int lc_model_kinds(lc_model* m, int* wkind, int* ckind);
@@ -252,6 +255,7 @@ int lc_tmodel_free(lc_tmodel* m);
 int lc_tmodel_dims(lc_tmodel* m, int* J, int* Itot, int* T, int* K, int* D, int* Dt);
 int lc_tmodel_get_qy(lc_tmodel* m, int j, double* qY /* Ij[j] x T row-major */);
 int lc_tmodel_get_qz(lc_tmodel* m, int doc, double* q, int64_t row_stride, int64_t col_stride); /* Nji[doc] x K */
+int lc_tmodel_get_qz_all(lc_tmodel* m, double* q); /* all documents, [sum N_ji x K] row-major */
 /* level 0: weights_j[idx] (T values each); level 1: weights_t[idx] (K values each) */
 int lc_tmodel_weights(lc_tmodel* m, int level, int idx, double* Elogweight, double* Nk);
 /* level 0: bottom-level clusters[idx] (D); level 1: top-level clusters_t[idx] (Dt, MCM only) */

@@ -35,7 +35,7 @@ def _threads(threads, nthreads):
 
 def _result(F, model, rows, grouped, return_info):
     J, K, D = model.dims()
-    qZ = [model.qz(j, rows[j]) for j in range(J)]
+    qZ = model.qz_all(rows)
     w = [np.exp(model.weights(j)[0]).reshape(-1, 1) for j in range(J)]  # ArrayXd -> (K, 1)
     cl = [model.cluster(k) for k in range(K)]
     # ExpGamma has no mean / covariance: its slot carries getrate(), covs is None per cluster

@@ -128,6 +128,9 @@ def lib() -> C.CDLL:
     L.lc_tmodel_dims.argtypes = [C.c_void_p, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p]
     L.lc_tmodel_get_qy.argtypes = [C.c_void_p, C.c_int, c_double_p]
     L.lc_tmodel_get_qz.argtypes = [C.c_void_p, C.c_int, c_double_p, C.c_int64, C.c_int64]
+    L.lc_tmodel_get_qz_all.argtypes = [C.c_void_p, c_double_p]
+    L.lc_model_get_qz_all.argtypes = [C.c_void_p, c_double_p]
+    L.lc_ctx_get_qz_all.argtypes = [C.c_void_p, c_double_p]
     L.lc_tmodel_weights.argtypes = [C.c_void_p, C.c_int, C.c_int, c_double_p, c_double_p]
     L.lc_tmodel_cluster.argtypes = [C.c_void_p, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p,
                                     c_double_p, c_double_p, c_double_p, c_double_p]
@@ -441,6 +444,14 @@ class Model:
             out.append((K.value, F.tolist()))
         return out
 
+    def qz_all(self, rows):
+        """All groups with one transfer -> list of (N_j, K) views."""
+        _, K, _ = self.dims()
+        allq = np.zeros((int(sum(rows)), K))
+        if allq.size:
+            check(lib().lc_model_get_qz_all(self._h, dptr(allq)))
+        return [allq[o - n:o] for n, o in zip(rows, np.cumsum(rows))]
+
     def qz(self, j, n):
         _, K, _ = self.dims()
         q = np.empty((n, K))
@@ -578,14 +589,15 @@ class TopicModel:
 
     def qZ(self):
         K = self.dims()["K"]
-        out, doc = [], 0
+        allq = np.zeros((int(sum(self.Nji)), K))
+        if allq.size:
+            check(lib().lc_tmodel_get_qz_all(self._h, dptr(allq)))  # one transfer, then views per document
+        out, doc, o = [], 0, 0
         for I in self.Ij:
             g = []
             for _ in range(I):
-                q = np.zeros((self.Nji[doc], K))
-                if self.Nji[doc]:
-                    check(lib().lc_tmodel_get_qz(self._h, doc, dptr(q), K, 1))
-                g.append(q)
+                g.append(allq[o:o + self.Nji[doc]])
+                o += self.Nji[doc]
                 doc += 1
             out.append(g)
         return out

@@ -573,6 +573,23 @@ int lc_model_get_qz(lc_model* m, int j, double* q, int64_t rs, int64_t cs) {
   });
 }
 
+int lc_model_get_qz_all(lc_model* m, double* q) {
+  return guarded([&] {
+    need(m, "model");
+    need(q, "q");
+    if (!m->ctx) throw std::invalid_argument("model has no context");
+    m->ctx->impl.qz_get_all(q);
+  });
+}
+
+int lc_ctx_get_qz_all(lc_ctx* ctx, double* q) {
+  return guarded([&] {
+    need(ctx, "ctx");
+    need(q, "q");
+    ctx->impl.qz_get_all(q);
+  });
+}
+
 int lc_model_weights(lc_model* m, int j, double* Elogweight, double* Nk) {
   return guarded([&] {
     need(m, "model");
@@ -841,6 +858,14 @@ int lc_tmodel_get_qz(lc_tmodel* m, int doc, double* q, int64_t rs, int64_t cs) {
     need(m, "model");
     need(q, "q");
     m->ctx->impl.qz_get(doc, q, rs, cs);
+  });
+}
+
+int lc_tmodel_get_qz_all(lc_tmodel* m, double* q) {
+  return guarded([&] {
+    need(m, "model");
+    need(q, "q");
+    m->ctx->impl.qz_get_all(q);
   });
 }
 

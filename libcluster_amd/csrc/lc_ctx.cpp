@@ -370,6 +370,22 @@ void Context::qz_get(int j, double* q, int64_t rs, int64_t cs) const {
   }
 }
 
+// all groups at once: out is [Ntotal x K] row-major, the groups' rows concatenated (one device-to-host copy of the
+// whole K x NP buffer instead of K copies per group: 20 000 small documents took 4.3 s the other way)
+void Context::qz_get_all(double* out) const {
+  const int K = qz_[cur_].K;
+  if (K < 1 || NP_ == 0) return;
+  std::vector<double> host((size_t)K * NP_);
+  LC_HIP(hipMemcpyAsync(host.data(), qz_[cur_].buf.p, host.size() * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  LC_HIP(hipStreamSynchronize(stream_));
+  int64_t o = 0;
+  for (int j = 0; j < J_; ++j) {
+    const int64_t b = goff_[(size_t)j];
+    for (int64_t r = 0; r < Nj_[(size_t)j]; ++r, ++o)
+      for (int k = 0; k < K; ++k) out[o * K + k] = host[(size_t)k * NP_ + b + r];
+  }
+}
+
 void Context::qz_keep_columns(const std::vector<int>& keep) {
   QZ& q = qz_[cur_];
   for (size_t i = 0; i < keep.size(); ++i) {

@@ -131,6 +131,7 @@ class Context {
   void qz_fill(int K, double value);  // K columns = value on valid rows
   void qz_set(int j, const double* q, int K, int64_t row_stride, int64_t col_stride);
   void qz_get(int j, double* q, int64_t row_stride, int64_t col_stride) const;
+  void qz_get_all(double* out) const;  // [Ntotal x K] row-major, groups concatenated
   void qz_get_rows(int j, int64_t row0, int64_t n, double* q, int64_t row_stride, int64_t col_stride) const;
   void qz_get_column(int j, int k, double* out) const;  // N(j) doubles
   void qz_keep_columns(const std::vector<int>& keep);    // prune_clusters

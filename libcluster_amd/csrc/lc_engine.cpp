@@ -148,6 +148,10 @@ bool greedcomp(const GreedOrder& i, const GreedOrder& j) {  // src/comutils.h:60
 
 }  // namespace
 
+void parallel_chunks(int nchunks, unsigned nthreads, double work_per_chunk, const std::function<void(int)>& fn) {
+  parallel_for(nchunks, nthreads, work_per_chunk, [&](int c) { fn(c); });
+}
+
 // ---------------------------------------------------------------------------
 // cluster.cpp:177-239
 // ---------------------------------------------------------------------------

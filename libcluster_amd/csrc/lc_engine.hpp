@@ -6,6 +6,7 @@
 // split_gr (366-495), cluster (564-629), learnVDP/BGMM/GMC (636-695, 763-784).
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <memory>
 #include <vector>
 
@@ -34,6 +35,9 @@ struct VbemOptions {
   std::vector<double>* trace = nullptr;  // F after every iteration
   unsigned nthreads = 1;
 };
+
+// fn(c) for c in [0, nchunks) on the persistent worker pool (inline when the work is small or the pool is busy)
+void parallel_chunks(int nchunks, unsigned nthreads, double work_per_chunk, const std::function<void(int)>& fn);
 
 // cluster.cpp:177-239 on the context's current qZ.  Returns F.
 double vbem(lcc::Context& ctx, Model& model, const VbemOptions& opt);

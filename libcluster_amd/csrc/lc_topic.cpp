@@ -1,5 +1,7 @@
 #include "lc_topic.hpp"
 
+#include "lc_engine.hpp"
+
 #include <algorithm>
 #include <cmath>
 #include <iostream>
@@ -72,7 +74,7 @@ double topic_vbem(lcc::Context& ctx, const TopicData& data, TopicModel& model, c
   m.assign((size_t)K * D, 0.0);
   c.assign((size_t)I * K, 0.0);
   cst.assign(K, 0.0);
-  std::vector<double> like((size_t)T), logq((size_t)T), Et(K);
+  std::vector<double> part, fpart;  // per-chunk partial sums of the document loops
   std::vector<double> At, ctt, wN(T), wxs, wxx, ellw;  // MCM top-level Gaussians
   if (mcm) {
     At.resize((size_t)T * Dt * Dt);
@@ -92,16 +94,26 @@ double topic_vbem(lcc::Context& ctx, const TopicData& data, TopicModel& model, c
     ctx.suffstat(nullptr, Nk.data(), xs.data(), xxs.data(), Njik.data());
 
     // Ntk = sum_ji qY_ji^T N_jik; weights_j[j].update(qY[j].colwise().sum())   (:199-207 / :221-233)
+    // The document loops run in NCH fixed chunks on the worker pool; chunk results are folded in chunk order, so the
+    // sums do not depend on the number of threads.
     std::fill(Ntk.begin(), Ntk.end(), 0.0);
     std::fill(qysum.begin(), qysum.end(), 0.0);
-    for (int i = 0; i < I; ++i) {
-      const double* qy = qY.data() + (size_t)i * T;
-      const double* nk = Njik.data() + (size_t)i * K;
-      for (int t = 0; t < T; ++t) {
-        for (int k = 0; k < K; ++k) Ntk[(size_t)t * K + k] += qy[t] * nk[k];
-        qysum[(size_t)data.doc_group[i] * T + t] += qy[t];
+    const int NCH = std::min(I, 64), per = (I + NCH - 1) / NCH;
+    const double docwork = 4.0 * T * K;
+    part.assign((size_t)NCH * T * K, 0.0);
+    parallel_chunks(NCH, opt.nthreads, docwork * per, [&](int ch) {
+      double* nt = part.data() + (size_t)ch * T * K;
+      for (int i = ch * per; i < std::min(I, (ch + 1) * per); ++i) {
+        const double* qy = qY.data() + (size_t)i * T;
+        const double* nk = Njik.data() + (size_t)i * K;
+        for (int t = 0; t < T; ++t)
+          for (int k = 0; k < K; ++k) nt[(size_t)t * K + k] += qy[t] * nk[k];
       }
-    }
+    });
+    for (int ch = 0; ch < NCH; ++ch)
+      for (int e = 0; e < T * K; ++e) Ntk[(size_t)e] += part[(size_t)ch * T * K + e];
+    for (int i = 0; i < I; ++i)
+      for (int t = 0; t < T; ++t) qysum[(size_t)data.doc_group[i] * T + t] += qY[(size_t)i * T + t];
     if (ctx.group_sharded()) ctx.allreduce_values(Ntk.data(), T * K);  // groups (and their documents) are sharded
     for (int j = 0; j < J; ++j) model.weights_j[j].update(qysum.data() + (size_t)j * T, T);
 
@@ -175,37 +187,47 @@ double topic_vbem(lcc::Context& ctx, const TopicData& data, TopicModel& model, c
         }
       }
     }
-    for (int i = 0; i < I; ++i) {
-      const WeightState& wj = model.weights_j[data.doc_group[i]];
-      const double* nk = Njik.data() + (size_t)i * K;
-      for (int t = 0; t < T; ++t) {
-        const std::vector<double>& el = model.weights_t[t].Elogpi;
-        double s = 0.0;
-        for (int k = 0; k < K; ++k) s += nk[k] * el[k];
-        like[t] = s;
-        logq[t] = mcm ? s + wj.Elogpi[t] + ellw[(size_t)i * T + t] : wj.Elogpi[t] + s;
+    fpart.assign((size_t)NCH, 0.0);
+    parallel_chunks(NCH, opt.nthreads, docwork * per, [&](int ch) {
+      std::vector<double> like((size_t)T), logq((size_t)T);
+      double f = 0.0;
+      for (int i = ch * per; i < std::min(I, (ch + 1) * per); ++i) {
+        const WeightState& wj = model.weights_j[data.doc_group[i]];
+        const double* nk = Njik.data() + (size_t)i * K;
+        for (int t = 0; t < T; ++t) {
+          const std::vector<double>& el = model.weights_t[t].Elogpi;
+          double s = 0.0;
+          for (int k = 0; k < K; ++k) s += nk[k] * el[k];
+          like[t] = s;
+          logq[t] = mcm ? s + wj.Elogpi[t] + ellw[(size_t)i * T + t] : wj.Elogpi[t] + s;
+        }
+        const double logZ = logsumexp_row(logq.data(), T);
+        double acc = 0.0;
+        for (int t = 0; t < T; ++t) {
+          const double q = std::exp(logq[t] - logZ);
+          qY[(size_t)i * T + t] = q;
+          acc += q * like[t];
+        }
+        f += acc - logZ;
       }
-      const double logZ = logsumexp_row(logq.data(), T);
-      double acc = 0.0;
-      for (int t = 0; t < T; ++t) {
-        const double q = std::exp(logq[t] - logZ);
-        qY[(size_t)i * T + t] = q;
-        acc += q * like[t];
-      }
-      Fyz += acc - logZ;
-    }
+      fpart[(size_t)ch] = f;
+    });
+    for (int ch = 0; ch < NCH; ++ch) Fyz += fpart[(size_t)ch];
     if (ctx.group_sharded()) Fyz = ctx.allreduce_value(Fyz);
 
     // VBE for the bottom-level indicators, vbeZ, with the NEW qY: one E-step launch over all documents
-    for (int i = 0; i < I; ++i) {
-      std::fill(Et.begin(), Et.end(), 0.0);
-      for (int t = 0; t < T; ++t) {
-        const double q = qY[(size_t)i * T + t];
-        const std::vector<double>& el = model.weights_t[t].Elogpi;
-        for (int k = 0; k < K; ++k) Et[k] += q * el[k];
+    parallel_chunks(NCH, opt.nthreads, docwork * per, [&](int ch) {
+      std::vector<double> Et((size_t)K);
+      for (int i = ch * per; i < std::min(I, (ch + 1) * per); ++i) {
+        std::fill(Et.begin(), Et.end(), 0.0);
+        for (int t = 0; t < T; ++t) {
+          const double q = qY[(size_t)i * T + t];
+          const std::vector<double>& el = model.weights_t[t].Elogpi;
+          for (int k = 0; k < K; ++k) Et[(size_t)k] += q * el[k];
+        }
+        for (int k = 0; k < K; ++k) c[(size_t)i * K + k] = Et[(size_t)k] + cst[k];
       }
-      for (int k = 0; k < K; ++k) c[(size_t)i * K + k] = Et[k] + cst[k];
-    }
+    });
     double Fz = 0.0;
     ctx.estep(K, A.data(), m.data(), c.data(), &Fz, nullptr);
 
