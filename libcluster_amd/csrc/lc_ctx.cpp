@@ -216,25 +216,33 @@ void Context::build_layout(int J, const int64_t* Nj, int D) {
 void Context::set_data(int J, const double* const* Xj, const int64_t* Nj, int D, int64_t rs, int64_t cs) {
   build_layout(J, Nj, D);
   if (NP_ == 0) return;
-  // stage in row chunks so the host copy stays bounded
-  const int64_t chunk = std::max<int64_t>(lck::RG, ((int64_t)32 << 20) / DP_ / lck::RG * lck::RG);
-  std::vector<double> stage;
-  for (int j = 0; j < J; ++j) {
-    const int64_t np = goff_[j + 1] - goff_[j];
-    for (int64_t r0 = 0; r0 < np; r0 += chunk) {
-      const int64_t nr = std::min(chunk, np - r0);
-      stage.assign((size_t)nr * DP_, 0.0);
-      const int64_t nvalid = std::max<int64_t>(0, std::min(nr, Nj[j] - r0));
-      for (int64_t r = 0; r < nvalid; ++r) {
-        const double* src = Xj[j] + (r0 + r) * rs;
-        double* dst = stage.data() + (size_t)r * DP_;
+  // The padded row-major image of X is contiguous over groups: pack it in 32 MB pieces that may span many (small)
+  // groups, into two page-locked buffers that alternate, so packing piece i+1 overlaps the transfer of piece i and
+  // thousands of small documents do not cost a transfer and a synchronisation each.
+  const int64_t chunk = std::max<int64_t>(lck::RG, ((int64_t)32 << 20) / 8 / DP_ / lck::RG * lck::RG);
+  PinnedBuf stage[2];
+  int j = 0, which = 0;
+  for (int64_t p0 = 0; p0 < NP_; p0 += chunk, which ^= 1) {
+    const int64_t nr = std::min(chunk, NP_ - p0);
+    PinnedBuf& st = stage[which];
+    if (st.size() == 0) st.resize((size_t)chunk * DP_);
+    else LC_HIP(hipStreamSynchronize(stream_));  // the transfer that last used this buffer (two pieces ago) is done
+    double* base = st.data();
+    std::memset(base, 0, (size_t)nr * DP_ * sizeof(double));
+    while (j < J && goff_[(size_t)j + 1] <= p0) ++j;
+    for (int jj = j; jj < J && goff_[(size_t)jj] < p0 + nr; ++jj) {
+      const int64_t g0 = goff_[(size_t)jj];
+      const int64_t lo = std::max<int64_t>(p0, g0), hi = std::min<int64_t>(p0 + nr, g0 + Nj[jj]);  // valid rows only
+      for (int64_t pr = lo; pr < hi; ++pr) {
+        const double* src = Xj[jj] + (pr - g0) * rs;
+        double* dst = base + (size_t)(pr - p0) * DP_;
         for (int d = 0; d < D; ++d) dst[d] = src[d * cs];
       }
-      LC_HIP(hipMemcpyAsync(X_.p + (size_t)(goff_[j] + r0) * DP_, stage.data(), stage.size() * sizeof(double),
-                            hipMemcpyHostToDevice, stream_));
-      LC_HIP(hipStreamSynchronize(stream_));
     }
+    LC_HIP(hipMemcpyAsync(X_.p + (size_t)p0 * DP_, base, (size_t)nr * DP_ * sizeof(double), hipMemcpyHostToDevice,
+                          stream_));
   }
+  LC_HIP(hipStreamSynchronize(stream_));
 }
 
 void Context::synth(int64_t N, int D, int K, const double* mu, const double* L, uint64_t seed, int64_t row_offset,
