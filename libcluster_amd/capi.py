@@ -269,14 +269,13 @@ class Context:
             check(lib().lc_ctx_set_qz(self._h, j, dptr(q), K, rs, cs))
 
     def get_qz(self, rows_per_group):
+        """qZ of every group (one device-to-host transfer) -> list of (N_j, K) arrays."""
         _, _, _, K = self.dims()
-        out = []
-        for j, n in enumerate(rows_per_group):
-            q = np.empty((n, K))
-            if n:
-                check(lib().lc_ctx_get_qz(self._h, j, dptr(q), K, 1))
-            out.append(q)
-        return out
+        rows = [int(n) for n in rows_per_group]
+        allq = np.zeros((sum(rows), K))
+        if allq.size:
+            check(lib().lc_ctx_get_qz_all(self._h, dptr(allq)))
+        return [allq[o - n:o] for n, o in zip(rows, np.cumsum(rows))]
 
     def get_qz_rows(self, j, row0, n):
         _, _, _, K = self.dims()
