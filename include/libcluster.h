@@ -81,11 +81,16 @@ inline double run(int algo, const vMatrixXd& X, vMatrixXd& qZ, std::vector<W>& w
   /* qZ, weights, clusters are overwritten exactly as the reference does (cluster.cpp:583-585, 192-193) */
   qZ.resize(J);
   weights.resize(J, W());
+  int64_t Ntot = 0;
+  for (int j = 0; j < J; ++j) Ntot += (int64_t)X[j].rows();
+  std::vector<double> allq((size_t)Ntot * K);
+  if (Ntot > 0) check(lc_model_get_qz_all(g.m, allq.data())); /* one transfer for all groups */
+  int64_t row0 = 0;
   for (int j = 0; j < J; ++j) {
     qZ[j].resize(X[j].rows(), K);
-    int64_t r, c;
-    lcmat::strides(qZ[j], r, c);
-    if (X[j].rows() > 0) check(lc_model_get_qz(g.m, j, qZ[j].data(), r, c));
+    for (std::ptrdiff_t r = 0; r < X[j].rows(); ++r)
+      for (int k = 0; k < K; ++k) qZ[j](r, k) = allq[(size_t)(row0 + r) * K + k];
+    row0 += (int64_t)X[j].rows();
     lcmat::ArrayXd Nk(K);
     check(lc_model_weights(g.m, j, 0, Nk.data()));
     weights[j].update(Nk); /* same arithmetic as inside the learner => identical Elogweight() */
@@ -257,6 +262,10 @@ inline double run_topic(const vMatrixXd* W, const vvMatrixXd& X, vMatrixXd& qY, 
   weights_j.assign(J, distributions::GDirichlet());
   weights_t.assign(T, W ? distributions::Dirichlet() : distributions::Dirichlet(prior_t));
   std::vector<double> buf;
+  int64_t Ntot = 0, qrow = 0;
+  for (size_t i = 0; i < n.size(); ++i) Ntot += n[i];
+  std::vector<double> allq((size_t)Ntot * K);
+  if (Ntot > 0) check(lc_tmodel_get_qz_all(g.m, allq.data())); /* one transfer for all documents */
   int doc = 0;
   for (int j = 0; j < J; ++j) {
     buf.resize((size_t)Ij[j] * T);
@@ -267,9 +276,9 @@ inline double run_topic(const vMatrixXd* W, const vvMatrixXd& X, vMatrixXd& qY, 
     qZ[j].resize(Ij[j]);
     for (int i = 0; i < Ij[j]; ++i, ++doc) {
       qZ[j][i].resize(X[j][i].rows(), K);
-      int64_t r, c;
-      lcmat::strides(qZ[j][i], r, c);
-      if (X[j][i].rows() > 0) check(lc_tmodel_get_qz(g.m, doc, qZ[j][i].data(), r, c));
+      for (std::ptrdiff_t r = 0; r < X[j][i].rows(); ++r)
+        for (int k = 0; k < K; ++k) qZ[j][i](r, k) = allq[(size_t)(qrow + r) * K + k];
+      qrow += (int64_t)X[j][i].rows();
     }
     lcmat::ArrayXd Nk(T);
     check(lc_tmodel_weights(g.m, 0, j, 0, Nk.data()));
