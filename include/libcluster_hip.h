@@ -120,6 +120,10 @@ int lc_estep(lc_ctx* ctx, int K, const double* A, const double* m, const double*
  * (no weights, no normalisation); fetch it with lc_ctx_get_qz. */
 int lc_eloglike(lc_ctx* ctx, int K, const double* nu, const double* beta, const double* m, const double* iW,
                 const double* logdW);
+/* probutils::mahaldist (probutils.cpp:113-138) on the context's observations: dist[n] = (x_n - mu) A^-1 (x_n - mu)^T
+ * for every row of every group (concatenated); A is D x D row-major, symmetric positive definite, else LC_EINVAL
+ * "Matrix A is not positive definite".  Overwrites the context's qZ (one scratch column). */
+int lc_mahaldist(lc_ctx* ctx, const double* mu, const double* A, double* dist);
 /* updateSS (cluster.cpp:53-82) + K x GaussWish::addobs (distributions.cpp:301-313)
  * for ALL groups on the current qZ: Nk[K], xs[K*D], xxs[K*D*D] (row-major),
  * Njk[J*K] (the returned `Njk` of every group).  smask[J*K]: sparse updates,

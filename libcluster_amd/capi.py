@@ -88,6 +88,7 @@ def lib() -> C.CDLL:
     L.lc_estep_posterior.argtypes = [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
                                      c_double_p, c_ubyte_p, c_double_p, c_double_p]
     L.lc_eloglike.argtypes = [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]
+    L.lc_mahaldist.argtypes = [C.c_void_p, c_double_p, c_double_p, c_double_p]
     L.lc_suffstat.argtypes = [C.c_void_p, c_ubyte_p, c_double_p, c_double_p, c_double_p, c_double_p]
     L.lc_suffstat_diag.argtypes = [C.c_void_p, c_ubyte_p, c_double_p, c_double_p, c_double_p, c_double_p]
     L.lc_estep_diag.argtypes = [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int,
@@ -316,6 +317,14 @@ class Context:
         ll = np.zeros(K)
         check(lib().lc_estep(self._h, K, dptr(A), dptr(m), dptr(c), C.byref(Fz), dptr(ll)))
         return Fz.value, ll
+
+    def mahaldist(self, mu, A):
+        """probutils::mahaldist for every resident row -> (N_total,) array."""
+        J, D, N, _ = self.dims()
+        mu, A = (np.ascontiguousarray(v, dtype=np.float64) for v in (mu, A))
+        out = np.zeros(N)
+        check(lib().lc_mahaldist(self._h, dptr(mu), dptr(A), dptr(out)))
+        return out
 
     def suffstat(self, smask=None):
         J, D, _, K = self.dims()

@@ -313,6 +313,29 @@ int lc_eloglike(lc_ctx* ctx, int K, const double* nu, const double* beta, const 
   });
 }
 
+int lc_mahaldist(lc_ctx* ctx, const double* mu, const double* A, double* dist) {
+  return guarded([&] {
+    need(ctx, "ctx");
+    need(mu, "mu");
+    need(A, "A");
+    need(dist, "dist");
+    const int D = ctx->impl.D(), J = ctx->impl.J();
+    std::vector<double> L(A, A + (size_t)D * D);
+    // probutils.cpp:128-132 (LDLT with a positive diagonal <=> Cholesky succeeds)
+    if (!lch::cholesky(L, D)) throw std::invalid_argument("Matrix A is not positive definite");
+    const std::vector<double> Li = lch::tril_inverse(L, D);  // (x-mu) A^-1 (x-mu)^T = || L^-1 (x-mu) ||^2
+    std::vector<double> c((size_t)J, 0.0);
+    ctx->impl.estep(1, Li.data(), mu, c.data(), nullptr, nullptr, /*raw=*/true);  // column 0 <- -0.5 d^2
+    int64_t o = 0;
+    for (int j = 0; j < J; ++j) {
+      const int64_t n = ctx->impl.N(j);
+      if (n > 0) ctx->impl.qz_get_column(j, 0, dist + o);
+      for (int64_t r = 0; r < n; ++r) dist[o + r] *= -2.0;
+      o += n;
+    }
+  });
+}
+
 int lc_suffstat(lc_ctx* ctx, const unsigned char* smask, double* Nk, double* xs, double* xxs, double* Njk) {
   return guarded([&] {
     need(ctx, "ctx");

@@ -9,6 +9,7 @@
 
 #include "distributions.h"
 #include "libcluster.h"
+#include "probutils.h"
 
 using namespace std;
 using namespace libcluster;
@@ -205,6 +206,43 @@ int main() {
     vMatrixXd W1(1, Wd[0]);
     try { learnMCM(W1, Xv, qYs, qZs, iw, sw, ict, sct); } catch (const invalid_argument&) { bad = true; }
     REQUIRE(bad);  // mcluster.cpp:548-549
+  }
+
+  // probutils.h: the public utility header (mahaldist runs on the GPU)
+  {
+    const lcmat::RowVectorXd mu = probutils::mean(Xcat);
+    const lcmat::MatrixXd C = probutils::cov(Xcat);
+    REQUIRE(mu.size() == D && C.rows() == D && fabs(C(0, 1) - C(1, 0)) < 1e-12);
+    const lcmat::VectorXd d2 = probutils::mahaldist(Xcat, mu, C);
+    REQUIRE(d2.size() == Xcat.rows());
+    double tot = 0.0;  // sum of squared Mahalanobis distances to the sample mean under the sample covariance
+    for (int r = 0; r < d2.size(); ++r) { REQUIRE(d2(r) >= 0.0); tot += d2(r); }
+    REQUIRE(fabs(tot - (double)D * (Xcat.rows() - 1)) < 1e-8 * tot);  // = D (N - 1) exactly
+    // 2 x 2 by hand: (x - mu) C^-1 (x - mu)^T
+    const double det = C(0, 0) * C(1, 1) - C(0, 1) * C(1, 0);
+    const double a0 = Xcat(3, 0) - mu(0), a1 = Xcat(3, 1) - mu(1);
+    const double ref = (C(1, 1) * a0 * a0 - 2 * C(0, 1) * a0 * a1 + C(0, 0) * a1 * a1) / det;
+    REQUIRE(fabs(d2(3) - ref) < 1e-10 * (1.0 + ref));
+    REQUIRE(fabs(probutils::logdet(C) - log(det)) < 1e-12);
+    lcmat::VectorXd ev;
+    const double lam = probutils::eigpower(C, ev);
+    const double tr = C(0, 0) + C(1, 1), lmax = 0.5 * (tr + sqrt(tr * tr - 4 * det));
+    REQUIRE(fabs(lam - lmax) < 1e-6 * lmax && ev.size() == D);
+    lcmat::MatrixXd L2(2, 3);
+    L2(0, 0) = 1; L2(0, 1) = 2; L2(0, 2) = 3; L2(1, 0) = -1000; L2(1, 1) = -1000; L2(1, 2) = -1001;
+    const lcmat::VectorXd ls = probutils::logsumexp(L2);
+    REQUIRE(fabs(ls(0) - log(exp(1.0) + exp(2.0) + exp(3.0))) < 1e-12 && fabs(ls(1) - (-1000 + log(2 + exp(-1.0)))) < 1e-12);
+    REQUIRE(fabs(probutils::mxdigamma(L2)(0, 0) - (-0.5772156649015329)) < 1e-13);
+    REQUIRE(fabs(probutils::mxlgamma(L2)(0, 2) - log(2.0)) < 1e-13);
+    REQUIRE(probutils::stdev(Xcat).size() == D && fabs(probutils::stdev(Xcat)(0) - sqrt(C(0, 0))) < 1e-12);
+    bool pd = false;
+    lcmat::MatrixXd bad(2, 2);
+    bad(0, 0) = 1; bad(0, 1) = 2; bad(1, 0) = 2; bad(1, 1) = 1;
+    try { probutils::mahaldist(Xcat, mu, bad); } catch (const invalid_argument&) { pd = true; }
+    REQUIRE(pd);  // probutils.cpp:131-132
+    pd = false;
+    try { probutils::logdet(bad); } catch (const domain_error&) { pd = true; }
+    REQUIRE(pd);  // probutils.cpp:200-201
   }
 
   // error behaviour (cluster.cpp:576-577, distributions.cpp:107-108/282-283)

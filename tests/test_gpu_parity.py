@@ -434,3 +434,21 @@ def test_randomised_kernel_fuzz():
                        text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "60 cases" in r.stdout and " 0 failures" in r.stdout
+
+
+def test_mahaldist_matches_numpy():
+    """probutils::mahaldist (probutils.cpp:113-138) on the GPU: ragged groups, D up to 128, SPD A; non-PD is refused."""
+    rng = np.random.default_rng(12)
+    for D, sizes in ((3, [50, 0, 7]), (23, [400]), (64, [1000, 33]), (128, [257])):
+        X = [rng.normal(size=(n, D)) * 2 + 1 for n in sizes]
+        B = rng.normal(size=(D, D))
+        A = B @ B.T / D + 0.3 * np.eye(D)
+        mu = rng.normal(size=D)
+        with capi.Context(0) as ctx:
+            ctx.set_data(X)
+            d2 = ctx.mahaldist(mu, A)
+            with pytest.raises(ValueError, match="not positive definite"):
+                ctx.mahaldist(mu, A - 5.0 * np.eye(D))
+        Xa = np.vstack(X) - mu
+        ref = np.einsum("nd,nd->n", Xa, np.linalg.solve(A, Xa.T).T)
+        np.testing.assert_allclose(d2, ref, rtol=1e-10, atol=1e-10)
