@@ -29,6 +29,8 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL fails with hipIpcGetMemHandle otherwise)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 FP64_PEAK_TFLOPS = 78.6  # MI355X fp64 vector = matrix spec; v_mfma_f64_4x4x4 measured 73.9 (profiles/)
 
