@@ -172,11 +172,16 @@ Context::~Context() {
 
 void Context::synchronize() const { LC_HIP(hipStreamSynchronize(stream_)); }
 
+void Context::require_gw_width() const {
+  if (DP_ > lck::GW_MAX_DP)
+    throw std::invalid_argument("D > 128 is not supported by the Gauss-Wishart kernels (the diagonal and exponential "
+                                "families take any D)");
+}
+
 void Context::build_layout(int J, const int64_t* Nj, int D) {
   if (J < 1) throw std::invalid_argument("need at least one group of observations");
   if (D < 1) throw std::invalid_argument("observations must have at least one dimension");
-  const int DP = lck::padded_dim(D);
-  if (DP < 0) throw std::invalid_argument("D > 128 is not supported by the gfx950 kernels");
+  const int DP = lck::padded_dim_wide(D);  // D > 128: diagonal / exponential families only (checked where it matters)
   J_ = J;
   D_ = D;
   DP_ = DP;
@@ -255,6 +260,7 @@ void Context::synth_groups(int J, const int64_t* Nj, int D, int K, const double*
                            double hard) {
   if (K < 1) throw std::invalid_argument("K must be >= 1");
   build_layout(J, Nj, D);
+  require_gw_width();  // the generator multiplies by full D x D Cholesky factors
   DevBuf<double> dmu, dL, dcdf;
   DevBuf<int64_t> dgid;
   if (group_ids) {
@@ -550,6 +556,7 @@ void Context::allreduce_values(double* v, int n) {
 
 void Context::estep(int K, const double* A, const double* m, const double* c, double* Fz, double* LLk, bool raw) {
   if (K < 1) throw std::invalid_argument("K must be >= 1");
+  require_gw_width();
   if (NP_ == 0 && !ar_fn_) {
     if (Fz) *Fz = -0.0;
     if (LLk) std::fill(LLk, LLk + K, 0.0);
@@ -715,6 +722,7 @@ int Context::build_sparse_worklist(const unsigned char* smask, int K, int64_t SS
 void Context::suffstat(const unsigned char* smask, double* Nk, double* xs, double* xxs, double* Njk) {
   const int K = qz_[cur_].K, D = D_, DP = DP_;
   if (K < 1) throw std::invalid_argument("qZ has not been set");
+  require_gw_width();
   LC_HIP(hipSetDevice(device_));
   const int64_t SS = lck::stat_stride(DP);
   const size_t nout = (size_t)K * SS + (size_t)J_ * K;

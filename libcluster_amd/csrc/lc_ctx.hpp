@@ -181,6 +181,7 @@ class Context {
   void ensure_qz(QZ& q, int K, bool preserve);
   void build_layout(int J, const int64_t* Nj, int D);
   void allreduce(double* dbuf, int64_t count);
+  void require_gw_width() const;  // throws for DP > 128 (full-covariance kernels)
   int build_sparse_worklist(const unsigned char* smask, int K, int64_t SS, lck::SuffstatLaunch& a);
 
   int device_;

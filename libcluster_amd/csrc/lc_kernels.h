@@ -14,6 +14,10 @@ namespace lck {
 constexpr int RG = 16;  // rows per row-group (one MFMA column block)
 
 inline int padded_dim(int D) { return D <= 16 ? 16 : D <= 32 ? 32 : D <= 64 ? 64 : D <= 128 ? 128 : -1; }
+// the separable (diagonal / exponential) families have no limit on D: wider observations are padded to a multiple of
+// 128 columns and processed in column blocks; the Gauss-Wishart kernels stop at 128
+inline int padded_dim_wide(int D) { return D <= 128 ? padded_dim(D) : (D + 127) / 128 * 128; }
+constexpr int GW_MAX_DP = 128;
 inline int ntiles(int DP) { int nt = DP / 4; return nt * (nt + 1) / 2; }
 // doubles per cluster in the packed E-step parameter stream
 inline int pstride(int DP) { return ntiles(DP) * 16 + DP; }
@@ -119,6 +123,7 @@ struct DiagStatLaunch {
   int64_t chunk_rows;    // multiple of 32
   int second = 1;        // 0: skip the second moments (ExpGamma)
   int nslice = 0, rsplit = 0;  // filled in by launch_suffstat_diag
+  int ldx = 0, col0 = 0, DPT = 0;  // ditto: row stride of X, first column and total padded width (wide D)
 };
 int suffstat_diag_rsplit(int K);
 hipError_t launch_suffstat_diag(const DiagStatLaunch& a, hipStream_t stream);

@@ -26,19 +26,20 @@ constexpr int DIAG_MAXT = 4;
 template <int MODE, int KT>
 __device__ __forceinline__ void diag_tile(const double* __restrict__ xr, const double* __restrict__ PA,
                                           const double* __restrict__ PW2, const double* __restrict__ PW1, int k0,
-                                          int K, int DP, double (&acc)[KT]) {
+                                          int K, int DPS, int DC, double (&acc)[KT]) {
+  // PA / PW2 / PW1 already point at the first dimension of this chunk; DPS = parameter row stride, DC = chunk length
   const double* pa[KT];
   const double* p2[KT];
   const double* p1[KT];
 #pragma unroll
   for (int j = 0; j < KT; ++j) {
     const int k = k0 + j < K ? k0 + j : K - 1;  // clamped: the caller discards clusters >= K
-    pa[j] = PA + (int64_t)k * DP;
-    p2[j] = PW2 + (int64_t)k * DP;
-    p1[j] = PW1 + (int64_t)k * DP;
+    pa[j] = PA + (int64_t)k * DPS;
+    p2[j] = PW2 + (int64_t)k * DPS;
+    p1[j] = PW1 + (int64_t)k * DPS;
     acc[j] = 0.0;
   }
-  for (int d = 0; d < DP; d += 4) {
+  for (int d = 0; d < DC; d += 4) {
     double x[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) x[u] = xr[d + u];
@@ -111,7 +112,7 @@ __global__ void __launch_bounds__(256)
       for (int j = 0; j < KT; ++j) lq[i][j] = NINF, dt[i][j] = 0.0;
       if (tile < ntiles) {
         double acc[KT];
-        diag_tile<MODE, KT>(xr, PA, PW2, PW1, tile * KT, K, DP, acc);
+        diag_tile<MODE, KT>(xr, PA, PW2, PW1, tile * KT, K, DP, DP, acc);
 #pragma unroll
         for (int j = 0; j < KT; ++j) {
           const int k = tile * KT + j;
@@ -128,7 +129,7 @@ __global__ void __launch_bounds__(256)
   } else {
     for (int tile = w; tile < ntiles; tile += 4) {
       double acc[KT];
-      diag_tile<MODE, KT>(xr, PA, PW2, PW1, tile * KT, K, DP, acc);
+      diag_tile<MODE, KT>(xr, PA, PW2, PW1, tile * KT, K, DP, DP, acc);
 #pragma unroll
       for (int j = 0; j < KT; ++j) {
         const int k = tile * KT + j;
@@ -217,15 +218,202 @@ __global__ void __launch_bounds__(256)
     for (int k = tid; k < K; k += 256) ll_part[(int64_t)blockIdx.x * K + k] = llw[k];
 }
 
+// The same kernel for wide observations (DP > 128): see the chunk loop.  Kept apart from the kernel above, whose
+// single-chunk body the compiler schedules markedly better (3.8 vs 6.5 ms at D = 64 when both shared one body).
+template <int MODE, int KT, bool REG>
+__global__ void __launch_bounds__(256)
+    estep_diag_wide_kernel(const double* __restrict__ X, const double* __restrict__ PA, const double* __restrict__ PW2,
+                      const double* __restrict__ PW1, const double* __restrict__ ctab, const int* __restrict__ rginfo,
+                      double* __restrict__ qZ, double* __restrict__ fz_part, double* __restrict__ ll_part, int DP, int K,
+                      int64_t NP, int64_t nrows, int64_t ldq, int raw) {
+  extern __shared__ double lds[];
+  // wide observations (DP > 128, the separable families have no limit on D): the row tile is staged in chunks of
+  // DC = 128 dimensions and the per-cluster sums run over the chunks; DP <= 128 is one chunk as before
+  const int DC = DP < 128 ? DP : 128;
+  const int LD = DC + 1;
+  double* xt = lds;             // [64][LD]
+  double* red = lds + 64 * LD;  // [4][64]
+  double* llw = red + 256;      // [K]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t row0 = (int64_t)blockIdx.x * 64;
+  const int64_t row = row0 + lane;
+  const bool inb = row < NP;
+  int grp = 0;
+  bool ok = false;
+  if (inb) {
+    if (rginfo) {
+      const int info = rginfo[row >> 4];
+      grp = info >> 5;
+      ok = (int)(row & 15) < (info & 31);
+    } else {
+      ok = row < nrows;
+    }
+  }
+  const double* xr = xt + lane * LD;
+  const double* crow = ctab + (int64_t)grp * K;
+  const int ntiles = (K + KT - 1) / KT;
+  const double NINF = -INFINITY;
+  double mx = NINF;
+  double lq[REG ? DIAG_MAXT : 1][KT], dt[REG ? DIAG_MAXT : 1][KT];
+  if (REG) {
+#pragma unroll
+    for (int i = 0; i < DIAG_MAXT; ++i)
+#pragma unroll
+      for (int j = 0; j < KT; ++j) dt[i][j] = 0.0;
+  }
+
+  // ---- pass 1: the data term of log q~ for this wave's tiles, chunk by chunk ----
+  for (int d0 = 0; d0 < DP; d0 += DC) {
+    if (d0 > 0) __syncthreads();  // every wave is done with the previous chunk
+    {
+      const int c2 = DC >> 1, sh = __builtin_ctz(c2);  // double2 columns per chunk row (DC is a power of two)
+      const double2* X2 = reinterpret_cast<const double2*>(X + d0);
+      for (int idx = tid; idx < 64 * c2; idx += 256) {
+        const int r = idx >> sh, c = idx & (c2 - 1);
+        double2 v = make_double2(0.0, 0.0);
+        if (row0 + r < NP) v = X2[(row0 + r) * (DP >> 1) + c];
+        xt[r * LD + 2 * c] = v.x;
+        xt[r * LD + 2 * c + 1] = v.y;
+      }
+    }
+    __syncthreads();
+    if (REG) {
+#pragma unroll
+      for (int i = 0; i < DIAG_MAXT; ++i) {
+        const int tile = w + 4 * i;
+        if (tile < ntiles) {
+          double acc[KT];
+          diag_tile<MODE, KT>(xr, PA + d0, PW2 + d0, PW1 + d0, tile * KT, K, DP, DC, acc);
+#pragma unroll
+          for (int j = 0; j < KT; ++j) dt[i][j] += acc[j];
+        }
+      }
+    } else {
+      for (int tile = w; tile < ntiles; tile += 4) {
+        double acc[KT];
+        diag_tile<MODE, KT>(xr, PA + d0, PW2 + d0, PW1 + d0, tile * KT, K, DP, DC, acc);
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {
+          const int k = tile * KT + j;
+          if (k < K && inb) {
+            double* qp = qZ + (int64_t)k * ldq + row;
+            *qp = (d0 == 0 ? crow[k] : *qp) + acc[j];  // running sum of the data term on top of c_jk
+          }
+        }
+      }
+    }
+  }
+  if (REG) {
+#pragma unroll
+    for (int i = 0; i < DIAG_MAXT; ++i) {
+      const int tile = w + 4 * i;
+#pragma unroll
+      for (int j = 0; j < KT; ++j) {
+        lq[i][j] = NINF;
+        const int k = tile * KT + j;
+        if (tile < ntiles && k < K) {
+          const double v = crow[k] + dt[i][j];
+          lq[i][j] = v;
+          mx = fmax(mx, v);
+          if (raw && inb) qZ[(int64_t)k * ldq + row] = v;
+        }
+      }
+    }
+  } else if (!raw) {
+    for (int tile = w; tile < ntiles; tile += 4)
+      for (int j = 0; j < KT; ++j) {
+        const int k = tile * KT + j;
+        if (k < K && inb) mx = fmax(mx, qZ[(int64_t)k * ldq + row]);
+      }
+  }
+  if (raw) return;
+
+  // ---- row maximum and sum of exponentials across the four waves (logsumexp, probutils.cpp:141-150) ----
+  red[w * 64 + lane] = mx;
+  __syncthreads();
+  mx = fmax(fmax(red[lane], red[64 + lane]), fmax(red[128 + lane], red[192 + lane]));
+  __syncthreads();
+  double se = 0.0;
+  if (REG) {
+#pragma unroll
+    for (int i = 0; i < DIAG_MAXT; ++i)
+#pragma unroll
+      for (int j = 0; j < KT; ++j) {
+        lq[i][j] = exp(lq[i][j] - mx);  // exp(-inf) = 0 for the slots past K
+        se += lq[i][j];
+      }
+  } else if (inb) {
+    for (int tile = w; tile < ntiles; tile += 4)
+      for (int j = 0; j < KT; ++j) {
+        const int k = tile * KT + j;
+        if (k < K) se += exp(qZ[(int64_t)k * ldq + row] - mx);
+      }
+  }
+  red[w * 64 + lane] = se;
+  __syncthreads();
+  se = red[lane] + red[64 + lane] + red[128 + lane] + red[192 + lane];
+  const double logZ = log(se) + mx;
+  const double inv = 1.0 / se;
+
+  // ---- pass 2: q = exp(log q~ - logZ), data term of the split ordering ----
+  if (REG) {
+#pragma unroll
+    for (int i = 0; i < DIAG_MAXT; ++i) {
+      const int tile = w + 4 * i;
+      if (tile < ntiles) {
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {
+          const int k = tile * KT + j;
+          if (k < K) {
+            const double q = ok ? lq[i][j] * inv : 0.0;
+            if (inb) qZ[(int64_t)k * ldq + row] = q;
+            if (ll_part) {
+              const double ll = wave_sum(q > 0.0 ? q * dt[i][j] : 0.0);
+              if (lane == 0) llw[k] = ll;
+            }
+          }
+        }
+      }
+    }
+  } else {
+    for (int tile = w; tile < ntiles; tile += 4)
+      for (int j = 0; j < KT; ++j) {
+        const int k = tile * KT + j;
+        if (k < K) {
+          double ll = 0.0;
+          if (inb) {
+            double* qp = qZ + (int64_t)k * ldq + row;
+            const double v = *qp;
+            const double q = ok ? exp(v - mx) * inv : 0.0;
+            *qp = q;
+            if (ll_part && q > 0.0) ll = q * (v - crow[k]);
+          }
+          if (ll_part) {
+            ll = wave_sum(ll);
+            if (lane == 0) llw[k] = ll;
+          }
+        }
+      }
+  }
+  double fz = (w == 0 && ok) ? logZ : 0.0;
+  fz = wave_sum(fz);
+  __syncthreads();
+  if (tid == 0) fz_part[blockIdx.x] = -fz;
+  if (ll_part)
+    for (int k = tid; k < K; k += 256) ll_part[(int64_t)blockIdx.x * K + k] = llw[k];
+}
+
 template <int MODE, int KT, bool REG>
 static hipError_t launch_ed_t(const DiagEstepLaunch& a, int64_t grid, size_t shmem, hipStream_t stream) {
-  auto kern = estep_diag_kernel<MODE, KT, REG>;
-  static size_t attr_set = 0;
-  if (shmem > 64 * 1024 && shmem > attr_set) {
+  auto kern = a.DP > 128 ? estep_diag_wide_kernel<MODE, KT, REG> : estep_diag_kernel<MODE, KT, REG>;
+  static size_t attr_set[2] = {0, 0};  // per kernel (narrow, wide)
+  size_t& granted = attr_set[a.DP > 128 ? 1 : 0];
+  if (shmem > 64 * 1024 && shmem > granted) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)shmem);
     if (e != hipSuccess) return e;
-    attr_set = shmem;
+    granted = shmem;
   }
   const double* PA = a.params;
   const double* PW2 = PA + (int64_t)a.K * a.DP;
@@ -247,7 +435,8 @@ static hipError_t launch_ed_m(const DiagEstepLaunch& a, int64_t grid, size_t shm
 hipError_t launch_estep_diag(const DiagEstepLaunch& a, hipStream_t stream) {
   const int64_t grid = (a.nrg * RG + 63) / 64;
   if (grid <= 0) return hipSuccess;
-  const size_t shmem = (size_t)(64 * (a.DP + 1) + 256 + a.K) * sizeof(double);
+  const int DC = a.DP < 128 ? a.DP : 128;
+  const size_t shmem = (size_t)(64 * (DC + 1) + 256 + a.K) * sizeof(double);
   switch (a.mode) {
     case 1:
       return launch_ed_m<1>(a, grid, shmem, stream);
@@ -310,7 +499,8 @@ __global__ void __launch_bounds__(256, 2) suffstat_diag_kernel(DiagStatLaunch a)
       const int idx = tid + i * 256;  // double2 index inside the batch, row-major [BR][DP/2]
       const int row = idx / (DP / 2), c2 = idx % (DP / 2);
       double2 v = make_double2(0.0, 0.0);
-      if (idx < NV2 && b0 + row < r1) v = *reinterpret_cast<const double2*>(a.X + (b0 + row) * DP + 2 * c2);
+      if (idx < NV2 && b0 + row < r1)
+        v = *reinterpret_cast<const double2*>(a.X + (b0 + row) * a.ldx + a.col0 + 2 * c2);
       pre[i][0] = v.x;
       pre[i][1] = v.y;
     }
@@ -380,19 +570,20 @@ __global__ void __launch_bounds__(256, 2) suffstat_diag_kernel(DiagStatLaunch a)
   if (!active) return;
 
   // output lane (lo2, blk, hi) of accumulator (c, jb): cluster 4 c + hi, dimension 16 jb + 4 blk + lo2
-  const int64_t SS = 1 + 2 * (int64_t)DP;
+  // record layout: [N_k | x_s (DPT) | xx_s (DPT)]; a launch over the column block [col0, col0 + DP) fills its part
+  const int64_t SS = 1 + 2 * (int64_t)a.DPT;
   double* rec = a.partial + ((int64_t)(chunk * RS + rcls) * K + kb0 + group * 16) * SS;
 #pragma unroll
   for (int c = 0; c < CT; ++c) {
     // N_k: this lane summed q[row class hi][cluster 4 c + lo2] (replicated over blk)
     const double n = sum_over_hi(nacc[c]);
-    if (hi == 0 && blk == 0 && group * 16 + 4 * c + lo2 < kc) rec[(int64_t)(4 * c + lo2) * SS] = n;
+    if (a.col0 == 0 && hi == 0 && blk == 0 && group * 16 + 4 * c + lo2 < kc) rec[(int64_t)(4 * c + lo2) * SS] = n;
     if (group * 16 + 4 * c + hi < kc) {
       double* out = rec + (int64_t)(4 * c + hi) * SS;
 #pragma unroll
       for (int jb = 0; jb < NB; ++jb) {
-        out[1 + 16 * jb + lo4] = acc1[c][jb];
-        out[1 + DP + 16 * jb + lo4] = SECOND ? acc2[c][jb] : 0.0;
+        out[1 + a.col0 + 16 * jb + lo4] = acc1[c][jb];
+        out[1 + a.DPT + a.col0 + 16 * jb + lo4] = SECOND ? acc2[c][jb] : 0.0;
       }
     }
   }
@@ -431,6 +622,18 @@ hipError_t launch_suffstat_diag(const DiagStatLaunch& a0, hipStream_t stream) {
   DiagStatLaunch a = a0;
   a.nslice = (a.K + SD_QMAX - 1) / SD_QMAX;
   a.rsplit = suffstat_diag_rsplit(a.K);
+  a.ldx = a0.DP;
+  a.DPT = a0.DP;
+  if (a0.DP > 128) {  // wide observations: one launch per block of 128 columns (q is re-read; X is read once in total)
+    if (a0.DP % 128) return hipErrorInvalidValue;
+    a.DP = 128;
+    for (int c0 = 0; c0 < a0.DP; c0 += 128) {
+      a.col0 = c0;
+      hipError_t e = launch_sd_t<128>(a, stream);
+      if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+  }
   switch (a.DP) {
     case 16:
       return launch_sd_t<16>(a, stream);

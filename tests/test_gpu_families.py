@@ -217,3 +217,51 @@ def test_cluster_on_device_resident_data(family):
         np.testing.assert_allclose(a, b, rtol=1e-8)
     assert abs(F - Fo) <= 1e-8 * abs(Fo)
     assert_q_close(q, qo, rtol=1e-6)
+
+
+@pytest.mark.parametrize("family", ["NormGamma", "ExpGamma"])
+@pytest.mark.parametrize("N,D,K,J", [(700, 129, 5, 1), (400, 300, 9, 2), (260, 1000, 3, 1), (150, 257, 70, 3)])
+def test_wide_observations_in_the_separable_families(family, N, D, K, J):
+    """D > 128 (no limit for NormGamma / ExpGamma): the E-step walks the row tile in chunks of 128 dimensions, the
+    statistics run one launch per block of 128 columns; fixed-K VBEM against the oracle, K > 64 included."""
+    rng = np.random.default_rng(N + D)
+    eg = family == "ExpGamma"
+    X, q0 = _data(rng, N, D, K, J, eg)
+    cf = o.ExpGamma if eg else o.NormGamma
+    wf = o.GDirichlet if J > 1 else o.StickBreak
+    wk = capi.W_GDIRICHLET if J > 1 else capi.W_STICKBREAK
+    tro, _, qo, _, clo = o.vbem_fixed(X, q0, wf, 1.0, 3, False, cf)
+    with capi.Context(0) as ctx:
+        ctx.set_data(X)
+        ctx.set_qz(q0)
+        Nk, xs, xxs, Njk = ctx.suffstat_diag(second=not eg)
+        np.testing.assert_allclose(xs, np.vstack(q0).T @ np.vstack(X), rtol=1e-10, atol=1e-9)
+        if not eg:
+            np.testing.assert_allclose(xxs, np.vstack(q0).T @ (np.vstack(X) ** 2), rtol=1e-10, atol=1e-9)
+        F, tr, model = ctx.vbem(wk, fixed_iters=3, ckind=capi.C_EXPGAMMA if eg else capi.C_NORMGAMMA)
+        q = ctx.get_qz([x.shape[0] for x in X])
+        model.close()
+    np.testing.assert_allclose(tr, tro, rtol=1e-9)
+    for j in range(J):  # sums over up to 1000 dimensions: absolute agreement to 1e-9 instead of 1e-11
+        np.testing.assert_allclose(q[j], qo[j], rtol=1e-7, atol=1e-9)
+
+
+def test_wide_learners_on_device():
+    """Model selection with D = 200 diagonal Gaussians and D = 150 exponentials, end to end against the oracle."""
+    import libcluster_amd as lc
+
+    rng = np.random.default_rng(3)
+    cent = rng.normal(0, 3.0, (3, 200))
+    X = cent[rng.integers(0, 3, 600)] + rng.normal(size=(600, 200))
+    tr = []
+    Fo, _, _, clo = o.learnDGMM(X, trace=tr)
+    F, qZ, w, mu, cov, info = lc.learnDGMM(X, return_info=True)
+    assert info["K"] == len(clo) and [k for k, _ in info["rounds"]] == [k for k, _ in tr]
+    assert abs(F - Fo) <= 1e-9 * abs(Fo)
+    rates = rng.uniform(0.2, 5.0, (2, 150))
+    Xe = [rng.exponential(1.0, (300, 150)) / rates[rng.integers(0, 2, 300)] for _ in range(2)]
+    tr = []
+    Fo, _, _, clo = o.learnEGMC(Xe, trace=tr)
+    F, qZ, w, mu, cov, info = lc.learnEGMC(Xe, return_info=True)
+    assert info["K"] == len(clo) and [k for k, _ in info["rounds"]] == [k for k, _ in tr]
+    assert abs(F - Fo) <= 1e-9 * abs(Fo)

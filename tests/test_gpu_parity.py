@@ -153,9 +153,15 @@ def test_edge_cases():
         np.testing.assert_allclose(Njk[1], 0.0)
         np.testing.assert_allclose(Njk[0], qg[0].sum(axis=0), rtol=1e-13)
         np.testing.assert_allclose(Njk[2], qg[2].sum(axis=0), rtol=1e-13)
-    with pytest.raises(ValueError):
-        with capi.Context(0) as ctx:
-            ctx.set_data(np.zeros((4, 129)))  # D > 128 unsupported
+    # D > 128: the Gauss-Wishart kernels refuse (the separable families accept it, tests/test_gpu_families.py)
+    with capi.Context(0) as ctx:
+        ctx.set_data(np.zeros((4, 129)))
+        ctx.fill_qz(1, 1.0)
+        with pytest.raises(ValueError, match="D > 128"):
+            ctx.suffstat()
+    import libcluster_amd as lc
+    with pytest.raises(ValueError, match="D > 128"):
+        lc.learnBGMM(rng.normal(size=(50, 130)))
 
 
 def _check_learn(res, ref, rows):
