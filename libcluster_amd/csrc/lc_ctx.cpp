@@ -174,7 +174,7 @@ void Context::synchronize() const { LC_HIP(hipStreamSynchronize(stream_)); }
 
 void Context::require_gw_width() const {
   if (DP_ > lck::GW_MAX_DP)
-    throw std::invalid_argument("D > 128 is not supported by the Gauss-Wishart kernels (the diagonal and exponential "
+    throw std::invalid_argument("D > 1024 is not supported by the Gauss-Wishart kernels (the diagonal and exponential "
                                 "families take any D)");
 }
 
@@ -260,7 +260,7 @@ void Context::synth_groups(int J, const int64_t* Nj, int D, int K, const double*
                            double hard) {
   if (K < 1) throw std::invalid_argument("K must be >= 1");
   build_layout(J, Nj, D);
-  require_gw_width();  // the generator multiplies by full D x D Cholesky factors
+  if (DP_ > 128) throw std::invalid_argument("the synthetic-data generator stops at D = 128");
   DevBuf<double> dmu, dL, dcdf;
   DevBuf<int64_t> dgid;
   if (group_ids) {
@@ -556,7 +556,7 @@ void Context::allreduce_values(double* v, int n) {
 
 void Context::estep(int K, const double* A, const double* m, const double* c, double* Fz, double* LLk, bool raw) {
   if (K < 1) throw std::invalid_argument("K must be >= 1");
-  require_gw_width();
+  require_gw_width();  // (an upper limit only: wide observations stream through estep_wide_kernel)
   if (NP_ == 0 && !ar_fn_) {
     if (Fz) *Fz = -0.0;
     if (LLk) std::fill(LLk, LLk + K, 0.0);
@@ -565,27 +565,42 @@ void Context::estep(int K, const double* A, const double* m, const double* c, do
   }
   LC_HIP(hipSetDevice(device_));
   const int D = D_, DP = DP_, NT = DP / 4;
-  const int PS = lck::pstride(DP), NTILES = lck::ntiles(DP);
-  // ---- pack: tiles of A_k in consumption order, then -b_k = -A_k m_k ------
+  const bool wide = DP > 128;
+  const int NTILES = wide ? 0 : lck::ntiles(DP);
+  const int64_t PS = wide ? (int64_t)lck::wide_chunks(DP) * lck::WIDE_CHUNK : lck::pstride(DP);
   hpack_.assign((size_t)K * PS + (size_t)J_ * K, 0.0);
+  std::vector<double> bneg((size_t)DP);
   for (int k = 0; k < K; ++k) {
     const double* Ak = A + (size_t)k * D * D;
     const double* mk = m + (size_t)k * D;
     double* P = hpack_.data() + (size_t)k * PS;
-    for (int it = 0; it < NT; ++it)
-      for (int jt = 0; jt <= it; ++jt) {
-        double* T = P + (size_t)(it * (it + 1) / 2 + jt) * 16;
-        for (int hi = 0; hi < 4; ++hi)
-          for (int lo = 0; lo < 4; ++lo) {
-            const int i = 4 * it + lo, j = 4 * jt + hi;
-            T[lo + 4 * hi] = (i < D && j <= i) ? Ak[(size_t)i * D + j] : 0.0;
-          }
-      }
-    double* b = P + (size_t)NTILES * 16;
+    std::fill(bneg.begin(), bneg.end(), 0.0);
     for (int i = 0; i < D; ++i) {
       double s = 0.0;
       for (int j = 0; j <= i; ++j) s += Ak[(size_t)i * D + j] * mk[j];
-      b[i] = -s;  // the kernel's accumulators start at -b so that y = A x - b
+      bneg[(size_t)i] = -s;  // the kernel's accumulators start at -b so that y = A x - b
+    }
+    auto fill_tile = [&](double* T, int i0, int j0) {  // element (lo, hi) of a 4x4 tile = A[i0 + lo][j0 + hi]
+      for (int hi = 0; hi < 4; ++hi)
+        for (int lo = 0; lo < 4; ++lo) {
+          const int i = i0 + lo, j = j0 + hi;
+          T[lo + 4 * hi] = (i < D && j <= i) ? Ak[(size_t)i * D + j] : 0.0;
+        }
+    };
+    if (!wide) {
+      // ---- tiles of A_k in consumption order, then -b_k = -A_k m_k ------
+      for (int it = 0; it < NT; ++it)
+        for (int jt = 0; jt <= it; ++jt) fill_tile(P + (size_t)(it * (it + 1) / 2 + jt) * 16, 4 * it, 4 * jt);
+      std::copy(bneg.begin(), bneg.end(), P + (size_t)NTILES * 16);
+    } else {
+      // ---- 64 x 64 blocks (I, J <= I), row-major; per chunk 16 x 16 tiles, then -b_I (estep_wide_kernel) ------
+      double* C = P;
+      for (int I = 0; I < DP / 64; ++I)
+        for (int Jb = 0; Jb <= I; ++Jb, C += lck::WIDE_CHUNK) {
+          for (int it = 0; it < 16; ++it)
+            for (int jt = 0; jt < 16; ++jt) fill_tile(C + (size_t)(it * 16 + jt) * 16, 64 * I + 4 * it, 64 * Jb + 4 * jt);
+          std::copy(bneg.begin() + 64 * I, bneg.begin() + 64 * (I + 1), C + 4096);
+        }
     }
   }
   std::memcpy(hpack_.data() + (size_t)K * PS, c, (size_t)J_ * K * sizeof(double));

@@ -17,10 +17,14 @@ inline int padded_dim(int D) { return D <= 16 ? 16 : D <= 32 ? 32 : D <= 64 ? 64
 // the separable (diagonal / exponential) families have no limit on D: wider observations are padded to a multiple of
 // 128 columns and processed in column blocks; the Gauss-Wishart kernels stop at 128
 inline int padded_dim_wide(int D) { return D <= 128 ? padded_dim(D) : (D + 127) / 128 * 128; }
-constexpr int GW_MAX_DP = 128;
+constexpr int GW_MAX_DP = 1024;  // Gauss-Wishart kernels: panel / chunk streaming beyond 128 (tested to 512)
 inline int ntiles(int DP) { int nt = DP / 4; return nt * (nt + 1) / 2; }
 // doubles per cluster in the packed E-step parameter stream
 inline int pstride(int DP) { return ntiles(DP) * 16 + DP; }
+// wide observations (DP > 128): the whitener streams as 64 x 64 blocks (I, J <= I), row-major; one chunk = 256 tiles
+// of 16 doubles + the 64 entries of -b_I
+constexpr int WIDE_CHUNK = 256 * 16 + 64;
+inline int wide_chunks(int DP) { int np = DP / 64; return np * (np + 1) / 2; }
 // doubles per cluster in a stats record: [N_k, s_k[DP], S_k[DP*DP]]
 inline int64_t stat_stride(int DP) { return 1 + (int64_t)DP + (int64_t)DP * DP; }
 
@@ -70,6 +74,9 @@ struct SuffstatLaunch {
   const SSItem* items = nullptr;  // sparse work list (device) or nullptr: dense (chunk, slice) grid
   const int* klist = nullptr;     // active cluster lists the items point into
   int nitems = 0;
+  // wide observations (DP > 128), filled in by launch_suffstat: the kernel works on 64-column panels
+  int64_t ldx = 0;                // row stride of X
+  int DPW = 0, colA = 0, colB = 0;  // record width, first column of the A-side / B-side panel
 };
 // choose a chunking for (NP, K); returns nchunks and sets chunk_rows
 int suffstat_plan(int DP, int64_t NP, int K, int64_t* chunk_rows);

@@ -352,6 +352,219 @@ __global__ void __launch_bounds__(WAVES * 64, EstepOcc<DP>::BLOCKS) estep_kernel
   }
 }
 
+// ===========================================================================
+// E-step for observations wider than 128 columns
+// ===========================================================================
+// Same arithmetic, same operand layout; what changes is what stays resident.  A cluster's whitener no longer fits in
+// LDS (268 KB at D = 256) and a row group's X fragments no longer fit in registers, so the lower-triangular A_k is cut
+// into 64 x 64 blocks (I, J <= I) that stream through a two-deep LDS ring in row-major order -- one chunk = the 256
+// 4x4 tiles of a block (zeros above the diagonal of a diagonal block) followed by -b_I -- and a wave keeps
+//   * the 16 tile-row accumulators of block row I for its R row groups (y_I = sum_J A_IJ x_J - b_I), and
+//   * the X fragments of column panel J only, re-read from L2 for every chunk (the loads return in order, so the
+//     first MFMAs start as soon as the first fragments are back).
+// After the diagonal chunk (J = I) the 16 accumulators are squared into the running distance.  Normalisation as in
+// estep_kernel (k-sliced scheme).  lc_ctx.cpp packs the chunks (wide_chunk_stride doubles each, K * NCH of them).
+template <int R, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64, 2) estep_wide_kernel(EstepLaunch a) {
+  constexpr int CHS = WIDE_CHUNK;  // 256 tiles x 16 + 64
+  constexpr int NTHR = WAVES * 64;
+  constexpr int NV2 = CHS / 2;
+  constexpr int NPRE = (NV2 + NTHR - 1) / NTHR;
+  constexpr int PF = 6;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* pbuf = lds;               // [2][CHS]
+  double* llw = lds + 2 * CHS;      // [WAVES][K]
+  double* fzw = llw + WAVES * a.K;  // [WAVES]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lo4 = lane & 15, hi = lane >> 4;
+  const int K = a.K, DPW = a.DP, NPAN = DPW / 64, NCH = NPAN * (NPAN + 1) / 2;
+  const int64_t rg0 = ((int64_t)blockIdx.x * WAVES + wave) * R;
+
+  const double* xbase[R];
+  int grp[R];
+  bool rowok[R], rgok[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int64_t rg = rg0 + r;
+    rgok[r] = rg < a.nrg;
+    int info = 0;
+    if (rgok[r]) {
+      if (a.rginfo) {
+        info = a.rginfo[rg];
+      } else {
+        const int64_t rem = a.nrows - rg * RG;
+        info = rem >= RG ? RG : (rem > 0 ? (int)rem : 0);
+      }
+    }
+    grp[r] = info >> 5;
+    rowok[r] = lo4 < (info & 31);
+    xbase[r] = a.X + ((rgok[r] ? rg : 0) * RG + lo4) * (int64_t)DPW + hi;
+  }
+
+  double pre[NPRE][2];
+  auto gload = [&](int64_t g) {
+    const double2* src = reinterpret_cast<const double2*>(a.params + g * CHS);
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) {
+      const int idx = tid + i * NTHR;
+      const double2 v = src[idx < NV2 ? idx : NV2 - 1];
+      pre[i][0] = v.x;
+      pre[i][1] = v.y;
+    }
+  };
+  auto lstore = [&](int b) {
+    double2* dst = reinterpret_cast<double2*>(pbuf + b * CHS);
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) {
+      const int idx = tid + i * NTHR;
+      if (idx < NV2) dst[idx] = make_double2(pre[i][0], pre[i][1]);
+    }
+  };
+
+  const int64_t total = (int64_t)K * NCH;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+
+  double mx[R], d2[R], acc[16][R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) mx[r] = -INFINITY, d2[r] = 0.0;
+  int I = 0, J = 0, k = 0;
+  for (int64_t g = 0; g < total; ++g) {
+    const int buf = (int)(g & 1);
+    if (g + 1 < total) gload(g + 1);
+    double xf[R][16];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int jt = 0; jt < 16; ++jt) xf[r][jt] = xbase[r][64 * J + 4 * jt];
+    const double* P = pbuf + buf * CHS;
+    const double* Pt = P + (lane & 3) + 4 * hi;  // this lane's element of every 4x4 tile
+    if (J == 0) {
+      const double* Pb = P + 4096 + hi;  // -b_I: the accumulators of a block row start there (y = A x - b)
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const double v = Pb[4 * it];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[it][r] = v;
+      }
+    }
+    // read n of the chunk: tile rows in pairs, so that 2R independent accumulator chains alternate
+    //   it = 2 (n / 32) + (n & 1), jt = (n % 32) / 2
+    double ring[PF];
+    static_for<PF>([&](auto ic) {
+      constexpr int n = ic, it = 2 * (n / 32) + (n & 1), jt = (n % 32) / 2;
+      ring[n] = Pt[16 * (it * 16 + jt)];
+    });
+    static_for<256>([&](auto nc) {
+      constexpr int n = nc, it = 2 * (n / 32) + (n & 1), jt = (n % 32) / 2;
+      const double v = ring[n % PF];
+      if constexpr (n + PF < 256) {
+        constexpr int m = n + PF, it2 = 2 * (m / 32) + (m & 1), jt2 = (m % 32) / 2;
+        ring[n % PF] = Pt[16 * (it2 * 16 + jt2)];
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc[it][r] = mfma4(v, xf[r][jt], acc[it][r]);
+    });
+    if (J == I) {  // block row complete
+#pragma unroll
+      for (int it = 0; it < 16; ++it)
+#pragma unroll
+        for (int r = 0; r < R; ++r) d2[r] = fma(acc[it][r], acc[it][r], d2[r]);
+      if (I == NPAN - 1) {  // cluster complete
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const double dd = mfma4(1.0, d2[r], 0.0);  // sum over the four hi lanes, total in every lane
+          const double lq = a.ctab[(int64_t)grp[r] * K + k] - 0.5 * dd;
+          mx[r] = fmax(mx[r], lq);
+          if (rgok[r] && hi == (k & 3)) a.qZ[(int64_t)k * a.ldq + (rg0 + r) * RG + lo4] = lq;
+          d2[r] = 0.0;
+        }
+      }
+    }
+    if (g + 1 < total) lstore(buf ^ 1);
+    __syncthreads();
+    if (J == I) {
+      J = 0;
+      if (++I == NPAN) I = 0, ++k;
+    } else {
+      ++J;
+    }
+  }
+  if (a.raw) return;
+
+  // ---- normalise (probutils.cpp:141-150, cluster.cpp:124-131), as in estep_kernel ----
+  double logZ[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    double s = 0.0;
+    if (rgok[r]) {
+      const double* qp = a.qZ + (rg0 + r) * RG + lo4;
+#pragma unroll 8
+      for (int kk = hi; kk < K; kk += 4) s += exp(qp[(int64_t)kk * a.ldq] - mx[r]);
+    }
+    s = sum_over_hi(s);
+    logZ[r] = log(s) + mx[r];
+  }
+  for (int kb = 0; kb < K; kb += 4) {
+    const int kk = kb + hi;
+    double ll = 0.0;
+    if (kk < K) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (rgok[r]) {
+          double* qp = a.qZ + (int64_t)kk * a.ldq + (rg0 + r) * RG + lo4;
+          const double lq = *qp;
+          double q = exp(lq - logZ[r]);
+          if (!rowok[r]) q = 0.0;
+          *qp = q;
+          if (a.ll_part && q > 0.0) ll += q * (lq - a.ctab[(int64_t)grp[r] * K + kk]);
+        }
+      }
+    }
+    if (a.ll_part) {  // wave-uniform
+      ll = sum_over_lo4(ll);
+      if (kk < K && lo4 == 0) llw[wave * K + kk] = ll;
+    }
+  }
+  double fz = 0.0;
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    if (rgok[r] && rowok[r] && hi == 0) fz += logZ[r];
+  fz = wave_sum(fz);
+  if (lane == 0) fzw[wave] = fz;
+  __syncthreads();
+  if (a.ll_part)
+    for (int kk = tid; kk < K; kk += NTHR) {
+      double s = 0.0;
+      for (int w = 0; w < WAVES; ++w) s += llw[w * K + kk];
+      a.ll_part[(int64_t)blockIdx.x * K + kk] = s;
+    }
+  if (tid == 0) {
+    double s = 0.0;
+    for (int w = 0; w < WAVES; ++w) s += fzw[w];
+    a.fz_part[blockIdx.x] = -s;  // cluster.cpp:137 returns -sum(logZ)
+  }
+}
+constexpr int WIDE_R = 2, WIDE_WAVES = 4;
+
+static hipError_t launch_estep_wide(const EstepLaunch& a, hipStream_t stream) {
+  if (a.DP % 64) return hipErrorInvalidValue;
+  const size_t shmem = (size_t)(2 * WIDE_CHUNK + WIDE_WAVES * a.K + WIDE_WAVES) * sizeof(double);
+  auto kern = estep_wide_kernel<WIDE_R, WIDE_WAVES>;
+  static size_t attr_set = 0;
+  if (shmem > 64 * 1024 && shmem > attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e != hipSuccess) return e;
+    attr_set = shmem;
+  }
+  const int64_t grid = estep_grid(a.DP, a.nrg);
+  if (grid <= 0) return hipSuccess;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WIDE_WAVES * 64), shmem, stream, a);
+  return hipGetLastError();
+}
+
 template <int DP>
 struct EstepCfg;
 template <>
@@ -373,6 +586,7 @@ int estep_rows_per_block(int DP) {
     case 64: return rows_per_block_t<64>();
     case 128: return rows_per_block_t<128>();
   }
+  if (DP > 128 && DP % 64 == 0) return WIDE_R * WIDE_WAVES * RG;
   return -1;
 }
 
@@ -406,6 +620,7 @@ static hipError_t launch_estep_t(const EstepLaunch& a, hipStream_t stream) {
 }
 
 hipError_t launch_estep(const EstepLaunch& a, hipStream_t stream) {
+  if (a.DP > 128) return launch_estep_wide(a, stream);  // -inf entries of ctab need no special handling there
   switch (a.DP) {
     case 16: return launch_estep_t<16>(a, stream);
     case 32: return launch_estep_t<32>(a, stream);

@@ -47,19 +47,31 @@ __host__ __device__ constexpr bool ss_in_half(int half, int jbp, int jb) {
   const bool first = NB == 8 ? (jbp < 5 || (jbp == 5 && jb < 3)) : (jbp == 1 || jbp == 2);  // 67|69 resp. 18|18 MFMAs
   return first == (half == 1);
 }
-template <int DP, int CPW, bool SKIP, int HALF>
+// PAN (observations wider than 128 columns, DP = 64 only): the statistics of a wide X are assembled from 64-column
+// panels, one launch per panel pair (P >= Q).  1 = diagonal pair (P, P): the triangle loop of the narrow kernel on
+// columns [colA, colA + 64) of rows with stride ldx; N_k rides with panel 0, s_k with every diagonal pair.
+// 2 = off-diagonal pair: A operands (all four rotations) from panel colA, q x from panel colB, the full 16 x 4 set of
+// MFMAs, block written to (P, Q) and mirrored to (Q, P).  Records are DPW wide.
+template <int PAN>
+constexpr int ss_batch_rows() { return PAN == 2 ? 16 : SS_BR; }
+template <int DP, int CPW, bool SKIP, int HALF, int PAN = 0>
 __global__ void __launch_bounds__(256, (DP <= 64 ? (HALF != 0 ? 3 : 2) : (HALF != 0 ? 2 : 1)))
     suffstat_kernel(SuffstatLaunch a) {
+  static_assert(PAN == 0 || (DP == 64 && HALF == 0), "panel variants are built on the D = 64 kernel");
   constexpr int NB = DP / 16;
-  constexpr int NACC = SSAcc<NB>::N;
-  constexpr int BR = SS_BR;
+  constexpr int NACC = PAN == 2 ? NB * NB * 4 : SSAcc<NB>::N;
+  constexpr int BR = ss_batch_rows<PAN>();
   constexpr int LD = DP + 16;            // padded LDS row stride (doubles)
-  constexpr int XBUF = BR * LD;          // doubles per X buffer
-  constexpr int NV2 = BR * DP / 2;       // double2 elements per staged batch
+  constexpr int NPB = PAN == 2 ? 2 : 1;  // column panels staged per batch
+  constexpr int XBUF = NPB * BR * LD;    // doubles per X buffer
+  constexpr int NV2 = BR * DP / 2;       // double2 elements per staged batch and panel
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int nwaves = 4, nthr = 256;  // always launched with 4 waves; surplus waves only help staging
-  double* xbuf = lds;                              // [2][BR][LD]
+  double* xbuf = lds;                              // [2][NPB][BR][LD]
   double* qbuf = lds + 2 * XBUF;                   // [2][nwaves][CPW][BR]
+  const int64_t ldx = PAN ? a.ldx : DP;            // row stride of X
+  const int DPW = PAN ? a.DPW : DP;                // record width
+  const int colA = PAN ? a.colA : 0, colB = PAN == 2 ? a.colB : colA;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lo4 = lane & 15, hi = lane >> 4, blk = (lane >> 2) & 3, lo2 = lane & 3;
   const int K = a.K;
@@ -122,18 +134,22 @@ __global__ void __launch_bounds__(256, (DP <= 64 ? (HALF != 0 ? 3 : 2) : (HALF !
 
   // ---- staging: registers hold the next batch while the current one is consumed
   constexpr int NPRE_MAX = (NV2 + nthr - 1) / nthr, npre = NPRE_MAX;
-  double pre[NPRE_MAX][2];
+  double pre[NPB][NPRE_MAX][2];
   double qpre[CPW];
   auto gload = [&](int64_t b0) {
 #pragma unroll
-    for (int i = 0; i < NPRE_MAX; ++i) {
-      if (i < npre) {
-        const int idx = tid + i * nthr;          // double2 index inside the batch: row-major [BR][DP/2]
-        const int row = idx / (DP / 2), c2 = idx % (DP / 2);
-        double2 v = make_double2(0.0, 0.0);
-        if (idx < NV2 && b0 + row < r1) v = *reinterpret_cast<const double2*>(a.X + (b0 + row) * DP + 2 * c2);
-        pre[i][0] = v.x;
-        pre[i][1] = v.y;
+    for (int pn = 0; pn < NPB; ++pn) {
+#pragma unroll
+      for (int i = 0; i < NPRE_MAX; ++i) {
+        if (i < npre) {
+          const int idx = tid + i * nthr;          // double2 index inside the batch: row-major [BR][DP/2]
+          const int row = idx / (DP / 2), c2 = idx % (DP / 2);
+          double2 v = make_double2(0.0, 0.0);
+          if (idx < NV2 && b0 + row < r1)
+            v = *reinterpret_cast<const double2*>(a.X + (b0 + row) * ldx + (pn == 0 ? colA : colB) + 2 * c2);
+          pre[pn][i][0] = v.x;
+          pre[pn][i][1] = v.y;
+        }
       }
     }
     // q: lanes 0..BR-1 of each wave fetch that wave's CPW columns (coalesced)
@@ -154,11 +170,15 @@ __global__ void __launch_bounds__(256, (DP <= 64 ? (HALF != 0 ? 3 : 2) : (HALF !
   auto lstore = [&](int buf) {
     double* xb = xbuf + buf * XBUF;
 #pragma unroll
-    for (int i = 0; i < NPRE_MAX; ++i) {
-      if (i < npre) {
-        const int idx = tid + i * nthr;
-        const int row = idx / (DP / 2), c2 = idx % (DP / 2);
-        if (idx < NV2) *reinterpret_cast<double2*>(xb + row * LD + 2 * c2) = make_double2(pre[i][0], pre[i][1]);
+    for (int pn = 0; pn < NPB; ++pn) {
+#pragma unroll
+      for (int i = 0; i < NPRE_MAX; ++i) {
+        if (i < npre) {
+          const int idx = tid + i * nthr;
+          const int row = idx / (DP / 2), c2 = idx % (DP / 2);
+          if (idx < NV2)
+            *reinterpret_cast<double2*>(xb + pn * BR * LD + row * LD + 2 * c2) = make_double2(pre[pn][i][0], pre[pn][i][1]);
+        }
       }
     }
     if (lane < BR) {
@@ -238,6 +258,39 @@ __global__ void __launch_bounds__(256, (DP <= 64 ? (HALF != 0 ? 3 : 2) : (HALF !
           step(st, xA, qA, xB, qB);
           step(st + 1, xB, qB, xA, qA);
         }
+      } else if constexpr (PAN == 2) {
+        const int nstep = (int)(((r1 - b0) < BR ? (r1 - b0) : BR) / 4);
+        for (int st = 0; st < nstep; ++st) {
+          if (SKIP) {
+            bool any = false;
+#pragma unroll
+            for (int c = 0; c < CPW; ++c) any = any || qb[c * BR + st * 4] != 0.0;
+            if (__builtin_amdgcn_ballot_w64(any) == 0) continue;
+          }
+          // A side: all four rotations of panel colA; B side: the unrotated fragments of panel colB
+          double xr[NB][4], xq[NB];
+#pragma unroll
+          for (int jb = 0; jb < NB; ++jb) {
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) xr[jb][s2] = xb[st * 4 * LD + 16 * jb + 4 * ((blk + s2) & 3)];
+            xq[jb] = xb[BR * LD + st * 4 * LD + 16 * jb + 4 * blk];
+          }
+#pragma unroll
+          for (int c = 0; c < CPW; ++c) {
+            const double q = qb[c * BR + st * 4];
+            if (SKIP && __builtin_amdgcn_ballot_w64(q != 0.0) == 0) continue;
+            double qx[NB];
+#pragma unroll
+            for (int jb = 0; jb < NB; ++jb) qx[jb] = q * xq[jb];
+#pragma unroll
+            for (int jbp = 0; jbp < NB; ++jbp)
+#pragma unroll
+              for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2)
+                  acc[c][(jbp * NB + jb) * 4 + s2] = mfma4(xr[jbp][s2], qx[jb], acc[c][(jbp * NB + jb) * 4 + s2]);
+          }
+        }
       } else {
         const int nstep = (int)(((r1 - b0) < BR ? (r1 - b0) : BR) / 4);
         for (int st = 0; st < nstep; ++st) {
@@ -287,21 +340,36 @@ __global__ void __launch_bounds__(256, (DP <= 64 ? (HALF != 0 ? 3 : 2) : (HALF !
   }
   if (nk == 0) return;
 
-  const int64_t SS = 1 + (int64_t)DP + (int64_t)DP * DP;
+  const int64_t SS = 1 + (int64_t)DPW + (int64_t)DPW * DPW;
 #pragma unroll
   for (int c = 0; c < CPW; ++c) {
     if (c < nk) {
       double* out = a.partial + recidx[c] * SS;
-      if (HALF != 2) {
-        const double nsum = sum_over_hi(nacc[c]);
-        if (lane == 0) out[0] = nsum;
+      if (HALF != 2 && PAN != 2) {
+        if (PAN == 0 || colA == 0) {
+          const double nsum = sum_over_hi(nacc[c]);
+          if (lane == 0) out[0] = nsum;
+        }
 #pragma unroll
         for (int jb = 0; jb < NB; ++jb) {
           const double s = sum_over_hi(sacc[c][jb]);
-          if (hi == 0) out[1 + 16 * jb + lo4] = s;
+          if (hi == 0) out[1 + colA + 16 * jb + lo4] = s;
         }
       }
-      double* S = out + 1 + DP;
+      double* S = out + 1 + DPW;
+      if constexpr (PAN == 2) {
+#pragma unroll
+        for (int jbp = 0; jbp < NB; ++jbp)
+#pragma unroll
+          for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              const int gi = colA + 16 * jbp + 4 * ((blk + s) & 3) + hi, gj = colB + 16 * jb + 4 * blk + lo2;
+              const double v = acc[c][(jbp * NB + jb) * 4 + s];
+              S[(int64_t)gi * DPW + gj] = v;
+              S[(int64_t)gj * DPW + gi] = v;
+            }
+      } else {
       int idx = 0;
 #pragma unroll
       for (int jbp = 0; jbp < NB; ++jbp) {
@@ -312,20 +380,21 @@ __global__ void __launch_bounds__(256, (DP <= 64 ? (HALF != 0 ? 3 : 2) : (HALF !
           for (int s = 0; s < 4; ++s) {
             if (s < ns) {
               const int ti = (blk + s) & 3, tj = blk;
-              const int gi = 16 * jbp + 4 * ti + hi, gj = 16 * jb + 4 * tj + lo2;
+              const int gi = colA + 16 * jbp + 4 * ti + hi, gj = colA + 16 * jb + 4 * tj + lo2;
               const bool diag = jb == jbp;
               // diagonal 16x16 blocks: s=0 gives the diagonal tiles, s=1 every pair {t,t+1 mod 4}
               // once, s=2 the pairs {0,2},{1,3} twice (keep the lower copy); s=3 is never issued
               const bool wr = (!diag || ti == tj || s == 1 || ti > tj) && ss_in_half<NB>(HALF, jbp, jb);
               const double v = acc[c][idx];
               if (wr) {
-                S[(int64_t)gi * DP + gj] = v;
-                if (!diag || ti != tj) S[(int64_t)gj * DP + gi] = v;
+                S[(int64_t)gi * DPW + gj] = v;
+                if (!diag || ti != tj) S[(int64_t)gj * DPW + gi] = v;
               }
               ++idx;
             }
           }
         }
+      }
       }
     }
   }
@@ -353,10 +422,10 @@ static int ss_cpw(int DP, int K) {
   return cpw;
 }
 
-int suffstat_clusters_per_block(int DP, int K) { return 4 * ss_cpw(DP, K); }
+int suffstat_clusters_per_block(int DP, int K) { return DP > 128 ? 4 : 4 * ss_cpw(DP, K); }
 
 int suffstat_plan(int DP, int64_t NP, int K, int64_t* chunk_rows) {
-  const int cpw = ss_cpw(DP, K);
+  const int cpw = DP > 128 ? 1 : ss_cpw(DP, K);  // wide: panel launches, one cluster per wave
   const int kwaves = (K + cpw - 1) / cpw;  // waves needed to cover the clusters
   // aim for ~8 waves per CU on 256 CUs, at least 256 rows per chunk
   int64_t want = (256 * 8 + kwaves - 1) / kwaves;
@@ -369,9 +438,11 @@ int suffstat_plan(int DP, int64_t NP, int K, int64_t* chunk_rows) {
     if (v >= 1 && v <= 16) rounds = v;
   }
   const int64_t rec = (int64_t)K * (1 + DP + (int64_t)DP * DP) * 8;
-  const int64_t cap = ((int64_t)1 << 30) / rec;
+  // (wide records are large: allow 4 GiB of them so that the grid still covers the chip)
+  const int64_t cap = ((int64_t)(DP > 128 ? 4 : 1) << 30) / rec;
   if (want * rounds <= cap) want *= rounds;
   else if (want < cap) want = cap;
+  else if (want > cap && DP > 128) want = cap > 1 ? cap : 1;
   int64_t maxchunks = (NP + 255) / 256;
   if (want > maxchunks) want = maxchunks;
   if (want < 1) want = 1;
@@ -381,15 +452,16 @@ int suffstat_plan(int DP, int64_t NP, int K, int64_t* chunk_rows) {
   return (int)((NP + rows - 1) / rows);
 }
 
-template <int DP, int CPW, bool SKIP, int HALF>
+template <int DP, int CPW, bool SKIP, int HALF, int PAN = 0>
 static hipError_t launch_ss_h(const SuffstatLaunch& a, hipStream_t stream) {
   const int kwaves = (a.K + CPW - 1) / CPW;
   const int wpb = 4;
   const int nslice = (kwaves + wpb - 1) / wpb;
   SuffstatLaunch b = a;
   b.nslice = nslice;
-  const size_t shmem = (size_t)(2 * SS_BR * (DP + 16) + 2 * wpb * CPW * SS_BR) * sizeof(double);
-  auto kern = suffstat_kernel<DP, CPW, SKIP, HALF>;
+  constexpr int BR = ss_batch_rows<PAN>();
+  const size_t shmem = (size_t)(2 * (PAN == 2 ? 2 : 1) * BR * (DP + 16) + 2 * wpb * CPW * BR) * sizeof(double);
+  auto kern = suffstat_kernel<DP, CPW, SKIP, HALF, PAN>;
   static bool attr_set = false;
   if (shmem > 64 * 1024 && !attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -401,6 +473,25 @@ static hipError_t launch_ss_h(const SuffstatLaunch& a, hipStream_t stream) {
   if (grid == 0) return hipSuccess;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(wpb * 64), shmem, stream, b);
   return hipGetLastError();
+}
+
+// Observations wider than 128 columns: one launch per pair of 64-column panels (P >= Q), one cluster per wave in all of
+// them so that every launch sees the same (chunk, slice) / work-list decomposition and writes the same records.
+template <bool SKIP>
+static hipError_t launch_ss_wide(const SuffstatLaunch& a, hipStream_t stream) {
+  SuffstatLaunch b = a;
+  b.ldx = a.DP;
+  b.DPW = a.DP;
+  b.DP = 64;
+  const int npan = a.DP / 64;
+  for (int P = 0; P < npan; ++P)
+    for (int Q = 0; Q <= P; ++Q) {
+      b.colA = 64 * P;
+      b.colB = 64 * Q;
+      const hipError_t e = P == Q ? launch_ss_h<64, 1, SKIP, 0, 1>(b, stream) : launch_ss_h<64, 1, SKIP, 0, 2>(b, stream);
+      if (e != hipSuccess) return e;
+    }
+  return hipSuccess;
 }
 
 template <int DP, int CPW, bool SKIP>
@@ -425,6 +516,11 @@ static hipError_t launch_ss_t(const SuffstatLaunch& a, hipStream_t stream) {
 
 hipError_t launch_suffstat(const SuffstatLaunch& a, hipStream_t stream) {
   if (a.K <= 0 || a.nchunks <= 0) return hipSuccess;
+  if (a.DP > 128) {
+    if (a.DP % 64) return hipErrorInvalidValue;
+    const bool skip = a.skip_zero > 0 || (a.skip_zero == 0 && a.smask);
+    return skip ? launch_ss_wide<true>(a, stream) : launch_ss_wide<false>(a, stream);
+  }
   const int cpw = ss_cpw(a.DP, a.K);
   switch (a.DP) {
     case 16:

@@ -82,7 +82,9 @@ def test_vbem_fixed_matches_golden(estep_cases):
 
 
 @pytest.mark.parametrize("N,D,K,J", [(1000, 16, 8, 1), (777, 23, 5, 3), (513, 64, 6, 1), (300, 128, 3, 2),
-                                      (4099, 2, 2, 1), (50, 7, 33, 1)])
+                                      (4099, 2, 2, 1), (50, 7, 33, 1),
+                                      # wider than 128 columns: panel / chunk streaming kernels
+                                      (700, 129, 3, 1), (1000, 200, 5, 2), (640, 256, 9, 1), (400, 300, 2, 3)])
 def test_estep_and_suffstat_vs_oracle_random(N, D, K, J):
     rng = np.random.default_rng(N + D + K)
     X, q0 = [], []
@@ -153,15 +155,12 @@ def test_edge_cases():
         np.testing.assert_allclose(Njk[1], 0.0)
         np.testing.assert_allclose(Njk[0], qg[0].sum(axis=0), rtol=1e-13)
         np.testing.assert_allclose(Njk[2], qg[2].sum(axis=0), rtol=1e-13)
-    # D > 128: the Gauss-Wishart kernels refuse (the separable families accept it, tests/test_gpu_families.py)
+    # beyond the widest Gauss-Wishart layout: refused (the separable families accept it, tests/test_gpu_families.py)
     with capi.Context(0) as ctx:
-        ctx.set_data(np.zeros((4, 129)))
+        ctx.set_data(np.zeros((4, 1025)))
         ctx.fill_qz(1, 1.0)
-        with pytest.raises(ValueError, match="D > 128"):
+        with pytest.raises(ValueError, match="D > 1024"):
             ctx.suffstat()
-    import libcluster_amd as lc
-    with pytest.raises(ValueError, match="D > 128"):
-        lc.learnBGMM(rng.normal(size=(50, 130)))
 
 
 def _check_learn(res, ref, rows):
@@ -443,9 +442,10 @@ def test_randomised_kernel_fuzz():
 
 
 def test_mahaldist_matches_numpy():
-    """probutils::mahaldist (probutils.cpp:113-138) on the GPU: ragged groups, D up to 128, SPD A; non-PD is refused."""
+    """probutils::mahaldist (probutils.cpp:113-138) on the GPU: ragged groups, narrow and wide D, SPD A; non-PD is
+    refused."""
     rng = np.random.default_rng(12)
-    for D, sizes in ((3, [50, 0, 7]), (23, [400]), (64, [1000, 33]), (128, [257])):
+    for D, sizes in ((3, [50, 0, 7]), (23, [400]), (64, [1000, 33]), (128, [257]), (190, [300, 5]), (320, [200])):
         X = [rng.normal(size=(n, D)) * 2 + 1 for n in sizes]
         B = rng.normal(size=(D, D))
         A = B @ B.T / D + 0.3 * np.eye(D)
@@ -458,3 +458,30 @@ def test_mahaldist_matches_numpy():
         Xa = np.vstack(X) - mu
         ref = np.einsum("nd,nd->n", Xa, np.linalg.solve(A, Xa.T).T)
         np.testing.assert_allclose(d2, ref, rtol=1e-10, atol=1e-10)
+
+
+def test_wide_gauss_wishart_learners():
+    """Full-covariance model selection on observations wider than 128 columns (estep_wide_kernel, the panel
+    launches of suffstat_kernel): same rounds, K, F and responsibilities as the oracle."""
+    import libcluster_amd as lc
+
+    rng = np.random.default_rng(33)
+    D = 140
+    X = np.vstack([rng.normal(size=(260, D)) + 4.0, rng.normal(size=(240, D)) * 0.7 - 3.0])
+    X = X[rng.permutation(len(X))]
+    tr = []
+    Fo, qo, wo, clo = o.learnBGMM(X, trace=tr)
+    F, qZ, w, mu, cov, info = lc.learnBGMM(X, return_info=True)
+    assert info["K"] == len(clo) and [k for k, _ in info["rounds"]] == [k for k, _ in tr]
+    assert abs(F - Fo) <= 1e-8 * abs(Fo)
+    assert_q_close(qZ, qo, rtol=1e-6)
+    np.testing.assert_allclose(np.vstack(mu), np.stack([c.getmean() for c in clo]), rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(np.array(cov), np.stack([c.getcov() for c in clo]), rtol=1e-7, atol=1e-9)
+    # grouped, sparse
+    Xg = [X[:200], X[200:330], X[330:]]
+    tr = []
+    Fo, qo, wo, clo = o.learnGMC(Xg, trace=tr)
+    F, qZ, w, mu, cov, info = lc.learnGMC(Xg, return_info=True)
+    assert info["K"] == len(clo) and abs(F - Fo) <= 1e-8 * abs(Fo)
+    for a, b in zip(qZ, qo):
+        assert_q_close(a, b, rtol=1e-6)
