@@ -33,12 +33,7 @@ __device__ __forceinline__ void diag_tile(const double* __restrict__ xr, const d
   const double* p1[KT];
 #pragma unroll
   for (int j = 0; j < KT; ++j) {
-#ifdef LC_EXP_SAMEK
-    int k = 0;
-    asm volatile("" : "+s"(k));  // opaque: no CSE across the tile's clusters
-#else
     const int k = k0 + j < K ? k0 + j : K - 1;  // clamped: the caller discards clusters >= K
-#endif
     pa[j] = PA + (int64_t)k * DPS;
     p2[j] = PW2 + (int64_t)k * DPS;
     p1[j] = PW1 + (int64_t)k * DPS;
@@ -76,22 +71,13 @@ __global__ void __launch_bounds__(256)
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t row0 = (int64_t)blockIdx.x * 64;
-#ifdef LC_EXP_STAGGER
-  if (blockIdx.x < 1024) {
-    const long long wait = (long long)((blockIdx.x >> 8) & 3) * LC_EXP_STAGGER;
-    const long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(16);
-  }
-#endif
   {
     const int c2 = DP >> 1, sh = __builtin_ctz(c2);  // double2 columns per row (DP is a power of two)
     const double2* X2 = reinterpret_cast<const double2*>(X);
     for (int idx = tid; idx < 64 * c2; idx += 256) {
       const int r = idx >> sh, c = idx & (c2 - 1);
       double2 v = make_double2(0.0, 0.0);
-#ifndef LC_EXP_NOLOAD
       if (row0 + r < NP) v = X2[(row0 + r) * c2 + c];
-#endif
       xt[r * LD + 2 * c] = v.x;
       xt[r * LD + 2 * c + 1] = v.y;
     }

@@ -358,12 +358,27 @@ __global__ void __launch_bounds__(WAVES * 64, EstepOcc<DP>::BLOCKS) estep_kernel
 // Same arithmetic, same operand layout; what changes is what stays resident.  A cluster's whitener no longer fits in
 // LDS (268 KB at D = 256) and a row group's X fragments no longer fit in registers, so the lower-triangular A_k is cut
 // into 64 x 64 blocks (I, J <= I) that stream through a two-deep LDS ring in row-major order -- one chunk = the 256
-// 4x4 tiles of a block (zeros above the diagonal of a diagonal block) followed by -b_I -- and a wave keeps
+// 4x4 tiles of a block (a diagonal block reads only the 136 on or below its diagonal) followed by -b_I -- and a wave keeps
 //   * the 16 tile-row accumulators of block row I for its R row groups (y_I = sum_J A_IJ x_J - b_I), and
 //   * the X fragments of column panel J only, re-read from L2 for every chunk (the loads return in order, so the
 //     first MFMAs start as soon as the first fragments are back).
 // After the diagonal chunk (J = I) the 16 accumulators are squared into the running distance.  Normalisation as in
 // estep_kernel (k-sliced scheme).  lc_ctx.cpp packs the chunks (wide_chunk_stride doubles each, K * NCH of them).
+// n-th tile read of a chunk -> 16 * it + jt.  Tile rows go in pairs (it = 2 (m / 32) + (m & 1), jt = (m % 32) / 2 over
+// m = 0..255) so that 2R independent accumulator chains alternate; the 136 tiles on or below the diagonal come first,
+// the 120 above it after them: a diagonal block stops after the first part.
+__host__ __device__ constexpr int wide_read(int n) {
+  int c = 0;
+  for (int part = 0; part < 2; ++part)
+    for (int m = 0; m < 256; ++m) {
+      const int it = 2 * (m / 32) + (m & 1), jt = (m % 32) / 2;
+      if ((jt <= it) == (part == 0)) {
+        if (c == n) return it * 16 + jt;
+        ++c;
+      }
+    }
+  return -1;
+}
 template <int R, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64, 2) estep_wide_kernel(EstepLaunch a) {
   constexpr int CHS = WIDE_CHUNK;  // 256 tiles x 16 + 64
@@ -449,23 +464,26 @@ __global__ void __launch_bounds__(WAVES * 64, 2) estep_wide_kernel(EstepLaunch a
         for (int r = 0; r < R; ++r) acc[it][r] = v;
       }
     }
-    // read n of the chunk: tile rows in pairs, so that 2R independent accumulator chains alternate
-    //   it = 2 (n / 32) + (n & 1), jt = (n % 32) / 2
+    // tile reads PF ahead of their use; the reads that run past the lower part of a diagonal block are not used
     double ring[PF];
     static_for<PF>([&](auto ic) {
-      constexpr int n = ic, it = 2 * (n / 32) + (n & 1), jt = (n % 32) / 2;
-      ring[n] = Pt[16 * (it * 16 + jt)];
+      constexpr int t0 = wide_read(ic);
+      ring[ic] = Pt[16 * t0];
     });
-    static_for<256>([&](auto nc) {
-      constexpr int n = nc, it = 2 * (n / 32) + (n & 1), jt = (n % 32) / 2;
-      const double v = ring[n % PF];
-      if constexpr (n + PF < 256) {
-        constexpr int m = n + PF, it2 = 2 * (m / 32) + (m & 1), jt2 = (m % 32) / 2;
-        ring[n % PF] = Pt[16 * (it2 * 16 + jt2)];
-      }
+    auto reads = [&](auto first_c, auto count_c) {
+      static_for<decltype(count_c)::value>([&](auto nc) {
+        constexpr int n = decltype(first_c)::value + nc, t = wide_read(n), it = t / 16, jt = t % 16;
+        const double v = ring[n % PF];
+        if constexpr (n + PF < 256) {
+          constexpr int tn = wide_read(n + PF);
+          ring[n % PF] = Pt[16 * tn];
+        }
 #pragma unroll
-      for (int r = 0; r < R; ++r) acc[it][r] = mfma4(v, xf[r][jt], acc[it][r]);
-    });
+        for (int r = 0; r < R; ++r) acc[it][r] = mfma4(v, xf[r][jt], acc[it][r]);
+      });
+    };
+    reads(std::integral_constant<int, 0>{}, std::integral_constant<int, 136>{});
+    if (J != I) reads(std::integral_constant<int, 136>{}, std::integral_constant<int, 120>{});
     if (J == I) {  // block row complete
 #pragma unroll
       for (int it = 0; it < 16; ++it)
