@@ -23,7 +23,7 @@ WK = [(o.Dirichlet, capi.W_DIRICHLET), (o.StickBreak, capi.W_STICKBREAK), (o.GDi
 CK = [(o.GaussWish, capi.C_GAUSSWISH), (o.NormGamma, capi.C_NORMGAMMA), (o.ExpGamma, capi.C_EXPGAMMA)]
 fails, t0 = [], time.time()
 for case in range(cases):
-    D = int(rng.choice([1, 2, 3, 5, 8, 15, 16, 17, 23, 31, 32, 33, 48, 64, 65, 100, 128]))
+    D = int(rng.choice([1, 2, 3, 5, 8, 15, 16, 17, 23, 31, 32, 33, 48, 64, 65, 100, 128, 129, 160, 257]))
     K = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 16, 17, 31, 33, 40, 65]))
     J = int(rng.choice([1, 1, 1, 2, 3, 5, 9, 40]))
     budget = max(40, int(200000 / (D * D * K) * 40))  # keep the numpy oracle fast
