@@ -72,12 +72,16 @@ __global__ void __launch_bounds__(256)
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t row0 = (int64_t)blockIdx.x * 64;
   {
+    // the 64 x DP tile is one contiguous piece of X (row length = tile width): element idx of the tile is element
+    // row0 * DP/2 + idx of X as double2; rows past NP are staged as zeros
     const int c2 = DP >> 1, sh = __builtin_ctz(c2);  // double2 columns per row (DP is a power of two)
-    const double2* X2 = reinterpret_cast<const double2*>(X);
+    const double2* T2 = reinterpret_cast<const double2*>(X) + row0 * c2;
+    const int64_t left = NP - row0;
+    const int lim = (int)(left < 64 ? left : 64) * c2;
     for (int idx = tid; idx < 64 * c2; idx += 256) {
       const int r = idx >> sh, c = idx & (c2 - 1);
       double2 v = make_double2(0.0, 0.0);
-      if (row0 + r < NP) v = X2[(row0 + r) * c2 + c];
+      if (idx < lim) v = T2[idx];
       xt[r * LD + 2 * c] = v.x;
       xt[r * LD + 2 * c + 1] = v.y;
     }
@@ -121,7 +125,7 @@ __global__ void __launch_bounds__(256)
             lq[i][j] = v;
             dt[i][j] = acc[j];
             mx = fmax(mx, v);
-            if (raw && inb) qZ[(int64_t)k * ldq + row] = v;
+            if (raw && inb) (qZ + (int64_t)k * ldq + row0)[lane] = v;
           }
         }
       }
@@ -136,7 +140,7 @@ __global__ void __launch_bounds__(256)
         if (k < K) {
           const double v = crow[k] + acc[j];
           mx = fmax(mx, v);
-          if (inb) qZ[(int64_t)k * ldq + row] = v;
+          if (inb) (qZ + (int64_t)k * ldq + row0)[lane] = v;
         }
       }
     }
@@ -151,17 +155,20 @@ __global__ void __launch_bounds__(256)
   double se = 0.0;
   if (REG) {
 #pragma unroll
-    for (int i = 0; i < DIAG_MAXT; ++i)
+    for (int i = 0; i < DIAG_MAXT; ++i) {
+      if (w + 4 * i < ntiles) {  // wave-uniform: no exponentials for tile slots this wave does not own
 #pragma unroll
-      for (int j = 0; j < KT; ++j) {
-        lq[i][j] = exp(lq[i][j] - mx);  // exp(-inf) = 0 for the slots past K
-        se += lq[i][j];
+        for (int j = 0; j < KT; ++j) {
+          lq[i][j] = exp(lq[i][j] - mx);  // exp(-inf) = 0 for the slots past K
+          se += lq[i][j];
+        }
       }
+    }
   } else if (inb) {
     for (int tile = w; tile < ntiles; tile += 4)
       for (int j = 0; j < KT; ++j) {
         const int k = tile * KT + j;
-        if (k < K) se += exp(qZ[(int64_t)k * ldq + row] - mx);
+        if (k < K) se += exp((qZ + (int64_t)k * ldq + row0)[lane] - mx);
       }
   }
   red[w * 64 + lane] = se;
@@ -181,7 +188,7 @@ __global__ void __launch_bounds__(256)
           const int k = tile * KT + j;
           if (k < K) {
             const double q = ok ? lq[i][j] * inv : 0.0;
-            if (inb) qZ[(int64_t)k * ldq + row] = q;
+            if (inb) (qZ + (int64_t)k * ldq + row0)[lane] = q;
             if (ll_part) {
               const double ll = wave_sum(q > 0.0 ? q * dt[i][j] : 0.0);
               if (lane == 0) llw[k] = ll;
@@ -197,7 +204,7 @@ __global__ void __launch_bounds__(256)
         if (k < K) {
           double ll = 0.0;
           if (inb) {
-            double* qp = qZ + (int64_t)k * ldq + row;
+            double* qp = qZ + (int64_t)k * ldq + row0 + lane;
             const double v = *qp;
             const double q = ok ? exp(v - mx) * inv : 0.0;
             *qp = q;
