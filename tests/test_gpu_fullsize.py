@@ -161,3 +161,65 @@ def test_full_size_properties_diagonal_families(family):
     if not eg:
         np.testing.assert_allclose(tot[2], xxs, rtol=1e-9, atol=1e-5)
     assert abs(tot_Fz - Fz) <= 1e-11 * abs(Fz)
+
+
+def test_rows_beyond_32bit_element_indices():
+    """N = 50M rows of D = 64 with K = 48: element indices of X (3.2e9) and of qZ (2.4e9) pass 2^31.  The same
+    size-independent properties: unit row sums, the LAST rows bit-identical to a stand-alone run on just those rows,
+    statistics and F_z equal to the sums over five 10M-row shards of the same Philox stream -- for the Gauss-Wishart
+    kernels and for the diagonal family."""
+    N, D, K, seed = 50_000_000, 64, 48, 1010
+    mu, L = _mixture(D, K, seed)
+    P = 2048
+    with capi.Context(0) as ctx:
+        ctx.synth(N, D, K, mu, L, seed, 0, 0.9)
+        Xt = ctx.get_rows(0, N - P, P)
+        Nk, xs, xxs, _ = ctx.suffstat()
+        assert abs(Nk.sum() - N) <= 1e-9 * N
+        post = [capi.gw_mstep(1.0, Nk[k], xs[k], xxs[k]) for k in range(K)]
+        elog, _ = capi.weights_update(capi.W_STICKBREAK, Nk)
+        args = ([p["nu"] for p in post], [p["beta"] for p in post], np.stack([p["m"] for p in post]),
+                np.stack([p["iW"] for p in post]), [p["logdW"] for p in post], elog[None, :])
+        Fz, _ = ctx.estep_posterior(*args, want_ll=False)
+        qt = ctx.get_qz_rows(0, N - P, P)
+        colsum = ctx.colsums()[0]
+        # diagonal family on the same rows
+        dNk, dxs, dxxs, _ = ctx.suffstat_diag(second=True)
+        dpost = [capi.ng_mstep(1.0, dNk[k], dxs[k], dxxs[k]) for k in range(K)]
+        da = np.stack([p["m"] for p in dpost])
+        dw2 = np.stack([-0.5 * p["nu"] / p["L"] for p in dpost])
+        delog, _ = capi.weights_update(capi.W_DIRICHLET, dNk)
+        dc = (delog + np.array([p["eloglike_const"] for p in dpost]))[None, :]
+        dFz, _ = ctx.estep_diag(da, dw2, np.zeros((K, D)), dc)
+        dqt = ctx.get_qz_rows(0, N - P, P)
+        dcol = ctx.colsums()[0]
+    assert abs(colsum.sum() - N) <= 1e-9 * N and abs(dcol.sum() - N) <= 1e-9 * N
+    np.testing.assert_allclose(qt.sum(axis=1), 1.0, rtol=1e-12)
+    np.testing.assert_allclose(dqt.sum(axis=1), 1.0, rtol=1e-12)
+    with capi.Context(0) as c2:
+        c2.set_data(Xt)
+        c2.estep_posterior(*args, want_ll=False)
+        np.testing.assert_array_equal(qt, c2.get_qz([P])[0])
+        c2.estep_diag(da, dw2, np.zeros((K, D)), dc)
+        np.testing.assert_array_equal(dqt, c2.get_qz([P])[0])
+    S = 5
+    part = N // S
+    tot, dtot, tFz, tdFz = None, None, 0.0, 0.0
+    for r in range(S):
+        with capi.Context(0) as cs:
+            cs.synth(part, D, K, mu, L, seed, r * part, 0.9)
+            st = cs.suffstat()[:3]
+            fz, _ = cs.estep_posterior(*args, want_ll=False)
+            dst = cs.suffstat_diag(second=True)[:3]  # (of the responsibilities just computed, as above)
+            dfz, _ = cs.estep_diag(da, dw2, np.zeros((K, D)), dc)
+        tFz += fz
+        tdFz += dfz
+        tot = st if tot is None else tuple(a + b for a, b in zip(tot, st))
+        dtot = dst if dtot is None else tuple(a + b for a, b in zip(dtot, dst))
+    np.testing.assert_allclose(tot[0], Nk, rtol=1e-12)
+    np.testing.assert_allclose(tot[1], xs, rtol=1e-9, atol=1e-5)
+    np.testing.assert_allclose(tot[2], xxs, rtol=1e-9, atol=1e-4)
+    np.testing.assert_allclose(dtot[0], dNk, rtol=1e-12)
+    np.testing.assert_allclose(dtot[1], dxs, rtol=1e-9, atol=1e-5)
+    np.testing.assert_allclose(dtot[2], dxxs, rtol=1e-9, atol=1e-4)
+    assert abs(tFz - Fz) <= 1e-11 * abs(Fz) and abs(tdFz - dFz) <= 1e-11 * abs(dFz)
