@@ -71,7 +71,8 @@ int lc_ctx_dims(lc_ctx* ctx, int* J, int* D, int64_t* Ntotal, int* K);
 
 /* Upload J groups of observations (the `const vMatrixXd& X` of
  * cluster.cpp:564-566; learnVDP/learnBGMM pass J = 1, cluster.cpp:651/682).
- * Element (n,d) of group j is Xj[j][n*row_stride + d*col_stride]. */
+ * Element (n,d) of group j is Xj[j][n*row_stride + d*col_stride].
+ * Any D for the diagonal / exponential families; the Gauss-Wishart entry points return LC_EINVAL beyond D = 1024. */
 int lc_ctx_set_data(lc_ctx* ctx, int J, const double* const* Xj, const int64_t* Nj, int D, int64_t row_stride,
                     int64_t col_stride);
 /* Synthetic K-component full-covariance Gaussian mixture generated on the
