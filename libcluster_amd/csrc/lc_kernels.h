@@ -8,15 +8,16 @@
 namespace lck {
 
 // ---- data layout constants -------------------------------------------------
-// X on device: row-major [NP x DP] doubles, DP = D rounded up to {16,32,64,128} (a multiple of 128 beyond that),
+// X on device: row-major [NP x DP] doubles, DP = D rounded up to {16,32,64,128} (a multiple of 64 beyond that),
 // pad columns zero.  Groups are padded to multiples of 16 rows (a "row-group"),
 // pad rows zero.  qZ on device: column-major, qZ[k*ldq + row], ldq = NP.
 constexpr int RG = 16;  // rows per row-group (one MFMA column block)
 
 inline int padded_dim(int D) { return D <= 16 ? 16 : D <= 32 ? 32 : D <= 64 ? 64 : D <= 128 ? 128 : -1; }
-// wider observations are padded to a multiple of 128 columns: the separable (diagonal / exponential) families process
-// them in 128-column blocks (any D), the Gauss-Wishart kernels in 64-column panels / 64 x 64 whitener blocks
-inline int padded_dim_wide(int D) { return D <= 128 ? padded_dim(D) : (D + 127) / 128 * 128; }
+// wider observations are padded to a multiple of 64 columns: the separable (diagonal / exponential) families process
+// them in 128-column blocks with a possible half block at the end (any D), the Gauss-Wishart kernels in 64-column
+// panels / 64 x 64 whitener blocks
+inline int padded_dim_wide(int D) { return D <= 128 ? padded_dim(D) : (D + 63) / 64 * 64; }
 constexpr int GW_MAX_DP = 1024;  // Gauss-Wishart kernels: panel / chunk streaming beyond 128 (tested to 512)
 inline int ntiles(int DP) { int nt = DP / 4; return nt * (nt + 1) / 2; }
 // doubles per cluster in the packed E-step parameter stream

@@ -235,9 +235,8 @@ __global__ void __launch_bounds__(256)
                       int64_t NP, int64_t nrows, int64_t ldq, int raw) {
   extern __shared__ double lds[];
   // wide observations (DP > 128, the separable families have no limit on D): the row tile is staged in chunks of
-  // DC = 128 dimensions and the per-cluster sums run over the chunks; DP <= 128 is one chunk as before
-  const int DC = DP < 128 ? DP : 128;
-  const int LD = DC + 1;
+  // 128 dimensions and the per-cluster sums run over the chunks
+  const int LD = 129;
   double* xt = lds;             // [64][LD]
   double* red = lds + 64 * LD;  // [4][64]
   double* llw = red + 256;      // [K]
@@ -271,8 +270,9 @@ __global__ void __launch_bounds__(256)
   }
 
   // ---- pass 1: the data term of log q~ for this wave's tiles, chunk by chunk ----
-  for (int d0 = 0; d0 < DP; d0 += DC) {
+  for (int d0 = 0; d0 < DP; d0 += 128) {
     if (d0 > 0) __syncthreads();  // every wave is done with the previous chunk
+    const int DC = DP - d0 < 128 ? DP - d0 : 128;  // (DP is a multiple of 64: the last chunk may be a half one)
     {
       const int c2 = DC >> 1, sh = __builtin_ctz(c2);  // double2 columns per chunk row (DC is a power of two)
       const double2* X2 = reinterpret_cast<const double2*>(X + d0);
@@ -632,11 +632,11 @@ hipError_t launch_suffstat_diag(const DiagStatLaunch& a0, hipStream_t stream) {
   a.ldx = a0.DP;
   a.DPT = a0.DP;
   if (a0.DP > 128) {  // wide observations: one launch per block of 128 columns (q is re-read; X is read once in total)
-    if (a0.DP % 128) return hipErrorInvalidValue;
-    a.DP = 128;
+    if (a0.DP % 64) return hipErrorInvalidValue;
     for (int c0 = 0; c0 < a0.DP; c0 += 128) {
       a.col0 = c0;
-      hipError_t e = launch_sd_t<128>(a, stream);
+      a.DP = a0.DP - c0 < 128 ? 64 : 128;  // (a multiple of 64: the last block may be a half one)
+      hipError_t e = a.DP == 128 ? launch_sd_t<128>(a, stream) : launch_sd_t<64>(a, stream);
       if (e != hipSuccess) return e;
     }
     return hipSuccess;
