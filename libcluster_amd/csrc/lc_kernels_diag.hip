@@ -74,16 +74,17 @@ __global__ void __launch_bounds__(256)
   {
     // the 64 x DP tile is one contiguous piece of X (row length = tile width): element idx of the tile is element
     // row0 * DP/2 + idx of X as double2; rows past NP are staged as zeros
-    const int c2 = DP >> 1, sh = __builtin_ctz(c2);  // double2 columns per row (DP is a power of two)
+    const int c2 = DP >> 1;  // double2 columns per row
+    const unsigned inv = ((1u << 20) + c2 - 1) / c2;  // idx / c2 == (idx * inv) >> 20 for idx < 64 * c2 <= 4096
     const double2* T2 = reinterpret_cast<const double2*>(X) + row0 * c2;
     const int64_t left = NP - row0;
     const int lim = (int)(left < 64 ? left : 64) * c2;
     for (int idx = tid; idx < 64 * c2; idx += 256) {
-      const int r = idx >> sh, c = idx & (c2 - 1);
+      const int r = (int)(((unsigned)idx * inv) >> 20);
       double2 v = make_double2(0.0, 0.0);
       if (idx < lim) v = T2[idx];
-      xt[r * LD + 2 * c] = v.x;
-      xt[r * LD + 2 * c + 1] = v.y;
+      xt[2 * idx + r] = v.x;  // = xt[r * LD + 2 * c] with LD = 2 * c2 + 1
+      xt[2 * idx + r + 1] = v.y;
     }
   }
   __syncthreads();
@@ -472,7 +473,7 @@ template <int DP, bool SECOND>
 __global__ void __launch_bounds__(256, 2) suffstat_diag_kernel(DiagStatLaunch a) {
   constexpr int NB = DP / 16, CT = 4;
   constexpr int BR = DP <= 64 ? 32 : 16;
-  constexpr int LD = DP + 16, XBUF = BR * LD;
+  constexpr int LD = lds_row_stride(DP), XBUF = BR * LD;
   constexpr int NV2 = BR * DP / 2, NPRE = (NV2 + 255) / 256;   // double2 per thread and batch
   constexpr int NQ = SD_QMAX * BR / 256;                       // q elements per thread and batch
   constexpr int QLD = BR + 4;                                  // padded q column stride: conflict-free A fragments
@@ -604,7 +605,7 @@ int suffstat_diag_rsplit(int K) {  // row classes per block: waves left over by 
 template <int DP>
 static hipError_t launch_sd_t(const DiagStatLaunch& a, hipStream_t stream) {
   constexpr int BR = DP <= 64 ? 32 : 16;
-  const size_t shmem = (size_t)(2 * BR * (DP + 16) + 2 * SD_QMAX * (BR + 4)) * sizeof(double);
+  const size_t shmem = (size_t)(2 * BR * lds_row_stride(DP) + 2 * SD_QMAX * (BR + 4)) * sizeof(double);
   static bool attr_set = false;
   if (shmem > 64 * 1024 && !attr_set) {
     hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(suffstat_diag_kernel<DP, true>),
@@ -646,8 +647,12 @@ hipError_t launch_suffstat_diag(const DiagStatLaunch& a0, hipStream_t stream) {
       return launch_sd_t<16>(a, stream);
     case 32:
       return launch_sd_t<32>(a, stream);
+    case 48:
+      return launch_sd_t<48>(a, stream);
     case 64:
       return launch_sd_t<64>(a, stream);
+    case 96:
+      return launch_sd_t<96>(a, stream);
     case 128:
       return launch_sd_t<128>(a, stream);
   }

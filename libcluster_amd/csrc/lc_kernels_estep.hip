@@ -590,7 +590,11 @@ struct EstepCfg<16> { static constexpr int R = 4, WAVES = 4; };
 template <>
 struct EstepCfg<32> { static constexpr int R = 4, WAVES = 4; };
 template <>
+struct EstepCfg<48> { static constexpr int R = 4, WAVES = 4; };
+template <>
 struct EstepCfg<64> { static constexpr int R = 3, WAVES = 4; };
+template <>
+struct EstepCfg<96> { static constexpr int R = 2, WAVES = 8; };
 template <>
 struct EstepCfg<128> { static constexpr int R = 2, WAVES = 8; };
 
@@ -601,7 +605,9 @@ int estep_rows_per_block(int DP) {
   switch (DP) {
     case 16: return rows_per_block_t<16>();
     case 32: return rows_per_block_t<32>();
+    case 48: return rows_per_block_t<48>();
     case 64: return rows_per_block_t<64>();
+    case 96: return rows_per_block_t<96>();
     case 128: return rows_per_block_t<128>();
   }
   if (DP > 128 && DP % 64 == 0) return WIDE_R * WIDE_WAVES * RG;
@@ -642,7 +648,9 @@ hipError_t launch_estep(const EstepLaunch& a, hipStream_t stream) {
   switch (a.DP) {
     case 16: return launch_estep_t<16>(a, stream);
     case 32: return launch_estep_t<32>(a, stream);
+    case 48: return launch_estep_t<48>(a, stream);
     case 64: return launch_estep_t<64>(a, stream);
+    case 96: return launch_estep_t<96>(a, stream);
     case 128: return launch_estep_t<128>(a, stream);
   }
   return hipErrorInvalidValue;

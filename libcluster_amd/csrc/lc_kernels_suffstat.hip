@@ -44,7 +44,9 @@ constexpr int SS_BR = 32;  // rows staged per batch
 template <int NB>
 __host__ __device__ constexpr bool ss_in_half(int half, int jbp, int jb) {
   if (half == 0) return true;
-  const bool first = NB == 8 ? (jbp < 5 || (jbp == 5 && jb < 3)) : (jbp == 1 || jbp == 2);  // 67|69 resp. 18|18 MFMAs
+  const bool first = NB == 8   ? (jbp < 5 || (jbp == 5 && jb < 3))    // 67 | 69 MFMAs
+                     : NB == 6 ? (jbp < 4 || (jbp == 4 && jb < 1))    // 40 | 38
+                               : (jbp == 1 || jbp == 2);              // 18 | 18 (NB = 4)
   return first == (half == 1);
 }
 // PAN (observations wider than 128 columns, DP = 64 only): the statistics of a wide X are assembled from 64-column
@@ -61,7 +63,7 @@ __global__ void __launch_bounds__(256, (DP <= 64 ? (HALF != 0 ? 3 : 2) : (HALF !
   constexpr int NB = DP / 16;
   constexpr int NACC = PAN == 2 ? NB * NB * 4 : SSAcc<NB>::N;
   constexpr int BR = ss_batch_rows<PAN>();
-  constexpr int LD = DP + 16;            // padded LDS row stride (doubles)
+  constexpr int LD = lds_row_stride(DP);  // padded LDS row stride (doubles)
   constexpr int NPB = PAN == 2 ? 2 : 1;  // column panels staged per batch
   constexpr int XBUF = NPB * BR * LD;    // doubles per X buffer
   constexpr int NV2 = BR * DP / 2;       // double2 elements per staged batch and panel
@@ -407,7 +409,11 @@ struct SSCfg<16> { static constexpr int CPW = 4; };
 template <>
 struct SSCfg<32> { static constexpr int CPW = 4; };
 template <>
+struct SSCfg<48> { static constexpr int CPW = 2; };  // (four clusters per wave spill at the 256-register budget)
+template <>
 struct SSCfg<64> { static constexpr int CPW = 2; };
+template <>
+struct SSCfg<96> { static constexpr int CPW = 1; };
 template <>
 struct SSCfg<128> { static constexpr int CPW = 1; };
 
@@ -416,7 +422,8 @@ static int ss_cpw(int DP, int K) {
     const int v = atoi(e);
     if (v == 1 || (v == 2 && DP <= 64) || (v == 4 && DP <= 32)) return v;
   }
-  int cpw = DP == 16 ? SSCfg<16>::CPW : DP == 32 ? SSCfg<32>::CPW : DP == 64 ? SSCfg<64>::CPW : SSCfg<128>::CPW;
+  int cpw = DP == 16 ? SSCfg<16>::CPW : DP == 32 ? SSCfg<32>::CPW : DP == 48 ? SSCfg<48>::CPW : DP == 64 ? SSCfg<64>::CPW
+                                                                                             : SSCfg<128>::CPW;  // (96, 128)
   // few clusters: spread them over more waves instead of stacking them in one
   while (cpw > 1 && (K + cpw - 1) / cpw < 4 && (K + cpw / 2 - 1) / (cpw / 2) <= 4) cpw /= 2;
   return cpw;
@@ -460,7 +467,7 @@ static hipError_t launch_ss_h(const SuffstatLaunch& a, hipStream_t stream) {
   SuffstatLaunch b = a;
   b.nslice = nslice;
   constexpr int BR = ss_batch_rows<PAN>();
-  const size_t shmem = (size_t)(2 * (PAN == 2 ? 2 : 1) * BR * (DP + 16) + 2 * wpb * CPW * BR) * sizeof(double);
+  const size_t shmem = (size_t)(2 * (PAN == 2 ? 2 : 1) * BR * lds_row_stride(DP) + 2 * wpb * CPW * BR) * sizeof(double);
   auto kern = suffstat_kernel<DP, CPW, SKIP, HALF, PAN>;
   static bool attr_set = false;
   if (shmem > 64 * 1024 && !attr_set) {
@@ -529,8 +536,12 @@ hipError_t launch_suffstat(const SuffstatLaunch& a, hipStream_t stream) {
     case 32:
       return cpw == 4 ? launch_ss_t<32, 4>(a, stream) : cpw == 2 ? launch_ss_t<32, 2>(a, stream)
                                                                 : launch_ss_t<32, 1>(a, stream);
+    case 48:
+      return cpw == 2 ? launch_ss_t<48, 2>(a, stream) : launch_ss_t<48, 1>(a, stream);
     case 64:
       return cpw == 2 ? launch_ss_t<64, 2>(a, stream) : launch_ss_t<64, 1>(a, stream);
+    case 96:
+      return launch_ss_t<96, 1>(a, stream);
     case 128:
       return launch_ss_t<128, 1>(a, stream);
   }

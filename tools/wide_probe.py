@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Gauss-Wishart kernels on observations wider than 128 columns: time of the E-step (estep_wide_kernel) and of the
-statistics pass (panel launches of suffstat_kernel) against the fp64 MFMA peak.  Usage: tools/wide_probe.py [N D K]"""
+"""Gauss-Wishart kernels at any width (host-generated data; the in-between layouts of 48 / 96 columns and
+observations wider than 128 columns): time of the E-step and of the statistics pass against the fp64 MFMA peak.  Usage: tools/wide_probe.py [N D K]"""
 import sys
 from pathlib import Path
 
@@ -20,7 +20,7 @@ m = rng.normal(size=(K, D))
 iW = np.stack([np.eye(D) * (1.0 + 0.1 * k) for k in range(K)])
 logdW = np.array([-np.linalg.slogdet(w)[1] for w in iW])
 elw = np.log(np.full((1, K), 1.0 / K))
-DP = (D + 63) // 64 * 64 if D > 128 else max(16, 1 << (D - 1).bit_length())
+DP = (D + 63) // 64 * 64 if D > 128 else next(w for w in (16, 32, 48, 64, 96, 128) if D <= w)  # lck::padded_dim_wide
 with capi.Context(0) as ctx:
     ctx.set_data(X)
     ctx.set_qz(q)
