@@ -65,6 +65,10 @@ __global__ void __launch_bounds__(256, (DP <= 64 ? (HALF != 0 ? 3 : 2) : (HALF !
   constexpr int BR = ss_batch_rows<PAN>();
   constexpr int LD = lds_row_stride(DP);  // padded LDS row stride (doubles)
   constexpr int NPB = PAN == 2 ? 2 : 1;  // column panels staged per batch
+  constexpr bool SORD = DP == 64;        // rotation-major MFMA order in the step loop (see there)
+  // step loop with the next step's unrotated fragments and q prefetched (see there); -2...4 % at every width but
+  // 16 (+20 %: four clusters per wave on 10 MFMAs each leave nothing to hide the extra reads behind)
+  constexpr bool PFETCH = DP >= 32 && (DP <= 64 || HALF != 0);
   constexpr int XBUF = NPB * BR * LD;    // doubles per X buffer
   constexpr int NV2 = BR * DP / 2;       // double2 elements per staged batch and panel
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -293,6 +297,59 @@ __global__ void __launch_bounds__(256, (DP <= 64 ? (HALF != 0 ? 3 : 2) : (HALF !
                   acc[c][(jbp * NB + jb) * 4 + s2] = mfma4(xr[jbp][s2], qx[jb], acc[c][(jbp * NB + jb) * 4 + s2]);
           }
         }
+      } else if constexpr (PFETCH && !SKIP) {
+        // Dense: the unrotated fragments and q of step st + 1 are fetched under the MFMAs of step st (12 registers at
+        // D = 64), so a step starts its rotation-0 MFMAs at once and its own rotated fragments arrive under them.
+        // All BR/4 steps run (rows past the chunk end were staged as zeros with q = 0).
+        double x0[NB], qv[CPW];
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb) x0[jb] = xb[16 * jb + 4 * blk];
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) qv[c] = qb[c * BR];
+#pragma unroll 1
+        for (int st = 0; st < BR / 4; ++st) {
+          double xr[NB][4], x0n[NB], qn[CPW];
+#pragma unroll
+          for (int s2 = 1; s2 < 4; ++s2)
+#pragma unroll
+            for (int jb = 0; jb < NB; ++jb) xr[jb][s2] = xb[st * 4 * LD + 16 * jb + 4 * ((blk + s2) & 3)];
+          const int sn = st + 1 < BR / 4 ? st + 1 : st;  // (the last step re-reads its own operands; not used)
+#pragma unroll
+          for (int jb = 0; jb < NB; ++jb) {
+            xr[jb][0] = x0[jb];
+            x0n[jb] = xb[sn * 4 * LD + 16 * jb + 4 * blk];
+          }
+#pragma unroll
+          for (int c = 0; c < CPW; ++c) qn[c] = qb[c * BR + sn * 4];
+#pragma unroll
+          for (int c = 0; c < CPW; ++c) {
+            double qx[NB];
+#pragma unroll
+            for (int jb = 0; jb < NB; ++jb) {
+              qx[jb] = qv[c] * xr[jb][0];
+              if (HALF != 2) sacc[c][jb] += qx[jb];
+            }
+            if (HALF != 2) nacc[c] += qv[c];
+#pragma unroll
+            for (int sp = 0; sp < 4; ++sp) {
+              int idx = 0;
+#pragma unroll
+              for (int jbp = 0; jbp < NB; ++jbp)
+#pragma unroll
+                for (int jb = 0; jb <= jbp; ++jb)
+#pragma unroll
+                  for (int s2 = 0; s2 < 4; ++s2)
+                    if (s2 < 3 || jb < jbp) {
+                      if (s2 == sp && ss_in_half<NB>(HALF, jbp, jb)) acc[c][idx] = mfma4(xr[jbp][s2], qx[jb], acc[c][idx]);
+                      ++idx;
+                    }
+            }
+          }
+#pragma unroll
+          for (int jb = 0; jb < NB; ++jb) x0[jb] = x0n[jb];
+#pragma unroll
+          for (int c = 0; c < CPW; ++c) qv[c] = qn[c];
+        }
       } else {
         const int nstep = (int)(((r1 - b0) < BR ? (r1 - b0) : BR) / 4);
         for (int st = 0; st < nstep; ++st) {
@@ -305,9 +362,10 @@ __global__ void __launch_bounds__(256, (DP <= 64 ? (HALF != 0 ? 3 : 2) : (HALF !
           // fragments: xr[jb][s] = x[row 4*st+hi][16*jb + 4*((blk+s)&3) + lo2]
           double xr[NB][4];
   #pragma unroll
-          for (int jb = 0; jb < NB; ++jb)
-  #pragma unroll
-            for (int s = 0; s < 4; ++s) xr[jb][s] = xb[st * 4 * LD + 16 * jb + 4 * ((blk + s) & 3)];
+          for (int t = 0; t < 4 * NB; ++t) {
+            const int jb = SORD ? t % NB : t / 4, s = SORD ? t / NB : t % 4;
+            xr[jb][s] = xb[st * 4 * LD + 16 * jb + 4 * ((blk + s) & 3)];
+          }
   #pragma unroll
           for (int c = 0; c < CPW; ++c) {
             const double q = qb[c * BR + st * 4];
@@ -319,16 +377,23 @@ __global__ void __launch_bounds__(256, (DP <= 64 ? (HALF != 0 ? 3 : 2) : (HALF !
               if (HALF != 2) sacc[c][jb] += qx[jb];
             }
             if (HALF != 2) nacc[c] += q;
-            int idx = 0;
+            // D = 64: rotation-major order -- the unrotated fragments (the first reads of the step) are consumed
+            // first, so the compiler can start the MFMAs on partial lgkmcnt waits while the rotated fragments are
+            // still in flight (23.5 -> 22.9 ms at the north-star shape; the other widths are 2-5 % slower that way)
   #pragma unroll
-            for (int jbp = 0; jbp < NB; ++jbp) {
+            for (int sp = 0; sp < (SORD ? 4 : 1); ++sp) {
+              int idx = 0;
   #pragma unroll
-              for (int jb = 0; jb <= jbp; ++jb) {
+              for (int jbp = 0; jbp < NB; ++jbp) {
   #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                  if (s < 3 || jb < jbp) {
-                    if (ss_in_half<NB>(HALF, jbp, jb)) acc[c][idx] = mfma4(xr[jbp][s], qx[jb], acc[c][idx]);
-                    ++idx;
+                for (int jb = 0; jb <= jbp; ++jb) {
+  #pragma unroll
+                  for (int s = 0; s < 4; ++s) {
+                    if (s < 3 || jb < jbp) {
+                      if ((!SORD || s == sp) && ss_in_half<NB>(HALF, jbp, jb))
+                        acc[c][idx] = mfma4(xr[jbp][s], qx[jb], acc[c][idx]);
+                      ++idx;
+                    }
                   }
                 }
               }
