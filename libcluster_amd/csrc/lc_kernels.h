@@ -8,17 +8,18 @@
 namespace lck {
 
 // ---- data layout constants -------------------------------------------------
-// X on device: row-major [NP x DP] doubles, DP = D rounded up to {16,32,48,64,96,128} (a multiple of 64 beyond that),
+// X on device: row-major [NP x DP] doubles, DP = D rounded up to a multiple of 16 up to 128 (a multiple of 64 beyond that),
 // pad columns zero.  Groups are padded to multiples of 16 rows (a "row-group"),
 // pad rows zero.  qZ on device: column-major, qZ[k*ldq + row], ldq = NP.
 constexpr int RG = 16;  // rows per row-group (one MFMA column block)
 
 inline int padded_dim(int D) {
-  return D <= 16 ? 16 : D <= 32 ? 32 : D <= 48 ? 48 : D <= 64 ? 64 : D <= 96 ? 96 : D <= 128 ? 128 : -1;
+  return D <= 16 ? 16 : D <= 32 ? 32 : D <= 48 ? 48 : D <= 64 ? 64 : D <= 80 ? 80 : D <= 96 ? 96 : D <= 112 ? 112 : D <= 128 ? 128 : -1;
 }
 // LDS row stride (doubles) of a staged X batch in the statistics kernels: DP + 16 puts the two rows a ds_read_b64
-// half-wave touches on disjoint banks when the stride is 16 mod 32; 48 needs 32 more for that
-__host__ __device__ constexpr int lds_row_stride(int DP) { return DP == 48 ? DP + 32 : DP + 16; }
+// half-wave touches on disjoint banks when the stride is 16 mod 32; 48, 80 and 112 need 32 more for that (16 keeps
+// the stride it was tuned with)
+__host__ __device__ constexpr int lds_row_stride(int DP) { return DP > 16 && (DP + 16) % 32 != 16 ? DP + 32 : DP + 16; }
 // wider observations are padded to a multiple of 64 columns: the separable (diagonal / exponential) families process
 // them in 128-column blocks with a possible half block at the end (any D), the Gauss-Wishart kernels in 64-column
 // panels / 64 x 64 whitener blocks

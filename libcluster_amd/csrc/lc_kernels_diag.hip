@@ -651,8 +651,12 @@ hipError_t launch_suffstat_diag(const DiagStatLaunch& a0, hipStream_t stream) {
       return launch_sd_t<48>(a, stream);
     case 64:
       return launch_sd_t<64>(a, stream);
+    case 80:
+      return launch_sd_t<80>(a, stream);
     case 96:
       return launch_sd_t<96>(a, stream);
+    case 112:
+      return launch_sd_t<112>(a, stream);
     case 128:
       return launch_sd_t<128>(a, stream);
   }

@@ -594,7 +594,11 @@ struct EstepCfg<48> { static constexpr int R = 4, WAVES = 4; };
 template <>
 struct EstepCfg<64> { static constexpr int R = 3, WAVES = 4; };
 template <>
+struct EstepCfg<80> { static constexpr int R = 3, WAVES = 4; };
+template <>
 struct EstepCfg<96> { static constexpr int R = 2, WAVES = 8; };
+template <>
+struct EstepCfg<112> { static constexpr int R = 2, WAVES = 8; };
 template <>
 struct EstepCfg<128> { static constexpr int R = 2, WAVES = 8; };
 
@@ -607,7 +611,9 @@ int estep_rows_per_block(int DP) {
     case 32: return rows_per_block_t<32>();
     case 48: return rows_per_block_t<48>();
     case 64: return rows_per_block_t<64>();
+    case 80: return rows_per_block_t<80>();
     case 96: return rows_per_block_t<96>();
+    case 112: return rows_per_block_t<112>();
     case 128: return rows_per_block_t<128>();
   }
   if (DP > 128 && DP % 64 == 0) return WIDE_R * WIDE_WAVES * RG;
@@ -650,7 +656,9 @@ hipError_t launch_estep(const EstepLaunch& a, hipStream_t stream) {
     case 32: return launch_estep_t<32>(a, stream);
     case 48: return launch_estep_t<48>(a, stream);
     case 64: return launch_estep_t<64>(a, stream);
+    case 80: return launch_estep_t<80>(a, stream);
     case 96: return launch_estep_t<96>(a, stream);
+    case 112: return launch_estep_t<112>(a, stream);
     case 128: return launch_estep_t<128>(a, stream);
   }
   return hipErrorInvalidValue;

@@ -45,6 +45,7 @@ template <int NB>
 __host__ __device__ constexpr bool ss_in_half(int half, int jbp, int jb) {
   if (half == 0) return true;
   const bool first = NB == 8   ? (jbp < 5 || (jbp == 5 && jb < 3))    // 67 | 69 MFMAs
+                     : NB == 7 ? (jbp < 4 || (jbp == 4 && jb < 4))    // 52 | 53
                      : NB == 6 ? (jbp < 4 || (jbp == 4 && jb < 1))    // 40 | 38
                                : (jbp == 1 || jbp == 2);              // 18 | 18 (NB = 4)
   return first == (half == 1);
@@ -57,7 +58,7 @@ __host__ __device__ constexpr bool ss_in_half(int half, int jbp, int jb) {
 template <int PAN>
 constexpr int ss_batch_rows() { return PAN == 2 ? 16 : SS_BR; }
 template <int DP, int CPW, bool SKIP, int HALF, int PAN = 0>
-__global__ void __launch_bounds__(256, (DP <= 64 ? (HALF != 0 ? 3 : 2) : (HALF != 0 ? 2 : 1)))
+__global__ void __launch_bounds__(256, (DP <= 64 ? (HALF != 0 ? 3 : 2) : (HALF != 0 || DP <= 80 ? 2 : 1)))
     suffstat_kernel(SuffstatLaunch a) {
   static_assert(PAN == 0 || (DP == 64 && HALF == 0), "panel variants are built on the D = 64 kernel");
   constexpr int NB = DP / 16;
@@ -68,7 +69,7 @@ __global__ void __launch_bounds__(256, (DP <= 64 ? (HALF != 0 ? 3 : 2) : (HALF !
   constexpr bool SORD = DP == 64;        // rotation-major MFMA order in the step loop (see there)
   // step loop with the next step's unrotated fragments and q prefetched (see there); -2...4 % at every width but
   // 16 (+20 %: four clusters per wave on 10 MFMAs each leave nothing to hide the extra reads behind)
-  constexpr bool PFETCH = DP >= 32 && (DP <= 64 || HALF != 0);
+  constexpr bool PFETCH = DP >= 32 && (DP <= 80 || HALF != 0);
   constexpr int XBUF = NPB * BR * LD;    // doubles per X buffer
   constexpr int NV2 = BR * DP / 2;       // double2 elements per staged batch and panel
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -206,7 +207,7 @@ __global__ void __launch_bounds__(256, (DP <= 64 ? (HALF != 0 ? 3 : 2) : (HALF !
     if (nk > 0) {
       const double* xb = xbuf + buf * XBUF + hi * LD + lo2;
       const double* qb = qbuf + ((buf * nwaves + wave) * CPW) * BR + hi;
-      if constexpr (DP > 64 && HALF == 0) {
+      if constexpr (DP > 80 && HALF == 0) {
         // One wave per SIMD (the accumulators need > 256 registers): nothing else hides the LDS
         // latency, so the step loop is software-pipelined by hand, unrolled by two with two register
         // sets (unrotated fragments + q of a step) that swap roles -- no copies.  A step fetches its
@@ -478,6 +479,8 @@ struct SSCfg<48> { static constexpr int CPW = 2; };  // (four clusters per wave 
 template <>
 struct SSCfg<64> { static constexpr int CPW = 2; };
 template <>
+struct SSCfg<80> { static constexpr int CPW = 1; };
+template <>
 struct SSCfg<96> { static constexpr int CPW = 1; };
 template <>
 struct SSCfg<128> { static constexpr int CPW = 1; };
@@ -568,7 +571,7 @@ static hipError_t launch_ss_wide(const SuffstatLaunch& a, hipStream_t stream) {
 
 template <int DP, int CPW, bool SKIP>
 static hipError_t launch_ss_s(const SuffstatLaunch& a, hipStream_t stream) {
-  if constexpr (DP > 64) {  // (at D = 64 the two-half variant is slower: 26.0 vs 23.6 ms)
+  if constexpr (DP > 80) {  // (at D = 64 the two-half variant is slower: 26.0 vs 23.6 ms)
     static const bool whole = getenv("LC_SS_WHOLE") != nullptr;  // tuning knob: one launch, one wave per SIMD
     if (!whole) {
       hipError_t e = launch_ss_h<DP, CPW, SKIP, 1>(a, stream);
@@ -605,8 +608,12 @@ hipError_t launch_suffstat(const SuffstatLaunch& a, hipStream_t stream) {
       return cpw == 2 ? launch_ss_t<48, 2>(a, stream) : launch_ss_t<48, 1>(a, stream);
     case 64:
       return cpw == 2 ? launch_ss_t<64, 2>(a, stream) : launch_ss_t<64, 1>(a, stream);
+    case 80:
+      return launch_ss_t<80, 1>(a, stream);
     case 96:
       return launch_ss_t<96, 1>(a, stream);
+    case 112:
+      return launch_ss_t<112, 1>(a, stream);
     case 128:
       return launch_ss_t<128, 1>(a, stream);
   }

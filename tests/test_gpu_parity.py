@@ -83,8 +83,9 @@ def test_vbem_fixed_matches_golden(estep_cases):
 
 @pytest.mark.parametrize("N,D,K,J", [(1000, 16, 8, 1), (777, 23, 5, 3), (513, 64, 6, 1), (300, 128, 3, 2),
                                       (4099, 2, 2, 1), (50, 7, 33, 1),
-                                      # the in-between layouts (48 and 96 columns)
+                                      # the in-between layouts (48, 80, 96 and 112 columns)
                                       (600, 40, 7, 2), (901, 48, 9, 1), (450, 80, 5, 3), (500, 96, 4, 1),
+                                      (333, 70, 6, 1), (512, 110, 3, 2),
                                       # wider than 128 columns: panel / chunk streaming kernels
                                       (700, 129, 3, 1), (1000, 200, 5, 2), (640, 256, 9, 1), (400, 300, 2, 3)])
 def test_estep_and_suffstat_vs_oracle_random(N, D, K, J):

@@ -20,7 +20,7 @@ m = rng.normal(size=(K, D))
 iW = np.stack([np.eye(D) * (1.0 + 0.1 * k) for k in range(K)])
 logdW = np.array([-np.linalg.slogdet(w)[1] for w in iW])
 elw = np.log(np.full((1, K), 1.0 / K))
-DP = (D + 63) // 64 * 64 if D > 128 else next(w for w in (16, 32, 48, 64, 96, 128) if D <= w)  # lck::padded_dim_wide
+DP = (D + 63) // 64 * 64 if D > 128 else max(16, (D + 15) // 16 * 16)  # lck::padded_dim_wide
 with capi.Context(0) as ctx:
     ctx.set_data(X)
     ctx.set_qz(q)
