@@ -56,7 +56,7 @@ __host__ __device__ constexpr bool ss_in_half(int half, int jbp, int jb) {
 // 2 = off-diagonal pair: A operands (all four rotations) from panel colA, q x from panel colB, the full 16 x 4 set of
 // MFMAs, block written to (P, Q) and mirrored to (Q, P).  Records are DPW wide.
 template <int PAN>
-constexpr int ss_batch_rows() { return PAN == 2 ? 16 : SS_BR; }
+constexpr int ss_batch_rows() { return PAN == 2 ? 24 : SS_BR; }  // (two panels per batch: 24 rows keep two blocks per CU)
 template <int DP, int CPW, bool SKIP, int HALF, int PAN = 0>
 __global__ void __launch_bounds__(256, (DP <= 64 ? (HALF != 0 ? 3 : 2) : (HALF != 0 || DP <= 80 ? 2 : 1)))
     suffstat_kernel(SuffstatLaunch a) {
@@ -275,13 +275,15 @@ __global__ void __launch_bounds__(256, (DP <= 64 ? (HALF != 0 ? 3 : 2) : (HALF !
             if (__builtin_amdgcn_ballot_w64(any) == 0) continue;
           }
           // A side: all four rotations of panel colA; B side: the unrotated fragments of panel colB
+          // (read in the order of use: the B side first, then the A side block row by block row, so that the
+          // MFMAs of block row 0 start on a partial lgkmcnt wait)
           double xr[NB][4], xq[NB];
 #pragma unroll
-          for (int jb = 0; jb < NB; ++jb) {
+          for (int jb = 0; jb < NB; ++jb) xq[jb] = xb[BR * LD + st * 4 * LD + 16 * jb + 4 * blk];
+#pragma unroll
+          for (int jb = 0; jb < NB; ++jb)
 #pragma unroll
             for (int s2 = 0; s2 < 4; ++s2) xr[jb][s2] = xb[st * 4 * LD + 16 * jb + 4 * ((blk + s2) & 3)];
-            xq[jb] = xb[BR * LD + st * 4 * LD + 16 * jb + 4 * blk];
-          }
 #pragma unroll
           for (int c = 0; c < CPW; ++c) {
             const double q = qb[c * BR + st * 4];
@@ -550,8 +552,10 @@ static hipError_t launch_ss_h(const SuffstatLaunch& a, hipStream_t stream) {
   return hipGetLastError();
 }
 
-// Observations wider than 128 columns: one launch per pair of 64-column panels (P >= Q), one cluster per wave in all of
-// them so that every launch sees the same (chunk, slice) / work-list decomposition and writes the same records.
+// Observations wider than 128 columns: one launch per pair of 64-column panels (P >= Q) over the same row chunks (and
+// the same work list in sparse mode, built for four clusters per block: any clusters-per-wave serves it), all
+// writing the same DP-wide records.  Two clusters per wave in the diagonal pairs (the D = 64 kernel as it is), one in
+// the off-diagonal ones (64 accumulators per cluster).
 template <bool SKIP>
 static hipError_t launch_ss_wide(const SuffstatLaunch& a, hipStream_t stream) {
   SuffstatLaunch b = a;
@@ -563,7 +567,7 @@ static hipError_t launch_ss_wide(const SuffstatLaunch& a, hipStream_t stream) {
     for (int Q = 0; Q <= P; ++Q) {
       b.colA = 64 * P;
       b.colB = 64 * Q;
-      const hipError_t e = P == Q ? launch_ss_h<64, 1, SKIP, 0, 1>(b, stream) : launch_ss_h<64, 1, SKIP, 0, 2>(b, stream);
+      const hipError_t e = P == Q ? launch_ss_h<64, 2, SKIP, 0, 1>(b, stream) : launch_ss_h<64, 1, SKIP, 0, 2>(b, stream);
       if (e != hipSuccess) return e;
     }
   return hipSuccess;
