@@ -23,7 +23,7 @@ GROUPED = ["learnGMC", "learnSGMC", "learnDGMC", "learnEGMC"]
 fails, t0 = [], time.time()
 for case in range(cases):
     kind = rng.choice(["flat", "grouped", "topic"], p=[0.45, 0.4, 0.15])
-    D = int(rng.choice([1, 2, 3, 5, 8, 17]))
+    D = int(rng.choice([1, 2, 3, 5, 8, 17, 23, 40, 70, 130], p=[0.15, 0.15, 0.15, 0.15, 0.12, 0.12, 0.06, 0.05, 0.03, 0.02]))
     Kt = int(rng.integers(1, 7))
     cent = rng.normal(0, 6.0, (Kt, D))
     spread = rng.uniform(0.4, 1.5)
