@@ -784,6 +784,16 @@ void Context::suffstat(const unsigned char* smask, double* Nk, double* xs, doubl
         a.skip_zero = -1;  // dense variant; masked q are staged as zeros
       }
     }
+    // ragged K (dense grid only): extra row-split records of the last cluster slice, folded in after the reduction
+    int klast0 = K;
+    const bool skipping = a.skip_zero > 0 || (a.skip_zero == 0 && a.smask);
+    const int extra = listed ? 0 : lck::suffstat_extra_records(DP, K, skipping, &klast0);
+    const int KR = K + extra;
+    if (extra > 0) {
+      sspart_.reserve((size_t)nchunks * KR * SS);
+      ssext_.reserve((size_t)KR * SS);
+    }
+    a.KR = KR;
     a.partial = sspart_.p;
     a.nchunks = nchunks;
     a.chunk_rows = chunk_rows;
@@ -801,7 +811,11 @@ void Context::suffstat(const unsigned char* smask, double* Nk, double* xs, doubl
     }
     if (listed)
       LC_HIP(lck::launch_reduce_records(sspart_.p, SS, K, sskptr_, sskrec_, ssout_.p, stream_));
-    else
+    else if (extra > 0) {
+      LC_HIP(lck::launch_reduce_partials(sspart_.p, nchunks, (int64_t)KR * SS, ssext_.p, stream_));
+      LC_HIP(lck::launch_fold_extra(ssext_.p, SS, K, klast0, extra, stream_));
+      LC_HIP(hipMemcpyAsync(ssout_.p, ssext_.p, (size_t)K * SS * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+    } else
       LC_HIP(lck::launch_reduce_partials(sspart_.p, nchunks, (int64_t)K * SS, ssout_.p, stream_));
     // per-group counts N_jk: with one group they are the N_k just reduced (filled in on the host below)
     if (J_ > 1) LC_HIP(lck::launch_group_colsum(qz_[cur_].buf.p, NP_, K, goff_d_.p, J_, njk_d, stream_));

@@ -204,7 +204,7 @@ class Context {
   QZ qz_[2];
   int cur_ = 0;
 
-  DevBuf<double> params_, ctab_, fzpart_, llpart_, red_, redtmp_, sspart_, ssout_;
+  DevBuf<double> params_, ctab_, fzpart_, llpart_, red_, redtmp_, sspart_, ssout_, ssext_;
   DevBuf<unsigned char> smask_;
   DevBuf<int> selcnt_;
   DevBuf<int64_t> seloff_;

@@ -81,6 +81,9 @@ struct SuffstatLaunch {
   const SSItem* items = nullptr;  // sparse work list (device) or nullptr: dense (chunk, slice) grid
   const int* klist = nullptr;     // active cluster lists the items point into
   int nitems = 0;
+  // ragged K (see suffstat_extra_records): records per chunk = K + extra; 0 = K
+  int KR = 0;
+  int slice0 = 0, rs = 1, klast0 = 0, nklast = 0;  // filled in by launch_suffstat for the row-split launch of the last slice
   // wide observations (DP > 128), filled in by launch_suffstat: the kernel works on 64-column panels
   int64_t ldx = 0;                // row stride of X
   int DPW = 0, colA = 0, colB = 0;  // record width, first column of the A-side / B-side panel
@@ -89,6 +92,12 @@ struct SuffstatLaunch {
 int suffstat_plan(int DP, int64_t NP, int K, int64_t* chunk_rows);
 hipError_t launch_suffstat(const SuffstatLaunch& a, hipStream_t stream);
 int suffstat_clusters_per_block(int DP, int K);  // 4 waves x clusters per wave
+// When the last cluster slice of the dense pass fills only one or two of its four waves, the idle waves take over part
+// of the active waves' rows (2 or 4 row classes) and write partial records of their own: `extra` more records per
+// chunk, laid out after the K regular ones ([row class - 1][cluster of the last slice]).  Returns extra (0: no split);
+// klast0 = first cluster of the last slice.  launch_fold_extra adds them into their clusters after the reduction.
+int suffstat_extra_records(int DP, int K, bool skip_or_items, int* klast0);
+hipError_t launch_fold_extra(double* rec, int64_t SS, int K, int klast0, int extra, hipStream_t stream);
 hipError_t launch_reduce_records(const double* partial, int64_t n, int K, const int* kptr, const int* krec, double* out,
                                  hipStream_t stream);
 

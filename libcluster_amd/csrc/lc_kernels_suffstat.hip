@@ -57,7 +57,7 @@ __host__ __device__ constexpr bool ss_in_half(int half, int jbp, int jb) {
 // MFMAs, block written to (P, Q) and mirrored to (Q, P).  Records are DPW wide.
 template <int PAN>
 constexpr int ss_batch_rows() { return PAN == 2 ? 24 : SS_BR; }  // (two panels per batch: 24 rows keep two blocks per CU)
-template <int DP, int CPW, bool SKIP, int HALF, int PAN = 0>
+template <int DP, int CPW, bool SKIP, int HALF, int PAN = 0, bool RSP = false>
 __global__ void __launch_bounds__(256, (DP <= 64 ? (HALF != 0 ? 3 : 2) : (HALF != 0 || DP <= 80 ? 2 : 1)))
     suffstat_kernel(SuffstatLaunch a) {
   static_assert(PAN == 0 || (DP == 64 && HALF == 0), "panel variants are built on the D = 64 kernel");
@@ -101,7 +101,17 @@ __global__ void __launch_bounds__(256, (DP <= 64 ? (HALF != 0 ? 3 : 2) : (HALF !
       slice = t % nslice;
     }
   }
-  const int kbase = (slice * nwaves + wave) * CPW;   // may be >= K: the wave still helps staging
+  // RSP (row split, launched for a last slice that fills only one or two waves): the idle waves share the rows of
+  // the active ones -- wave w works on the clusters of wave w % f, 4-row steps st = rcls mod RS, and writes its own record
+  int wslot = wave, rcls = 0;
+  if constexpr (RSP) {
+    slice += a.slice0;
+    const int f = nwaves / a.rs;
+    wslot = wave % f;
+    rcls = wave / f;
+  }
+  const int KR = a.KR;                                // records per chunk (K, or K + extra row-split records)
+  const int kbase = (slice * nwaves + wslot) * CPW;   // may be >= K: the wave still helps staging
   int nk = kbase >= K ? 0 : ((K - kbase) < CPW ? (K - kbase) : CPW);
   int64_t r0 = (int64_t)chunk * a.chunk_rows;
   int64_t r1 = (r0 + a.chunk_rows) < a.NP ? (r0 + a.chunk_rows) : a.NP;
@@ -110,7 +120,8 @@ __global__ void __launch_bounds__(256, (DP <= 64 ? (HALF != 0 ? 3 : 2) : (HALF !
 #pragma unroll
   for (int c = 0; c < CPW; ++c) {
     kidx[c] = kbase + c;
-    recidx[c] = (int64_t)chunk * K + kbase + c;
+    recidx[c] = (int64_t)chunk * KR + kbase + c;
+    if (RSP && rcls > 0) recidx[c] = (int64_t)chunk * KR + K + (rcls - 1) * a.nklast + (kbase + c - a.klast0);
   }
   if (a.items) {
     // sparse work list: one block = (row range inside ONE group, up to 4*CPW clusters of that group's active
@@ -298,6 +309,37 @@ __global__ void __launch_bounds__(256, (DP <= 64 ? (HALF != 0 ? 3 : 2) : (HALF !
 #pragma unroll
                 for (int s2 = 0; s2 < 4; ++s2)
                   acc[c][(jbp * NB + jb) * 4 + s2] = mfma4(xr[jbp][s2], qx[jb], acc[c][(jbp * NB + jb) * 4 + s2]);
+          }
+        }
+      } else if constexpr (RSP) {
+        const int nstep = (int)(((r1 - b0) < BR ? (r1 - b0) : BR) / 4);
+        for (int st = rcls; st < nstep; st += a.rs) {
+          double xr[NB][4];
+#pragma unroll
+          for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) xr[jb][s2] = xb[st * 4 * LD + 16 * jb + 4 * ((blk + s2) & 3)];
+#pragma unroll
+          for (int c = 0; c < CPW; ++c) {
+            const double q = qb[c * BR + st * 4];
+            double qx[NB];
+#pragma unroll
+            for (int jb = 0; jb < NB; ++jb) {
+              qx[jb] = q * xr[jb][0];
+              if (HALF != 2) sacc[c][jb] += qx[jb];
+            }
+            if (HALF != 2) nacc[c] += q;
+            int idx = 0;
+#pragma unroll
+            for (int jbp = 0; jbp < NB; ++jbp)
+#pragma unroll
+              for (int jb = 0; jb <= jbp; ++jb)
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2)
+                  if (s2 < 3 || jb < jbp) {
+                    if (ss_in_half<NB>(HALF, jbp, jb)) acc[c][idx] = mfma4(xr[jbp][s2], qx[jb], acc[c][idx]);
+                    ++idx;
+                  }
           }
         }
       } else if constexpr (PFETCH && !SKIP) {
@@ -499,6 +541,38 @@ static int ss_cpw(int DP, int K) {
   return cpw;
 }
 
+// row classes for a last slice with `active` of its four waves in use
+static int ss_row_classes(int active) { return active == 1 ? 4 : active == 2 ? 2 : 1; }
+
+int suffstat_extra_records(int DP, int K, bool skip_or_items, int* klast0) {
+  if (klast0) *klast0 = K;
+  if (DP > 128 || skip_or_items || K < 1) return 0;
+  const int cpw = ss_cpw(DP, K), kwaves = (K + cpw - 1) / cpw, nslice = (kwaves + 3) / 4;
+  const int rs = ss_row_classes(kwaves - (nslice - 1) * 4);
+  if (rs == 1) return 0;
+  const int k0 = (nslice - 1) * 4 * cpw;
+  if (klast0) *klast0 = k0;
+  return (rs - 1) * (K - k0);
+}
+
+// rec[(klast0 + e % nlast) * SS + i] += rec[(K + e) * SS + i], e = 0 .. extra-1 in order (deterministic)
+__global__ void __launch_bounds__(256) fold_extra_kernel(double* rec, int64_t SS, int K, int klast0, int extra) {
+  const int nlast = K - klast0;
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (int64_t)nlast * SS) return;
+  const int kk = (int)(t / SS);
+  const int64_t i = t % SS;
+  double v = rec[(int64_t)(klast0 + kk) * SS + i];
+  for (int e = kk; e < extra; e += nlast) v += rec[(int64_t)(K + e) * SS + i];
+  rec[(int64_t)(klast0 + kk) * SS + i] = v;
+}
+hipError_t launch_fold_extra(double* rec, int64_t SS, int K, int klast0, int extra, hipStream_t stream) {
+  if (extra <= 0) return hipSuccess;
+  const int64_t n = (int64_t)(K - klast0) * SS;
+  hipLaunchKernelGGL(fold_extra_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rec, SS, K, klast0, extra);
+  return hipGetLastError();
+}
+
 int suffstat_clusters_per_block(int DP, int K) { return DP > 128 ? 4 : 4 * ss_cpw(DP, K); }
 
 int suffstat_plan(int DP, int64_t NP, int K, int64_t* chunk_rows) {
@@ -529,16 +603,12 @@ int suffstat_plan(int DP, int64_t NP, int K, int64_t* chunk_rows) {
   return (int)((NP + rows - 1) / rows);
 }
 
-template <int DP, int CPW, bool SKIP, int HALF, int PAN = 0>
-static hipError_t launch_ss_h(const SuffstatLaunch& a, hipStream_t stream) {
-  const int kwaves = (a.K + CPW - 1) / CPW;
+template <int DP, int CPW, bool SKIP, int HALF, int PAN = 0, bool RSP = false>
+static hipError_t launch_ss_k(const SuffstatLaunch& b, unsigned grid, hipStream_t stream) {
   const int wpb = 4;
-  const int nslice = (kwaves + wpb - 1) / wpb;
-  SuffstatLaunch b = a;
-  b.nslice = nslice;
   constexpr int BR = ss_batch_rows<PAN>();
   const size_t shmem = (size_t)(2 * (PAN == 2 ? 2 : 1) * BR * lds_row_stride(DP) + 2 * wpb * CPW * BR) * sizeof(double);
-  auto kern = suffstat_kernel<DP, CPW, SKIP, HALF, PAN>;
+  auto kern = suffstat_kernel<DP, CPW, SKIP, HALF, PAN, RSP>;
   static bool attr_set = false;
   if (shmem > 64 * 1024 && !attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -546,10 +616,35 @@ static hipError_t launch_ss_h(const SuffstatLaunch& a, hipStream_t stream) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  const unsigned grid = a.items ? (unsigned)a.nitems : (unsigned)(a.nchunks * nslice);
   if (grid == 0) return hipSuccess;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(wpb * 64), shmem, stream, b);
   return hipGetLastError();
+}
+
+template <int DP, int CPW, bool SKIP, int HALF, int PAN = 0>
+static hipError_t launch_ss_h(const SuffstatLaunch& a, hipStream_t stream) {
+  const int kwaves = (a.K + CPW - 1) / CPW;
+  const int wpb = 4;
+  const int nslice = (kwaves + wpb - 1) / wpb;
+  SuffstatLaunch b = a;
+  b.nslice = nslice;
+  if (b.KR < a.K) b.KR = a.K;
+  if constexpr (PAN == 0 && !SKIP) {
+    // ragged K: the last slice runs as its own launch with the idle waves sharing the rows (suffstat_extra_records)
+    const int rs = ss_row_classes(kwaves - (nslice - 1) * wpb);
+    if (!a.items && rs > 1 && b.KR > a.K) {
+      b.nslice = nslice - 1;
+      hipError_t e = launch_ss_k<DP, CPW, SKIP, HALF, PAN>(b, (unsigned)(a.nchunks * (nslice - 1)), stream);
+      if (e != hipSuccess) return e;
+      b.nslice = 1;
+      b.slice0 = nslice - 1;
+      b.rs = rs;
+      b.klast0 = (nslice - 1) * wpb * CPW;
+      b.nklast = a.K - b.klast0;
+      return launch_ss_k<DP, CPW, SKIP, HALF, PAN, true>(b, (unsigned)a.nchunks, stream);
+    }
+  }
+  return launch_ss_k<DP, CPW, SKIP, HALF, PAN>(b, a.items ? (unsigned)a.nitems : (unsigned)(a.nchunks * nslice), stream);
 }
 
 // Observations wider than 128 columns: one launch per pair of 64-column panels (P >= Q) over the same row chunks (and
