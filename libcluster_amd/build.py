@@ -55,9 +55,9 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         o = OBJ / (Path(src).stem + ".o")
         objs.append(o)
         if force or _newer(o, [s, *hdrs]):
-            cmd = [hipcc, *common, "-c", str(s), "-o", str(o)]
+            cmd = [hipcc, f"--offload-arch={ARCH}", *common, "-c", str(s), "-o", str(o)]
             if src.endswith(".hip"):
-                cmd[1:1] = [f"--offload-arch={ARCH}", *DEVICE_FLAGS]
+                cmd[2:2] = DEVICE_FLAGS
             jobs.append(cmd)
     if jobs:  # the translation units are independent: compile them side by side
         from concurrent.futures import ThreadPoolExecutor

@@ -766,7 +766,6 @@ void Context::suffstat(const unsigned char* smask, double* Nk, double* xs, doubl
     }
     a.skip_zero = skip_zero_ ? 1 : 0;
     bool listed = false;  // sparse work list instead of the dense (chunk, slice) grid
-    int nrec = 0;
     if (a.smask) {
       double off = 0.0, tot = 0.0;
       for (int j2 = 0; j2 < J_; ++j2)
@@ -779,7 +778,7 @@ void Context::suffstat(const unsigned char* smask, double* Nk, double* xs, doubl
       // work is proportional to sum_j N_j * K_active(j); otherwise the dense grid with masked q staged as zeros.
       if (off > 0.3 * tot) {
         listed = true;
-        nrec = build_sparse_worklist(smask, K, SS, a);
+        build_sparse_worklist(smask, K, SS, a);  // (sizes the partial buffer for its records)
       } else if (!skip_zero_) {
         a.skip_zero = -1;  // dense variant; masked q are staged as zeros
       }
