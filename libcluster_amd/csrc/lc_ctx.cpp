@@ -1,10 +1,12 @@
 #include "lc_ctx.hpp"
+#include "lc_engine.hpp"  // the host worker pool (parallel_chunks)
 
 #include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <limits>
 #include <mutex>
+#include <thread>
 
 namespace lcc {
 
@@ -226,24 +228,61 @@ void Context::set_data(int J, const double* const* Xj, const int64_t* Nj, int D,
   // thousands of small documents do not cost a transfer and a synchronisation each.
   const int64_t chunk = std::max<int64_t>(lck::RG, ((int64_t)32 << 20) / 8 / DP_ / lck::RG * lck::RG);
   PinnedBuf stage[2];
-  int j = 0, which = 0;
+  int which = 0;
+  const unsigned pack_threads = std::max(1u, std::min(8u, std::thread::hardware_concurrency() / 2));
   for (int64_t p0 = 0; p0 < NP_; p0 += chunk, which ^= 1) {
     const int64_t nr = std::min(chunk, NP_ - p0);
     PinnedBuf& st = stage[which];
     if (st.size() == 0) st.resize((size_t)chunk * DP_);
     else LC_HIP(hipStreamSynchronize(stream_));  // the transfer that last used this buffer (two pieces ago) is done
     double* base = st.data();
-    std::memset(base, 0, (size_t)nr * DP_ * sizeof(double));
-    while (j < J && goff_[(size_t)j + 1] <= p0) ++j;
-    for (int jj = j; jj < J && goff_[(size_t)jj] < p0 + nr; ++jj) {
-      const int64_t g0 = goff_[(size_t)jj];
-      const int64_t lo = std::max<int64_t>(p0, g0), hi = std::min<int64_t>(p0 + nr, g0 + Nj[jj]);  // valid rows only
-      for (int64_t pr = lo; pr < hi; ++pr) {
-        const double* src = Xj[jj] + (pr - g0) * rs;
-        double* dst = base + (size_t)(pr - p0) * DP_;
-        for (int d = 0; d < D; ++d) dst[d] = src[d * cs];
+    // 1024-row blocks of the piece on the worker pool: one host thread packs at about the rate of the link, and
+    // column-major callers (Eigen's default) need a blocked transpose rather than a strided gather
+    const int DP = DP_;
+    const int nblk = (int)((nr + 1023) / 1024);
+    auto pack = [&](int blk) {
+      const int64_t pa = p0 + (int64_t)blk * 1024, pb = std::min<int64_t>(pa + 1024, p0 + nr);
+      int jj = (int)(std::upper_bound(goff_.begin(), goff_.end(), pa) - goff_.begin()) - 1;
+      if (jj < 0) jj = 0;
+      int64_t pr = pa;
+      while (pr < pb) {
+        while (jj + 1 < J && goff_[(size_t)jj + 1] <= pr) ++jj;
+        const int64_t g0 = goff_[(size_t)jj], vend = g0 + Nj[jj], gend = jj + 1 <= J ? goff_[(size_t)jj + 1] : pb;
+        const int64_t v1 = std::min(pb, vend);
+        if (pr < v1) {  // valid rows [pr, v1) of group jj
+          const double* src = Xj[jj] + (pr - g0) * rs;
+          double* dst = base + (size_t)(pr - p0) * DP;
+          const int64_t n = v1 - pr;
+          if (cs == 1) {
+            for (int64_t r = 0; r < n; ++r) {
+              std::memcpy(dst + r * DP, src + r * rs, (size_t)D * sizeof(double));
+              for (int d = D; d < DP; ++d) dst[r * DP + d] = 0.0;
+            }
+          } else {  // blocked transpose: contiguous (or short-stride) reads along the rows, writes inside a 64-row tile
+            for (int64_t r0 = 0; r0 < n; r0 += 64) {
+              const int64_t r1 = std::min<int64_t>(r0 + 64, n);
+              for (int d = 0; d < D; ++d) {
+                const double* sc = src + d * cs;
+                for (int64_t r = r0; r < r1; ++r) dst[r * DP + d] = sc[r * rs];
+              }
+              for (int64_t r = r0; r < r1; ++r)
+                for (int d = D; d < DP; ++d) dst[r * DP + d] = 0.0;
+            }
+          }
+          pr = v1;
+        }
+        const int64_t z1 = std::min(pb, gend);  // pad rows of the group
+        if (pr < z1) {
+          std::memset(base + (size_t)(pr - p0) * DP, 0, (size_t)(z1 - pr) * DP * sizeof(double));
+          pr = z1;
+        }
+        if (pr < pb && jj + 1 >= J) {  // (cannot happen: the image ends with the last group's padding)
+          std::memset(base + (size_t)(pr - p0) * DP, 0, (size_t)(pb - pr) * DP * sizeof(double));
+          pr = pb;
+        }
       }
-    }
+    };
+    lce::parallel_chunks(nblk, pack_threads, 1024.0 * DP * 8.0, pack);
     LC_HIP(hipMemcpyAsync(X_.p + (size_t)p0 * DP_, base, (size_t)nr * DP_ * sizeof(double), hipMemcpyHostToDevice,
                           stream_));
   }
