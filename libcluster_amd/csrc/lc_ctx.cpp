@@ -428,14 +428,56 @@ void Context::qz_get(int j, double* q, int64_t rs, int64_t cs) const {
 void Context::qz_get_all(double* out) const {
   const int K = qz_[cur_].K;
   if (K < 1 || NP_ == 0) return;
-  std::vector<double> host((size_t)K * NP_);
-  LC_HIP(hipMemcpyAsync(host.data(), qz_[cur_].buf.p, host.size() * sizeof(double), hipMemcpyDeviceToHost, stream_));
-  LC_HIP(hipStreamSynchronize(stream_));
-  int64_t o = 0;
-  for (int j = 0; j < J_; ++j) {
-    const int64_t b = goff_[(size_t)j];
-    for (int64_t r = 0; r < Nj_[(size_t)j]; ++r, ++o)
-      for (int k = 0; k < K; ++k) out[o * K + k] = host[(size_t)k * NP_ + b + r];
+  LC_HIP(hipSetDevice(device_));
+  {
+    // transpose on the device (row-major [NP x K], pad rows included), bring it over in 32 MB pieces through two
+    // alternating page-locked buffers, and copy the valid row ranges of every group out on the worker pool
+    DevBuf<double> qT;
+    qT.reserve((size_t)NP_ * K);
+    LC_HIP(lck::launch_transpose_qz(qz_[cur_].buf.p, NP_, K, NP_, qT.p, stream_));
+    std::vector<int64_t> ooff((size_t)J_ + 1, 0);  // first output row of every group
+    for (int j = 0; j < J_; ++j) ooff[(size_t)j + 1] = ooff[(size_t)j] + Nj_[(size_t)j];
+    const int64_t chunk = std::max<int64_t>(lck::RG, ((int64_t)32 << 20) / 8 / K / lck::RG * lck::RG);
+    const unsigned nthr = std::max(1u, std::min(8u, std::thread::hardware_concurrency() / 2));
+    PinnedBuf stage[2];
+    hipEvent_t done[2] = {nullptr, nullptr};
+    auto unpack = [&](const double* base, int64_t p0, int64_t nr) {
+      const int nblk = (int)((nr + 4095) / 4096);
+      lce::parallel_chunks(nblk, nthr, 4096.0 * K * 8.0, [&](int blk) {
+        const int64_t pa = p0 + (int64_t)blk * 4096, pb = std::min<int64_t>(pa + 4096, p0 + nr);
+        int jj = (int)(std::upper_bound(goff_.begin(), goff_.end(), pa) - goff_.begin()) - 1;
+        if (jj < 0) jj = 0;
+        for (; jj < J_ && goff_[(size_t)jj] < pb; ++jj) {
+          const int64_t g0 = goff_[(size_t)jj];
+          const int64_t lo = std::max(pa, g0), hi = std::min(pb, g0 + Nj_[(size_t)jj]);
+          if (lo < hi)
+            std::memcpy(out + (size_t)(ooff[(size_t)jj] + lo - g0) * K, base + (size_t)(lo - p0) * K,
+                        (size_t)(hi - lo) * K * sizeof(double));
+        }
+      });
+    };
+    int64_t prev0 = -1, prevn = 0;
+    int which = 0;
+    for (int64_t p0 = 0; p0 < NP_; p0 += chunk, which ^= 1) {
+      const int64_t nr = std::min(chunk, NP_ - p0);
+      PinnedBuf& st = stage[which];
+      if (st.size() == 0) st.resize((size_t)chunk * K);
+      if (!done[which]) LC_HIP(hipEventCreateWithFlags(&done[which], hipEventDisableTiming));
+      LC_HIP(hipMemcpyAsync(st.data(), qT.p + (size_t)p0 * K, (size_t)nr * K * sizeof(double), hipMemcpyDeviceToHost,
+                            stream_));
+      LC_HIP(hipEventRecord(done[which], stream_));
+      if (prev0 >= 0) {  // unpack the previous piece while this one is in flight
+        LC_HIP(hipEventSynchronize(done[which ^ 1]));
+        unpack(stage[which ^ 1].data(), prev0, prevn);
+      }
+      prev0 = p0;
+      prevn = nr;
+    }
+    which ^= 1;  // the piece issued last
+    LC_HIP(hipEventSynchronize(done[which]));
+    unpack(stage[which].data(), prev0, prevn);
+    for (auto& e : done)
+      if (e) (void)hipEventDestroy(e);
   }
 }
 

@@ -158,6 +158,8 @@ hipError_t launch_select_compact(const double* qcol, int64_t NP, double thresh, 
                                  hipStream_t stream);
 hipError_t launch_group_starts(const int64_t* idx, int64_t M, const int64_t* goff, int J, int64_t* starts,
                                hipStream_t stream);
+// qT[row * K + k] = qZ[k * ldq + row]
+hipError_t launch_transpose_qz(const double* qZ, int64_t ldq, int K, int64_t NP, double* qT, hipStream_t stream);
 hipError_t launch_gather_rows(const double* X, int DP, const int64_t* idx, int64_t M, const int64_t* starts,
                               const int64_t* goff_sub, int J, double* Xdst, hipStream_t stream);
 hipError_t launch_split_init(const double* X, int DP, int D, int64_t NP, const int* rginfo, int64_t nrows,

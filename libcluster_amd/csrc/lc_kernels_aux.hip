@@ -492,4 +492,32 @@ hipError_t launch_synth(const SynthLaunch& a, hipStream_t stream) {
 }
 
 
+// qT[row * K + k] = qZ[k * ldq + row]: the device-side half of handing responsibilities back in the caller's row-major
+// layout.  One block = 64 rows x up to 64 columns through LDS: 512-byte column reads, row segments of up to 512 bytes
+// written (one contiguous 64 * K block when K <= 64).
+__global__ void __launch_bounds__(256) transpose_qz_kernel(const double* __restrict__ qZ, int64_t ldq, int K,
+                                                           int64_t NP, double* __restrict__ qT) {
+  __shared__ double tile[64][65];
+  const int64_t row0 = (int64_t)blockIdx.x * 64;
+  const int k0 = blockIdx.y * 64, kc = K - k0 < 64 ? K - k0 : 64;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int k = w; k < kc; k += 4) {
+    const int64_t row = row0 + lane;
+    tile[lane][k] = row < NP ? qZ[(int64_t)(k0 + k) * ldq + row] : 0.0;
+  }
+  __syncthreads();
+  const int64_t left = NP - row0;
+  const int n = (int)(left < 64 ? left : 64) * kc;
+  for (int t = threadIdx.x; t < n; t += 256) {
+    const int r = t / kc, c = t - r * kc;
+    qT[(row0 + r) * K + k0 + c] = tile[r][c];
+  }
+}
+hipError_t launch_transpose_qz(const double* qZ, int64_t ldq, int K, int64_t NP, double* qT, hipStream_t stream) {
+  if (NP <= 0 || K <= 0) return hipSuccess;
+  hipLaunchKernelGGL(transpose_qz_kernel, dim3((unsigned)((NP + 63) / 64), (unsigned)((K + 63) / 64)), dim3(256), 0,
+                     stream, qZ, ldq, K, NP, qT);
+  return hipGetLastError();
+}
+
 }  // namespace lck
