@@ -108,6 +108,12 @@ class Pool {
   bool stop_ = false;
 };
 
+// environment switch: set and not "0" / empty
+bool env_on(const char* name) {
+  const char* e = std::getenv(name);
+  return e && *e && !(e[0] == '0' && e[1] == 0);
+}
+
 // Run fn(k) for k in [0,n) on up to nthreads host threads.  Exceptions are collected and the first one
 // re-thrown on the calling thread.
 template <typename F>
@@ -185,7 +191,7 @@ double vbem(lcc::Context& ctx, Model& model, const VbemOptions& opt) {
   int i = 0, done = 0;
   bool again;
   // LC_TRACE_PHASES=1: wall time per phase of every iteration on stderr (tuning aid)
-  static const bool trace_phases = std::getenv("LC_TRACE_PHASES") != nullptr;
+  static const bool trace_phases = env_on("LC_TRACE_PHASES");
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
     return std::chrono::duration<double, std::milli>(b - a).count();
@@ -344,7 +350,7 @@ static bool split_gr(lcc::Context& ctx, Model& model, std::vector<int>& tally, d
   std::vector<double> njs;
   std::vector<double> eigv;
 
-  static const bool trace_phases = std::getenv("LC_TRACE_PHASES") != nullptr;
+  static const bool trace_phases = env_on("LC_TRACE_PHASES");
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto msec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
     return std::chrono::duration<double, std::milli>(b - a).count();
@@ -462,7 +468,7 @@ double cluster(lcc::Context& ctx, Model& model, const ClusterOptions& opt) {
     if (opt.trace) opt.trace->emplace_back((int)model.clusters.size(), tr);
     int nkeep = 0;
     for (const auto& cl : model.clusters) nkeep += !(cl.N() < lch::ZEROCUTOFF);
-    static const bool trace_phases = std::getenv("LC_TRACE_PHASES") != nullptr;
+    static const bool trace_phases = env_on("LC_TRACE_PHASES");
     const auto c0 = std::chrono::steady_clock::now();
     if (!(nkeep >= opt.maxclusters && opt.maxclusters >= 0)) data_loglik(ctx, model);  // split_gr will need it
     prune_clusters(ctx, model, opt.verbose);
