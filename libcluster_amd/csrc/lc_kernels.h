@@ -35,6 +35,21 @@ inline int wide_chunks(int DP) { int np = DP / 64; return np * (np + 1) / 2; }
 // doubles per cluster in a stats record: [N_k, s_k[DP], S_k[DP*DP]]
 inline int64_t stat_stride(int DP) { return 1 + (int64_t)DP + (int64_t)DP * DP; }
 
+// Kernels that need more than 64 KB of dynamic LDS must be told so once per device (function attributes are per
+// device; one process may hold contexts on several).  granted = a static per launcher instance.
+struct LdsGrant {
+  size_t granted[16] = {};
+};
+inline hipError_t grant_dynamic_lds(const void* fn, size_t bytes, LdsGrant& g) {
+  if (bytes <= 64 * 1024) return hipSuccess;
+  int dev = -1;
+  const bool tracked = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16;
+  if (tracked && bytes <= g.granted[dev]) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess && tracked) g.granted[dev] = bytes;
+  return e;
+}
+
 // rginfo word per row-group: (group << 5) | nvalid   (nvalid in 0..16)
 inline int rginfo_pack(int group, int nvalid) { return (group << 5) | nvalid; }
 

@@ -415,14 +415,9 @@ __global__ void __launch_bounds__(256)
 template <int MODE, int KT, bool REG>
 static hipError_t launch_ed_t(const DiagEstepLaunch& a, int64_t grid, size_t shmem, hipStream_t stream) {
   auto kern = a.DP > 128 ? estep_diag_wide_kernel<MODE, KT, REG> : estep_diag_kernel<MODE, KT, REG>;
-  static size_t attr_set[2] = {0, 0};  // per kernel (narrow, wide)
-  size_t& granted = attr_set[a.DP > 128 ? 1 : 0];
-  if (shmem > 64 * 1024 && shmem > granted) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)shmem);
-    if (e != hipSuccess) return e;
-    granted = shmem;
-  }
+  static LdsGrant grants[2];  // per kernel (narrow, wide)
+  if (hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(kern), shmem, grants[a.DP > 128 ? 1 : 0]); e != hipSuccess)
+    return e;
   const double* PA = a.params;
   const double* PW2 = PA + (int64_t)a.K * a.DP;
   const double* PW1 = PW2 + (int64_t)a.K * a.DP;
@@ -606,16 +601,13 @@ template <int DP>
 static hipError_t launch_sd_t(const DiagStatLaunch& a, hipStream_t stream) {
   constexpr int BR = DP <= 64 ? 32 : 16;
   const size_t shmem = (size_t)(2 * BR * lds_row_stride(DP) + 2 * SD_QMAX * (BR + 4)) * sizeof(double);
-  static bool attr_set = false;
-  if (shmem > 64 * 1024 && !attr_set) {
-    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(suffstat_diag_kernel<DP, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(suffstat_diag_kernel<DP, false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    if (e1 != hipSuccess) return e1;
-    if (e2 != hipSuccess) return e2;
-    attr_set = true;
-  }
+  static LdsGrant grants[2];
+  if (hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(suffstat_diag_kernel<DP, true>), shmem, grants[0]);
+      e != hipSuccess)
+    return e;
+  if (hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(suffstat_diag_kernel<DP, false>), shmem, grants[1]);
+      e != hipSuccess)
+    return e;
   const dim3 grid((unsigned)(a.nchunks * a.nslice));
   if (a.second)
     hipLaunchKernelGGL((suffstat_diag_kernel<DP, true>), grid, dim3(256), shmem, stream, a);

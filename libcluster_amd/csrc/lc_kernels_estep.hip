@@ -570,13 +570,8 @@ static hipError_t launch_estep_wide(const EstepLaunch& a, hipStream_t stream) {
   if (a.DP % 64) return hipErrorInvalidValue;
   const size_t shmem = (size_t)(2 * WIDE_CHUNK + WIDE_WAVES * a.K + WIDE_WAVES) * sizeof(double);
   auto kern = estep_wide_kernel<WIDE_R, WIDE_WAVES>;
-  static size_t attr_set = 0;
-  if (shmem > 64 * 1024 && shmem > attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    if (e != hipSuccess) return e;
-    attr_set = shmem;
-  }
+  static LdsGrant grant;
+  if (hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(kern), shmem, grant); e != hipSuccess) return e;
   const int64_t grid = estep_grid(a.DP, a.nrg);
   if (grid <= 0) return hipSuccess;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WIDE_WAVES * 64), shmem, stream, a);
@@ -631,13 +626,8 @@ static hipError_t launch_estep_s(const EstepLaunch& a, hipStream_t stream) {
   const size_t shmem = (size_t)(2 * pstride(DP) + WAVES * a.K + WAVES) * sizeof(double) +
                        (size_t)(2 * a.K + WAVES * R + 2) * sizeof(int);
   auto kern = estep_kernel<DP, R, WAVES, SPARSE>;
-  static size_t attr_set = 0;  // largest dynamic-LDS size already granted
-  if (shmem > 64 * 1024 && shmem > attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    if (e != hipSuccess) return e;
-    attr_set = shmem;
-  }
+  static LdsGrant grant;  // largest dynamic-LDS size already granted, per device
+  if (hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(kern), shmem, grant); e != hipSuccess) return e;
   const int64_t grid = estep_grid(DP, a.nrg);
   if (grid <= 0) return hipSuccess;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVES * 64), shmem, stream, a);

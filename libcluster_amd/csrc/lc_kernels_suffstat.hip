@@ -609,13 +609,8 @@ static hipError_t launch_ss_k(const SuffstatLaunch& b, unsigned grid, hipStream_
   constexpr int BR = ss_batch_rows<PAN>();
   const size_t shmem = (size_t)(2 * (PAN == 2 ? 2 : 1) * BR * lds_row_stride(DP) + 2 * wpb * CPW * BR) * sizeof(double);
   auto kern = suffstat_kernel<DP, CPW, SKIP, HALF, PAN, RSP>;
-  static bool attr_set = false;
-  if (shmem > 64 * 1024 && !attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(96 * 1024));
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static LdsGrant grant;
+  if (hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(kern), shmem, grant); e != hipSuccess) return e;
   if (grid == 0) return hipSuccess;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(wpb * 64), shmem, stream, b);
   return hipGetLastError();
