@@ -547,6 +547,7 @@ static int ss_row_classes(int active) { return active == 1 ? 4 : active == 2 ? 2
 int suffstat_extra_records(int DP, int K, bool skip_or_items, int* klast0) {
   if (klast0) *klast0 = K;
   if (DP > 128 || skip_or_items || K < 1) return 0;
+  if (DP > 80 && getenv("LC_SS_WHOLE")) return 0;  // (the one-launch tuning variant has no row-split instance)
   const int cpw = ss_cpw(DP, K), kwaves = (K + cpw - 1) / cpw, nslice = (kwaves + 3) / 4;
   const int rs = ss_row_classes(kwaves - (nslice - 1) * 4);
   if (rs == 1) return 0;
@@ -624,7 +625,7 @@ static hipError_t launch_ss_h(const SuffstatLaunch& a, hipStream_t stream) {
   SuffstatLaunch b = a;
   b.nslice = nslice;
   if (b.KR < a.K) b.KR = a.K;
-  if constexpr (PAN == 0 && !SKIP) {
+  if constexpr (PAN == 0 && !SKIP && !(DP > 80 && HALF == 0)) {
     // ragged K: the last slice runs as its own launch with the idle waves sharing the rows (suffstat_extra_records)
     const int rs = ss_row_classes(kwaves - (nslice - 1) * wpb);
     if (!a.items && rs > 1 && b.KR > a.K) {
