@@ -83,14 +83,27 @@ inline double run(int algo, const vMatrixXd& X, vMatrixXd& qZ, std::vector<W>& w
   weights.resize(J, W());
   int64_t Ntot = 0;
   for (int j = 0; j < J; ++j) Ntot += (int64_t)X[j].rows();
-  std::vector<double> allq((size_t)Ntot * K);
-  if (Ntot > 0) check(lc_model_get_qz_all(g.m, allq.data())); /* one transfer for all groups */
-  int64_t row0 = 0;
+  /* one pipelined transfer for all groups, straight into the (column-major) matrices */
+  std::vector<double*> qptr(J);
   for (int j = 0; j < J; ++j) {
     qZ[j].resize(X[j].rows(), K);
-    for (std::ptrdiff_t r = 0; r < X[j].rows(); ++r)
-      for (int k = 0; k < K; ++k) qZ[j](r, k) = allq[(size_t)(row0 + r) * K + k];
-    row0 += (int64_t)X[j].rows();
+    qptr[j] = qZ[j].data();
+  }
+  if (Ntot > 0) {
+    if (!lcmat::MatrixXd::IsRowMajor) {
+      check(lc_model_get_qz_all_colmajor(g.m, qptr.data()));
+    } else { /* EIGEN_DEFAULT_TO_ROW_MAJOR builds: the row-major bulk transfer, then one block copy per group */
+      std::vector<double> allq((size_t)Ntot * K);
+      check(lc_model_get_qz_all(g.m, allq.data()));
+      size_t o = 0;
+      for (int j = 0; j < J; ++j) {
+        const size_t nj = (size_t)X[j].rows() * K;
+        for (size_t t = 0; t < nj; ++t) qptr[j][t] = allq[o + t];
+        o += nj;
+      }
+    }
+  }
+  for (int j = 0; j < J; ++j) {
     lcmat::ArrayXd Nk(K);
     check(lc_model_weights(g.m, j, 0, Nk.data()));
     weights[j].update(Nk); /* same arithmetic as inside the learner => identical Elogweight() */

@@ -97,6 +97,9 @@ int lc_ctx_get_qz(lc_ctx* ctx, int j, double* q, int64_t row_stride, int64_t col
 int lc_ctx_get_qz_rows(lc_ctx* ctx, int j, int64_t row0, int64_t n, double* q, int64_t row_stride, int64_t col_stride);
 /* every group at once: q is [sum_j N_j x K] row-major, the groups' rows concatenated (one transfer) */
 int lc_ctx_get_qz_all(lc_ctx* ctx, double* q);
+/* every group at once, q[j] = the N_j x K matrix of group j in column-major order (Eigen's default: the `vMatrixXd& qZ`
+ * of cluster.cpp:179 as the caller holds it); no transpose on either side */
+int lc_ctx_get_qz_all_colmajor(lc_ctx* ctx, double* const* q);
 int lc_ctx_fill_qz(lc_ctx* ctx, int K, double value); /* qZ[j].setOnes(N,1): cluster.cpp:583-585 */
 
 /* ---- the hot path ------------------------------------------------------ */
@@ -213,6 +216,7 @@ int lc_model_rounds(lc_model* m, int* nrounds);                       /* vbem ro
 int lc_model_round(lc_model* m, int r, int* K, int* niter, double* F, int nF); /* F trace of round r */
 int lc_model_get_qz(lc_model* m, int j, double* q, int64_t row_stride, int64_t col_stride);
 int lc_model_get_qz_all(lc_model* m, double* q); /* all groups, [sum_j N_j x K] row-major */
+int lc_model_get_qz_all_colmajor(lc_model* m, double* const* q); /* q[j]: N_j x K column-major (see lc_ctx_...) */
 /* WeightDist::Elogweight() / getNk() of group j (K values each; may be NULL) */
 int lc_model_weights(lc_model* m, int j, double* Elogweight, double* Nk);
 int lc_model_kinds(lc_model* m, int* wkind, int* ckind);

@@ -278,6 +278,17 @@ class Context:
             check(lib().lc_ctx_get_qz_all(self._h, dptr(allq)))
         return [allq[o - n:o] for n, o in zip(rows, np.cumsum(rows))]
 
+    def get_qz_colmajor(self, rows_per_group):
+        """The same through the column-major bulk getter (what Eigen callers use): list of Fortran-ordered (N_j, K)."""
+        _, _, _, K = self.dims()
+        out = [np.zeros((int(n), K), order="F") for n in rows_per_group]
+        ptrs = (c_double_p * len(out))(*[dptr(a) if a.size else None for a in out])
+        if sum(a.size for a in out):
+            fn = lib().lc_ctx_get_qz_all_colmajor
+            fn.argtypes = [C.c_void_p, C.POINTER(c_double_p)]
+            check(fn(self._h, ptrs))
+        return out
+
     def get_qz_rows(self, j, row0, n):
         _, _, _, K = self.dims()
         q = np.empty((n, K))

@@ -605,6 +605,23 @@ int lc_model_get_qz_all(lc_model* m, double* q) {
   });
 }
 
+int lc_model_get_qz_all_colmajor(lc_model* m, double* const* q) {
+  return guarded([&] {
+    need(m, "model");
+    need(q, "q");
+    if (!m->ctx) throw std::invalid_argument("model has no context");
+    m->ctx->impl.qz_get_all_colmajor(q);
+  });
+}
+
+int lc_ctx_get_qz_all_colmajor(lc_ctx* ctx, double* const* q) {
+  return guarded([&] {
+    need(ctx, "ctx");
+    need(q, "q");
+    ctx->impl.qz_get_all_colmajor(q);
+  });
+}
+
 int lc_ctx_get_qz_all(lc_ctx* ctx, double* q) {
   return guarded([&] {
     need(ctx, "ctx");

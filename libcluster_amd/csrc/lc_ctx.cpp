@@ -481,6 +481,61 @@ void Context::qz_get_all(double* out) const {
   }
 }
 
+// Every group at once in the layout Eigen callers hold (one column-major N_j x K matrix per group): the device buffer
+// is column-major already, so no transpose anywhere -- the flat [K x NP] array crosses in 32 MB pieces through two
+// alternating page-locked buffers and pool threads copy the runs (column k, valid rows of group j) to their places
+// while the next piece is in flight.
+void Context::qz_get_all_colmajor(double* const* out) const {
+  const int K = qz_[cur_].K;
+  if (K < 1 || NP_ == 0) return;
+  LC_HIP(hipSetDevice(device_));
+  const int64_t total = (int64_t)K * NP_, chunk = ((int64_t)32 << 20) / 8;
+  const unsigned nthr = std::max(1u, std::min(8u, std::thread::hardware_concurrency() / 2));
+  PinnedBuf stage[2];
+  hipEvent_t done[2] = {nullptr, nullptr};
+  auto unpack = [&](const double* base, int64_t f0, int64_t n) {
+    const int64_t blk = 262144;
+    lce::parallel_chunks((int)((n + blk - 1) / blk), nthr, (double)blk * 8.0, [&](int b) {
+      int64_t f = f0 + (int64_t)b * blk;
+      const int64_t fe = std::min(f + blk, f0 + n);
+      while (f < fe) {
+        const int64_t k = f / NP_, p = f - k * NP_;              // column k, padded row p
+        const int64_t pe = std::min<int64_t>(NP_, p + (fe - f));  // this column's rows inside the block
+        int jj = (int)(std::upper_bound(goff_.begin(), goff_.end(), p) - goff_.begin()) - 1;
+        if (jj < 0) jj = 0;
+        for (; jj < J_ && goff_[(size_t)jj] < pe; ++jj) {
+          const int64_t g0 = goff_[(size_t)jj], nj = Nj_[(size_t)jj];
+          const int64_t lo = std::max(p, g0), hi = std::min(pe, g0 + nj);
+          if (lo < hi)
+            std::memcpy(out[jj] + (size_t)k * nj + (lo - g0), base + (f - f0) + (lo - p), (size_t)(hi - lo) * sizeof(double));
+        }
+        f += pe - p;
+      }
+    });
+  };
+  int64_t prev0 = -1, prevn = 0;
+  int which = 0;
+  for (int64_t f0 = 0; f0 < total; f0 += chunk, which ^= 1) {
+    const int64_t n = std::min(chunk, total - f0);
+    PinnedBuf& st = stage[which];
+    if (st.size() == 0) st.resize((size_t)std::min(chunk, total));
+    if (!done[which]) LC_HIP(hipEventCreateWithFlags(&done[which], hipEventDisableTiming));
+    LC_HIP(hipMemcpyAsync(st.data(), qz_[cur_].buf.p + f0, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    LC_HIP(hipEventRecord(done[which], stream_));
+    if (prev0 >= 0) {
+      LC_HIP(hipEventSynchronize(done[which ^ 1]));
+      unpack(stage[which ^ 1].data(), prev0, prevn);
+    }
+    prev0 = f0;
+    prevn = n;
+  }
+  which ^= 1;
+  LC_HIP(hipEventSynchronize(done[which]));
+  unpack(stage[which].data(), prev0, prevn);
+  for (auto& e : done)
+    if (e) (void)hipEventDestroy(e);
+}
+
 void Context::qz_keep_columns(const std::vector<int>& keep) {
   QZ& q = qz_[cur_];
   for (size_t i = 0; i < keep.size(); ++i) {

@@ -132,6 +132,7 @@ class Context {
   void qz_set(int j, const double* q, int K, int64_t row_stride, int64_t col_stride);
   void qz_get(int j, double* q, int64_t row_stride, int64_t col_stride) const;
   void qz_get_all(double* out) const;  // [Ntotal x K] row-major, groups concatenated
+  void qz_get_all_colmajor(double* const* out) const;  // out[j] = [N_j x K] column-major (Eigen's default layout)
   void qz_get_rows(int j, int64_t row0, int64_t n, double* q, int64_t row_stride, int64_t col_stride) const;
   void qz_get_column(int j, int k, double* out) const;  // N(j) doubles
   void qz_keep_columns(const std::vector<int>& keep);    // prune_clusters

@@ -141,6 +141,24 @@ def test_input_layouts_are_equivalent():
             out.append(ctx.suffstat())
     for a, b in zip(out[0], out[1]):
         assert np.array_equal(a, b)
+    # several packing blocks per group (the upload packs 1024-row blocks on pool threads), ragged groups, and the
+    # way back: rows fetched from the device equal the input whatever its layout was
+    sizes = [2500, 0, 1777, 1030]
+    Xg = [rng.normal(size=(n, 23)) for n in sizes]
+    qg = [rng.dirichlet(np.ones(5), n) for n in sizes]
+    res = []
+    for order in ("C", "F"):
+        with capi.Context(0) as ctx:
+            ctx.set_data([np.array(x, order=order) for x in Xg])
+            ctx.set_qz([np.array(q, order=order) for q in qg])
+            assert np.array_equal(ctx.get_rows(2, 1000, 777), Xg[2][1000:1777])
+            for a, b in zip(ctx.get_qz(sizes), qg):
+                assert np.array_equal(a, b)
+            for a, b in zip(ctx.get_qz_colmajor(sizes), qg):  # the Eigen-layout bulk getter
+                assert a.flags.f_contiguous and np.array_equal(a, b)
+            res.append(ctx.suffstat())
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b)
 
 
 def test_edge_cases():
