@@ -277,8 +277,21 @@ inline double run_topic(const vMatrixXd* W, const vvMatrixXd& X, vMatrixXd& qY, 
   std::vector<double> buf;
   int64_t Ntot = 0, qrow = 0;
   for (size_t i = 0; i < n.size(); ++i) Ntot += n[i];
-  std::vector<double> allq((size_t)Ntot * K);
-  if (Ntot > 0) check(lc_tmodel_get_qz_all(g.m, allq.data())); /* one transfer for all documents */
+  const bool cm = !lcmat::MatrixXd::IsRowMajor;
+  std::vector<double> allq(cm ? 0 : (size_t)Ntot * K);
+  if (cm) { /* one pipelined transfer straight into the (column-major) matrices of all documents */
+    std::vector<double*> qptr;
+    for (int j = 0; j < J; ++j) {
+      qZ[j].resize(Ij[j]);
+      for (int i = 0; i < Ij[j]; ++i) {
+        qZ[j][i].resize(X[j][i].rows(), K);
+        qptr.push_back(qZ[j][i].data());
+      }
+    }
+    if (Ntot > 0) check(lc_tmodel_get_qz_all_colmajor(g.m, qptr.data()));
+  } else if (Ntot > 0) {
+    check(lc_tmodel_get_qz_all(g.m, allq.data())); /* one transfer for all documents */
+  }
   int doc = 0;
   for (int j = 0; j < J; ++j) {
     buf.resize((size_t)Ij[j] * T);
@@ -287,7 +300,7 @@ inline double run_topic(const vMatrixXd* W, const vvMatrixXd& X, vMatrixXd& qY, 
     for (int i = 0; i < Ij[j]; ++i)
       for (int t = 0; t < T; ++t) qY[j](i, t) = buf[(size_t)i * T + t];
     qZ[j].resize(Ij[j]);
-    for (int i = 0; i < Ij[j]; ++i, ++doc) {
+    for (int i = 0; i < Ij[j] && !cm; ++i, ++doc) {
       qZ[j][i].resize(X[j][i].rows(), K);
       for (std::ptrdiff_t r = 0; r < X[j][i].rows(); ++r)
         for (int k = 0; k < K; ++k) qZ[j][i](r, k) = allq[(size_t)(qrow + r) * K + k];

@@ -265,6 +265,7 @@ int lc_tmodel_dims(lc_tmodel* m, int* J, int* Itot, int* T, int* K, int* D, int*
 int lc_tmodel_get_qy(lc_tmodel* m, int j, double* qY /* Ij[j] x T row-major */);
 int lc_tmodel_get_qz(lc_tmodel* m, int doc, double* q, int64_t row_stride, int64_t col_stride); /* Nji[doc] x K */
 int lc_tmodel_get_qz_all(lc_tmodel* m, double* q); /* all documents, [sum N_ji x K] row-major */
+int lc_tmodel_get_qz_all_colmajor(lc_tmodel* m, double* const* q); /* q[doc]: N_ji x K column-major, documents in (j, i) order */
 /* level 0: weights_j[idx] (T values each); level 1: weights_t[idx] (K values each) */
 int lc_tmodel_weights(lc_tmodel* m, int level, int idx, double* Elogweight, double* Nk);
 /* level 0: bottom-level clusters[idx] (D); level 1: top-level clusters_t[idx] (Dt, MCM only) */

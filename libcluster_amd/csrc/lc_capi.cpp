@@ -909,6 +909,14 @@ int lc_tmodel_get_qz_all(lc_tmodel* m, double* q) {
   });
 }
 
+int lc_tmodel_get_qz_all_colmajor(lc_tmodel* m, double* const* q) {
+  return guarded([&] {
+    need(m, "model");
+    need(q, "q");
+    m->ctx->impl.qz_get_all_colmajor(q);
+  });
+}
+
 int lc_tmodel_weights(lc_tmodel* m, int level, int idx, double* Elogweight, double* Nk) {
   return guarded([&] {
     need(m, "model");
