@@ -80,7 +80,11 @@ __global__ void __launch_bounds__(WAVES * 64, EstepOcc<DP>::BLOCKS) estep_kernel
   double* pbuf = lds;              // [2][PS]
   double* llw = lds + 2 * PS;      // [WAVES][K]
   double* fzw = llw + WAVES * a.K; // [WAVES]
-  int* klist = reinterpret_cast<int*>(fzw + WAVES);  // sparse mode: [K] active clusters of this block, [K] flags,
+  // lq_lds (four row groups per wave, where every lane owns one row outright, and K small enough): log q~ waits in
+  // LDS for the normalisation, [K][threads], instead of making a round trip through the qZ buffer
+  double* lql = fzw + WAVES;
+  const bool lqm = R == 4 && a.lq_lds != 0;
+  int* klist = reinterpret_cast<int*>(lql + (lqm ? (size_t)a.K * NTHR : 0));  // sparse mode: [K] active clusters of this block, [K] flags,
   int* kflag = klist + a.K;                          // [WAVES*R] groups of the block's row groups, [1] count
   int* bgrp = kflag + a.K;
 
@@ -166,7 +170,8 @@ __global__ void __launch_bounds__(WAVES * 64, EstepOcc<DP>::BLOCKS) estep_kernel
     for (int k = 0; k < K; ++k) {
       if (kflag[k]) continue;
       if constexpr (ROWLANES) {
-        if (myok) a.qZ[(int64_t)k * a.ldq + (rg0 + hi) * RG + lo4] = -INFINITY;
+        if (lqm) lql[k * NTHR + tid] = -INFINITY;
+        else if (myok) a.qZ[(int64_t)k * a.ldq + (rg0 + hi) * RG + lo4] = -INFINITY;
       } else {
 #pragma unroll
         for (int r = 0; r < R; ++r)
@@ -255,7 +260,8 @@ __global__ void __launch_bounds__(WAVES * 64, EstepOcc<DP>::BLOCKS) estep_kernel
     // R == 4: lane (lo4, hi) keeps row group hi -- ONE 512-byte store per cluster column instead of four
     // 128-byte ones, and the normalisation below needs no cross-lane sums
     if constexpr (ROWLANES) {
-      if (myok) a.qZ[(int64_t)k * a.ldq + (rg0 + hi) * RG + lo4] = lqsel;
+      if (lqm) lql[k * NTHR + tid] = lqsel;
+      else if (myok) a.qZ[(int64_t)k * a.ldq + (rg0 + hi) * RG + lo4] = lqsel;
     }
     if (ii + 1 < nact) LC_LSTORE(buf ^ 1);
     __syncthreads();
@@ -280,13 +286,13 @@ __global__ void __launch_bounds__(WAVES * 64, EstepOcc<DP>::BLOCKS) estep_kernel
     double s = 0.0;
     if (myok) {
 #pragma unroll 8
-      for (int k = 0; k < K; ++k) s += exp(qp[(int64_t)k * a.ldq] - mymx);
+      for (int k = 0; k < K; ++k) s += exp((lqm ? lql[k * NTHR + tid] : qp[(int64_t)k * a.ldq]) - mymx);
     }
     const double logZ = log(s) + mymx;
     for (int k = 0; k < K; ++k) {
       double ll = 0.0;
       if (myok) {
-        const double lq = qp[(int64_t)k * a.ldq];
+        const double lq = lqm ? lql[k * NTHR + tid] : qp[(int64_t)k * a.ldq];
         double q = exp(lq - logZ);
         if (!myrow) q = 0.0;
         qp[(int64_t)k * a.ldq] = q;
@@ -623,14 +629,20 @@ int64_t estep_grid(int DP, int64_t nrg) {
 template <int DP, bool SPARSE>
 static hipError_t launch_estep_s(const EstepLaunch& a, hipStream_t stream) {
   constexpr int R = EstepCfg<DP>::R, WAVES = EstepCfg<DP>::WAVES;
-  const size_t shmem = (size_t)(2 * pstride(DP) + WAVES * a.K + WAVES) * sizeof(double) +
-                       (size_t)(2 * a.K + WAVES * R + 2) * sizeof(int);
+  size_t shmem = (size_t)(2 * pstride(DP) + WAVES * a.K + WAVES) * sizeof(double) +
+                 (size_t)(2 * a.K + WAVES * R + 2) * sizeof(int);
+  EstepLaunch b = a;
+  static const bool no_lql = getenv("LC_ES_NOLQL") != nullptr;  // tuning knob: log q~ through the qZ buffer everywhere
+  if (R == 4 && !a.raw && !no_lql && shmem + (size_t)a.K * WAVES * 64 * sizeof(double) <= 64 * 1024) {
+    b.lq_lds = 1;  // log q~ stays in LDS until the normalisation
+    shmem += (size_t)a.K * WAVES * 64 * sizeof(double);
+  }
   auto kern = estep_kernel<DP, R, WAVES, SPARSE>;
   static LdsGrant grant;  // largest dynamic-LDS size already granted, per device
   if (hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(kern), shmem, grant); e != hipSuccess) return e;
   const int64_t grid = estep_grid(DP, a.nrg);
   if (grid <= 0) return hipSuccess;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVES * 64), shmem, stream, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVES * 64), shmem, stream, b);
   return hipGetLastError();
 }
 
