@@ -953,7 +953,10 @@ void Context::suffstat(const unsigned char* smask, double* Nk, double* xs, doubl
     } else
       LC_HIP(lck::launch_reduce_partials(sspart_.p, nchunks, (int64_t)K * SS, ssout_.p, stream_));
     // per-group counts N_jk: with one group they are the N_k just reduced (filled in on the host below)
-    if (J_ > 1) LC_HIP(lck::launch_group_colsum(qz_[cur_].buf.p, NP_, K, goff_d_.p, J_, njk_d, stream_));
+    if (J_ > 1) {
+      redtmp_.reserve((size_t)lck::REDUCE_TMP_ELEMS * 64);
+      LC_HIP(lck::launch_group_colsum(qz_[cur_].buf.p, NP_, K, goff_d_.p, J_, njk_d, stream_, redtmp_.p, NP_));
+    }
     else LC_HIP(hipMemsetAsync(njk_d, 0, (size_t)K * sizeof(double), stream_));
   } else {
     LC_HIP(hipMemsetAsync(ssout_.p, 0, nout * sizeof(double), stream_));
@@ -994,9 +997,10 @@ void Context::colsums(double* Njk) {
   const int K = qz_[cur_].K;
   if (K < 1) throw std::invalid_argument("qZ has not been set");
   red_.reserve((size_t)std::max(1 + K, J_ * K));
-  if (NP_ > 0)
-    LC_HIP(lck::launch_group_colsum(qz_[cur_].buf.p, NP_, K, goff_d_.p, J_, red_.p, stream_));
-  else
+  if (NP_ > 0) {
+    redtmp_.reserve((size_t)lck::REDUCE_TMP_ELEMS * 64);
+    LC_HIP(lck::launch_group_colsum(qz_[cur_].buf.p, NP_, K, goff_d_.p, J_, red_.p, stream_, redtmp_.p, NP_));
+  } else
     LC_HIP(hipMemsetAsync(red_.p, 0, (size_t)J_ * K * sizeof(double), stream_));
   if (!group_sharded_) allreduce(red_.p, (int64_t)J_ * K);
   LC_HIP(hipMemcpyAsync(Njk, red_.p, (size_t)J_ * K * sizeof(double), hipMemcpyDeviceToHost, stream_));
@@ -1133,7 +1137,10 @@ void Context::suffstat_diag(const unsigned char* smask, double* Nk, double* xs, 
       pending_.push_back(ev);
     }
     LC_HIP(lck::launch_reduce_partials(sspart_.p, nparts, (int64_t)K * SS, ssout_.p, stream_));
-    if (J_ > 1) LC_HIP(lck::launch_group_colsum(qz_[cur_].buf.p, NP_, K, goff_d_.p, J_, njk_d, stream_));
+    if (J_ > 1) {
+      redtmp_.reserve((size_t)lck::REDUCE_TMP_ELEMS * 64);
+      LC_HIP(lck::launch_group_colsum(qz_[cur_].buf.p, NP_, K, goff_d_.p, J_, njk_d, stream_, redtmp_.p, NP_));
+    }
     else LC_HIP(hipMemsetAsync(njk_d, 0, (size_t)K * sizeof(double), stream_));
   } else {
     LC_HIP(hipMemsetAsync(ssout_.p, 0, nout * sizeof(double), stream_));

@@ -123,8 +123,9 @@ constexpr int REDUCE_TMP_ELEMS = 512;
 hipError_t launch_reduce_partials(const double* partial, int nparts, int64_t n, double* out, hipStream_t stream,
                                   double* tmp = nullptr);
 // out[j*K+k] = sum over rows of group j of qZ[k*ldq + row]; goff = padded row offsets [J+1]
+// tmp (optional, REDUCE_TMP_ELEMS * 64 doubles) and rows (total padded rows) enable the sliced path for few large groups
 hipError_t launch_group_colsum(const double* qZ, int64_t ldq, int K, const int64_t* goff, int J, double* out,
-                               hipStream_t stream);
+                               hipStream_t stream, double* tmp = nullptr, int64_t rows = 0);
 // qZ[:, 0..K) = value on valid rows, 0 on pad rows
 hipError_t launch_fill_qz(double* qZ, int64_t ldq, int K, const int* rginfo, int64_t nrows, int64_t nrg, double value,
                           hipStream_t stream);

@@ -157,9 +157,43 @@ __global__ void __launch_bounds__(256) group_colsum_small_kernel(const double* q
   }
 }
 
+// few groups with many rows each (one block per (k, j) would leave most of the chip idle: 1.5 ms per million rows at
+// K = 32, J = 1): 64 row slices per (k, j), then a fixed-order sum of the 64 partials => still deterministic
+constexpr int GCS_SLICES = 64;
+__global__ void __launch_bounds__(256) group_colsum_slice_kernel(const double* qZ, int64_t ldq, int K,
+                                                                 const int64_t* goff, double* tmp) {
+  __shared__ double sh[256];
+  const int k = blockIdx.x, j = blockIdx.y, sl = blockIdx.z;
+  const int64_t b = goff[j], e = goff[j + 1], len = (e - b + GCS_SLICES - 1) / GCS_SLICES;
+  const int64_t r0 = b + sl * len, r1 = r0 + len < e ? r0 + len : e;
+  double s = 0.0;
+  for (int64_t r = r0 + threadIdx.x; r < r1; r += 256) s += qZ[(int64_t)k * ldq + r];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) tmp[((int64_t)j * K + k) * GCS_SLICES + sl] = sh[0];
+}
+__global__ void __launch_bounds__(256) group_colsum_fold_kernel(const double* tmp, int n, double* out) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= n) return;
+  double s = 0.0;
+  for (int i = 0; i < GCS_SLICES; ++i) s += tmp[(int64_t)t * GCS_SLICES + i];
+  out[t] = s;
+}
+
 hipError_t launch_group_colsum(const double* qZ, int64_t ldq, int K, const int64_t* goff, int J, double* out,
-                               hipStream_t stream) {
+                               hipStream_t stream, double* tmp, int64_t rows) {
   if (K <= 0 || J <= 0) return hipSuccess;
+  if (tmp && (int64_t)J * K * GCS_SLICES <= (int64_t)REDUCE_TMP_ELEMS * 64 && rows >= (int64_t)J * 65536) {
+    hipLaunchKernelGGL(group_colsum_slice_kernel, dim3((unsigned)K, (unsigned)J, GCS_SLICES), dim3(256), 0, stream, qZ,
+                       ldq, K, goff, tmp);
+    hipLaunchKernelGGL(group_colsum_fold_kernel, dim3((unsigned)((J * K + 255) / 256)), dim3(256), 0, stream, tmp, J * K,
+                       out);
+    return hipGetLastError();
+  }
   if (J > 1024)
     hipLaunchKernelGGL(group_colsum_small_kernel, dim3((unsigned)J), dim3(256), 0, stream, qZ, ldq, K, goff, out);
   else
