@@ -51,6 +51,9 @@ typedef struct lc_tmodel lc_tmodel; /* two-level (SCM / MCM) model: qY, qZ, weig
 
 const char* lc_last_error(void);
 int lc_version(void);
+/* hash of the sources this binary was built from (libcluster_amd/build.py::source_hash); the Python loader compares it
+ * with the tree it sits in and rebuilds or refuses a stale binary */
+const char* lc_source_hash(void);
 /* number of visible HIP devices (0 on a host without a GPU; never fails) */
 int lc_device_count(void);
 
@@ -156,6 +159,24 @@ int lc_colsums(lc_ctx* ctx, double* Njk);
  * enqueued on `stream`; return 0 on success. */
 typedef int (*lc_allreduce_fn)(void* user, void* device_buf, int64_t count, void* stream);
 int lc_ctx_set_allreduce(lc_ctx* ctx, lc_allreduce_fn fn, void* user);
+/* Native collectives (libcluster_amd/csrc/lc_comm.cpp) -- nothing in the reference corresponds: its loop over groups
+ * (cluster.cpp:207-223) is single-process OpenMP; this is that loop distributed.  A context with a communicator sums
+ * its packed statistics and [Fz; LL_k] over the ranks on its own stream; the communicator takes precedence over a hook.
+ *   RCCL: rank 0 calls lc_comm_unique_id and ships the LC_COMM_ID_BYTES to the other ranks (any channel); every rank
+ *         then calls lc_ctx_comm_init_rccl (ncclCommInitRank on the context's device; one rank per GPU;
+ *         ncclAllReduce(ncclDouble, ncclSum) over xGMI).  librccl is bound on first use.
+ *   host: staged through the POSIX shared-memory object "/lc_comm_<name>", summed in rank order by every rank -- any
+ *         placement of the ranks of one node, including several ranks on one GPU (which RCCL refuses). */
+#define LC_COMM_ID_BYTES 128
+int lc_comm_rccl_available(void); /* 1 when librccl could be loaded */
+int lc_comm_unique_id(void* id /* LC_COMM_ID_BYTES */);
+int lc_ctx_comm_init_rccl(lc_ctx* ctx, const void* id, int rank, int world);
+int lc_ctx_comm_init_host(lc_ctx* ctx, const char* name, int rank, int world);
+int lc_ctx_comm_free(lc_ctx* ctx);
+/* kind: "rccl" | "host-shm" | "host-local" | "hook" | "none" (static string) */
+int lc_ctx_comm_info(lc_ctx* ctx, int* rank, int* world, const char** kind);
+/* sum n host doubles over the ranks of the context's communicator / hook (identity without one) */
+int lc_ctx_allreduce(lc_ctx* ctx, double* values, int n);
 /* How a distributed run is sharded.  0 (default): every rank holds rows of the SAME groups (BGMM / VDP row
  * blocks; also GMC with every group split by rows) -- statistics and per-group counts are summed.
  * 1: every rank holds WHOLE, different groups (GMC) -- cluster statistics, Fz, LL_k and the
@@ -197,6 +218,10 @@ int lc_vbem(lc_ctx* ctx, lc_model** model, int wkind, int ckind, double wprior, 
  * caller's `weights` argument carried (1.0 = default-constructed); ignored
  * for the multi-group learners (default-constructed GDirichlet / Dirichlet per group, cluster.cpp:192).
  * BEMM / EGMC: LC_EINVAL "X has to be in the range [0, inf)!" on a negative observation (cluster.cpp:742, 862). */
+/* Environment (the frozen learn*() signatures have no room for it): LIBCLUSTER_GPUS = N | "all" shards the
+ * observations over N GPUs of this node inside this one call -- row blocks for the single-matrix learners, whole
+ * groups for the GMC family -- one host thread and one context per GPU, RCCL all-reduce of the statistics; results
+ * (F, rounds, qZ, weights, clusters) are returned exactly as from one GPU.  `device` is then ignored (GPUs 0..N-1). */
 int lc_learn(int algo, int J, const double* const* Xj, const int64_t* Nj, int D, int64_t row_stride,
              int64_t col_stride, double wprior, double clusterprior, int maxclusters, int sparse, int verbose,
              unsigned nthreads, int device, lc_model** out, double* F);

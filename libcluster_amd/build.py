@@ -25,8 +25,25 @@ ARCH = "gfx950"
 DEVICE_FLAGS = ["-mllvm", "-amdgpu-use-amdgpu-trackers=1", "-mllvm", "-amdgpu-disable-unclustered-high-rp-reschedule=1"]
 
 SOURCES = ["lc_kernels_estep.hip", "lc_kernels_suffstat.hip", "lc_kernels_diag.hip", "lc_kernels_aux.hip", "lc_ctx.cpp",
-           "lc_engine.cpp", "lc_topic.cpp", "lc_capi.cpp"]
-HEADERS = ["lc_kernels.h", "lc_device.hpp", "lc_ctx.hpp", "lc_engine.hpp", "lc_topic.hpp", "lc_host.hpp", "../../include/libcluster_hip.h"]
+           "lc_comm.cpp", "lc_engine.cpp", "lc_topic.cpp", "lc_capi.cpp"]
+HEADERS = ["lc_kernels.h", "lc_device.hpp", "lc_ctx.hpp", "lc_comm.hpp", "lc_engine.hpp", "lc_topic.hpp", "lc_host.hpp",
+           "../../include/libcluster_hip.h"]
+HASH_STAMP = OBJ / "source_hash.txt"
+LAST_BUILD = {"compiled": [], "linked": False}  # what the last build() call did (reported by __graft_entry__.build)
+
+
+def source_hash() -> str:
+    """sha256 over every file the library is built from (csrc/* and the C header), in name order.  Compiled into the
+    library (lc_source_hash) so that a stale binary is noticed at load time (capi.lib)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    files = sorted(p for p in CSRC.iterdir() if p.suffix in (".hip", ".cpp", ".hpp", ".h")) + [PKG.parent / "include" / "libcluster_hip.h"]
+    for p in files:
+        h.update(p.name.encode())
+        h.update(b"\0")
+        h.update(p.read_bytes())
+    return h.hexdigest()[:32]
 
 
 def _hipcc() -> str:
@@ -50,12 +67,18 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     common = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", f"-I{PKG.parent / 'include'}"]
     common += os.environ.get("LC_EXTRA_CXXFLAGS", "").split()  # kernel tuning experiments (-DLC_SS_UNROLL=2 ...)
     objs, jobs = [], []
+    shash = source_hash()
+    stale_hash = not HASH_STAMP.exists() or HASH_STAMP.read_text().strip() != shash
+    LAST_BUILD["compiled"], LAST_BUILD["linked"] = [], False
     for src in SOURCES:
         s = CSRC / src
         o = OBJ / (Path(src).stem + ".o")
         objs.append(o)
-        if force or _newer(o, [s, *hdrs]):
+        if force or _newer(o, [s, *hdrs]) or (src == "lc_capi.cpp" and stale_hash):
             cmd = [hipcc, f"--offload-arch={ARCH}", *common, "-c", str(s), "-o", str(o)]
+            if src == "lc_capi.cpp":
+                cmd.insert(-4, f'-DLC_SOURCE_HASH="{shash}"')
+            LAST_BUILD["compiled"].append(src)
             if src.endswith(".hip"):
                 cmd[2:2] = DEVICE_FLAGS
             jobs.append(cmd)
@@ -69,11 +92,15 @@ def build(force: bool = False, verbose: bool = False) -> Path:
 
         with ThreadPoolExecutor(max_workers=min(len(jobs), max(1, (os.cpu_count() or 2) // 2))) as ex:
             list(ex.map(run, jobs))
+    if jobs:
+        HASH_STAMP.write_text(shash)
     if force or _newer(LIB, objs):
-        cmd = [hipcc, "-shared", "-o", str(LIB), *map(str, objs), "-lpthread"]
+        # librccl is bound lazily by lc_comm.cpp (dlopen): it is not a link-time dependency
+        cmd = [hipcc, "-shared", "-o", str(LIB), *map(str, objs), "-lpthread", "-ldl", "-lrt"]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
+        LAST_BUILD["linked"] = True
     return LIB
 
 

@@ -23,6 +23,18 @@ c_int64_p = C.POINTER(C.c_int64)
 c_int_p = C.POINTER(C.c_int)
 c_ubyte_p = C.POINTER(C.c_ubyte)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id() -> bytes:
+    """ncclGetUniqueId: rank 0 calls it and ships the bytes to the other ranks."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    check(lib().lc_comm_unique_id(buf))
+    return buf.raw
+
+
+def rccl_available() -> bool:
+    return bool(lib().lc_comm_rccl_available())
 
 
 class HipError(RuntimeError):
@@ -44,6 +56,50 @@ def declared_symbols() -> list[str]:
     return sorted(set(n for n in names if n != "lc_allreduce_fn"))
 
 
+def _load_checked() -> C.CDLL:
+    """dlopen the library and compare the source hash compiled into it (lc_source_hash) with the tree it sits in: a
+    stale binary (sources edited after the last build; the .so is git-ignored and travels prebuilt) is rebuilt when
+    hipcc is there and refused otherwise.  LC_ALLOW_STALE_LIB=1 skips the check."""
+    import os
+
+    from . import build as _build
+
+    def load():
+        L = C.CDLL(str(LIB_PATH))
+        try:
+            L.lc_source_hash.restype = C.c_char_p
+            return L, L.lc_source_hash().decode()
+        except AttributeError:  # a binary from before the guard existed
+            return L, "missing"
+
+    L, have = load()
+    if os.environ.get("LC_ALLOW_STALE_LIB"):
+        return L
+    want = _build.source_hash()
+    if have == want:
+        return L
+    # dlopen caches by path: a rebuilt file must be loaded under a new name, so rebuild BEFORE anything else binds to
+    # the stale handle, then load a private copy of the fresh file
+    try:
+        _build.build()
+    except Exception as e:  # noqa: BLE001
+        raise ImportError(f"{LIB_PATH} is stale (built from sources {have}, tree is {want}) and rebuilding failed: {e}. "
+                          "Run `python -m libcluster_amd.build`.") from e
+    import shutil
+    import tempfile
+
+    tmp = Path(tempfile.mkdtemp(prefix="lc_fresh_")) / LIB_PATH.name
+    shutil.copy2(LIB_PATH, tmp)
+    L2 = C.CDLL(str(tmp))
+    L2.lc_source_hash.restype = C.c_char_p
+    if L2.lc_source_hash().decode() != want:
+        raise ImportError(f"{LIB_PATH} is stale and the rebuild did not pick up the current sources")
+    import sys
+
+    print(f"libcluster_amd: rebuilt a stale {LIB_PATH.name} (was {have}, now {want})", file=sys.stderr)
+    return L2
+
+
 def lib() -> C.CDLL:
     global _lib
     if _lib is not None:
@@ -61,8 +117,14 @@ def lib() -> C.CDLL:
         import torch  # noqa: F401
     except ImportError:
         pass
-    L = C.CDLL(str(LIB_PATH))
+    L = _load_checked()
     L.lc_last_error.restype = C.c_char_p
+    L.lc_comm_unique_id.argtypes = [C.c_void_p]
+    L.lc_ctx_comm_init_rccl.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    L.lc_ctx_comm_init_host.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int]
+    L.lc_ctx_comm_free.argtypes = [C.c_void_p]
+    L.lc_ctx_comm_info.argtypes = [C.c_void_p, c_int_p, c_int_p, C.POINTER(C.c_char_p)]
+    L.lc_ctx_allreduce.argtypes = [C.c_void_p, c_double_p, C.c_int]
     for f in ("lc_const_converge", "lc_const_fengydel", "lc_const_zerocutoff"):
         getattr(L, f).restype = C.c_double
     L.lc_digamma.restype = C.c_double
@@ -391,6 +453,31 @@ class Context:
 
         self._cb = ALLREDUCE_FN(tramp)
         check(lib().lc_ctx_set_allreduce(self._h, self._cb, None))
+
+    # -- native collectives (lc_comm.cpp) ---------------------------------------
+    def comm_init_rccl(self, unique_id: bytes, rank: int, world: int):
+        """ncclCommInitRank on this context's device with the id rank 0 got from comm_unique_id()."""
+        assert len(unique_id) == COMM_ID_BYTES
+        buf = C.create_string_buffer(unique_id, COMM_ID_BYTES)
+        check(lib().lc_ctx_comm_init_rccl(self._h, buf, rank, world))
+
+    def comm_init_host(self, name: str, rank: int, world: int):
+        """Host-staged communicator over the shared-memory object /lc_comm_<name> (any placement of ranks)."""
+        check(lib().lc_ctx_comm_init_host(self._h, name.encode(), rank, world))
+
+    def comm_free(self):
+        check(lib().lc_ctx_comm_free(self._h))
+
+    def comm_info(self):
+        r, w, k = C.c_int(), C.c_int(), C.c_char_p()
+        check(lib().lc_ctx_comm_info(self._h, C.byref(r), C.byref(w), C.byref(k)))
+        return {"rank": r.value, "world": w.value, "kind": (k.value or b"none").decode()}
+
+    def allreduce(self, values):
+        """Sum a small host vector over the ranks (through the context's communicator / hook)."""
+        v = np.ascontiguousarray(values, dtype=np.float64).copy()
+        check(lib().lc_ctx_allreduce(self._h, dptr(v), v.size))
+        return v
 
     def timing_enable(self, on=True):
         check(lib().lc_ctx_timing_enable(self._h, int(on)))

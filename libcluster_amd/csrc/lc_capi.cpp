@@ -5,7 +5,9 @@
 #include <limits>
 #include <memory>
 #include <new>
+#include <algorithm>
 #include <string>
+#include <thread>
 
 #include "../../include/libcluster_hip.h"
 #include "lc_ctx.hpp"
@@ -30,6 +32,25 @@ struct lc_model {
   lce::Model model;
   std::vector<std::pair<int, std::vector<double>>> rounds;
   int D = 0;
+  // One process driving several GPUs (LIBCLUSTER_GPUS, lc_learn): every shard's context holds a block of rows
+  // (single-matrix learners) or whole groups (GMC family); `ctx` stays null and the accessors walk the shards.
+  struct Shard {
+    std::unique_ptr<lc_ctx> ctx;
+    hipStream_t stream = nullptr;
+    int device = 0;
+    std::vector<int> groups;  // global group ids in local order (whole-group sharding)
+    int64_t row0 = 0;         // first global row (row sharding)
+    ~Shard() {
+      ctx.reset();
+      if (stream) {
+        (void)hipSetDevice(device);
+        (void)hipStreamDestroy(stream);
+      }
+    }
+  };
+  std::vector<std::unique_ptr<Shard>> shards;
+  bool rows_sharded = false;
+  std::vector<int64_t> Nj;  // global group sizes
 };
 
 struct lc_tmodel {
@@ -92,12 +113,194 @@ int guarded(F f) {
 void need(const void* p, const char* what) {
   if (!p) throw std::invalid_argument(std::string(what) + " must not be NULL");
 }
+
+// ---- lc_learn: algorithm set-up shared by the one-GPU and the sharded path ------------------------------------
+bool algo_single(int algo) {
+  return algo == LC_ALGO_VDP || algo == LC_ALGO_BGMM || algo == LC_ALGO_DGMM || algo == LC_ALGO_BEMM;
+}
+
+void algo_configure(int algo, lce::Model& model, bool verbose, bool sparse) {
+  const char* sp = sparse ? "(sparse) " : "";
+  switch (algo) {
+    case LC_ALGO_VDP:
+      if (verbose) std::cout << "Learning VDP..." << std::endl;  // cluster.cpp:647-648
+      model.wkind = lch::W_STICKBREAK;
+      break;
+    case LC_ALGO_BGMM:
+      if (verbose) std::cout << "Learning Bayesian GMM..." << std::endl;  // :678-679
+      model.wkind = lch::W_DIRICHLET;
+      break;
+    case LC_ALGO_DGMM:
+      if (verbose) std::cout << "Learning Bayesian diagonal GMM..." << std::endl;  // :708-709
+      model.wkind = lch::W_DIRICHLET;
+      model.ckind = lch::C_NORMGAMMA;
+      break;
+    case LC_ALGO_BEMM:
+      if (verbose) std::cout << "Learning Bayesian EMM..." << std::endl;  // :745-746
+      model.wkind = lch::W_DIRICHLET;
+      model.ckind = lch::C_EXPGAMMA;
+      break;
+    case LC_ALGO_GMC:
+      if (verbose) std::cout << "Learning " << sp << "GMC..." << std::endl;  // :775-779
+      model.wkind = lch::W_GDIRICHLET;
+      break;
+    case LC_ALGO_SGMC:
+      if (verbose) std::cout << "Learning " << sp << "Symmetric GMC..." << std::endl;  // :799-803
+      model.wkind = lch::W_DIRICHLET;
+      break;
+    case LC_ALGO_DGMC:
+      if (verbose) std::cout << "Learning " << sp << "Diagonal GMC..." << std::endl;  // :825-829
+      model.wkind = lch::W_GDIRICHLET;
+      model.ckind = lch::C_NORMGAMMA;
+      break;
+    default:
+      if (verbose) std::cout << "Learning " << sp << "Exponential GMC..." << std::endl;  // :866-868
+      model.wkind = lch::W_GDIRICHLET;
+      model.ckind = lch::C_EXPGAMMA;
+      break;
+  }
+}
+
+// LIBCLUSTER_GPUS = N | "all": learn*() shard their observations over N GPUs of this node, one host thread and one
+// context per GPU, statistics summed with RCCL (SURVEY 5 "Config / flags": GPU selection cannot go into the frozen
+// learnBGMM / learnVDP / learnGMC signatures).  LIBCLUSTER_GPUS_SAME_DEVICE=1 places every shard on `device` with the
+// host-staged transport (exercises the sharded path on a one-GPU machine; RCCL refuses two ranks on one GPU).
+int requested_gpus(bool* same_device) {
+  const char* e = std::getenv("LIBCLUSTER_GPUS");
+  *same_device = false;
+  if (!e || !*e) return 1;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return 1;  // (the one-GPU path reports the missing device)
+  const char* sd = std::getenv("LIBCLUSTER_GPUS_SAME_DEVICE");
+  *same_device = sd && *sd && !(sd[0] == '0' && sd[1] == 0);
+  int n = std::string(e) == "all" ? ndev : std::atoi(e);
+  if (n < 1) throw std::invalid_argument("LIBCLUSTER_GPUS must be a positive number or \"all\"");
+  if (!*same_device && n > ndev) n = ndev;
+  return std::min(n, 64);
+}
+
+// whole groups to shards, largest first onto the least loaded (per-group counts N_jk stay local)
+std::vector<std::vector<int>> assign_groups(int J, const int64_t* Nj, int W) {
+  std::vector<int> order((size_t)J);
+  for (int j = 0; j < J; ++j) order[(size_t)j] = j;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return Nj[a] > Nj[b]; });
+  std::vector<int64_t> load((size_t)W, 0);
+  std::vector<std::vector<int>> mine((size_t)W);
+  for (int j : order) {
+    int r = 0;
+    for (int t = 1; t < W; ++t)
+      if (load[(size_t)t] < load[(size_t)r]) r = t;
+    load[(size_t)r] += Nj[j];
+    mine[(size_t)r].push_back(j);
+  }
+  for (auto& v : mine) std::sort(v.begin(), v.end());
+  return mine;
+}
+
+double learn_sharded(int algo, int J, const double* const* Xj, const int64_t* Nj, int D, int64_t rs, int64_t cs,
+                     double wprior, double clusterprior, int maxclusters, int sparse, int verbose, unsigned nthreads,
+                     int device, int W, bool same_device, lc_model* m) {
+  const bool single = algo_single(algo);
+  if (single) W = (int)std::max<int64_t>(1, std::min<int64_t>(W, Nj[0] / 64));  // at least a few row groups per shard
+  else W = std::min(W, J);
+  algo_configure(algo, m->model, verbose != 0, sparse != 0);
+  m->rows_sharded = single;
+  m->Nj.assign(Nj, Nj + J);
+  std::vector<std::vector<int>> groups;
+  if (!single) groups = assign_groups(J, Nj, W);
+  std::vector<int> devices((size_t)W);
+  for (int r = 0; r < W; ++r) devices[(size_t)r] = same_device ? device : r;
+  const char* force = std::getenv("LIBCLUSTER_COMM");
+  const bool host = same_device || (force && std::string(force) == "host");
+  std::vector<std::shared_ptr<lcm::Comm>> comms = host ? lcm::host_init_local(W) : lcm::rccl_init_all(devices);
+  if (verbose) std::cout << "Sharding over " << W << " GPU(s), " << comms[0]->kind() << " all-reduce" << std::endl;
+
+  std::vector<lce::Model> models((size_t)W, m->model);
+  std::vector<std::vector<std::pair<int, std::vector<double>>>> traces((size_t)W);
+  std::vector<std::exception_ptr> errs((size_t)W);
+  std::vector<double> Fs((size_t)W, 0.0);
+  m->shards.clear();
+  for (int r = 0; r < W; ++r) m->shards.emplace_back(new lc_model::Shard());
+  const int64_t N0 = single ? Nj[0] : 0;
+  auto work = [&](int r) {
+    try {
+      lc_model::Shard& sh = *m->shards[(size_t)r];
+      sh.device = devices[(size_t)r];
+      if (hipSetDevice(sh.device) != hipSuccess) throw lcc::HipFailure("hipSetDevice failed for a shard");
+      if (hipStreamCreateWithFlags(&sh.stream, hipStreamNonBlocking) != hipSuccess)
+        throw lcc::HipFailure("hipStreamCreate failed for a shard");
+      sh.ctx.reset(new lc_ctx(sh.device, sh.stream));
+      lcc::Context& ctx = sh.ctx->impl;
+      ctx.set_comm(comms[(size_t)r]);
+      lce::Model& model = models[(size_t)r];
+      if (single) {
+        const int64_t base = N0 / W, rem = N0 % W;
+        const int64_t lo = r * base + std::min<int64_t>(r, rem), n = base + (r < rem ? 1 : 0);
+        sh.row0 = lo;
+        const double* xp = Xj[0] + lo * rs;
+        ctx.set_data(1, &xp, &n, D, rs, cs);
+        model.weights.emplace_back(model.wkind, wprior);  // vecweights(1, weights), cluster.cpp:653/684/715/752
+      } else {
+        sh.groups = groups[(size_t)r];
+        std::vector<const double*> xp;
+        std::vector<int64_t> nn;
+        for (int j : sh.groups) {
+          xp.push_back(Xj[j]);
+          nn.push_back(Nj[j]);
+        }
+        ctx.set_data((int)xp.size(), xp.data(), nn.data(), D, rs, cs);
+        ctx.set_group_sharded(true);
+      }
+      lce::ClusterOptions co;
+      co.clusterprior = clusterprior;
+      co.maxclusters = maxclusters;
+      co.sparse = !single && sparse;  // the single-matrix learners pass sparse=false, :657/:688/:719/:756
+      co.verbose = verbose != 0 && r == 0;
+      co.nthreads = std::max(1u, nthreads / (unsigned)W);
+      co.trace = &traces[(size_t)r];
+      Fs[(size_t)r] = lce::cluster(ctx, model, co);
+    } catch (...) {
+      errs[(size_t)r] = std::current_exception();
+      for (auto& c : comms) c->abort();  // the other shards fail in their next collective instead of waiting
+    }
+  };
+  std::vector<std::thread> th;
+  for (int r = 1; r < W; ++r) th.emplace_back(work, r);
+  work(0);
+  for (auto& t : th) t.join();
+  for (auto& e : errs)
+    if (e) {
+      m->shards.clear();
+      std::rethrow_exception(e);
+    }
+  // every shard ran the same M-steps on the same reduced statistics: clusters, F and the rounds are identical; the
+  // group weights live with the shard that holds the group
+  lce::Model out = std::move(models[0]);
+  if (!single) {
+    std::vector<lch::WeightState> w;
+    w.reserve((size_t)J);
+    for (int j = 0; j < J; ++j) w.emplace_back(out.wkind, lch::ALPHA1PRIOR);
+    for (int r = 0; r < W; ++r) {
+      lce::Model& mr = r == 0 ? out : models[(size_t)r];
+      for (size_t l = 0; l < m->shards[(size_t)r]->groups.size(); ++l)
+        w[(size_t)m->shards[(size_t)r]->groups[l]] = mr.weights[l];
+    }
+    out.weights = std::move(w);
+  }
+  m->model = std::move(out);
+  m->rounds = std::move(traces[0]);
+  return Fs[0];
+}
 }  // namespace
 
 extern "C" {
 
 const char* lc_last_error(void) { return g_err.c_str(); }
-int lc_version(void) { return 100; }
+int lc_version(void) { return 200; }
+#ifndef LC_SOURCE_HASH
+#define LC_SOURCE_HASH "unknown"
+#endif
+const char* lc_source_hash(void) { return LC_SOURCE_HASH; }
 
 int lc_device_count(void) {
   int n = 0;
@@ -377,6 +580,57 @@ int lc_ctx_set_allreduce(lc_ctx* ctx, lc_allreduce_fn fn, void* user) {
   });
 }
 
+int lc_comm_unique_id(void* id) {
+  return guarded([&] {
+    need(id, "id");
+    lcm::rccl_unique_id(id);
+  });
+}
+
+int lc_comm_rccl_available(void) { return lcm::rccl_available() ? 1 : 0; }
+
+int lc_ctx_comm_init_rccl(lc_ctx* ctx, const void* id, int rank, int world) {
+  return guarded([&] {
+    need(ctx, "ctx");
+    need(id, "id");
+    ctx->impl.set_comm(lcm::rccl_init_rank(id, rank, world, ctx->impl.device()));
+  });
+}
+
+int lc_ctx_comm_init_host(lc_ctx* ctx, const char* name, int rank, int world) {
+  return guarded([&] {
+    need(ctx, "ctx");
+    need(name, "name");
+    ctx->impl.set_comm(lcm::host_init_shm(name, rank, world));
+  });
+}
+
+int lc_ctx_comm_free(lc_ctx* ctx) {
+  return guarded([&] {
+    need(ctx, "ctx");
+    ctx->impl.synchronize();
+    ctx->impl.set_comm(nullptr);
+  });
+}
+
+int lc_ctx_comm_info(lc_ctx* ctx, int* rank, int* world, const char** kind) {
+  return guarded([&] {
+    need(ctx, "ctx");
+    const auto& c = ctx->impl.comm();
+    if (rank) *rank = c ? c->rank() : 0;
+    if (world) *world = c ? c->world() : 1;
+    if (kind) *kind = c ? c->kind() : (ctx->impl.distributed() ? "hook" : "none");
+  });
+}
+
+int lc_ctx_allreduce(lc_ctx* ctx, double* values, int n) {
+  return guarded([&] {
+    need(ctx, "ctx");
+    need(values, "values");
+    ctx->impl.allreduce_values(values, n);
+  });
+}
+
 int lc_trim_cache(void) {
   return guarded([&] { lcc::trim_cache(); });
 }
@@ -457,7 +711,7 @@ int lc_learn(int algo, int J, const double* const* Xj, const int64_t* Nj, int D,
     need(Nj, "Nj");
     need(out, "out");
     if (algo < 0 || algo > LC_ALGO_EGMC) throw std::invalid_argument("unknown algorithm");
-    const bool single = algo == LC_ALGO_VDP || algo == LC_ALGO_BGMM || algo == LC_ALGO_DGMM || algo == LC_ALGO_BEMM;
+    const bool single = algo_single(algo);
     if (single && J != 1) throw std::invalid_argument("this algorithm takes a single observation matrix");
     if (nthreads < 1) throw std::invalid_argument("Must specify at least one thread for execution!");  // cluster.cpp:576-577
     if (algo == LC_ALGO_BEMM || algo == LC_ALGO_EGMC) {  // cluster.cpp:742-743, 862-864 (before anything is printed)
@@ -469,50 +723,22 @@ int lc_learn(int algo, int J, const double* const* Xj, const int64_t* Nj, int D,
       }
     }
     std::unique_ptr<lc_model> m(new lc_model());
+    m->D = D;
+    bool same_device = false;
+    const int ngpu = requested_gpus(&same_device);
+    if (ngpu > 1 && (single ? Nj[0] >= 128 : J >= 2)) {
+      for (int j = 0; j < J; ++j) need(Xj[j], "Xj[j]");
+      const double f = learn_sharded(algo, J, Xj, Nj, D, rs, cs, wprior, clusterprior, maxclusters, sparse, verbose,
+                                     nthreads, device, ngpu, same_device, m.get());
+      if (F) *F = f;
+      *out = m.release();
+      return;
+    }
     m->owned_ctx.reset(new lc_ctx(device, nullptr));
     m->ctx = m->owned_ctx.get();
-    m->D = D;
     lcc::Context& ctx = m->ctx->impl;
     ctx.set_data(J, Xj, Nj, D, rs, cs);
-    const char* sp = sparse ? "(sparse) " : "";
-    switch (algo) {
-      case LC_ALGO_VDP:
-        if (verbose) std::cout << "Learning VDP..." << std::endl;  // cluster.cpp:647-648
-        m->model.wkind = lch::W_STICKBREAK;
-        break;
-      case LC_ALGO_BGMM:
-        if (verbose) std::cout << "Learning Bayesian GMM..." << std::endl;  // :678-679
-        m->model.wkind = lch::W_DIRICHLET;
-        break;
-      case LC_ALGO_DGMM:
-        if (verbose) std::cout << "Learning Bayesian diagonal GMM..." << std::endl;  // :708-709
-        m->model.wkind = lch::W_DIRICHLET;
-        m->model.ckind = lch::C_NORMGAMMA;
-        break;
-      case LC_ALGO_BEMM:
-        if (verbose) std::cout << "Learning Bayesian EMM..." << std::endl;  // :745-746
-        m->model.wkind = lch::W_DIRICHLET;
-        m->model.ckind = lch::C_EXPGAMMA;
-        break;
-      case LC_ALGO_GMC:
-        if (verbose) std::cout << "Learning " << sp << "GMC..." << std::endl;  // :775-779
-        m->model.wkind = lch::W_GDIRICHLET;
-        break;
-      case LC_ALGO_SGMC:
-        if (verbose) std::cout << "Learning " << sp << "Symmetric GMC..." << std::endl;  // :799-803
-        m->model.wkind = lch::W_DIRICHLET;
-        break;
-      case LC_ALGO_DGMC:
-        if (verbose) std::cout << "Learning " << sp << "Diagonal GMC..." << std::endl;  // :825-829
-        m->model.wkind = lch::W_GDIRICHLET;
-        m->model.ckind = lch::C_NORMGAMMA;
-        break;
-      default:
-        if (verbose) std::cout << "Learning " << sp << "Exponential GMC..." << std::endl;  // :866-868
-        m->model.wkind = lch::W_GDIRICHLET;
-        m->model.ckind = lch::C_EXPGAMMA;
-        break;
-    }
+    algo_configure(algo, m->model, verbose != 0, sparse != 0);
     if (single) m->model.weights.emplace_back(m->model.wkind, wprior);  // vecweights(1, weights), :653/:684/:715/:752
     lce::ClusterOptions co;
     co.clusterprior = clusterprior;
@@ -591,6 +817,18 @@ int lc_model_get_qz(lc_model* m, int j, double* q, int64_t rs, int64_t cs) {
   return guarded([&] {
     need(m, "model");
     need(q, "q");
+    if (!m->shards.empty()) {
+      if (j < 0 || j >= (int)m->Nj.size()) throw std::invalid_argument("group index out of range");
+      for (auto& sh : m->shards) {
+        if (m->rows_sharded) {
+          sh->ctx->impl.qz_get(0, q + sh->row0 * rs, rs, cs);
+        } else {
+          for (size_t l = 0; l < sh->groups.size(); ++l)
+            if (sh->groups[l] == j) sh->ctx->impl.qz_get((int)l, q, rs, cs);
+        }
+      }
+      return;
+    }
     if (!m->ctx) throw std::invalid_argument("model has no context");
     m->ctx->impl.qz_get(j, q, rs, cs);
   });
@@ -600,6 +838,28 @@ int lc_model_get_qz_all(lc_model* m, double* q) {
   return guarded([&] {
     need(m, "model");
     need(q, "q");
+    if (!m->shards.empty()) {
+      const size_t K = m->model.clusters.size();
+      if (m->rows_sharded) {
+        for (auto& sh : m->shards) sh->ctx->impl.qz_get_all(q + (size_t)sh->row0 * K);
+      } else {
+        std::vector<int64_t> off(m->Nj.size() + 1, 0);
+        for (size_t j = 0; j < m->Nj.size(); ++j) off[j + 1] = off[j] + m->Nj[j];
+        std::vector<double> tmp;
+        for (auto& sh : m->shards) {
+          int64_t n = 0;
+          for (int j : sh->groups) n += m->Nj[(size_t)j];
+          tmp.resize((size_t)n * K);
+          sh->ctx->impl.qz_get_all(tmp.data());
+          int64_t at = 0;
+          for (int j : sh->groups) {
+            std::memcpy(q + (size_t)off[(size_t)j] * K, tmp.data() + (size_t)at * K, (size_t)m->Nj[(size_t)j] * K * sizeof(double));
+            at += m->Nj[(size_t)j];
+          }
+        }
+      }
+      return;
+    }
     if (!m->ctx) throw std::invalid_argument("model has no context");
     m->ctx->impl.qz_get_all(q);
   });
@@ -609,6 +869,20 @@ int lc_model_get_qz_all_colmajor(lc_model* m, double* const* q) {
   return guarded([&] {
     need(m, "model");
     need(q, "q");
+    if (!m->shards.empty()) {
+      for (auto& sh : m->shards) {
+        if (m->rows_sharded) {  // a block of rows of the one N x K matrix: same columns, taller stride
+          double* base = q[0] + sh->row0;
+          const int64_t ld = m->Nj[0];
+          sh->ctx->impl.qz_get_all_colmajor(&base, &ld);
+        } else {
+          std::vector<double*> ptrs;
+          for (int j : sh->groups) ptrs.push_back(q[j]);
+          sh->ctx->impl.qz_get_all_colmajor(ptrs.data());
+        }
+      }
+      return;
+    }
     if (!m->ctx) throw std::invalid_argument("model has no context");
     m->ctx->impl.qz_get_all_colmajor(q);
   });

@@ -80,7 +80,7 @@ void DevBuf<T>::release() {
     if (bytes <= DEV_BLOCK_LIMIT) {
       std::lock_guard<std::mutex> g(c.m);
       if (c.dev_bytes + bytes <= DEV_CACHE_LIMIT && c.dev.size() < 4096) {
-        c.dev.push_back({p, bytes, current_device()});
+        c.dev.push_back({p, bytes, device >= 0 ? device : current_device()});
         c.dev_bytes += bytes;
         kept = true;
       }
@@ -89,6 +89,7 @@ void DevBuf<T>::release() {
   }
   p = nullptr;
   cap = 0;
+  device = -1;
 }
 
 template <typename T>
@@ -97,7 +98,8 @@ void DevBuf<T>::reserve(size_t n) {
   release();
   BlockCache& c = BlockCache::get();
   size_t got = 0;
-  void* q = c.take(c.dev, n * sizeof(T), current_device(), &got);
+  const int dev = current_device();  // (Context methods select their own device first: use_device)
+  void* q = c.take(c.dev, n * sizeof(T), dev, &got);
   if (!q) {
     hipError_t e = hipMalloc(&q, n * sizeof(T));
     if (e != hipSuccess) {  // make room and retry once
@@ -111,6 +113,7 @@ void DevBuf<T>::reserve(size_t n) {
   }
   p = static_cast<T*>(q);
   cap = got / sizeof(T);
+  device = dev;
 }
 
 PinnedBuf::~PinnedBuf() {
@@ -162,7 +165,10 @@ Context::Context(int device, hipStream_t stream) : device_(device), stream_(stre
   LC_HIP(hipSetDevice(device_));
 }
 
+void Context::use_device() const { LC_HIP(hipSetDevice(device_)); }
+
 Context::~Context() {
+  (void)hipSetDevice(device_);  // the blocks below are released to this device's cache bin
   // the buffers go back to the block cache (no implicit device synchronisation like hipFree): make sure nothing
   // enqueued by this context still uses them
   if (X_.p || qz_[0].buf.p || qz_[1].buf.p) (void)hipStreamSynchronize(stream_);
@@ -172,7 +178,10 @@ Context::~Context() {
   }
 }
 
-void Context::synchronize() const { LC_HIP(hipStreamSynchronize(stream_)); }
+void Context::synchronize() const {
+  use_device();
+  LC_HIP(hipStreamSynchronize(stream_));
+}
 
 void Context::require_gw_width() const {
   if (DP_ > lck::GW_MAX_DP)
@@ -297,6 +306,7 @@ void Context::synth(int64_t N, int D, int K, const double* mu, const double* L, 
 void Context::synth_groups(int J, const int64_t* Nj, int D, int K, const double* mu, const double* L,
                            const double* cdf, uint64_t seed, const int64_t* group_ids, int64_t row_offset,
                            double hard) {
+  use_device();
   if (K < 1) throw std::invalid_argument("K must be >= 1");
   build_layout(J, Nj, D);
   if (DP_ > 128) throw std::invalid_argument("the synthetic-data generator stops at D = 128");
@@ -340,6 +350,7 @@ void Context::synth_groups(int J, const int64_t* Nj, int D, int K, const double*
 }
 
 void Context::get_rows(int j, int64_t row0, int64_t n, double* out) const {
+  use_device();
   if (j < 0 || j >= J_ || row0 < 0 || n < 0 || row0 + n > Nj_[j]) throw std::invalid_argument("row range out of bounds");
   if (n == 0) return;
   std::vector<double> tmp((size_t)n * DP_);
@@ -353,6 +364,7 @@ void Context::get_rows(int j, int64_t row0, int64_t n, double* out) const {
 // qZ
 // ---------------------------------------------------------------------------
 void Context::ensure_qz(QZ& q, int K, bool preserve) {
+  use_device();
   if (K <= q.cap && q.buf.p) return;
   int newcap = std::max(K, q.cap > 0 ? q.cap + std::max(4, q.cap / 2) : K);
   DevBuf<double> nb;
@@ -363,10 +375,12 @@ void Context::ensure_qz(QZ& q, int K, bool preserve) {
   LC_HIP(hipStreamSynchronize(stream_));
   std::swap(q.buf.p, nb.p);
   std::swap(q.buf.cap, nb.cap);
+  std::swap(q.buf.device, nb.device);
   q.cap = newcap;
 }
 
 void Context::qz_fill(int K, double value) {
+  use_device();
   if (K < 1) throw std::invalid_argument("K must be >= 1");
   ensure_qz(qz_[cur_], K, false);
   qz_[cur_].K = K;
@@ -374,6 +388,7 @@ void Context::qz_fill(int K, double value) {
 }
 
 void Context::qz_set(int j, const double* q, int K, int64_t rs, int64_t cs) {
+  use_device();
   if (j < 0 || j >= J_) throw std::invalid_argument("group index out of range");
   if (K < 1) throw std::invalid_argument("K must be >= 1");
   if (K != qz_[cur_].K) {
@@ -394,6 +409,7 @@ void Context::qz_set(int j, const double* q, int K, int64_t rs, int64_t cs) {
 }
 
 void Context::qz_get_column(int j, int k, double* out) const {
+  use_device();
   if (j < 0 || j >= J_ || k < 0 || k >= qz_[cur_].K) throw std::invalid_argument("qZ column out of range");
   if (Nj_[j] == 0) return;
   LC_HIP(hipMemcpyAsync(out, qz_[cur_].buf.p + (size_t)k * NP_ + goff_[j], Nj_[j] * sizeof(double),
@@ -402,6 +418,7 @@ void Context::qz_get_column(int j, int k, double* out) const {
 }
 
 void Context::qz_get_rows(int j, int64_t row0, int64_t n, double* q, int64_t rs, int64_t cs) const {
+  use_device();
   if (j < 0 || j >= J_ || row0 < 0 || n < 0 || row0 + n > Nj_[j]) throw std::invalid_argument("row range out of bounds");
   if (n == 0) return;
   std::vector<double> col((size_t)n);
@@ -485,7 +502,7 @@ void Context::qz_get_all(double* out) const {
 // is column-major already, so no transpose anywhere -- the flat [K x NP] array crosses in 32 MB pieces through two
 // alternating page-locked buffers and pool threads copy the runs (column k, valid rows of group j) to their places
 // while the next piece is in flight.
-void Context::qz_get_all_colmajor(double* const* out) const {
+void Context::qz_get_all_colmajor(double* const* out, const int64_t* ld) const {
   const int K = qz_[cur_].K;
   if (K < 1 || NP_ == 0) return;
   LC_HIP(hipSetDevice(device_));
@@ -507,7 +524,8 @@ void Context::qz_get_all_colmajor(double* const* out) const {
           const int64_t g0 = goff_[(size_t)jj], nj = Nj_[(size_t)jj];
           const int64_t lo = std::max(p, g0), hi = std::min(pe, g0 + nj);
           if (lo < hi)
-            std::memcpy(out[jj] + (size_t)k * nj + (lo - g0), base + (f - f0) + (lo - p), (size_t)(hi - lo) * sizeof(double));
+            std::memcpy(out[jj] + (size_t)k * (ld ? ld[jj] : nj) + (lo - g0), base + (f - f0) + (lo - p),
+                        (size_t)(hi - lo) * sizeof(double));
         }
         f += pe - p;
       }
@@ -537,6 +555,7 @@ void Context::qz_get_all_colmajor(double* const* out) const {
 }
 
 void Context::qz_keep_columns(const std::vector<int>& keep) {
+  use_device();
   QZ& q = qz_[cur_];
   for (size_t i = 0; i < keep.size(); ++i) {
     const int src = keep[i];
@@ -549,6 +568,7 @@ void Context::qz_keep_columns(const std::vector<int>& keep) {
 }
 
 void Context::qz_clone_to_alt() {
+  use_device();
   QZ& a = qz_[cur_ ^ 1];
   const int Ksave = qz_[cur_].K;
   ensure_qz(a, Ksave + 1, false);
@@ -599,6 +619,7 @@ void Context::select_rows(int k, double thresh, RowSelection& sel) {
 }
 
 void Context::set_data_gather(const Context& src, const RowSelection& sel) {
+  use_device();
   if (src.device_ != device_) throw std::invalid_argument("contexts live on different devices");
   std::vector<int64_t> mj((size_t)src.J_);
   for (int j = 0; j < src.J_; ++j) mj[(size_t)j] = sel.starts[(size_t)j + 1] - sel.starts[(size_t)j];
@@ -609,6 +630,7 @@ void Context::set_data_gather(const Context& src, const RowSelection& sel) {
 }
 
 void Context::qz_init_split(const double* m, const double* v) {
+  use_device();
   ensure_qz(qz_[cur_], 2, false);
   qz_[cur_].K = 2;
   if (NP_ == 0) return;
@@ -623,6 +645,7 @@ void Context::qz_init_split(const double* m, const double* v) {
 }
 
 void Context::qz_init_split_mean(const double* v) {
+  use_device();
   ensure_qz(qz_[cur_], 2, false);
   qz_[cur_].K = 2;
   // rows of one group may be spread over ranks (row sharding): the group means are global quantities, so every
@@ -656,6 +679,7 @@ void Context::qz_init_split_mean(const double* v) {
 }
 
 void Context::qz_split_from(const Context& sub, const RowSelection& sel, int k) {
+  use_device();
   QZ& q = qz_[cur_];
   if (k < 0 || k >= q.K) throw std::invalid_argument("split column out of range");
   if (sub.qz_[sub.cur_].K < 2) throw std::invalid_argument("sub-problem has no second column");
@@ -670,6 +694,10 @@ void Context::qz_split_from(const Context& sub, const RowSelection& sel, int k) 
 // hot path
 // ---------------------------------------------------------------------------
 void Context::allreduce(double* dbuf, int64_t count) {
+  if (comm_) {  // RCCL / host-staged sum on this context's stream
+    comm_->allreduce_sum(dbuf, count, stream_);
+    return;
+  }
   if (!ar_fn_) return;
   const int rc = ar_fn_(ar_user_, dbuf, count, (void*)stream_);
   if (rc != 0) throw std::runtime_error("all-reduce hook failed with status " + std::to_string(rc));
@@ -681,7 +709,7 @@ double Context::allreduce_value(double v) {
 }
 
 void Context::allreduce_values(double* v, int n) {
-  if (!ar_fn_ || n <= 0) return;
+  if (!distributed() || n <= 0) return;
   LC_HIP(hipSetDevice(device_));
   red_.reserve((size_t)n);
   LC_HIP(hipMemcpyAsync(red_.p, v, (size_t)n * sizeof(double), hipMemcpyHostToDevice, stream_));
@@ -693,7 +721,7 @@ void Context::allreduce_values(double* v, int n) {
 void Context::estep(int K, const double* A, const double* m, const double* c, double* Fz, double* LLk, bool raw) {
   if (K < 1) throw std::invalid_argument("K must be >= 1");
   require_gw_width();  // (an upper limit only: wide observations stream through estep_wide_kernel)
-  if (NP_ == 0 && !ar_fn_) {
+  if (NP_ == 0 && !distributed()) {
     if (Fz) *Fz = -0.0;
     if (LLk) std::fill(LLk, LLk + K, 0.0);
     qz_[cur_].K = K;
@@ -994,6 +1022,7 @@ void Context::suffstat(const unsigned char* smask, double* Nk, double* xs, doubl
 }
 
 void Context::colsums(double* Njk) {
+  use_device();
   const int K = qz_[cur_].K;
   if (K < 1) throw std::invalid_argument("qZ has not been set");
   red_.reserve((size_t)std::max(1 + K, J_ * K));
@@ -1010,7 +1039,7 @@ void Context::colsums(double* Njk) {
 void Context::estep_diag(int K, const double* av, const double* w2, const double* w1, const double* c, double* Fz,
                          double* LLk, bool raw) {
   if (K < 1) throw std::invalid_argument("K must be >= 1");
-  if (NP_ == 0 && !ar_fn_) {
+  if (NP_ == 0 && !distributed()) {
     if (Fz) *Fz = -0.0;
     if (LLk) std::fill(LLk, LLk + K, 0.0);
     qz_[cur_].K = K;
@@ -1170,6 +1199,7 @@ void Context::suffstat_diag(const unsigned char* smask, double* Nk, double* xs, 
 // timing
 // ---------------------------------------------------------------------------
 KernelTimes Context::timing_get() {
+  use_device();
   if (!pending_.empty()) LC_HIP(hipStreamSynchronize(stream_));
   for (auto& p : pending_) {
     float ms = 0.f;

@@ -10,6 +10,7 @@
 #include <string>
 #include <vector>
 
+#include "lc_comm.hpp"
 #include "lc_kernels.h"
 
 namespace lcc {
@@ -26,6 +27,7 @@ template <typename T>
 struct DevBuf {
   T* p = nullptr;
   size_t cap = 0;  // elements
+  int device = -1;  // the GPU the block lives on (tagged when it is taken, so it returns to the right cache bin)
   ~DevBuf() { release(); }
   void release();  // back to the block cache (lc_ctx.cpp), not to the driver
   // grow (contents NOT preserved)
@@ -107,7 +109,10 @@ class Context {
     ar_fn_ = f;
     ar_user_ = user;
   }
-  bool distributed() const { return ar_fn_ != nullptr; }
+  // native collective (RCCL or host-staged, lc_comm.hpp); takes precedence over the hook
+  void set_comm(std::shared_ptr<lcm::Comm> c) { comm_ = std::move(c); }
+  const std::shared_ptr<lcm::Comm>& comm() const { return comm_; }
+  bool distributed() const { return ar_fn_ != nullptr || comm_ != nullptr; }
   // sum of one host value over all ranks (identity without a hook); via the device hook
   double allreduce_value(double v);
   void allreduce_values(double* v, int n);
@@ -118,11 +123,12 @@ class Context {
   // statistics pass: skip (4-row step, cluster) pairs whose responsibilities are all exactly 0.0 (bit-identical
   // results; pays off once qZ is mostly hard).  Always on in sparse mode.
   void set_skip_zero(bool on) { skip_zero_ = on; }
-  bool group_sharded() const { return group_sharded_ && ar_fn_ != nullptr; }
+  bool group_sharded() const { return group_sharded_ && distributed(); }
   // a context for a sub-problem of this one: same device, stream and all-reduce hook
   void inherit_comm(const Context& parent) {
     ar_fn_ = parent.ar_fn_;
     ar_user_ = parent.ar_user_;
+    comm_ = parent.comm_;
     group_sharded_ = parent.group_sharded_;
     skip_zero_ = parent.skip_zero_;
   }
@@ -132,7 +138,9 @@ class Context {
   void qz_set(int j, const double* q, int K, int64_t row_stride, int64_t col_stride);
   void qz_get(int j, double* q, int64_t row_stride, int64_t col_stride) const;
   void qz_get_all(double* out) const;  // [Ntotal x K] row-major, groups concatenated
-  void qz_get_all_colmajor(double* const* out) const;  // out[j] = [N_j x K] column-major (Eigen's default layout)
+  // out[j] = [N_j x K] column-major (Eigen's default layout); ld[j] (optional) = column stride of out[j] when the
+  // group's rows are a block of a taller matrix (row-sharded learners), default N_j
+  void qz_get_all_colmajor(double* const* out, const int64_t* ld = nullptr) const;
   void qz_get_rows(int j, int64_t row0, int64_t n, double* q, int64_t row_stride, int64_t col_stride) const;
   void qz_get_column(int j, int k, double* out) const;  // N(j) doubles
   void qz_keep_columns(const std::vector<int>& keep);    // prune_clusters
@@ -182,6 +190,7 @@ class Context {
   void ensure_qz(QZ& q, int K, bool preserve);
   void build_layout(int J, const int64_t* Nj, int D);
   void allreduce(double* dbuf, int64_t count);
+  void use_device() const;         // hipSetDevice(device_): every method that allocates, launches or copies starts here
   void require_gw_width() const;  // throws for DP > 128 (full-covariance kernels)
   int build_sparse_worklist(const unsigned char* smask, int K, int64_t SS, lck::SuffstatLaunch& a);
 
@@ -189,6 +198,7 @@ class Context {
   hipStream_t stream_;
   allreduce_fn ar_fn_ = nullptr;
   void* ar_user_ = nullptr;
+  std::shared_ptr<lcm::Comm> comm_;
   bool group_sharded_ = false;
   bool skip_zero_ = false;
 

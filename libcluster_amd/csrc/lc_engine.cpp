@@ -26,8 +26,9 @@ namespace {
 // threads fall back to running their loop inline).
 class Pool {
  public:
+  // one pool per calling host thread: with LIBCLUSTER_GPUS every shard's thread runs its own (replicated) M-step
   static Pool& get() {
-    static Pool p;
+    static thread_local Pool p;
     return p;
   }
   template <typename F>

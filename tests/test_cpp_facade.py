@@ -37,8 +37,17 @@ def test_c_header_is_plain_c(lib, tmp_path):
 
 
 @pytest.mark.gpu
-def test_reference_test_main_passes_on_gpu(lib, xcat, xcat_traces):
+@pytest.mark.parametrize("gpus", [None, 3])
+def test_reference_test_main_passes_on_gpu(lib, xcat, xcat_traces, gpus):
+    """gpus = 3: the same main with LIBCLUSTER_GPUS=3 -- every learn*() call with enough groups / rows shards itself over
+    three contexts (all on GPU 0 here, host-staged sums) and must still satisfy every assertion, qZ included (the
+    facade fetches it through lc_model_get_qz_all_colmajor)."""
+    import os
+
     exe = _compile(lib)
+    env = dict(os.environ)
+    if gpus:
+        env.update({"LIBCLUSTER_GPUS": str(gpus), "LIBCLUSTER_GPUS_SAME_DEVICE": "1"})
     X = xcat["X"]
     lines = [f"{len(X)} {X[0].shape[0]} {X[0].shape[1]}"]
     for g in X:
@@ -49,7 +58,7 @@ def test_reference_test_main_passes_on_gpu(lib, xcat, xcat_traces):
     lines.append(str(len(X)))  # the O data of testdata.h (document observations of mcluster_test.cpp)
     for g in xcat["O"]:
         lines += [" ".join(repr(float(v)) for v in row) for row in g]
-    r = subprocess.run([str(exe)], input="\n".join(lines) + "\n", capture_output=True, text=True, timeout=300)
+    r = subprocess.run([str(exe)], input="\n".join(lines) + "\n", capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "cluster_test OK" in r.stdout
     # the reference's verbose progress glyphs (README.md:355-376, cluster.cpp:232-233, 605-617)

@@ -1,0 +1,182 @@
+"""The library's own collectives (libcluster_amd/csrc/lc_comm.cpp) and the one-call multi-GPU switch.
+
+  * tests/cpp/dist_test.cpp: two ranks = two processes through the C ABI alone (no Python, no torch) reproduce the
+    single-rank model selection -- host-staged transport on one GPU, RCCL when the box has two GPUs (world of one
+    otherwise, the two-rank part reported as skipped);
+  * LIBCLUSTER_GPUS: learnBGMM / learnVDP / learnGMC / ... shard their observations over several contexts inside one
+    call (one host thread per shard) and return F, rounds, qZ, weights and clusters as from one GPU
+    (LIBCLUSTER_GPUS_SAME_DEVICE=1 puts every shard on GPU 0 with the host-staged transport);
+  * the RCCL communicator with a world of one inside the EM loop.
+The loop being distributed: src/cluster.cpp:207-223 (single-process OpenMP in the reference)."""
+import os
+import signal
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+EXE = ROOT / "tests" / "cpp" / "_build" / "dist_test"
+
+
+def _compile():
+    from libcluster_amd import capi
+
+    EXE.parent.mkdir(exist_ok=True)
+    libdir = capi.LIB_PATH.parent
+    cmd = ["g++", "-std=c++11", "-O2", "-Wall", f"-I{ROOT / 'include'}", str(ROOT / "tests/cpp/dist_test.cpp"),
+           "-o", str(EXE), f"-L{libdir}", "-lcluster_hip", f"-Wl,-rpath,{libdir}"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return EXE
+
+
+def test_dist_test_compiles_against_the_c_abi(lib):
+    _compile()
+
+
+def test_comm_symbols_and_lazy_rccl(lib):
+    """The collectives are part of the C ABI; librccl is bound on demand, not at load time."""
+    from libcluster_amd import capi
+
+    for s in ("lc_comm_unique_id", "lc_ctx_comm_init_rccl", "lc_ctx_comm_init_host", "lc_ctx_comm_free",
+              "lc_ctx_comm_info", "lc_ctx_allreduce", "lc_comm_rccl_available", "lc_source_hash"):
+        assert hasattr(lib, s), s
+    out = subprocess.run(["ldd", str(capi.LIB_PATH)], capture_output=True, text=True).stdout
+    assert "librccl" not in out  # dlopen on first use: single-GPU callers never page in the 570 MB library
+
+
+def _run_group(cmd, timeout):
+    """Run in its own process group so that a hung rank is killed with its parent."""
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, start_new_session=True,
+                         cwd=str(ROOT))
+    try:
+        out, _ = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        os.killpg(p.pid, signal.SIGKILL)
+        out, _ = p.communicate()
+        pytest.fail("dist_test timed out:\n" + out[-3000:])
+    return p.returncode, out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["host", "rccl"])
+def test_two_ranks_through_the_c_abi(lib, mode):
+    exe = _compile()
+    rc, out = _run_group([str(exe), mode, "40000", "8", "4"], 300)
+    assert rc == 0, out[-3000:]
+    assert f"dist_test {mode} OK" in out, out[-3000:]
+    if mode == "host":
+        assert "2 ranks" in out and "host all-reduce" in out
+
+
+def _blobs(seed, n, D, K):
+    rng = np.random.default_rng(seed)
+    mu = rng.normal(0, 6.0, (K, D))
+    z = rng.integers(0, K, n)
+    return mu[z] + rng.normal(size=(n, D)) * rng.uniform(0.5, 1.2, (K, 1))[z]
+
+
+@pytest.fixture
+def sharded_env():
+    keys = ("LIBCLUSTER_GPUS", "LIBCLUSTER_GPUS_SAME_DEVICE", "LIBCLUSTER_COMM")
+    old = {k: os.environ.get(k) for k in keys}
+
+    def set_(n):
+        if n:
+            os.environ["LIBCLUSTER_GPUS"] = str(n)
+            os.environ["LIBCLUSTER_GPUS_SAME_DEVICE"] = "1"
+        else:
+            for k in keys:
+                os.environ.pop(k, None)
+
+    yield set_
+    for k, v in old.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("learner,shards", [("learnBGMM", 2), ("learnVDP", 3), ("learnDGMM", 2), ("learnBEMM", 2)])
+def test_libcluster_gpus_rows_sharded_equals_one_gpu(lib, sharded_env, learner, shards):
+    """LIBCLUSTER_GPUS inside the single-matrix learners: row blocks on `shards` contexts, statistics summed by the
+    library's collective, replicated M-step -- the same rounds, K, F, qZ, weights and clusters as one context."""
+    import libcluster_amd as lc
+
+    X = _blobs(5, 6001, 5, 4)
+    if learner == "learnBEMM":
+        X = np.abs(X) * np.array([1.0, 10.0, 100.0, 1.0, 5.0])
+    fn = getattr(lc, learner)
+    sharded_env(0)
+    F1, q1, w1, *rest1, info1 = fn(X, return_info=True)
+    sharded_env(shards)
+    F2, q2, w2, *rest2, info2 = fn(X, return_info=True)
+    assert info1["K"] == info2["K"] and info1["K"] >= 2
+    assert [k for k, _ in info1["rounds"]] == [k for k, _ in info2["rounds"]]
+    assert abs(F1 - F2) <= 1e-10 * abs(F1)
+    assert q2.shape == q1.shape
+    np.testing.assert_allclose(q2, q1, atol=1e-9)
+    np.testing.assert_allclose(w2, w1, rtol=1e-9)
+    for a, b in zip(rest1, rest2):
+        for u, v in zip(a, b):
+            if u is None:  # exponential clusters have no covariance
+                assert v is None
+            else:
+                np.testing.assert_allclose(v, u, rtol=1e-8, atol=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("learner,sparse", [("learnGMC", False), ("learnSGMC", True), ("learnDGMC", False)])
+def test_libcluster_gpus_whole_groups_equals_one_gpu(lib, sharded_env, learner, sparse):
+    """GMC family under LIBCLUSTER_GPUS: whole groups per shard (largest first), per-group counts and weights stay with
+    the shard that holds the group, qZ and weights come back in the caller's group order."""
+    import libcluster_amd as lc
+
+    sizes = [900, 1500, 400, 1200, 700]
+    X = [_blobs(40 + j, n, 4, 3 + (j % 2)) + (j % 2) * 3.0 for j, n in enumerate(sizes)]
+    fn = getattr(lc, learner)
+    sharded_env(0)
+    F1, q1, w1, *rest1, info1 = fn(X, sparse=sparse, return_info=True)
+    sharded_env(3)
+    F2, q2, w2, *rest2, info2 = fn(X, sparse=sparse, return_info=True)
+    assert info1["K"] == info2["K"] and info1["K"] >= 2
+    assert [k for k, _ in info1["rounds"]] == [k for k, _ in info2["rounds"]]
+    assert abs(F1 - F2) <= 1e-10 * abs(F1)
+    assert len(q2) == len(sizes)
+    for a, b in zip(q1, q2):
+        assert a.shape == b.shape
+        np.testing.assert_allclose(b, a, atol=1e-9)
+    for a, b in zip(w1, w2):
+        np.testing.assert_allclose(b, a, rtol=1e-9)
+
+
+@pytest.mark.gpu
+def test_rccl_world_of_one_inside_the_em_loop(lib):
+    """ncclCommInitRank + ncclAllReduce(ncclDouble, ncclSum) on the context's stream in every iteration: with one rank
+    the sums are identities, so the trace must equal the communicator-free run bit for bit."""
+    from libcluster_amd import capi
+
+    if not capi.rccl_available():
+        pytest.skip("librccl could not be loaded on this box")
+    X = _blobs(9, 20000, 16, 5)
+    q0 = np.random.default_rng(1).dirichlet(np.ones(5), X.shape[0])
+    traces = []
+    for use in (False, True):
+        with capi.Context(0) as ctx:
+            ctx.set_data(X)
+            ctx.set_qz(q0)
+            if use:
+                ctx.comm_init_rccl(capi.comm_unique_id(), 0, 1)
+                info = ctx.comm_info()
+                assert info == {"rank": 0, "world": 1, "kind": "rccl"}
+                np.testing.assert_array_equal(ctx.allreduce([1.5, -2.0, 3.25]), [1.5, -2.0, 3.25])
+            F, tr, m = ctx.vbem(capi.W_STICKBREAK, fixed_iters=4)
+            m.close()
+            if use:
+                ctx.comm_free()
+                assert ctx.comm_info()["kind"] == "none"
+        traces.append(tr)
+    np.testing.assert_array_equal(traces[0], traces[1])
