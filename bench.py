@@ -2,6 +2,7 @@
 """Benchmark of the libcluster E-step hot path on MI355X.
 
     python bench.py --gpus 1 --steps 10 --warmup 1
+    python bench.py --gpus 8 ...          # starts the 8 ranks itself (torch.distributed.run, one process per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -14,25 +15,36 @@ ranks per second (weak scaling: every GPU holds `N` rows).
 
 Default workload: the configuration BASELINE.json's north_star quotes the
 metric on -- BGMM, N=10M rows per GPU, D=64, K=32 (configs[3] is the same
-shape at 8 GPUs).  --config 2 / 3 select BASELINE.json configs[1] / configs[2].
+shape at 8 GPUs).  --config 2 / 3 / 5 select BASELINE.json configs[1] / [2] / [4 per GPU].
+
+Multi-GPU: the all-reduce of the packed statistics is the library's own RCCL collective
+(lc_ctx_comm_init_rccl: ncclAllReduce(ncclDouble, ncclSum) on the context's stream); torch.distributed is only the
+launcher's rendezvous (broadcast of the RCCL unique id, the barriers and the max-over-ranks of the timing).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
-
-import numpy as np
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 # multi-process GPU work on this pool needs dmabuf IPC (RCCL fails with hipIpcGetMemHandle otherwise)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+if int(os.environ.get("WORLD_SIZE", "1")) == 1:
+    # the CPU baseline (single-rank runs only) pins its OpenMP threads: one per physical core, neighbours adjacent
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
+
+import numpy as np  # noqa: E402
 
 FP64_PEAK_TFLOPS = 78.6  # MI355X fp64 vector = matrix spec (BASELINE.md); v_mfma_f64_4x4x4 measured 73.9 (profiles/)
+HBM_PEAK_GBS = 8000.0    # MI355X HBM3E (/opt/skills/guides/MI355X_MICROARCH.md)
 
 CONFIGS = {
     # name: (N per GPU, D, K, weight kind, seed)
@@ -50,21 +62,24 @@ CONFIGS = {
     "bemm": dict(N=10_000_000, D=64, K=32, w="Dirichlet", c="ExpGamma", seed=1007,
                  label="BEMM (exponential clusters, ExpGamma) N=10M/GPU D=64 K=32"),
 }
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E (/opt/skills/guides/MI355X_MICROARCH.md)
+OTHER_CONFIGS = ["2", "3", "5", "dgmm", "bemm"]  # short runs reported under "other_configs" of the default line
 
 
-def mixture(D, K, seed, family="GaussWish"):
+def mixture(D, K, seed, family="GaussWish", overlap=False):
     """mu_k ~ N(0, 9 I), Sigma_k = B B^T / D + 0.5 I.  Diagonal families: axis-aligned components
-    (ExpGamma needs x >= 0: means 20..60, unit-scale spread)."""
+    (ExpGamma needs x >= 0: means 20..60, unit-scale spread).
+    overlap=True (parity leg only): mu_k ~ N(0, 0.09 I), Sigma_k = 0.2 B B^T / D + I -- components on top of each
+    other, so that most responsibilities are soft (the 8(d) mixture is ~770 Mahalanobis^2 apart at D = 64: every
+    responsibility above the comparison mask is exactly 1 and a qZ comparison cannot fail)."""
     rng = np.random.default_rng(seed)
     if family != "GaussWish":
         mu = rng.normal(0.0, 3.0, (K, D)) if family == "NormGamma" else rng.uniform(20.0, 60.0, (K, D))
         return mu, np.stack([np.diag(rng.uniform(0.5, 1.5, D)) for _ in range(K)])
-    mu = rng.normal(0.0, 3.0, (K, D))
+    mu = rng.normal(0.0, 0.3 if overlap else 3.0, (K, D))
     L = np.empty((K, D, D))
     for k in range(K):
         B = rng.normal(size=(D, D))
-        L[k] = np.linalg.cholesky(B @ B.T / D + 0.5 * np.eye(D))
+        L[k] = np.linalg.cholesky((0.2 * (B @ B.T) / D + np.eye(D)) if overlap else (B @ B.T / D + 0.5 * np.eye(D)))
     return mu, L
 
 
@@ -94,9 +109,11 @@ def cpu_baseline_family(ctx, cfg, sample_rows):
                       f"(numpy, 1 thread), mean of 2"}
 
 
-def cpu_baseline(ctx, model, cfg, wkind_name, sample_rows):
-    """Time the C port of the reference arithmetic (oracle/lc_oracle_c.c) on the
-    first `sample_rows` rows of the same workload, on this host's cores."""
+def cpu_baseline(ctx, model, cfg, sample_rows, reps=5):
+    """Time the C port of the reference arithmetic (oracle/lc_oracle_c.c) on the first `sample_rows` rows of the same
+    workload, on this host's cores: mode B of SURVEY 8(d) (rows chunked over all physical cores, threads pinned) and
+    mode A (one thread: what learnBGMM / learnVDP really use, cluster.cpp:207-223 + the `critical` at :77-78), both on
+    the SAME rows.  Dense flops per point K(4 D^2 + 5 D + 1): two triangular solves + the full D x D product."""
     sys.path.insert(0, str(ROOT / "oracle"))
     import lc_oracle_c as oc
 
@@ -108,25 +125,31 @@ def cpu_baseline(ctx, model, cfg, wkind_name, sample_rows):
     post = ([c["nu"] for c in cl], [c["beta"] for c in cl], np.stack([c["m"] if "m" in c else c["mean"] for c in cl]),
             np.stack([c["iW"] for c in cl]), [c["logdW"] for c in cl], el)
     cores = oc.physical_cores()
-    out = {}
-    for label, nt, rows in (("all_cores", cores, n), ("one_thread", 1, max(1000, n // 32))):
-        Xs = X[:rows]
-        q, _ = oc.estep(Xs, *post, nthreads=nt)  # warm-up (also produces the q the suff-stat pass consumes)
-        oc.suffstat(Xs, q, nt)
-        ts = []
-        for _ in range(3):
-            t0 = time.perf_counter()
-            q, _ = oc.estep(Xs, *post, nthreads=nt)
-            oc.suffstat(Xs, q, nt)
-            ts.append(time.perf_counter() - t0)
-        out[label] = {"pts_per_s": rows / float(np.median(ts)), "rows": rows, "threads": nt}
+    w_dense = K * (4 * D * D + 5 * D + 1)
+
+    def one(nt, rows):
+        t0 = time.perf_counter()
+        q, _ = oc.estep(X[:rows], *post, nthreads=nt)
+        oc.suffstat(X[:rows], q, nt)
+        return time.perf_counter() - t0
+
+    one(cores, n)  # warm-up (page faults, thread pool)
+    ts = [one(cores, n) for _ in range(reps)]
+    all_pts = n / float(np.median(ts))
+    one(1, min(n, 20_000))  # 1-thread warm-up on a short prefix, then ONE timed pass over the same n rows
+    one_pts = n / one(1, n)
+    peak, peak_desc = oc.host_fp64_peak_gflops(cores)
+    gf = all_pts * w_dense / 1e9
     return {
-        "value": out["all_cores"]["pts_per_s"], "unit": "points/s", "cores": cores, "kind": "port",
-        "sample": f"first {n} rows of the same synthetic stream, E-step + suff-stats per cluster pass "
-                  f"(oracle/lc_oracle_c.c, gcc -O3 -march=native -fopenmp, rows chunked over {cores} threads), "
-                  f"median of 3",
-        "one_thread_value": out["one_thread"]["pts_per_s"],
-        "one_thread_sample_rows": out["one_thread"]["rows"],
+        "value": all_pts, "unit": "points/s", "cores": cores, "kind": "port",
+        "sample": f"first {n} rows of the same synthetic stream, E-step + suff-stats (oracle/lc_oracle_c.c, gcc -O3 "
+                  f"-march=native -fopenmp, rows chunked over {cores} threads pinned with OMP_PROC_BIND=close "
+                  f"OMP_PLACES=cores, X read once per 128-row tile for all K), median of {reps} after 1 warm-up",
+        "dense_gflops": gf, "dense_flops_per_point": w_dense,
+        "host_fp64_peak_gflops": peak, "host_fp64_peak_is": peak_desc,
+        "frac_of_host_peak": (gf / peak) if peak else None,
+        "one_thread_value": one_pts, "one_thread_sample_rows": n, "one_thread_dense_gflops": one_pts * w_dense / 1e9,
+        "scaling_over_one_thread": all_pts / one_pts,
     }
 
 
@@ -135,9 +158,18 @@ def group_mix(cfg, gids):
     return np.stack([np.random.default_rng([cfg["seed"], int(g)]).dirichlet(np.full(cfg["K"], 0.5)) for g in gids])
 
 
-def parity(capi, cfg, wkind, mu, L, device, rows=20000, iters=3, ckind=0):
-    """Free-energy / qZ delta of the GPU path vs the numpy oracle on identical inputs
-    (the first `rows` rows of the Philox stream of every group, same initial qZ)."""
+def _qz_delta(q, qT):
+    big = qT > 1e-12
+    soft = (qT > 1e-6) & (qT < 1.0 - 1e-6)
+    return {"max_rel_dqZ": float(np.max(np.abs(q[big] - qT[big]) / qT[big])),
+            "max_abs_dqZ": float(np.max(np.abs(q - qT))),
+            "soft_entry_fraction": float(soft.mean()),
+            "max_rel_dqZ_soft": float(np.max(np.abs(q[soft] - qT[soft]) / qT[soft])) if soft.any() else None}
+
+
+def parity_numpy(capi, cfg, wkind, mu, L, device, rows=20000, iters=3, ckind=0):
+    """Grouped workloads and the separable families: F / qZ delta of the GPU path vs the numpy oracle on identical
+    inputs (the first `rows` rows of the Philox stream of every group, same initial qZ)."""
     sys.path.insert(0, str(ROOT / "oracle"))
     import lc_oracle as o
 
@@ -156,14 +188,184 @@ def parity(capi, cfg, wkind, mu, L, device, rows=20000, iters=3, ckind=0):
     wf = {"Dirichlet": o.Dirichlet, "StickBreak": o.StickBreak, "GDirichlet": o.GDirichlet}[cfg["w"]]
     cf = {"GaussWish": o.GaussWish, "NormGamma": o.NormGamma, "ExpGamma": o.ExpGamma}[cfg.get("c", "GaussWish")]
     Ftr, _, qT, _, _ = o.vbem_fixed(X, q0, wf, 1.0, iters, False, cf)
-    q, qT = np.vstack(q), np.vstack(qT)
-    big = qT > 1e-12
-    return {
-        "rows": rows, "iters": iters, "F_gpu": float(tr[-1]), "F_cpu": float(Ftr[-1]),
-        "rel_dF": float(abs(tr[-1] - Ftr[-1]) / abs(Ftr[-1])),
-        "max_rel_dqZ": float(np.max(np.abs(q[big] - qT[big]) / qT[big])),
-        "max_abs_dqZ": float(np.max(np.abs(q - qT))),
+    out = {"checker": "oracle/lc_oracle.py (numpy)", "rows": rows, "iters": iters, "F_gpu": float(tr[-1]),
+           "F_cpu": float(Ftr[-1]), "rel_dF": float(abs(tr[-1] - Ftr[-1]) / abs(Ftr[-1]))}
+    out.update(_qz_delta(np.vstack(q), np.vstack(qT)))
+    return out
+
+
+def parity_c(capi, cfg, wkind, device, rows, iters, overlap, nthreads):
+    """GPU and CPU both run the first N_par = 1e6 rows of a Philox stream from the same initial qZ for the
+    same T iterations; F and qZ are compared there.  CPU side: oracle/lc_oracle_c.c (data passes, all cores) + the
+    numpy oracle's M-step and free energy (lc_oracle_c.vbem_fixed; equal to the pure numpy oracle,
+    tests/test_oracle_c.py).  overlap=False: the workload's own mixture (hard responsibilities -- F is the meaningful
+    figure); overlap=True: components on top of each other (see mixture()), where most entries of qZ are soft."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import lc_oracle as o
+    import lc_oracle_c as oc
+
+    D, K = cfg["D"], cfg["K"]
+    seed = cfg["seed"] + (7919 if overlap else 0)
+    mu, L = mixture(D, K, seed, "GaussWish", overlap)
+    with capi.Context(device) as c2:
+        c2.synth(rows, D, K, mu, L, seed, 0, 0.9)
+        X = c2.get_rows(0, 0, rows)
+        q0 = c2.get_qz_rows(0, 0, rows)
+        F, tr, m = c2.vbem(wkind, fixed_iters=iters, nthreads=8)
+        q = c2.get_qz_rows(0, 0, rows)
+        m.close()
+    wf = {"Dirichlet": o.Dirichlet, "StickBreak": o.StickBreak, "GDirichlet": o.GDirichlet}[cfg["w"]]
+    Ftr, qT = oc.vbem_fixed(X, q0, wf, 1.0, iters, nthreads)
+    out = {"checker": "oracle/lc_oracle_c.c + numpy M-step (lc_oracle_c.vbem_fixed)", "rows": rows, "iters": iters,
+           "mixture": ("overlapping: mu ~ N(0, 0.09 I), Sigma = 0.2 B B^T / D + I" if overlap
+                       else "the workload's (SURVEY 8(d)): mu ~ N(0, 9 I), Sigma = B B^T / D + 0.5 I"),
+           "F_gpu": float(tr[-1]), "F_cpu": float(Ftr[-1]),
+           "rel_dF": float(abs(tr[-1] - Ftr[-1]) / abs(Ftr[-1])),
+           "max_rel_dF_trace": float(np.max(np.abs(np.array(tr) - np.array(Ftr)) / np.abs(Ftr)))}
+    out.update(_qz_delta(q, qT))
+    return out
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children (one process per GPU) BEFORE this
+    process touches the GPU, wait, and pass rank 0's line through."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(Path(__file__).resolve()), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.pop("OMP_PROC_BIND", None)  # (N ranks must not all pin their threads to the same cores)
+    env.pop("OMP_PLACES", None)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def setup_comm(ctx, capi, lcd, dist, torch, rank, world, local_rank, want):
+    """The statistics all-reduce of a multi-rank run.  "native": the library's own collective -- RCCL (one rank per GPU)
+    or, with the gloo test backend (several ranks on one GPU), its host-staged transport; checked with a known sum on
+    every rank before it is trusted, else (or with --comm torch) the Python hook over torch.distributed."""
+    kind, note = None, None
+    if want == "native":
+        ok = 1.0
+        try:
+            if dist.get_backend() == "nccl":
+                idt = torch.zeros(capi.COMM_ID_BYTES, dtype=torch.uint8, device="cuda")
+                if rank == 0:
+                    idt.copy_(torch.frombuffer(bytearray(capi.comm_unique_id()), dtype=torch.uint8))
+                dist.broadcast(idt, 0)
+                ctx.comm_init_rccl(bytes(idt.cpu().numpy().tobytes()), rank, world)
+            else:
+                ctx.comm_init_host(f"bench_{os.environ.get('MASTER_PORT', '0')}", rank, world)
+            got = ctx.allreduce([rank + 1.0, 1.0, -0.25 * (rank + 1)])
+            tot = 0.5 * world * (world + 1)
+            if not np.array_equal(got, [tot, float(world), -0.25 * tot]):
+                raise RuntimeError(f"all-reduce self-check returned {got.tolist()}")
+            kind = ctx.comm_info()["kind"]
+        except Exception as e:  # noqa: BLE001
+            ok, note = 0.0, f"native collective unavailable on rank {rank}: {e}"
+        flag = torch.tensor([ok], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if float(flag.item()) < 1.0:  # every rank falls back together
+            try:
+                ctx.comm_free()
+            except Exception:  # noqa: BLE001
+                pass
+            kind = None
+    if kind is None:
+        ctx.set_allreduce(lcd.make_device_hook(local_rank))
+        kind = "hook (torch.distributed " + dist.get_backend() + ")"
+    return kind, note
+
+
+def measure(capi, cfg, steps, warmup, rank, world, local_rank, stream, nthreads, comm=None, dist=None, torch=None):
+    """Synthesise the workload in HBM, run `warmup` untimed and `steps` timed VBEM iterations; returns everything the
+    JSON line needs plus the live context / model (for the CPU baseline)."""
+    N, D, K = cfg["N"], cfg["D"], cfg["K"]
+    wkind = {"Dirichlet": capi.W_DIRICHLET, "StickBreak": capi.W_STICKBREAK, "GDirichlet": capi.W_GDIRICHLET}[cfg["w"]]
+    J = cfg.get("J", 1)
+    family = cfg.get("c", "GaussWish")
+    ckind = {"GaussWish": capi.C_GAUSSWISH, "NormGamma": capi.C_NORMGAMMA, "ExpGamma": capi.C_EXPGAMMA}[family]
+    mu, L = mixture(D, K, cfg["seed"], family)
+    ctx = capi.Context(local_rank, stream)
+    if J == 1:
+        ctx.synth(N, D, K, mu, L, cfg["seed"], rank * N, 0.9)  # this rank's row block of the one stream
+    else:
+        gids = list(range(rank * J, (rank + 1) * J))  # whole groups per rank (SURVEY 8(e))
+        ctx.synth_groups([N // J] * J, D, K, mu, L, cfg["seed"], mix=group_mix(cfg, gids), group_ids=gids)
+        ctx.set_sharding(True)
+    comm_kind = comm_note = None
+    if world > 1:
+        comm_kind, comm_note = comm(ctx)
+
+    model = None
+    if warmup > 0:
+        _, _, model = ctx.vbem(wkind, fixed_iters=warmup, nthreads=nthreads, ckind=ckind)
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    if dist is not None:
+        dist.barrier()
+    if torch is not None:
+        torch.cuda.synchronize()
+    else:
+        ctx.synchronize()
+    t0 = time.perf_counter()
+    F, tr, model = ctx.vbem(wkind, fixed_iters=steps, nthreads=nthreads, model=model, ckind=ckind)
+    if torch is not None:
+        torch.cuda.synchronize()
+    else:
+        ctx.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    kt = ctx.timing_get()
+    ctx.timing_enable(False)
+
+    fl = alg_flops(N, D, K)
+    est = kt["estep_ms"] / max(1, kt["estep_calls"])
+    sst = kt["suffstat_ms"] / max(1, kt["suffstat_calls"])
+    dom = "estep_kernel" if est >= sst else "suffstat_kernel"
+    if family != "GaussWish":
+        dom = dom.replace("_kernel", "_diag_kernel")
+    dom_ms = max(est, sst)
+    dom_fl = fl["estep"] if est >= sst else fl["suffstat"]
+    achieved = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+    both = (fl["estep"] + fl["suffstat"]) / ((est + sst) * 1e-3) / 1e12 if est + sst > 0 else 0.0
+    res = {
+        "value": world * N * steps / dt, "ms_per_step": dt / steps * 1e3, "free_energy": float(F),
+        "kernels": {"estep_ms": est, "suffstat_ms": sst, "estep_calls": kt["estep_calls"],
+                    "suffstat_calls": kt["suffstat_calls"],
+                    "estep_kernel_points_per_s": N / (est * 1e-3) if est > 0 else None,
+                    "both_kernels_alg_tflops": both},
+        "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+                     "alg_flops_per_launch": dom_fl, "avg_launch_ms": dom_ms,
+                     "estep_frac": fl["estep"] / (est * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if est > 0 else None,
+                     "suffstat_frac": fl["suffstat"] / (sst * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if sst > 0 else None},
+        "config": {"workload": cfg["label"], "rows_per_gpu": N, "D": D, "K": K, "weights": cfg["w"],
+                   "seed": cfg["seed"], "groups_per_gpu": J,
+                   "parallelism": (f"rows sharded x{world}" if J == 1 else f"whole groups sharded x{world}")
+                   + ", all-reduce of suff-stats"},
     }
+    if family != "GaussWish":
+        # separable families: 8 (D + K) algorithmic bytes per row and launch (X read + q column written / read)
+        gbs = 8.0 * N * (D + K) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        res["config"]["clusters"] = family
+        res["kernels"].pop("both_kernels_alg_tflops")
+        res["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                           "alg_bytes_per_launch": 8.0 * N * (D + K), "avg_launch_ms": dom_ms}
+    if comm_kind:
+        res["config"]["collective"] = comm_kind
+        if comm_note:
+            res["config"]["collective_note"] = comm_note
+    return res, ctx, model, (wkind, ckind, mu, L, family)
 
 
 def main():
@@ -175,15 +377,20 @@ def main():
     ap.add_argument("--rows", type=int, default=0, help="override rows per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
+    ap.add_argument("--parity-rows", type=int, default=1_000_000, help="N_par of SURVEY 8(d)")
+    ap.add_argument("--comm", default="native", choices=["native", "torch"],
+                    help="multi-GPU all-reduce: the library's own RCCL collective, or the torch.distributed hook")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s)")
     import torch
 
     if os.environ.get("LC_ALL_RANKS_ON_GPU0"):  # multi-rank smoke test on a 1-GPU box
@@ -207,103 +414,67 @@ def main():
     cfg = dict(CONFIGS[args.config])
     if args.rows:
         cfg["N"] = args.rows
-    N, D, K = cfg["N"], cfg["D"], cfg["K"]
-    wkind = {"Dirichlet": capi.W_DIRICHLET, "StickBreak": capi.W_STICKBREAK, "GDirichlet": capi.W_GDIRICHLET}[cfg["w"]]
-    J = cfg.get("J", 1)
-    family = cfg.get("c", "GaussWish")
-    ckind = {"GaussWish": capi.C_GAUSSWISH, "NormGamma": capi.C_NORMGAMMA, "ExpGamma": capi.C_EXPGAMMA}[family]
-    mu, L = mixture(D, K, cfg["seed"], family)
     nthreads = max(1, min(32, (os.cpu_count() or 2) // max(1, world)))
-
     stream = torch.cuda.current_stream().cuda_stream
-    ctx = capi.Context(local_rank, stream)
-    if J == 1:
-        ctx.synth(N, D, K, mu, L, cfg["seed"], rank * N, 0.9)  # this rank's row block of the one stream
-    else:
-        gids = list(range(rank * J, (rank + 1) * J))  # whole groups per rank
-        ctx.synth_groups([N // J] * J, D, K, mu, L, cfg["seed"], mix=group_mix(cfg, gids), group_ids=gids)
-        ctx.set_sharding(True)
-    if world > 1:
-        ctx.set_allreduce(lcd.make_device_hook(local_rank))
 
-    model = None
-    if args.warmup > 0:
-        _, _, model = ctx.vbem(wkind, fixed_iters=args.warmup, nthreads=nthreads, ckind=ckind)
-    ctx.timing_enable(True)
-    ctx.timing_reset()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    F, tr, model = ctx.vbem(wkind, fixed_iters=args.steps, nthreads=nthreads, model=model, ckind=ckind)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    kt = ctx.timing_get()
-    ctx.timing_enable(False)
+    def comm(ctx):
+        return setup_comm(ctx, capi, lcd, dist, torch, rank, world, local_rank, args.comm)
 
+    res, ctx, model, (wkind, ckind, mu, L, family) = measure(capi, cfg, args.steps, args.warmup, rank, world,
+                                                              local_rank, stream, nthreads, comm, dist, torch)
     if rank == 0:
-        steps = args.steps
-        fl = alg_flops(N, D, K)
-        est = kt["estep_ms"] / max(1, kt["estep_calls"])
-        sst = kt["suffstat_ms"] / max(1, kt["suffstat_calls"])
-        dom = "estep_kernel" if est >= sst else "suffstat_kernel"
-        if family != "GaussWish":
-            dom = dom.replace("_kernel", "_diag_kernel")
-        dom_ms = max(est, sst)
-        dom_fl = fl["estep"] if est >= sst else fl["suffstat"]
-        achieved = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-        both = (fl["estep"] + fl["suffstat"]) / ((est + sst) * 1e-3) / 1e12 if est + sst > 0 else 0.0
-        traffic = None  # HBM bytes per launch of the dominant kernel, from the committed PMC passes (not live)
-        tf = ROOT / "profiles" / "r01_pmc_traffic.json"
-        if tf.exists() and not args.rows:
-            traffic = json.loads(tf.read_text()).get(args.config, {}).get(dom)
+        tf = ROOT / "profiles" / "r02_pmc_traffic.json"  # HBM bytes per launch from the committed PMC passes (not live)
+        if not tf.exists():
+            tf = ROOT / "profiles" / "r01_pmc_traffic.json"
+        traffic = json.loads(tf.read_text()) if tf.exists() else {}
+        if not args.rows:
+            res["roofline"]["traffic"] = traffic.get(args.config, {}).get(res["roofline"]["kernel"])
         line = {
             "metric": "E-step data-points/sec (full VBEM iteration: suff-stats + M-step + E-step)",
-            "value": world * N * steps / dt,
-            "unit": "points/s",
-            "n_gpus": world,
-            "steps": steps,
-            "warmup": args.warmup,
-            "ms_per_step": dt / steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": cfg["label"], "rows_per_gpu": N, "D": D, "K": K, "weights": cfg["w"],
-                       "seed": cfg["seed"], "groups_per_gpu": J,
-                       "parallelism": (f"rows sharded x{world}" if J == 1 else f"whole groups sharded x{world}")
-                       + ", all-reduce of suff-stats"},
-            "free_energy": float(F),
-            "kernels": {"estep_ms": est, "suffstat_ms": sst, "estep_calls": kt["estep_calls"],
-                        "suffstat_calls": kt["suffstat_calls"],
-                        "estep_kernel_points_per_s": N / (est * 1e-3) if est > 0 else None,
-                        "both_kernels_alg_tflops": both},
-            "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
-                         "alg_flops_per_launch": dom_fl, "avg_launch_ms": dom_ms},
+            "value": res["value"], "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic", "config": res["config"], "free_energy": res["free_energy"],
+            "kernels": res["kernels"], "roofline": res["roofline"],
         }
-        if family != "GaussWish":
-            # separable families: 8 (D + K) algorithmic bytes per row and launch (X read + q column written / read)
-            gbs = 8.0 * N * (D + K) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-            line["config"]["clusters"] = family
-            line["kernels"].pop("both_kernels_alg_tflops")
-            line["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
-                                "alg_bytes_per_launch": 8.0 * N * (D + K), "avg_launch_ms": dom_ms}
+        N, D, K = cfg["N"], cfg["D"], cfg["K"]
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = (cpu_baseline(ctx, model, cfg, cfg["w"], args.cpu_sample_rows)
-                                    if family == "GaussWish" else
+            line["cpu_baseline"] = (cpu_baseline(ctx, model, cfg, args.cpu_sample_rows) if family == "GaussWish" else
                                     cpu_baseline_family(ctx, cfg, min(args.cpu_sample_rows, 400_000)))
         if world == 1 and not args.no_parity:
-            line["parity"] = parity(capi, cfg, wkind, mu, L, local_rank, ckind=ckind)
+            if family == "GaussWish" and cfg.get("J", 1) == 1:
+                sys.path.insert(0, str(ROOT / "oracle"))
+                import lc_oracle_c as oc
+
+                rows = min(args.parity_rows, N)
+                nt = oc.physical_cores()
+                line["parity"] = parity_c(capi, cfg, wkind, local_rank, rows, 3, False, nt)
+                line["parity_overlap"] = parity_c(capi, cfg, wkind, local_rank, rows, 3, True, nt)
+            else:
+                line["parity"] = parity_numpy(capi, cfg, wkind, mu, L, local_rank, ckind=ckind)
+        if world == 1 and args.config == "northstar" and not args.rows and not args.no_other_configs:
+            # the other BASELINE configurations and the separable families, 5 timed steps each: driver-visible
+            # ms_per_step / roofline of the kernels that are NOT on the headline line
+            if model is not None:
+                model.close()
+            ctx.close()
+            ctx = model = None
+            others = []
+            for name in OTHER_CONFIGS:
+                c2 = dict(CONFIGS[name])
+                r2, x2, m2, _ = measure(capi, c2, 5, 1, 0, 1, local_rank, stream, nthreads, None, None, torch)
+                r2["roofline"]["traffic"] = traffic.get(name, {}).get(r2["roofline"]["kernel"])
+                others.append({"config": name, "workload": c2["label"], "steps": 5, "warmup": 1,
+                               "value": r2["value"], "ms_per_step": r2["ms_per_step"], "kernels": r2["kernels"],
+                               "roofline": r2["roofline"]})
+                if m2 is not None:
+                    m2.close()
+                x2.close()
+            line["other_configs"] = others
         print(json.dumps(line), flush=True)
+    if model is not None:
+        model.close()
+    if ctx is not None:
+        ctx.close()  # (destroys the RCCL communicator while the process group is still up)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

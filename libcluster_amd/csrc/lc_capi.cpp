@@ -259,6 +259,8 @@ double learn_sharded(int algo, int J, const double* const* Xj, const int64_t* Nj
       co.nthreads = std::max(1u, nthreads / (unsigned)W);
       co.trace = &traces[(size_t)r];
       Fs[(size_t)r] = lce::cluster(ctx, model, co);
+      ctx.synchronize();
+      lcc::cache_release_thread();  // this thread ends here: its cached blocks may serve other threads from now on
     } catch (...) {
       errs[(size_t)r] = std::current_exception();
       for (auto& c : comms) c->abort();  // the other shards fail in their next collective instead of waiting

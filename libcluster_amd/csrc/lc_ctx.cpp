@@ -29,20 +29,28 @@ struct BlockCache {
     void* p;
     size_t bytes;
     int device;
+    size_t owner;  // host thread that released it (0: anybody).  A thread works on ONE stream, so handing a block back
+                   // to the thread that freed it is ordered by that stream; another thread (LIBCLUSTER_GPUS: another
+                   // stream) may only take it once the owner has let go of it (cache_release_thread, after a sync)
   };
   std::mutex m;
   std::vector<Block> dev, pinned;
   size_t dev_bytes = 0;
+  static size_t thread_tag() {
+    const size_t h = std::hash<std::thread::id>()(std::this_thread::get_id());
+    return h ? h : 1;
+  }
   static BlockCache& get() {
     static BlockCache* c = new BlockCache();  // intentionally leaked
     return *c;
   }
   void* take(std::vector<Block>& v, size_t need, int device, size_t* got) {
     std::lock_guard<std::mutex> g(m);
+    const size_t me = thread_tag();
     int best = -1;
     for (int i = 0; i < (int)v.size(); ++i)
       if (v[i].device == device && v[i].bytes >= need && v[i].bytes <= 2 * need + 4096 &&
-          (best < 0 || v[i].bytes < v[best].bytes))
+          (v[i].owner == 0 || v[i].owner == me) && (best < 0 || v[i].bytes < v[best].bytes))
         best = i;
     if (best < 0) return nullptr;
     void* p = v[best].p;
@@ -60,6 +68,16 @@ int current_device() {
   return d;
 }
 }  // namespace
+
+void cache_release_thread() {
+  BlockCache& c = BlockCache::get();
+  const size_t me = BlockCache::thread_tag();
+  std::lock_guard<std::mutex> g(c.m);
+  for (auto& b : c.dev)
+    if (b.owner == me) b.owner = 0;
+  for (auto& b : c.pinned)
+    if (b.owner == me) b.owner = 0;
+}
 
 void trim_cache() {
   BlockCache& c = BlockCache::get();
@@ -80,7 +98,7 @@ void DevBuf<T>::release() {
     if (bytes <= DEV_BLOCK_LIMIT) {
       std::lock_guard<std::mutex> g(c.m);
       if (c.dev_bytes + bytes <= DEV_CACHE_LIMIT && c.dev.size() < 4096) {
-        c.dev.push_back({p, bytes, device >= 0 ? device : current_device()});
+        c.dev.push_back({p, bytes, device >= 0 ? device : current_device(), BlockCache::thread_tag()});
         c.dev_bytes += bytes;
         kept = true;
       }
@@ -120,7 +138,7 @@ PinnedBuf::~PinnedBuf() {
   if (!p) return;
   BlockCache& c = BlockCache::get();
   std::lock_guard<std::mutex> g(c.m);
-  if (c.pinned.size() < 256) c.pinned.push_back({p, cap * sizeof(double), 0});
+  if (c.pinned.size() < 256) c.pinned.push_back({p, cap * sizeof(double), 0, BlockCache::thread_tag()});
   else (void)hipHostFree(p);
 }
 
@@ -129,7 +147,7 @@ void PinnedBuf::resize(size_t count) {
     BlockCache& c = BlockCache::get();
     if (p) {
       std::lock_guard<std::mutex> g(c.m);
-      c.pinned.push_back({p, cap * sizeof(double), 0});
+      c.pinned.push_back({p, cap * sizeof(double), 0, BlockCache::thread_tag()});
     }
     p = nullptr;
     cap = 0;
@@ -907,6 +925,7 @@ void Context::suffstat(const unsigned char* smask, double* Nk, double* xs, doubl
   const size_t nout = (size_t)K * SS + (size_t)J_ * K;
   ssout_.reserve(nout);
   double* njk_d = ssout_.p + (size_t)K * SS;
+  const bool own_counts = J_ > 1 || group_sharded() || smask != nullptr;  // N_jk from a column-sum pass of their own
   if (NP_ > 0) {
     int64_t chunk_rows = 0;
     const int nchunks = lck::suffstat_plan(DP, NP_, K, &chunk_rows);
@@ -980,12 +999,16 @@ void Context::suffstat(const unsigned char* smask, double* Nk, double* xs, doubl
       LC_HIP(hipMemcpyAsync(ssout_.p, ssext_.p, (size_t)K * SS * sizeof(double), hipMemcpyDeviceToDevice, stream_));
     } else
       LC_HIP(lck::launch_reduce_partials(sspart_.p, nchunks, (int64_t)K * SS, ssout_.p, stream_));
-    // per-group counts N_jk: with one group they are the N_k just reduced (filled in on the host below)
-    if (J_ > 1) {
+    // per-group counts N_jk: with one group they are the N_k just reduced (filled in on the host below) -- unless the
+    // records are about to be summed over ranks that hold OTHER groups, or a mask removes clusters from them
+    if (own_counts) {
       redtmp_.reserve((size_t)lck::REDUCE_TMP_ELEMS * 64);
       LC_HIP(lck::launch_group_colsum(qz_[cur_].buf.p, NP_, K, goff_d_.p, J_, njk_d, stream_, redtmp_.p, NP_));
     }
     else LC_HIP(hipMemsetAsync(njk_d, 0, (size_t)K * sizeof(double), stream_));
+    if (smask && J_ == 1)  // single group: a masked cluster receives nothing from it (cluster.cpp:67-70)
+      for (int k = 0; k < K; ++k)
+        if (!smask[k]) LC_HIP(hipMemsetAsync(ssout_.p + (size_t)k * SS, 0, (size_t)SS * sizeof(double), stream_));
   } else {
     LC_HIP(hipMemsetAsync(ssout_.p, 0, nout * sizeof(double), stream_));
   }
@@ -997,7 +1020,7 @@ void Context::suffstat(const unsigned char* smask, double* Nk, double* xs, doubl
   LC_HIP(hipStreamSynchronize(stream_));
   for (int k = 0; k < K; ++k) {
     const double* rec = hss_.data() + (size_t)k * SS;
-    const bool off = smask && J_ == 1 && !smask[k];
+    const bool off = false;  // (a single group's masked clusters were zeroed on the device, before the sum over ranks)
     if (Nk) Nk[k] = off ? 0.0 : rec[0];
     if (xs)
       for (int d = 0; d < D; ++d) xs[(size_t)k * D + d] = off ? 0.0 : rec[1 + d];
@@ -1014,7 +1037,7 @@ void Context::suffstat(const unsigned char* smask, double* Nk, double* xs, doubl
     }
   }
   if (Njk) {
-    if (J_ == 1)  // qZ.colwise().sum() of the only group == the (unmasked) N_k record
+    if (!own_counts)  // qZ.colwise().sum() of the only group == the N_k record
       for (int k = 0; k < K; ++k) Njk[k] = hss_[(size_t)k * SS];
     else
       std::copy(hss_.begin() + (size_t)K * SS, hss_.end(), Njk);
@@ -1124,6 +1147,7 @@ void Context::suffstat_diag(const unsigned char* smask, double* Nk, double* xs, 
   const size_t nout = (size_t)K * SS + (size_t)J_ * K;
   ssout_.reserve(nout);
   double* njk_d = ssout_.p + (size_t)K * SS;
+  const bool own_counts = J_ > 1 || group_sharded() || smask != nullptr;
   if (NP_ > 0) {
     // about four blocks per resident slot (2 blocks per CU), whole 32-row batches; the partial records
     // (chunks x row classes x K x (1 + 2 DP) doubles) stay small next to the data
@@ -1166,11 +1190,14 @@ void Context::suffstat_diag(const unsigned char* smask, double* Nk, double* xs, 
       pending_.push_back(ev);
     }
     LC_HIP(lck::launch_reduce_partials(sspart_.p, nparts, (int64_t)K * SS, ssout_.p, stream_));
-    if (J_ > 1) {
+    if (own_counts) {
       redtmp_.reserve((size_t)lck::REDUCE_TMP_ELEMS * 64);
       LC_HIP(lck::launch_group_colsum(qz_[cur_].buf.p, NP_, K, goff_d_.p, J_, njk_d, stream_, redtmp_.p, NP_));
     }
     else LC_HIP(hipMemsetAsync(njk_d, 0, (size_t)K * sizeof(double), stream_));
+    if (smask && J_ == 1)
+      for (int k = 0; k < K; ++k)
+        if (!smask[k]) LC_HIP(hipMemsetAsync(ssout_.p + (size_t)k * SS, 0, (size_t)SS * sizeof(double), stream_));
   } else {
     LC_HIP(hipMemsetAsync(ssout_.p, 0, nout * sizeof(double), stream_));
   }
@@ -1180,7 +1207,7 @@ void Context::suffstat_diag(const unsigned char* smask, double* Nk, double* xs, 
   LC_HIP(hipStreamSynchronize(stream_));
   for (int k = 0; k < K; ++k) {
     const double* rec = hss_.data() + (size_t)k * SS;
-    const bool off = smask && J_ == 1 && !smask[k];
+    const bool off = false;  // (see suffstat)
     if (Nk) Nk[k] = off ? 0.0 : rec[0];
     for (int d = 0; d < D; ++d) {
       if (xs) xs[(size_t)k * D + d] = off ? 0.0 : rec[1 + d];
@@ -1188,7 +1215,7 @@ void Context::suffstat_diag(const unsigned char* smask, double* Nk, double* xs, 
     }
   }
   if (Njk) {
-    if (J_ == 1)
+    if (!own_counts)
       for (int k = 0; k < K; ++k) Njk[k] = hss_[(size_t)k * SS];
     else
       std::copy(hss_.begin() + (size_t)K * SS, hss_.end(), Njk);

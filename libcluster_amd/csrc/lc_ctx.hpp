@@ -67,6 +67,9 @@ struct RowSelection {
 
 // return every cached device / page-locked block to the driver
 void trim_cache();
+// Cached blocks are handed back only to the host thread that released them (one thread = one stream = ordered re-use).
+// A thread that is about to end calls this AFTER synchronising its stream: its blocks become available to everybody.
+void cache_release_thread();
 
 struct KernelTimes {
   double estep_ms = 0, suffstat_ms = 0;

@@ -130,7 +130,13 @@ int lco_estep(const double* X, int64_t N, int D, int K, const double* nu, const 
 
 /* Suff-stats.  qZ: N x K row-major.  Nk[K], xs[K*D], xxs[K*D*D] are
  * overwritten.  Per cluster: qX = diag(q_k) X (an N x D temporary in the
- * reference), N_s += sum q, x_s += colsum(qX), xx_s += qX^T X. */
+ * reference), N_s += sum q, x_s += colsum(qX), xx_s += qX^T X (the full D x D
+ * product, as Eigen computes it).  Row-parallel structure: every thread owns a
+ * contiguous block of rows and walks it in tiles of TB rows; a tile of X is
+ * read ONCE and serves all K clusters (the per-thread accumulators, K records,
+ * stream from L2/L3), so the pass is bound by the FMAs, not by re-reading X K
+ * times as a literal per-cluster loop over all rows would be. */
+#define TB 128 /* rows per tile: 64 KB of X at D = 64 stays in L2 across the K clusters */
 int lco_suffstat(const double* X, const double* qZ, int64_t N, int D, int K, double* Nk, double* xs, double* xxs,
                  int nthreads) {
   const size_t SS = 1 + (size_t)D + (size_t)D * D;
@@ -146,17 +152,17 @@ int lco_suffstat(const double* X, const double* qZ, int64_t N, int D, int K, dou
 #else
     const int tid = 0, nth = 1;
 #endif
-    const int64_t ntile = (N + RB - 1) / RB;
+    const int64_t ntile = (N + TB - 1) / TB;
     const int64_t t0 = ntile * tid / nth, t1 = ntile * (tid + 1) / nth;
     double* my = acc + (size_t)tid * K * SS;
-    for (int k = 0; k < K; ++k) { /* one "addobs" per cluster, cluster.cpp:75-79 */
-      double* a = my + (size_t)k * SS;
-      double* ax = a + 1;
-      double* axx = a + 1 + D;
-      for (int64_t t = t0; t < t1; ++t) {
-        const int64_t r0 = t * RB;
-        const int nr = (int)((N - r0) < RB ? (N - r0) : RB);
-        double qx[RB][128]; /* qZkX = qZk.asDiagonal() * X, distributions.cpp:308 */
+    double(*qx)[128] = (double(*)[128])malloc(sizeof(double) * TB * 128); /* qZkX = qZk.asDiagonal() * X, distributions.cpp:308 */
+    for (int64_t t = t0; t < t1 && qx; ++t) {
+      const int64_t r0 = t * TB;
+      const int nr = (int)((N - r0) < TB ? (N - r0) : TB);
+      for (int k = 0; k < K; ++k) { /* one "addobs" per cluster, cluster.cpp:75-79 */
+        double* a = my + (size_t)k * SS;
+        double* ax = a + 1;
+        double* axx = a + 1 + D;
         for (int r = 0; r < nr; ++r) {
           const double q = qZ[(size_t)(r0 + r) * K + k];
           const double* x = X + (size_t)(r0 + r) * D;
@@ -166,8 +172,27 @@ int lco_suffstat(const double* X, const double* qZ, int64_t N, int D, int K, dou
             ax[i] += qx[r][i];
           }
         }
-        /* xx_s += qZkX^T * X (:312): row i of the accumulator stays hot over the tile's rows */
-        for (int i = 0; i < D; ++i) {
+        /* xx_s += qZkX^T * X (:312): 4 rows of the accumulator at a time share every load of x */
+        int i = 0;
+        for (; i + 4 <= D; i += 4) {
+          double* w0 = axx + (size_t)i * D;
+          double* w1 = w0 + D;
+          double* w2 = w1 + D;
+          double* w3 = w2 + D;
+          for (int r = 0; r < nr; ++r) {
+            const double v0 = qx[r][i], v1 = qx[r][i + 1], v2 = qx[r][i + 2], v3 = qx[r][i + 3];
+            const double* x = X + (size_t)(r0 + r) * D;
+#pragma omp simd
+            for (int j = 0; j < D; ++j) {
+              const double xj = x[j];
+              w0[j] += v0 * xj;
+              w1[j] += v1 * xj;
+              w2[j] += v2 * xj;
+              w3[j] += v3 * xj;
+            }
+          }
+        }
+        for (; i < D; ++i) {
           double* row = axx + (size_t)i * D;
           for (int r = 0; r < nr; ++r) {
             const double v = qx[r][i];
@@ -178,11 +203,18 @@ int lco_suffstat(const double* X, const double* qZ, int64_t N, int D, int K, dou
         }
       }
     }
+    free(qx);
   }
   for (int k = 0; k < K; ++k) {
     Nk[k] = 0.0;
     memset(xs + (size_t)k * D, 0, sizeof(double) * D);
     memset(xxs + (size_t)k * D * D, 0, sizeof(double) * (size_t)D * D);
+  }
+  /* fold the per-thread records in thread order (deterministic), clusters in parallel */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(nt)
+#endif
+  for (int k = 0; k < K; ++k) {
     for (int t = 0; t < nt; ++t) {
       const double* a = acc + ((size_t)t * K + k) * SS;
       Nk[k] += a[0];

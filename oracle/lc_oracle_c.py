@@ -87,3 +87,54 @@ def suffstat(X, qZ, nthreads=1):
     if rc:
         raise MemoryError
     return Nk, xs, xxs
+
+
+def vbem_fixed(X, qZ0, wfactory, clusterprior, iters, nthreads=1):
+    """``iters`` VBEM iterations of cluster.cpp:198-234 on ONE group with Gauss-Wishart clusters: the two data passes
+    (updateSS / vbexpectation) by the C port above with rows chunked over ``nthreads``, the M-step, the weights and
+    the free energy by the numpy oracle (lc_oracle.py).  Same results as lc_oracle.vbem_fixed (tests/test_oracle_c.py)
+    at sizes the numpy oracle cannot run in seconds.  Returns (F trace, qZ)."""
+    import lc_oracle as o
+
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    D, K = X.shape[1], qZ0.shape[1]
+    w = wfactory()
+    clusters = [o.GaussWish(clusterprior, D) for _ in range(K)]
+    q = np.ascontiguousarray(qZ0, dtype=np.float64)
+    Ftrace = []
+    for _ in range(iters):
+        Nk, xs, xxs = suffstat(X, q, nthreads)
+        for k, c in enumerate(clusters):
+            c.clearobs()
+            c.addstats(Nk[k], xs[k], xxs[k])
+        w.update(Nk)  # Njk = qZ.colwise().sum() of the only group (cluster.cpp:62, 211)
+        for c in clusters:
+            c.update()
+        q, Fz = estep(X, [c.nu for c in clusters], [c.beta for c in clusters], np.stack([c.m for c in clusters]),
+                      np.stack([c.iW for c in clusters]), [c.logdW for c in clusters], w.Elogweight(), nthreads)
+        Ftrace.append(o.fenergy([w], clusters, Fz))
+    return Ftrace, q
+
+
+def host_fp64_peak_gflops(cores: int):
+    """Nominal fp64 peak of `cores` cores of this host: cores x max clock x flop per cycle (two 512-bit FMA pipes = 32
+    with AVX-512 as on Zen 4/5 and recent Xeons, 16 with AVX2).  Returns (GFLOP/s, description) -- an upper bound for
+    putting the measured CPU rate in proportion, not a measurement."""
+    flags, mhz = "", 0.0
+    try:
+        txt = Path("/proc/cpuinfo").read_text()
+        for line in txt.splitlines():
+            if line.startswith("flags") and not flags:
+                flags = line
+        for p in ("/sys/devices/system/cpu/cpu0/cpufreq/cpuinfo_max_freq",):
+            if Path(p).exists():
+                mhz = float(Path(p).read_text()) / 1e3
+        if not mhz:
+            vals = [float(l.split(":")[1]) for l in txt.splitlines() if l.startswith("cpu MHz")]
+            mhz = max(vals) if vals else 0.0
+    except (OSError, ValueError):
+        pass
+    per_cycle = 32 if "avx512f" in flags else 16
+    if not mhz:
+        return None, "clock unknown"
+    return cores * mhz * 1e-3 * per_cycle, f"{cores} cores x {mhz / 1e3:.2f} GHz x {per_cycle} flop/cycle"

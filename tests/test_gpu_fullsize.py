@@ -223,3 +223,141 @@ def test_rows_beyond_32bit_element_indices():
     np.testing.assert_allclose(dtot[1], dxs, rtol=1e-9, atol=1e-5)
     np.testing.assert_allclose(dtot[2], dxxs, rtol=1e-9, atol=1e-4)
     assert abs(tFz - Fz) <= 1e-11 * abs(Fz) and abs(tdFz - dFz) <= 1e-11 * abs(dFz)
+
+
+def test_config4_full_80M_rows_on_one_gpu():
+    """BASELINE configs[3] at its FULL size on one GPU: BGMM (Dirichlet weights), N = 80M, D = 64, K = 32 -- 41 GB of X
+    and 20.5 GB of qZ resident (the 8-GPU run shards exactly these rows, 10M per rank, and sums the statistics).
+    Size-independent properties: unit row sums, a prefix bit-identical to a stand-alone run and equal to the oracle,
+    exactly symmetric statistics, and SHARD ADDITIVITY over the eight 10M-row Philox shards the 8-GPU run would hold:
+    statistics, N_k and F_z of the shards add up to the unsharded values (what the all-reduce computes); F does not
+    increase over VBEM iterations with the Dirichlet weights."""
+    N, D, K, seed, S = 80_000_000, 64, 32, 1004, 8
+    mu, L = _mixture(D, K, seed)
+    P = 4096
+    with capi.Context(0) as ctx:
+        ctx.synth(N, D, K, mu, L, seed, 0, 0.9)
+        Xp = ctx.get_rows(0, 0, P)
+        Xt = ctx.get_rows(0, N - P, P)  # rows past 2^32 elements of X
+        Nk, xs, xxs, Njk = ctx.suffstat()
+        assert abs(Nk.sum() - N) <= 1e-9 * N
+        assert np.array_equal(xxs, np.transpose(xxs, (0, 2, 1)))
+        np.testing.assert_array_equal(Njk[0], Nk)
+        post = [capi.gw_mstep(1.0, Nk[k], xs[k], xxs[k]) for k in range(K)]
+        elog, _ = capi.weights_update(capi.W_DIRICHLET, Nk)
+        args = ([p["nu"] for p in post], [p["beta"] for p in post], np.stack([p["m"] for p in post]),
+                np.stack([p["iW"] for p in post]), [p["logdW"] for p in post], elog[None, :])
+        Fz, _ = ctx.estep_posterior(*args, want_ll=False)
+        qp = ctx.get_qz_rows(0, 0, P)
+        qt = ctx.get_qz_rows(0, N - P, P)
+        colsum = ctx.colsums()[0]
+        Nk2, xs2, xxs2, _ = ctx.suffstat()  # statistics of the NEW responsibilities (what iteration 2 starts from)
+        F, tr, m = ctx.vbem(capi.W_DIRICHLET, fixed_iters=2, nthreads=16)
+        m.close()
+    assert abs(colsum.sum() - N) <= 1e-9 * N
+    np.testing.assert_allclose(qp.sum(axis=1), 1.0, rtol=1e-12)
+    np.testing.assert_allclose(qt.sum(axis=1), 1.0, rtol=1e-12)
+    assert np.all(np.diff(tr) <= 1e-9 * abs(tr[0]))
+
+    for Xs, qs in ((Xp, qp), (Xt, qt)):  # first and last rows: bit-identical to a stand-alone run
+        with capi.Context(0) as c2:
+            c2.set_data(Xs)
+            c2.estep_posterior(*args, want_ll=False)
+            np.testing.assert_array_equal(qs, c2.get_qz([P])[0])
+    cl = []
+    for k in range(K):
+        g = o.GaussWish(1.0, D)
+        g.nu, g.beta, g.m, g.iW, g.logdW = (post[k]["nu"], post[k]["beta"], post[k]["m"], post[k]["iW"],
+                                            post[k]["logdW"])
+        cl.append(g)
+    w = o.Dirichlet()
+    w.E_logpi, w.Nk = elog, Nk
+    qref, _ = o.vbexpectation(Xp, w, cl)
+    big = qref > 1e-12
+    assert np.max(np.abs(qp[big] - qref[big]) / qref[big]) < 1e-9
+
+    part = N // S
+    tot, tot2, tFz = None, None, 0.0
+    for r in range(S):
+        with capi.Context(0) as cs:
+            cs.synth(part, D, K, mu, L, seed, r * part, 0.9)  # rank r's rows of the one stream
+            st = cs.suffstat()[:3]
+            fz, _ = cs.estep_posterior(*args, want_ll=False)
+            st2 = cs.suffstat()[:3]
+        tFz += fz
+        tot = st if tot is None else tuple(a + b for a, b in zip(tot, st))
+        tot2 = st2 if tot2 is None else tuple(a + b for a, b in zip(tot2, st2))
+    np.testing.assert_allclose(tot[0], Nk, rtol=1e-12)
+    np.testing.assert_allclose(tot[1], xs, rtol=1e-9, atol=1e-5)
+    np.testing.assert_allclose(tot[2], xxs, rtol=1e-9, atol=1e-4)
+    np.testing.assert_allclose(tot2[0], Nk2, rtol=1e-11)
+    np.testing.assert_allclose(tot2[1], xs2, rtol=1e-9, atol=1e-5)
+    np.testing.assert_allclose(tot2[2], xxs2, rtol=1e-9, atol=1e-4)
+    assert abs(tFz - Fz) <= 1e-11 * abs(Fz)
+
+
+def test_config5_per_gpu_size_gmc():
+    """BASELINE configs[4] at the size ONE of its eight GPUs holds: GMC (one GDirichlet per group), 8 groups x 500k
+    rows, D = 128, K = 64.  The property set of test_full_size_properties for grouped data: per-group counts add up to
+    the group sizes, statistics exactly symmetric, unit row sums, a 512-row prefix of EVERY group (4096 rows) equal to
+    the oracle's vbexpectation with that group's GDirichlet weights and bit-identical to a stand-alone run,
+    additivity over whole-group shards (the multi-GPU partition of SURVEY 8(e): N_jk stay local, cluster statistics
+    and F_z add up), non-increasing F."""
+    J, NJ, D, K, seed = 8, 500_000, 128, 64, 1005
+    mu, L = _mixture(D, K, seed)
+    mix = np.stack([np.random.default_rng([seed, g]).dirichlet(np.full(K, 0.5)) for g in range(J)])
+    P = 512
+    with capi.Context(0) as ctx:
+        ctx.synth_groups([NJ] * J, D, K, mu, L, seed, mix=mix, group_ids=list(range(J)))
+        Xp = [ctx.get_rows(j, 0, P) for j in range(J)]
+        Nk, xs, xxs, Njk = ctx.suffstat()
+        np.testing.assert_allclose(Njk.sum(axis=1), NJ, rtol=1e-9)      # rows of the initial qZ sum to 1, per group
+        np.testing.assert_allclose(Njk.sum(axis=0), Nk, rtol=1e-12)
+        assert np.array_equal(xxs, np.transpose(xxs, (0, 2, 1)))
+        post = [capi.gw_mstep(1.0, Nk[k], xs[k], xxs[k]) for k in range(K)]
+        elog = np.stack([capi.weights_update(capi.W_GDIRICHLET, Njk[j])[0] for j in range(J)])
+        args = ([p["nu"] for p in post], [p["beta"] for p in post], np.stack([p["m"] for p in post]),
+                np.stack([p["iW"] for p in post]), [p["logdW"] for p in post], elog)
+        Fz, _ = ctx.estep_posterior(*args, want_ll=False)
+        qp = [ctx.get_qz_rows(j, 0, P) for j in range(J)]
+        cols = ctx.colsums()
+        F, tr, m = ctx.vbem(capi.W_GDIRICHLET, fixed_iters=3, nthreads=16)
+        m.close()
+    np.testing.assert_allclose(cols.sum(axis=1), NJ, rtol=1e-9)
+    for q in qp:
+        np.testing.assert_allclose(q.sum(axis=1), 1.0, rtol=1e-12)
+    assert np.all(np.diff(tr) <= 1e-9 * abs(tr[0]))
+
+    with capi.Context(0) as c2:  # the 8 x 512 prefix rows as a data set of their own: identical rows
+        c2.set_data(Xp)
+        c2.estep_posterior(*args, want_ll=False)
+        for a, b in zip(qp, c2.get_qz([P] * J)):
+            np.testing.assert_array_equal(a, b)
+    cl = []
+    for k in range(K):
+        g = o.GaussWish(1.0, D)
+        g.nu, g.beta, g.m, g.iW, g.logdW = (post[k]["nu"], post[k]["beta"], post[k]["m"], post[k]["iW"],
+                                            post[k]["logdW"])
+        cl.append(g)
+    for j in range(J):  # against the oracle, with group j's own weights
+        w = o.GDirichlet()
+        w.update(Njk[j])
+        np.testing.assert_allclose(w.Elogweight(), elog[j], rtol=1e-10, atol=1e-12)
+        qref, _ = o.vbexpectation(Xp[j], w, cl)
+        big = qref > 1e-12
+        assert np.max(np.abs(qp[j][big] - qref[big]) / qref[big]) < 1e-9
+
+    tot, tFz = None, 0.0
+    for gs in ([0, 1, 2], [3, 4], [5, 6, 7]):  # whole groups per shard
+        with capi.Context(0) as cs:
+            cs.synth_groups([NJ] * len(gs), D, K, mu, L, seed, mix=mix[gs], group_ids=gs)
+            st = cs.suffstat()
+            np.testing.assert_allclose(st[3], Njk[gs], rtol=1e-12)  # the per-group counts are local
+            sub = tuple(a[gs] if i == 5 else a for i, a in enumerate(args))
+            fz, _ = cs.estep_posterior(*sub, want_ll=False)
+        tFz += fz
+        tot = st[:3] if tot is None else tuple(a + b for a, b in zip(tot, st[:3]))
+    np.testing.assert_allclose(tot[0], Nk, rtol=1e-12)
+    np.testing.assert_allclose(tot[1], xs, rtol=1e-9, atol=1e-5)
+    np.testing.assert_allclose(tot[2], xxs, rtol=1e-9, atol=1e-4)
+    assert abs(tFz - Fz) <= 1e-11 * abs(Fz)
