@@ -414,7 +414,7 @@ def main():
     cfg = dict(CONFIGS[args.config])
     if args.rows:
         cfg["N"] = args.rows
-    nthreads = max(1, min(32, (os.cpu_count() or 2) // max(1, world)))
+    nthreads = max(1, min(32, len(os.sched_getaffinity(0)) // max(1, world)))  # host M-step threads of this rank
     stream = torch.cuda.current_stream().cuda_stream
 
     def comm(ctx):
