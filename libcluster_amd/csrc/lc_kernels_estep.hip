@@ -18,6 +18,13 @@
 //   D[i][j] of block blk : j = lo2, i = hi
 #include "lc_device.hpp"
 
+// log q~ on chip for the k-sliced scheme (LQW below): measured at the north-star shape 23.8 ms against 22.9 ms for the
+// round trip through the qZ buffer (two waves per SIMD instead of three cost more than the 5 GB of traffic they save:
+// the kernel is bound by the matrix pipe, not by HBM) -- off by default, LC_ES_LQW=1 selects it
+#ifndef LC_ES_LQW_DEFAULT
+#define LC_ES_LQW_DEFAULT 0
+#endif
+
 namespace lck {
 
 // ===========================================================================
@@ -65,9 +72,16 @@ __device__ __forceinline__ void static_for(F&& f) {
 // three waves per SIMD measured 22.2 ms against 22.6 for four row groups at two waves per SIMD (N=10M, K=32).
 template <int DP>
 struct EstepOcc { static constexpr int BLOCKS = DP == 64 ? 3 : 2; };
+// waves per block of the standard variant (EstepCfg below): what estep_grid and the partial slots are sized for
+template <int DP>
+struct EstepWavesStd { static constexpr int W = DP >= 112 ? 8 : 4; };
 
-template <int DP, int R, int WAVES, bool SPARSE>
-__global__ void __launch_bounds__(WAVES * 64, EstepOcc<DP>::BLOCKS) estep_kernel(EstepLaunch a) {
+// LQW (k-sliced scheme, R < 4): log q~ waits for the normalisation in LDS, in per-lane slots [K/4][R][64] of the wave
+// (the lane that wrote a value is the lane that reads it back: no barrier), instead of making a round trip through the
+// qZ buffer -- the kernel then reads X once and writes q once.  12 KB per wave at K = 32, R = 3: one block of eight
+// waves per CU next to the 36 KB parameter ring (two waves per SIMD instead of three).
+template <int DP, int R, int WAVES, bool SPARSE, bool LQW = false>
+__global__ void __launch_bounds__(WAVES * 64, LQW ? 2 : EstepOcc<DP>::BLOCKS) estep_kernel(EstepLaunch a) {
   constexpr int NT = DP / 4;
   constexpr int NTILES = NT * (NT + 1) / 2;
   constexpr int NREAD = NTILES + NT;  // LDS reads per cluster
@@ -84,7 +98,10 @@ __global__ void __launch_bounds__(WAVES * 64, EstepOcc<DP>::BLOCKS) estep_kernel
   // LDS for the normalisation, [K][threads], instead of making a round trip through the qZ buffer
   double* lql = fzw + WAVES;
   const bool lqm = R == 4 && a.lq_lds != 0;
-  int* klist = reinterpret_cast<int*>(lql + (lqm ? (size_t)a.K * NTHR : 0));  // sparse mode: [K] active clusters of this block, [K] flags,
+  const int KQ = (a.K + 3) / 4;
+  // this lane's slots of the wave's log q~ table: slot (k / 4, r) holds cluster k of row group r for hi == (k & 3)
+  double* lqw = lql + ((size_t)(threadIdx.x >> 6) * KQ * R) * 64 + (threadIdx.x & 63);
+  int* klist = reinterpret_cast<int*>(lql + (lqm ? (size_t)a.K * NTHR : LQW ? (size_t)WAVES * KQ * R * 64 : 0));  // sparse mode: [K] active clusters of this block, [K] flags,
   int* kflag = klist + a.K;                          // [WAVES*R] groups of the block's row groups, [1] count
   int* bgrp = kflag + a.K;
 
@@ -174,8 +191,13 @@ __global__ void __launch_bounds__(WAVES * 64, EstepOcc<DP>::BLOCKS) estep_kernel
         else if (myok) a.qZ[(int64_t)k * a.ldq + (rg0 + hi) * RG + lo4] = -INFINITY;
       } else {
 #pragma unroll
-        for (int r = 0; r < R; ++r)
-          if (rgok[r] && hi == (k & 3)) a.qZ[(int64_t)k * a.ldq + (rg0 + r) * RG + lo4] = -INFINITY;
+        for (int r = 0; r < R; ++r) {
+          if constexpr (LQW) {
+            if (hi == (k & 3)) lqw[((k >> 2) * R + r) * 64] = -INFINITY;
+          } else {
+            if (rgok[r] && hi == (k & 3)) a.qZ[(int64_t)k * a.ldq + (rg0 + r) * RG + lo4] = -INFINITY;
+          }
+        }
       }
     }
   }
@@ -253,6 +275,8 @@ __global__ void __launch_bounds__(WAVES * 64, EstepOcc<DP>::BLOCKS) estep_kernel
       mx[r] = fmax(mx[r], lq);
       if constexpr (ROWLANES) {
         if (hi == r) lqsel = lq;
+      } else if constexpr (LQW) {
+        if (hi == (k & 3)) lqw[((k >> 2) * R + r) * 64] = lq;
       } else {
         if (rgok[r] && hi == (k & 3)) a.qZ[(int64_t)k * a.ldq + (rg0 + r) * RG + lo4] = lq;
       }
@@ -312,7 +336,7 @@ __global__ void __launch_bounds__(WAVES * 64, EstepOcc<DP>::BLOCKS) estep_kernel
     if (rgok[r]) {
       const double* qp = a.qZ + (rg0 + r) * RG + lo4;
 #pragma unroll 8
-      for (int k = hi; k < K; k += 4) s += exp(qp[(int64_t)k * a.ldq] - mx[r]);
+      for (int k = hi; k < K; k += 4) s += exp((LQW ? lqw[((k >> 2) * R + r) * 64] : qp[(int64_t)k * a.ldq]) - mx[r]);
     }
     s = sum_over_hi(s);
     logZ[r] = log(s) + mx[r];
@@ -325,7 +349,7 @@ __global__ void __launch_bounds__(WAVES * 64, EstepOcc<DP>::BLOCKS) estep_kernel
       for (int r = 0; r < R; ++r) {
         if (rgok[r]) {
           double* qp = a.qZ + (int64_t)k * a.ldq + (rg0 + r) * RG + lo4;
-          const double lq = *qp;
+          const double lq = LQW ? lqw[((kb >> 2) * R + r) * 64] : *qp;
           double q = exp(lq - logZ[r]);
           if (!rowok[r]) q = 0.0;
           *qp = q;
@@ -345,16 +369,23 @@ __global__ void __launch_bounds__(WAVES * 64, EstepOcc<DP>::BLOCKS) estep_kernel
   fz = wave_sum(fz);
   if (lane == 0) fzw[wave] = fz;
   __syncthreads();
+  // partial slots are sized for the 4-wave blocks of the standard variant (estep_grid): a block of 2 x 4 waves fills two
+  constexpr int SLOTS = LQW ? WAVES / EstepWavesStd<DP>::W : 1;
+  const int64_t slot0 = (int64_t)blockIdx.x * SLOTS;
   if (a.ll_part)
     for (int k = tid; k < K; k += NTHR) {
       double s = 0.0;
       for (int w = 0; w < WAVES; ++w) s += llw[w * K + k];
-      a.ll_part[(int64_t)blockIdx.x * K + k] = s;
+      a.ll_part[slot0 * K + k] = s;
+      for (int e = 1; e < SLOTS; ++e)
+        if (slot0 + e < a.nslots) a.ll_part[(slot0 + e) * K + k] = 0.0;
     }
   if (tid == 0) {
     double s = 0.0;
     for (int w = 0; w < WAVES; ++w) s += fzw[w];
-    a.fz_part[blockIdx.x] = -s;  // cluster.cpp:137 returns -sum(logZ)
+    a.fz_part[slot0] = -s;  // cluster.cpp:137 returns -sum(logZ)
+    for (int e = 1; e < SLOTS; ++e)
+      if (slot0 + e < a.nslots) a.fz_part[slot0 + e] = 0.0;
   }
 }
 
@@ -626,12 +657,44 @@ int64_t estep_grid(int DP, int64_t nrg) {
   return (nrg + rgpb - 1) / rgpb;
 }
 
+// log q~ in LDS for the k-sliced scheme (LQW): D = 64 with up to 32 clusters (8 waves x 12 KB next to the 36 KB ring)
+template <int DP, bool SPARSE>
+static hipError_t launch_estep_lqw(const EstepLaunch& a, hipStream_t stream, bool* done) {
+  *done = false;
+  if constexpr (DP == 64) {
+    constexpr int R = EstepCfg<DP>::R, WAVES = 8;
+    static_assert(EstepWavesStd<DP>::W == EstepCfg<DP>::WAVES, "slot bookkeeping");
+    static const int mode = getenv("LC_ES_LQW") ? atoi(getenv("LC_ES_LQW")) : LC_ES_LQW_DEFAULT;  // 0 off, 1 on
+    const size_t shmem = (size_t)(2 * pstride(DP) + WAVES * a.K + WAVES) * sizeof(double) +
+                         (size_t)WAVES * ((a.K + 3) / 4) * R * 64 * sizeof(double) +
+                         (size_t)(2 * a.K + WAVES * R + 2) * sizeof(int);
+    if (mode == 0 || a.raw || shmem > 160 * 1024) return hipSuccess;
+    auto kern = estep_kernel<DP, R, WAVES, SPARSE, true>;
+    static LdsGrant grant;
+    if (hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(kern), shmem, grant); e != hipSuccess) return e;
+    EstepLaunch b = a;
+    b.nslots = estep_grid(DP, a.nrg);
+    const int64_t grid = (b.nslots + 1) / 2;
+    *done = true;
+    if (grid <= 0) return hipSuccess;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVES * 64), shmem, stream, b);
+    return hipGetLastError();
+  }
+  return hipSuccess;
+}
+
 template <int DP, bool SPARSE>
 static hipError_t launch_estep_s(const EstepLaunch& a, hipStream_t stream) {
+  {
+    bool done = false;
+    const hipError_t e = launch_estep_lqw<DP, SPARSE>(a, stream, &done);
+    if (e != hipSuccess || done) return e;
+  }
   constexpr int R = EstepCfg<DP>::R, WAVES = EstepCfg<DP>::WAVES;
   size_t shmem = (size_t)(2 * pstride(DP) + WAVES * a.K + WAVES) * sizeof(double) +
                  (size_t)(2 * a.K + WAVES * R + 2) * sizeof(int);
   EstepLaunch b = a;
+  b.nslots = estep_grid(DP, a.nrg);
   static const bool no_lql = getenv("LC_ES_NOLQL") != nullptr;  // tuning knob: log q~ through the qZ buffer everywhere
   if (R == 4 && !a.raw && !no_lql && shmem + (size_t)a.K * WAVES * 64 * sizeof(double) <= 40 * 1024) {  // (four blocks per CU still fit; at 74 KB, K = 32, the lost occupancy costs 8 %)
     b.lq_lds = 1;  // log q~ stays in LDS until the normalisation

@@ -63,6 +63,12 @@ def test_multiple_level_models_like_testapi():
     _check_gmm(ws, mu, cov)
     f, qY, qZ, wi, ws, mui, mus, covi, covs = lc.learnMCM([W], [X], trunc=30)  # 9-tuple, libclusterpy.cpp:305-307
     assert len(mui) == len(covi) == qY[0].shape[1] and mui[0].shape == (1, 2)
+    # Without qY0 the start is the reference's: Eigen's Random() = std::rand() (scluster.cpp:519-521), whose state depends
+    # on everything this process has drawn before (RCCL's bootstrap draws too) -- shapes only.  The clusters are checked
+    # on a reproducible start of the same form (|U(-1,1)| rows, normalised).
+    r = np.abs(np.random.default_rng(0).uniform(-1.0, 1.0, (I, 30)))
+    f, qY, qZ, wi, ws, mui, mus, covi, covs = lc.learnMCM([W], [X], trunc=30, qY0=[r / r.sum(axis=1, keepdims=True)])
+    assert len(mui) == len(covi) == qY[0].shape[1] == 3
     _check_gmm(ws, mus, covs)
     # the document-level Gaussians sit on the three document classes
     got = np.vstack(mui)
