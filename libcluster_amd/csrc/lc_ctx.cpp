@@ -1044,6 +1044,36 @@ void Context::suffstat(const unsigned char* smask, double* Nk, double* xs, doubl
   }
 }
 
+void Context::suffstat_columns(const int* cols, int n, bool diag, double* Nk, double* xs, double* xxs, double* Njk) {
+  use_device();
+  QZ& cur = qz_[cur_];
+  if (n < 1) throw std::invalid_argument("need at least one column");
+  for (int t = 0; t < n; ++t)
+    if (cols[t] < 0 || cols[t] >= cur.K) throw std::invalid_argument("qZ column out of range");
+  ensure_qz(qzcols_, n, false);
+  qzcols_.K = n;
+  for (int t = 0; t < n && NP_ > 0; ++t)
+    LC_HIP(hipMemcpyAsync(qzcols_.buf.p + (size_t)t * NP_, cur.buf.p + (size_t)cols[t] * NP_, (size_t)NP_ * sizeof(double),
+                          hipMemcpyDeviceToDevice, stream_));
+  // run the ordinary pass with the scratch columns standing in for qZ (the buffers trade places, nothing is copied)
+  auto swap_qz = [](QZ& a, QZ& b) {
+    std::swap(a.buf.p, b.buf.p);
+    std::swap(a.buf.cap, b.buf.cap);
+    std::swap(a.buf.device, b.buf.device);
+    std::swap(a.cap, b.cap);
+    std::swap(a.K, b.K);
+  };
+  swap_qz(cur, qzcols_);
+  try {
+    if (diag) suffstat_diag(nullptr, Nk, xs, xxs, Njk);
+    else suffstat(nullptr, Nk, xs, xxs, Njk);
+  } catch (...) {
+    swap_qz(cur, qzcols_);
+    throw;
+  }
+  swap_qz(cur, qzcols_);
+}
+
 void Context::colsums(double* Njk) {
   use_device();
   const int K = qz_[cur_].K;

@@ -210,8 +210,21 @@ double vbem(lcc::Context& ctx, Model& model, const VbemOptions& opt) {
       for (size_t t = 0; t < mask.size(); ++t) mask[t] = Njk[t] >= lch::ZEROCUTOFF ? 1 : 0;
       maskp = mask.data();
     }
-    if (full) ctx.suffstat(maskp, Nk.data(), xs.data(), xxs.data(), Njk.data());
+    if (done == 0 && opt.preset && opt.preset->K == K && !opt.sparse) {
+      Nk = opt.preset->Nk;
+      xs = opt.preset->xs;
+      xxs = opt.preset->xxs;
+      xxs.resize((size_t)K * std::max<size_t>(XX, 1));
+      Njk = opt.preset->Njk;
+    } else if (full) ctx.suffstat(maskp, Nk.data(), xs.data(), xxs.data(), Njk.data());
     else ctx.suffstat_diag(maskp, Nk.data(), xs.data(), XX ? xxs.data() : nullptr, Njk.data());
+    if (done == 0 && opt.capture) {
+      opt.capture->K = K;
+      opt.capture->Nk = Nk;
+      opt.capture->xs = xs;
+      opt.capture->xxs = xxs;
+      opt.capture->Njk = Njk;
+    }
     for (int j = 0; j < J; ++j) model.weights[j].update(Njk.data() + (size_t)j * K, K);
     const auto t1 = now();
 
@@ -254,7 +267,7 @@ double vbem(lcc::Context& ctx, Model& model, const VbemOptions& opt) {
     }
     double Fz = 0.0;
     const auto t2 = now();
-    run_estep(ctx, model, K, &Fz, nullptr);
+    run_estep(ctx, model, K, &Fz, opt.want_ll ? model.LLk.data() : nullptr);
     const auto t3 = now();
 
     // fenergy (:145-165)
@@ -350,6 +363,12 @@ static bool split_gr(lcc::Context& ctx, Model& model, std::vector<int>& tally, d
   lcc::RowSelection sel;
   std::vector<double> njs;
   std::vector<double> eigv;
+  // Statistics of the round's converged qZ (K columns), known after the first candidate's full-data iteration: a
+  // candidate changes two columns of qZ (auglabels moves mass from column k to the new column K), so every later
+  // candidate recomputes those two only.  Not in sparse mode (the masks depend on all columns).
+  static const bool no_incremental = env_on("LC_SPLIT_FULL_STATS");
+  StatsBlock round_stats;
+  const size_t XX = ClusterAny::xx_size(model.ckind, D), XS = std::max<size_t>(XX, 1);
 
   static const bool trace_phases = env_on("LC_TRACE_PHASES");
   auto now = [] { return std::chrono::steady_clock::now(); };
@@ -422,12 +441,56 @@ static bool split_gr(lcc::Context& ctx, Model& model, std::vector<int>& tally, d
     vo.maxit = 1;
     vo.sparse = opt.sparse;
     vo.nthreads = opt.nthreads;
+    StatsBlock first;  // statistics of the augmented qZ (K + 1 columns) for the first of the two iterations
+    const bool incremental = !opt.sparse && !no_incremental;
     double Fsplit;
     try {
+      if (incremental && round_stats.K == K) {
+        const int cols[2] = {k, K};
+        std::vector<double> n2(2), x2((size_t)2 * D), xx2((size_t)2 * XS), nj2((size_t)J * 2);
+        ctx.suffstat_columns(cols, 2, model.ckind != lch::C_GAUSSWISH, n2.data(), x2.data(), XX ? xx2.data() : nullptr,
+                             nj2.data());
+        first.K = K + 1;
+        first.Nk.assign(round_stats.Nk.begin(), round_stats.Nk.end());
+        first.Nk.push_back(0.0);
+        first.xs.assign(round_stats.xs.begin(), round_stats.xs.end());
+        first.xs.resize((size_t)(K + 1) * D, 0.0);
+        first.xxs.assign(round_stats.xxs.begin(), round_stats.xxs.begin() + (size_t)K * XS);
+        first.xxs.resize((size_t)(K + 1) * XS, 0.0);
+        first.Njk.assign((size_t)J * (K + 1), 0.0);
+        for (int j = 0; j < J; ++j)
+          for (int c = 0; c < K; ++c) first.Njk[(size_t)j * (K + 1) + c] = round_stats.Njk[(size_t)j * K + c];
+        for (int t = 0; t < 2; ++t) {
+          const int c = cols[t];
+          first.Nk[(size_t)c] = n2[(size_t)t];
+          std::copy(x2.begin() + (size_t)t * D, x2.begin() + (size_t)(t + 1) * D, first.xs.begin() + (size_t)c * D);
+          if (XX) std::copy(xx2.begin() + (size_t)t * XX, xx2.begin() + (size_t)(t + 1) * XX, first.xxs.begin() + (size_t)c * XX);
+          for (int j = 0; j < J; ++j) first.Njk[(size_t)j * (K + 1) + c] = nj2[(size_t)j * 2 + t];
+        }
+        vo.preset = &first;
+      } else if (incremental) {
+        vo.capture = &first;
+      }
       Fsplit = vbem(ctx, ms, vo);
     } catch (...) {
       ctx.qz_swap_alt();
       throw;
+    }
+    if (vo.capture && first.K == K + 1) {
+      // the converged qZ's statistics from this candidate's: columns other than k are untouched, column k gave its
+      // moved mass to column K (q_t[:,k] = q_aug[:,k] + q_aug[:,K] row by row, and the statistics are linear in q)
+      round_stats.K = K;
+      round_stats.Nk.assign(first.Nk.begin(), first.Nk.begin() + K);
+      round_stats.xs.assign(first.xs.begin(), first.xs.begin() + (size_t)K * D);
+      round_stats.xxs.assign(first.xxs.begin(), first.xxs.begin() + (size_t)K * XS);
+      round_stats.Njk.assign((size_t)J * K, 0.0);
+      round_stats.Nk[(size_t)k] += first.Nk[(size_t)K];
+      for (int d = 0; d < D; ++d) round_stats.xs[(size_t)k * D + d] += first.xs[(size_t)K * D + d];
+      for (size_t e = 0; e < XX; ++e) round_stats.xxs[(size_t)k * XX + e] += first.xxs[(size_t)K * XX + e];
+      for (int j = 0; j < J; ++j) {
+        for (int c = 0; c < K; ++c) round_stats.Njk[(size_t)j * K + c] = first.Njk[(size_t)j * (K + 1) + c];
+        round_stats.Njk[(size_t)j * K + k] += first.Njk[(size_t)j * (K + 1) + K];
+      }
     }
     if (anyempty(ms.clusters)) {  // :476
       ctx.qz_swap_alt();
@@ -465,13 +528,17 @@ double cluster(lcc::Context& ctx, Model& model, const ClusterOptions& opt) {
     vo.verbose = opt.verbose;
     vo.nthreads = opt.nthreads;
     vo.trace = &tr;
+    // the split ordering needs the data term LL_k of the converged responsibilities (cluster.cpp:407-410): it comes out
+    // of the last iteration's E-step (a by-product of the normalisation sweep) instead of a full extra pass per round
+    static const bool ll_extra_pass = env_on("LC_LL_EXTRA_PASS");  // (the round-1 behaviour, for A/B timing)
+    vo.want_ll = !ll_extra_pass;
     F = vbem(ctx, model, vo);
     if (opt.trace) opt.trace->emplace_back((int)model.clusters.size(), tr);
     int nkeep = 0;
     for (const auto& cl : model.clusters) nkeep += !(cl.N() < lch::ZEROCUTOFF);
     static const bool trace_phases = env_on("LC_TRACE_PHASES");
     const auto c0 = std::chrono::steady_clock::now();
-    if (!(nkeep >= opt.maxclusters && opt.maxclusters >= 0)) data_loglik(ctx, model);  // split_gr will need it
+    if (!vo.want_ll && !(nkeep >= opt.maxclusters && opt.maxclusters >= 0)) data_loglik(ctx, model);  // split_gr will need it
     prune_clusters(ctx, model, opt.verbose);
     const auto c1 = std::chrono::steady_clock::now();
     if (opt.verbose) std::cout << '<' << std::flush;

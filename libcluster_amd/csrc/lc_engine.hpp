@@ -26,6 +26,12 @@ struct Model {
   std::vector<double> lastA, lastm, lastc;
 };
 
+// Sufficient statistics of one qZ: N_k [K], sum q x [K*D], second moments [K*XX] (XX = D*D / D / 0 by family), N_jk [J*K]
+struct StatsBlock {
+  int K = 0;
+  std::vector<double> Nk, xs, xxs, Njk;
+};
+
 struct VbemOptions {
   double clusterprior = lch::PRIORVAL;
   int maxit = -1;
@@ -34,6 +40,14 @@ struct VbemOptions {
   int fixed_iters = -1;            // >= 0: run exactly this many iterations, no convergence / increase test
   std::vector<double>* trace = nullptr;  // F after every iteration
   unsigned nthreads = 1;
+  // the E-step of every iteration also produces the split-ordering data term LL_k (model.LLk is then that of the LAST
+  // iteration: cluster() needs no extra pass for it)
+  bool want_ll = false;
+  // first iteration: use these statistics instead of a pass over the data (they must be those of the current qZ) /
+  // hand the first iteration's statistics back.  The split search uses both to recompute only the two changed columns
+  // per candidate (cluster.cpp:473 prescribes a full vbem; the statistics are a pure function of (X, qZ)).
+  const StatsBlock* preset = nullptr;
+  StatsBlock* capture = nullptr;
 };
 
 // fn(c) for c in [0, nchunks) on the persistent worker pool (inline when the work is small or the pool is busy)
