@@ -1113,6 +1113,81 @@ void Context::estep_diag(int K, const double* av, const double* w2, const double
     }
   }
   std::memcpy(hpack_.data() + (size_t)K * 3 * DP, c, (size_t)J_ * K * sizeof(double));
+  const int mode = only_w1 ? 2 : no_w1 ? 1 : 0;  // same arithmetic with the identically-zero terms left out
+  // Matrix-pipe path (estep_diag_mfma_kernel): the log-likelihood expanded around a centre mu is bilinear in
+  // [x'^2, x'].  Exact for the exponential family (linear in x); for the quadratic term the expansion cancels, so it is
+  // taken only when max_d max_k |w2_kd| * reach_d^2 is small, reach_d = the farthest 6-sigma edge of any cluster from
+  // the centre (the mean of the cluster centres): the absolute error of log q~ is then about D * cond * 2^-53.
+  size_t wt_off = 0, mu_off = 0, ck_off = 0;
+  {
+    static const int force = std::getenv("LC_ED_MFMA") ? std::atoi(std::getenv("LC_ED_MFMA")) : -1;  // 0 never, 1 always
+    const int64_t nw = lck::estep_diag_mfma_weights(DP, K, mode);
+    bool use = nw > 0 && force != 0;
+    std::vector<double> muv((size_t)DP, 0.0);
+    if (use && mode != 2) {
+      double cond = 0.0;
+      for (int d = 0; d < D; ++d) {
+        double m = 0.0;
+        for (int k = 0; k < K; ++k) m += av[(size_t)k * D + d];
+        m /= K;
+        muv[(size_t)d] = m;
+        double wmax = 0.0, reach = 0.0;
+        for (int k = 0; k < K; ++k) {
+          const double w = std::fabs(w2[(size_t)k * D + d]);
+          wmax = std::max(wmax, w);
+          const double sig = w > 0 ? std::sqrt(0.5 / w) : 0.0;
+          reach = std::max(reach, std::fabs(av[(size_t)k * D + d] - m) + 6.0 * sig);
+        }
+        cond = std::max(cond, wmax * reach * reach);
+      }
+      if (!(cond <= 4096.0) && force != 1) use = false;  // (NaN-safe)
+    }
+    if (use) {
+      const int NT = DP / 4, NTF = mode == 2 ? NT : 2 * NT, KT = (K + 3) / 4;
+      const size_t base = hpack_.size();
+      mu_off = base;
+      ck_off = mu_off + (size_t)DP;
+      wt_off = (ck_off + (size_t)K + 1) & ~(size_t)1;  // 16-byte aligned (double2 loads)
+      hpack_.resize(wt_off + (size_t)nw);
+      std::memcpy(hpack_.data() + (size_t)K * 3 * DP, c, (size_t)J_ * K * sizeof(double));  // (resize may have moved the block)
+      for (int k = 0; k < K; ++k) {  // re-pack after a possible reallocation
+        double* P = hpack_.data() + (size_t)k * DP;
+        std::fill(P, P + DP, 0.0);
+        std::fill(P + (size_t)K * DP, P + (size_t)K * DP + DP, 0.0);
+        std::fill(P + (size_t)2 * K * DP, P + (size_t)2 * K * DP + DP, 0.0);
+        std::copy(av + (size_t)k * D, av + (size_t)(k + 1) * D, P);
+        std::copy(w2 + (size_t)k * D, w2 + (size_t)(k + 1) * D, P + (size_t)K * DP);
+        std::copy(w1 + (size_t)k * D, w1 + (size_t)(k + 1) * D, P + (size_t)2 * K * DP);
+      }
+      std::copy(muv.begin(), muv.end(), hpack_.begin() + mu_off);
+      double* ck = hpack_.data() + ck_off;
+      double* wt = hpack_.data() + wt_off;
+      std::fill(ck, ck + K + 1, 0.0);
+      std::fill(wt, wt + nw, 0.0);
+      // W[k][f]: f < NT*4 quadratic weights (w2), then linear weights (w1 - 2 w2 a'); tile (it, jt) element
+      // (lo, hi) = W[4 it + lo][4 jt + hi]
+      auto put = [&](int k, int f, double v) {
+        const int it = k >> 2, lo = k & 3, jt = f >> 2, hh = f & 3;
+        wt[((size_t)it * NTF + jt) * 16 + lo + 4 * hh] = v;
+      };
+      (void)KT;
+      for (int k = 0; k < K; ++k) {
+        double cs = 0.0;
+        for (int d = 0; d < D; ++d) {
+          const double a2 = w2[(size_t)k * D + d], a1 = w1[(size_t)k * D + d];
+          const double ac = av[(size_t)k * D + d] - muv[(size_t)d];
+          if (mode == 2) {
+            put(k, d, a1);
+          } else {
+            put(k, d, a2);
+            put(k, DP + d, a1 - 2.0 * a2 * ac);
+            cs += a2 * ac * ac + a1 * muv[(size_t)d];
+          }
+        }
+        ck[k] = cs;
+      }
+    }
+  }
   params_.reserve(hpack_.size());
   LC_HIP(hipMemcpyAsync(params_.p, hpack_.data(), hpack_.size() * sizeof(double), hipMemcpyHostToDevice, stream_));
   ensure_qz(qz_[cur_], K, false);
@@ -1136,7 +1211,12 @@ void Context::estep_diag(int K, const double* av, const double* w2, const double
   a.fz_part = fzpart_.p;
   a.ll_part = LLk ? llpart_.p : nullptr;
   a.raw = raw ? 1 : 0;
-  a.mode = only_w1 ? 2 : no_w1 ? 1 : 0;  // same arithmetic with the identically-zero terms left out
+  a.mode = mode;
+  if (wt_off) {
+    a.wt = params_.p + wt_off;
+    a.mu = params_.p + mu_off;
+    a.constk = params_.p + ck_off;
+  }
   EvPair ev{};
   if (timing_) {
     LC_HIP(hipEventCreate(&ev.a));

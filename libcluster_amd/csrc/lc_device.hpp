@@ -23,6 +23,16 @@ __device__ __forceinline__ double mfma4(double a, double b, double c) {
   return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
 }
 
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(<N-1>)
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
 // sum over the 4 lanes {l, l^16, l^32, l^48}
 __device__ __forceinline__ double sum_over_hi(double v) {
   v += __shfl_xor(v, 16);

@@ -146,8 +146,13 @@ struct DiagEstepLaunch {
   double* fz_part;       // [ceil(NP/64)]
   double* ll_part;       // [ceil(NP/64) x K] or nullptr
   int raw = 0;
+  // matrix-pipe path (estep_diag_mfma_kernel), chosen by lc_ctx.cpp when the expansion around `mu` is well conditioned:
+  const double* wt = nullptr;      // packed weight tiles [ceil(K/4)][NTF][16]; nullptr: the difference-form VALU kernel
+  const double* mu = nullptr;      // [DP] centre (unused in mode 2)
+  const double* constk = nullptr;  // [K] sum_d (w2 a'^2 + w1 mu)
 };
 inline int64_t estep_diag_grid(int64_t nrg) { return (nrg * RG + 63) / 64; }
+int64_t estep_diag_mfma_weights(int DP, int K, int mode);
 hipError_t launch_estep_diag(const DiagEstepLaunch& a, hipStream_t stream);
 
 struct DiagStatLaunch {

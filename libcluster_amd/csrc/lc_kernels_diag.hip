@@ -2,6 +2,8 @@
 // (one translation unit per kernel family; the file header of lc_kernels_estep.hip maps kernels to the reference)
 #include "lc_device.hpp"
 
+#include <algorithm>
+
 namespace lck {
 
 // ===========================================================================
@@ -412,6 +414,239 @@ __global__ void __launch_bounds__(256)
     for (int k = tid; k < K; k += 256) ll_part[(int64_t)blockIdx.x * K + k] = llw[k];
 }
 
+// ===========================================================================
+// The same E-step on the matrix pipe
+// ===========================================================================
+// Around a fixed centre mu_d (x' = x - mu, a' = a - mu) the separable log-likelihood is bilinear in the features
+// phi(x) = [x'^2, x']:
+//     sum_d w2 (x - a)^2 + w1 x  =  sum_d w2 x'^2 + (w1 - 2 w2 a') x'  +  sum_d (w2 a'^2 + w1 mu)
+// i.e. one N x NF . NF x K product (NF = 2 DP, or DP when w2 == 0: the exponential family is linear in x) plus a
+// per-cluster constant -- 2 NF MACs per (row, cluster) on v_mfma_f64_4x4x4_4b instead of 3 D fp64 VALU instructions,
+// which leaves the kernel bound by HBM (X once, q once).  The expansion cancels where |x'| is large against a
+// cluster's width, so lc_ctx.cpp takes this path only when max |w2| x'^2 over the clusters' 6-sigma ranges is small
+// (the centre is the mean of the cluster centres); otherwise the difference form above runs (estep_diag_kernel).
+// Layout as in estep_kernel: MFMA block b <-> rows 4b..4b+3 of a 16-row group,
+//   A operand = tile W[cluster 4it+lo2][feature 4jt+hi] (LDS, staged once per persistent block: all K clusters fit),
+//   B operand = phi[row = lane&15][4jt+hi] (registers),  D = y[cluster 4it+hi][row].
+// log q~ of a row group lives in registers (K <= 4*KTM clusters: KTM values per lane); max / sum cross the four hi
+// lanes with two shuffles.  Reference operation order of logsumexp and of the normalisation (probutils.cpp:141-150,
+// cluster.cpp:130-131).
+template <int NT, bool QUAD, int R>
+__global__ void __launch_bounds__(256, 2)
+    estep_diag_mfma_kernel(const double* __restrict__ X, const double* __restrict__ Wt, const double* __restrict__ mu,
+                           const double* __restrict__ constk, const double* __restrict__ ctab,
+                           const int* __restrict__ rginfo, double* __restrict__ qZ, double* __restrict__ fz_part,
+                           double* __restrict__ ll_part, int K, int64_t nrg, int64_t nrows, int64_t ldq, int raw,
+                           int64_t nslots) {
+  constexpr int DP = NT * 4;
+  constexpr int NTF = QUAD ? 2 * NT : NT;  // feature tiles per cluster tile
+  constexpr int PF = NTF < 8 ? NTF : 8;    // weight-tile reads in flight ahead of their MFMAs
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int KT = (K + 3) / 4;
+  double* wl = lds;                           // [KT][NTF][16]
+  double* cst = wl + (size_t)KT * NTF * 16;   // [4 KT] per-cluster constant
+  double* mul = cst + 4 * KT;                 // [DP] centre
+  double* fzw = mul + DP;                     // [4]
+  double* lqs = fzw + 4;                      // [KT][R][256]: every lane's own log q~ slots
+  double* lls = lqs + (size_t)KT * R * 256;   // [KT][256] (only when ll_part): running q * data term per lane
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lo4 = lane & 15, hi = lane >> 4;
+  {
+    const double2* src = reinterpret_cast<const double2*>(Wt);
+    double2* dst = reinterpret_cast<double2*>(wl);
+    for (int i = tid; i < KT * NTF * 8; i += 256) dst[i] = src[i];
+    for (int i = tid; i < 4 * KT; i += 256) cst[i] = i < K ? constk[i] : 0.0;
+    for (int i = tid; i < DP; i += 256) mul[i] = QUAD ? mu[i] : 0.0;
+    if (ll_part)
+      for (int it = 0; it < KT; ++it) lls[it * 256 + tid] = 0.0;
+  }
+  __syncthreads();
+  const double* Pt = wl + (lane & 3) + 4 * hi;  // this lane's element of every 4x4 tile
+  double* lqme = lqs + tid;
+  double fz = 0.0;
+  const int64_t ntile = (nrg + 4 * R - 1) / (4 * R);  // tiles of 4 waves x R row groups
+  for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const int64_t rg0 = (tile * 4 + wave) * R;
+    double f[R][NTF];
+    int grp[R];
+    bool rowok[R], rgok[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t rg = rg0 + r;
+      rgok[r] = rg < nrg;
+      int info = 0;
+      if (rgok[r]) {
+        if (rginfo) {
+          info = rginfo[rg];
+        } else {
+          const int64_t rem = nrows - rg * RG;
+          info = rem >= RG ? RG : (rem > 0 ? (int)rem : 0);
+        }
+      }
+      grp[r] = info >> 5;
+      rowok[r] = lo4 < (info & 31);
+      const double* xr = X + ((rgok[r] ? rg : 0) * RG + lo4) * DP + hi;
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) f[r][QUAD ? NT + jt : jt] = xr[4 * jt];
+    }
+    if constexpr (QUAD) {
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) {
+        const double m = mul[4 * jt + hi];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const double xc = f[r][NT + jt] - m;
+          f[r][NT + jt] = xc;
+          f[r][jt] = xc * xc;
+        }
+      }
+    }
+    double mx[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) mx[r] = -INFINITY;
+#pragma unroll 1
+    for (int it = 0; it < KT; ++it) {
+      const double* Pi = Pt + (size_t)it * NTF * 16;
+      double acc[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc[r] = 0.0;
+      double ring[PF];
+      static_for<PF>([&](auto ic) { ring[ic] = Pi[ic * 16]; });
+      static_for<NTF>([&](auto jc) {
+        constexpr int jt = jc;
+        const double v = ring[jt % PF];
+        if constexpr (jt + PF < NTF) ring[jt % PF] = Pi[(jt + PF) * 16];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = mfma4(v, f[r][jt], acc[r]);
+      });
+      const int k = 4 * it + hi;
+      const double ck = cst[k];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        // data term + per-cluster constant + E[log weight]; clusters past K (padding of the last tile) drop out as -inf
+        const double v = k < K ? ctab[(int64_t)grp[r] * K + k] + (acc[r] + ck) : -INFINITY;
+        mx[r] = fmax(mx[r], v);
+        if (raw) {
+          if (k < K && rgok[r]) qZ[(int64_t)k * ldq + (rg0 + r) * RG + lo4] = v;
+        } else {
+          lqme[(it * R + r) * 256] = v;
+        }
+      }
+    }
+    if (raw) continue;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      double m = mx[r];
+      m = fmax(m, __shfl_xor(m, 16));
+      m = fmax(m, __shfl_xor(m, 32));
+      double se = 0.0;
+      for (int it = 0; it < KT; ++it) se += exp(lqme[(it * R + r) * 256] - m);
+      se = sum_over_hi(se);
+      const double logZ = log(se) + m;
+      for (int it = 0; it < KT; ++it) {
+        const int k = 4 * it + hi;
+        if (k < K) {
+          const double lq = lqme[(it * R + r) * 256];
+          double q = exp(lq - logZ);
+          if (!rowok[r]) q = 0.0;
+          if (rgok[r]) qZ[(int64_t)k * ldq + (rg0 + r) * RG + lo4] = q;
+          if (ll_part && q > 0.0) lls[it * 256 + tid] += q * (lq - ctab[(int64_t)grp[r] * K + k]);
+        }
+      }
+      if (rgok[r] && rowok[r] && hi == 0) fz += logZ;
+    }
+  }
+  if (raw) return;
+  fz = wave_sum(fz);
+  if (lane == 0) fzw[wave] = fz;
+  if (ll_part) {
+    for (int it = 0; it < KT; ++it) {
+      const double v = sum_over_lo4(lls[it * 256 + tid]);  // cluster 4 it + hi, summed over the 16 rows' lanes
+      __builtin_amdgcn_wave_barrier();
+      if (lo4 == 0) lls[it * 256 + tid] = v;  // lanes 0, 16, 32, 48 of every wave hold the wave's sums
+    }
+  }
+  __syncthreads();
+  // partial slots are sized by the caller (nslots >= gridDim.x): this block fills its own and zeroes its share of the rest
+  if (ll_part)
+    for (int k = tid; k < K; k += 256) {
+      const int it = k >> 2, h = k & 3;
+      double v = 0.0;
+      for (int w = 0; w < 4; ++w) v += lls[it * 256 + w * 64 + 16 * h];
+      ll_part[(int64_t)blockIdx.x * K + k] = v;
+      for (int64_t sl = blockIdx.x + gridDim.x; sl < nslots; sl += gridDim.x) ll_part[sl * K + k] = 0.0;
+    }
+  if (tid == 0) {
+    fz_part[blockIdx.x] = -(fzw[0] + fzw[1] + fzw[2] + fzw[3]);
+    for (int64_t sl = blockIdx.x + gridDim.x; sl < nslots; sl += gridDim.x) fz_part[sl] = 0.0;
+  }
+}
+
+template <int NT, bool QUAD, int R>
+static hipError_t launch_edm_k(const DiagEstepLaunch& a, hipStream_t stream) {
+  const int KT = (a.K + 3) / 4, NTF = QUAD ? 2 * NT : NT;
+  const size_t shmem = ((size_t)KT * NTF * 16 + 4 * KT + 4 * NT + 4 + (size_t)KT * R * 256 + (a.ll_part ? (size_t)KT * 256 : 0)) *
+                       sizeof(double);
+  auto kern = estep_diag_mfma_kernel<NT, QUAD, R>;
+  static LdsGrant grant;
+  if (hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(kern), shmem, grant); e != hipSuccess) return e;
+  const int64_t ntile = (a.nrg + 4 * R - 1) / (4 * R);
+  const int64_t nslots = estep_diag_grid(a.nrg);
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  // persistent blocks (the weights are staged once per block): as many as are resident, a few tiles each
+  const int per_cu = shmem <= 80 * 1024 ? 2 : 1;
+  int64_t grid = std::min<int64_t>(std::min<int64_t>(ntile, nslots), (int64_t)cus * per_cu);
+  if (grid <= 0) return hipSuccess;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), shmem, stream, a.X, a.wt, a.mu, a.constk, a.ctab, a.rginfo,
+                     a.qZ, a.fz_part, a.ll_part, a.K, a.nrg, a.nrows, a.ldq, a.raw, nslots);
+  return hipGetLastError();
+}
+
+template <int NT, bool QUAD>
+static hipError_t launch_edm_q(const DiagEstepLaunch& a, hipStream_t stream) {
+  // row groups per wave by the register budget (R x NTF feature fragments of two registers each)
+  constexpr int NTF = QUAD ? 2 * NT : NT;
+  constexpr int R = NTF <= 16 ? 4 : NTF <= 32 ? 2 : 1;
+  return launch_edm_k<NT, QUAD, R>(a, stream);
+}
+
+template <int NT>
+static hipError_t launch_edm_t(const DiagEstepLaunch& a, hipStream_t stream) {
+  return a.mode == 2 ? launch_edm_q<NT, false>(a, stream) : launch_edm_q<NT, true>(a, stream);
+}
+
+// doubles of the packed weight tiles lc_ctx.cpp uploads for the matrix-pipe path; 0: this shape has no such path
+int64_t estep_diag_mfma_weights(int DP, int K, int mode) {
+  if (DP > 128 || DP % 16 || K < 1) return 0;
+  const int NT = DP / 4, NTF = mode == 2 ? NT : 2 * NT, KT = (K + 3) / 4;
+  const int R = NTF <= 16 ? 4 : NTF <= 32 ? 2 : 1;
+  // the weights of all clusters and every lane's log q~ slots (and, with the split-ordering term, its running sums)
+  // must fit in the CU's LDS
+  const size_t lds = ((size_t)KT * NTF * 16 + 4 * KT + 4 * NT + 4 + (size_t)KT * R * 256 + (size_t)KT * 256) * sizeof(double);
+  if (lds > 150 * 1024) return 0;
+  return (int64_t)KT * NTF * 16;
+}
+
+static hipError_t launch_estep_diag_mfma(const DiagEstepLaunch& a, hipStream_t stream) {
+  switch (a.DP) {
+    case 16: return launch_edm_t<4>(a, stream);
+    case 32: return launch_edm_t<8>(a, stream);
+    case 48: return launch_edm_t<12>(a, stream);
+    case 64: return launch_edm_t<16>(a, stream);
+    case 80: return launch_edm_t<20>(a, stream);
+    case 96: return launch_edm_t<24>(a, stream);
+    case 112: return launch_edm_t<28>(a, stream);
+    case 128: return launch_edm_t<32>(a, stream);
+  }
+  return hipErrorInvalidValue;
+}
+
 template <int MODE, int KT, bool REG>
 static hipError_t launch_ed_t(const DiagEstepLaunch& a, int64_t grid, size_t shmem, hipStream_t stream) {
   auto kern = a.DP > 128 ? estep_diag_wide_kernel<MODE, KT, REG> : estep_diag_kernel<MODE, KT, REG>;
@@ -438,6 +673,7 @@ static hipError_t launch_ed_m(const DiagEstepLaunch& a, int64_t grid, size_t shm
 hipError_t launch_estep_diag(const DiagEstepLaunch& a, hipStream_t stream) {
   const int64_t grid = (a.nrg * RG + 63) / 64;
   if (grid <= 0) return hipSuccess;
+  if (a.wt) return launch_estep_diag_mfma(a, stream);
   const int DC = a.DP < 128 ? a.DP : 128;
   const size_t shmem = (size_t)(64 * (DC + 1) + 256 + a.K) * sizeof(double);
   switch (a.mode) {

@@ -58,15 +58,6 @@ __host__ __device__ constexpr RdInfo rd_info(int n) {
   }
   return n == 0 ? RdInfo{it, -1, 4 * it} : RdInfo{it, n - 1, (it * (it + 1) / 2 + (n - 1)) * 16};
 }
-// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(<N-1>)
-template <typename F, int... I>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
-  (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-  static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
-}
 
 // blocks per CU the register budget is set for.  D = 64: three row groups per wave (96 VGPRs of X fragments) at
 // three waves per SIMD measured 22.2 ms against 22.6 for four row groups at two waves per SIMD (N=10M, K=32).
