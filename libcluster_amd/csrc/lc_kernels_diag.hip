@@ -431,7 +431,8 @@ __global__ void __launch_bounds__(256)
 // log q~ of a row group lives in registers (K <= 4*KTM clusters: KTM values per lane); max / sum cross the four hi
 // lanes with two shuffles.  Reference operation order of logsumexp and of the normalisation (probutils.cpp:141-150,
 // cluster.cpp:130-131).
-template <int NT, bool QUAD, int R>
+// KTM > 0: K <= 4 KTM and log q~ stays in registers (KTM x R values per lane); KTM == 0: any K, per-lane LDS slots.
+template <int NT, bool QUAD, int R, int KTM>
 __global__ void __launch_bounds__(256, 2)
     estep_diag_mfma_kernel(const double* __restrict__ X, const double* __restrict__ Wt, const double* __restrict__ mu,
                            const double* __restrict__ constk, const double* __restrict__ ctab,
@@ -441,14 +442,16 @@ __global__ void __launch_bounds__(256, 2)
   constexpr int DP = NT * 4;
   constexpr int NTF = QUAD ? 2 * NT : NT;  // feature tiles per cluster tile
   constexpr int PF = NTF < 8 ? NTF : 8;    // weight-tile reads in flight ahead of their MFMAs
+  constexpr bool REGS = KTM > 0;
+  constexpr int NLQ = REGS ? KTM : 1;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int KT = (K + 3) / 4;
   double* wl = lds;                           // [KT][NTF][16]
   double* cst = wl + (size_t)KT * NTF * 16;   // [4 KT] per-cluster constant
   double* mul = cst + 4 * KT;                 // [DP] centre
   double* fzw = mul + DP;                     // [4]
-  double* lqs = fzw + 4;                      // [KT][R][256]: every lane's own log q~ slots
-  double* lls = lqs + (size_t)KT * R * 256;   // [KT][256] (only when ll_part): running q * data term per lane
+  double* lls = fzw + 4;                      // [KT][256]: running q * data term per lane (split-ordering term)
+  double* lqs = lls + (size_t)KT * 256;       // [KT][R][256] (KTM == 0): every lane's own log q~ slots
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lo4 = lane & 15, hi = lane >> 4;
   {
@@ -457,25 +460,24 @@ __global__ void __launch_bounds__(256, 2)
     for (int i = tid; i < KT * NTF * 8; i += 256) dst[i] = src[i];
     for (int i = tid; i < 4 * KT; i += 256) cst[i] = i < K ? constk[i] : 0.0;
     for (int i = tid; i < DP; i += 256) mul[i] = QUAD ? mu[i] : 0.0;
-    if (ll_part)
-      for (int it = 0; it < KT; ++it) lls[it * 256 + tid] = 0.0;
+    for (int it = 0; it < KT; ++it) lls[it * 256 + tid] = 0.0;
   }
   __syncthreads();
   const double* Pt = wl + (lane & 3) + 4 * hi;  // this lane's element of every 4x4 tile
   double* lqme = lqs + tid;
   double fz = 0.0;
   const int64_t ntile = (nrg + 4 * R - 1) / (4 * R);  // tiles of 4 waves x R row groups
-  for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+  // the next tile's rows are in flight while the current one is computed (registers: R x NT fragments)
+  double xn[R][NT];
+  int infon[R];
+  auto fetch = [&](int64_t tile) {
     const int64_t rg0 = (tile * 4 + wave) * R;
-    double f[R][NTF];
-    int grp[R];
-    bool rowok[R], rgok[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int64_t rg = rg0 + r;
-      rgok[r] = rg < nrg;
-      int info = 0;
-      if (rgok[r]) {
+      const bool ok = tile < ntile && rg < nrg;
+      int info = -1;  // -1: no such row group
+      if (ok) {
         if (rginfo) {
           info = rginfo[rg];
         } else {
@@ -483,75 +485,170 @@ __global__ void __launch_bounds__(256, 2)
           info = rem >= RG ? RG : (rem > 0 ? (int)rem : 0);
         }
       }
+      infon[r] = info;
+      const double* xr = X + ((ok ? rg : 0) * RG + lo4) * DP + hi;
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) xn[r][jt] = xr[4 * jt];
+    }
+  };
+  fetch(blockIdx.x);
+  for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const int64_t rg0 = (tile * 4 + wave) * R;
+    double f[R][NT];  // x' (then x'^2: the linear half of the weights is applied first, the features are squared in place)
+    int grp[R];
+    bool rowok[R], rgok[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      rgok[r] = infon[r] >= 0;
+      const int info = rgok[r] ? infon[r] : 0;
       grp[r] = info >> 5;
       rowok[r] = lo4 < (info & 31);
-      const double* xr = X + ((rgok[r] ? rg : 0) * RG + lo4) * DP + hi;
 #pragma unroll
-      for (int jt = 0; jt < NT; ++jt) f[r][QUAD ? NT + jt : jt] = xr[4 * jt];
+      for (int jt = 0; jt < NT; ++jt) f[r][jt] = xn[r][jt];
     }
     if constexpr (QUAD) {
 #pragma unroll
       for (int jt = 0; jt < NT; ++jt) {
         const double m = mul[4 * jt + hi];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const double xc = f[r][NT + jt] - m;
-          f[r][NT + jt] = xc;
-          f[r][jt] = xc * xc;
-        }
+        for (int r = 0; r < R; ++r) f[r][jt] -= m;
       }
     }
-    double mx[R];
+    fetch(tile + gridDim.x);
+    double mx[R], lq[NLQ][R];
 #pragma unroll
     for (int r = 0; r < R; ++r) mx[r] = -INFINITY;
-#pragma unroll 1
-    for (int it = 0; it < KT; ++it) {
-      const double* Pi = Pt + (size_t)it * NTF * 16;
+    // one cluster tile (4 clusters) and one half of the features: out += W_tile[half] . f for the wave's R row groups
+    auto half_tile = [&](int it, int half, double (&out)[R]) {
+      const double* Pi = Pt + ((size_t)it * NTF + (size_t)half * NT) * 16;
       double acc[R];
 #pragma unroll
       for (int r = 0; r < R; ++r) acc[r] = 0.0;
-      double ring[PF];
-      static_for<PF>([&](auto ic) { ring[ic] = Pi[ic * 16]; });
-      static_for<NTF>([&](auto jc) {
+      constexpr int PFH = NT < PF ? NT : PF;
+      double ring[PFH];
+      static_for<PFH>([&](auto ic) { ring[ic] = Pi[ic * 16]; });
+      static_for<NT>([&](auto jc) {
         constexpr int jt = jc;
-        const double v = ring[jt % PF];
-        if constexpr (jt + PF < NTF) ring[jt % PF] = Pi[(jt + PF) * 16];
+        const double v = ring[jt % PFH];
+        if constexpr (jt + PFH < NT) ring[jt % PFH] = Pi[(jt + PFH) * 16];
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = mfma4(v, f[r][jt], acc[r]);
       });
+#pragma unroll
+      for (int r = 0; r < R; ++r) out[r] += acc[r];
+    };
+    // constants of a cluster tile: E[log weight] + per-cluster constant; clusters past K (padding of the last tile)
+    // drop out as -inf
+    auto tile_const = [&](int it, double (&out)[R]) {
       const int k = 4 * it + hi;
       const double ck = cst[k];
 #pragma unroll
+      for (int r = 0; r < R; ++r) out[r] = k < K ? ctab[(int64_t)grp[r] * K + k] + ck : -INFINITY;
+    };
+    auto tile_done = [&](int it, double (&v)[R]) {
+      const int k = 4 * it + hi;
+#pragma unroll
       for (int r = 0; r < R; ++r) {
-        // data term + per-cluster constant + E[log weight]; clusters past K (padding of the last tile) drop out as -inf
-        const double v = k < K ? ctab[(int64_t)grp[r] * K + k] + (acc[r] + ck) : -INFINITY;
-        mx[r] = fmax(mx[r], v);
-        if (raw) {
-          if (k < K && rgok[r]) qZ[(int64_t)k * ldq + (rg0 + r) * RG + lo4] = v;
+        mx[r] = fmax(mx[r], v[r]);
+        if (raw && k < K && rgok[r]) qZ[(int64_t)k * ldq + (rg0 + r) * RG + lo4] = v[r];
+      }
+    };
+    // the half of the weights that multiplies x' (QUAD: tiles NT..2NT-1; otherwise the only half)
+    if constexpr (REGS) {
+#pragma unroll
+      for (int it = 0; it < KTM; ++it) {
+        if (it < KT) {  // block-uniform
+          tile_const(it, lq[it]);
+          half_tile(it, QUAD ? 1 : 0, lq[it]);
+          if constexpr (!QUAD) tile_done(it, lq[it]);
         } else {
-          lqme[(it * R + r) * 256] = v;
+#pragma unroll
+          for (int r = 0; r < R; ++r) lq[it][r] = -INFINITY;
+        }
+      }
+    } else {
+#pragma unroll 1
+      for (int it = 0; it < KT; ++it) {
+        tile_const(it, lq[0]);
+        half_tile(it, QUAD ? 1 : 0, lq[0]);
+        if constexpr (!QUAD) tile_done(it, lq[0]);
+        if (QUAD || !raw) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) lqme[(it * R + r) * 256] = lq[0][r];
+        }
+      }
+    }
+    if constexpr (QUAD) {
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) f[r][jt] *= f[r][jt];
+      if constexpr (REGS) {
+#pragma unroll
+        for (int it = 0; it < KTM; ++it) {
+          if (it < KT) {
+            half_tile(it, 0, lq[it]);
+            tile_done(it, lq[it]);
+          }
+        }
+      } else {
+#pragma unroll 1
+        for (int it = 0; it < KT; ++it) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) lq[0][r] = lqme[(it * R + r) * 256];
+          half_tile(it, 0, lq[0]);
+          tile_done(it, lq[0]);
+          if (!raw) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) lqme[(it * R + r) * 256] = lq[0][r];
+          }
         }
       }
     }
     if (raw) continue;
+    // logsumexp (probutils.cpp:141-150): max, sum exp(x - max), log + max; q = exp(x - max) / sum = exp(x - logZ)
+    // (cluster.cpp:130-131) with ONE exponential per entry -- e is kept (registers or the lane's slot) and scaled
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       double m = mx[r];
       m = fmax(m, __shfl_xor(m, 16));
       m = fmax(m, __shfl_xor(m, 32));
       double se = 0.0;
-      for (int it = 0; it < KT; ++it) se += exp(lqme[(it * R + r) * 256] - m);
+      if constexpr (REGS) {
+#pragma unroll
+        for (int it = 0; it < KTM; ++it) {
+          if (it < KT) {
+            const double e = exp(lq[it][r] - m);
+            se += e;
+            lq[it][r] = ll_part ? lq[it][r] : e;      // with the split-ordering term the log value is still needed
+          }
+        }
+      } else {
+        for (int it = 0; it < KT; ++it) {
+          const double v = lqme[(it * R + r) * 256];
+          const double e = exp(v - m);
+          se += e;
+          if (!ll_part) lqme[(it * R + r) * 256] = e;
+        }
+      }
       se = sum_over_hi(se);
       const double logZ = log(se) + m;
-      for (int it = 0; it < KT; ++it) {
+      const double inv = 1.0 / se;
+      auto finish = [&](int it, double v) {
         const int k = 4 * it + hi;
         if (k < K) {
-          const double lq = lqme[(it * R + r) * 256];
-          double q = exp(lq - logZ);
+          double q = ll_part ? exp(v - logZ) : v * inv;
           if (!rowok[r]) q = 0.0;
           if (rgok[r]) qZ[(int64_t)k * ldq + (rg0 + r) * RG + lo4] = q;
-          if (ll_part && q > 0.0) lls[it * 256 + tid] += q * (lq - ctab[(int64_t)grp[r] * K + k]);
+          if (ll_part && q > 0.0) lls[it * 256 + tid] += q * (v - ctab[(int64_t)grp[r] * K + k]);
         }
+      };
+      if constexpr (REGS) {
+#pragma unroll
+        for (int it = 0; it < KTM; ++it)
+          if (it < KT) finish(it, lq[it][r]);
+      } else {
+        for (int it = 0; it < KT; ++it) finish(it, lqme[(it * R + r) * 256]);
       }
       if (rgok[r] && rowok[r] && hi == 0) fz += logZ;
     }
@@ -562,8 +659,7 @@ __global__ void __launch_bounds__(256, 2)
   if (ll_part) {
     for (int it = 0; it < KT; ++it) {
       const double v = sum_over_lo4(lls[it * 256 + tid]);  // cluster 4 it + hi, summed over the 16 rows' lanes
-      __builtin_amdgcn_wave_barrier();
-      if (lo4 == 0) lls[it * 256 + tid] = v;  // lanes 0, 16, 32, 48 of every wave hold the wave's sums
+      if (lo4 == 0) lls[it * 256 + tid] = v;               // lanes 0, 16, 32, 48 of every wave hold the wave's sums
     }
   }
   __syncthreads();
@@ -582,12 +678,15 @@ __global__ void __launch_bounds__(256, 2)
   }
 }
 
-template <int NT, bool QUAD, int R>
+static size_t edm_lds_bytes(int NT, int NTF, int KT, int R, bool slots) {
+  return ((size_t)KT * NTF * 16 + 4 * KT + 4 * NT + 4 + (size_t)KT * 256 + (slots ? (size_t)KT * R * 256 : 0)) * sizeof(double);
+}
+
+template <int NT, bool QUAD, int R, int KTM>
 static hipError_t launch_edm_k(const DiagEstepLaunch& a, hipStream_t stream) {
   const int KT = (a.K + 3) / 4, NTF = QUAD ? 2 * NT : NT;
-  const size_t shmem = ((size_t)KT * NTF * 16 + 4 * KT + 4 * NT + 4 + (size_t)KT * R * 256 + (a.ll_part ? (size_t)KT * 256 : 0)) *
-                       sizeof(double);
-  auto kern = estep_diag_mfma_kernel<NT, QUAD, R>;
+  const size_t shmem = edm_lds_bytes(NT, NTF, KT, R, KTM == 0);
+  auto kern = estep_diag_mfma_kernel<NT, QUAD, R, KTM>;
   static LdsGrant grant;
   if (hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(kern), shmem, grant); e != hipSuccess) return e;
   const int64_t ntile = (a.nrg + 4 * R - 1) / (4 * R);
@@ -611,9 +710,9 @@ static hipError_t launch_edm_k(const DiagEstepLaunch& a, hipStream_t stream) {
 template <int NT, bool QUAD>
 static hipError_t launch_edm_q(const DiagEstepLaunch& a, hipStream_t stream) {
   // row groups per wave by the register budget (R x NTF feature fragments of two registers each)
-  constexpr int NTF = QUAD ? 2 * NT : NT;
-  constexpr int R = NTF <= 16 ? 4 : NTF <= 32 ? 2 : 1;
-  return launch_edm_k<NT, QUAD, R>(a, stream);
+  constexpr int R = NT <= 16 ? 2 : 1;  // two sets of R x NT fragments live (current tile, next tile in flight)
+  if (a.K <= 32) return launch_edm_k<NT, QUAD, R, 8>(a, stream);
+  return launch_edm_k<NT, QUAD, R, 0>(a, stream);
 }
 
 template <int NT>
@@ -625,11 +724,9 @@ static hipError_t launch_edm_t(const DiagEstepLaunch& a, hipStream_t stream) {
 int64_t estep_diag_mfma_weights(int DP, int K, int mode) {
   if (DP > 128 || DP % 16 || K < 1) return 0;
   const int NT = DP / 4, NTF = mode == 2 ? NT : 2 * NT, KT = (K + 3) / 4;
-  const int R = NTF <= 16 ? 4 : NTF <= 32 ? 2 : 1;
-  // the weights of all clusters and every lane's log q~ slots (and, with the split-ordering term, its running sums)
-  // must fit in the CU's LDS
-  const size_t lds = ((size_t)KT * NTF * 16 + 4 * KT + 4 * NT + 4 + (size_t)KT * R * 256 + (size_t)KT * 256) * sizeof(double);
-  if (lds > 150 * 1024) return 0;
+  const int R = NT <= 16 ? 2 : 1;
+  // the weights of all clusters, every lane's split-ordering sums and (K > 32) its log q~ slots must fit in the CU's LDS
+  if (edm_lds_bytes(NT, NTF, KT, R, K > 32) > 150 * 1024) return 0;
   return (int64_t)KT * NTF * 16;
 }
 

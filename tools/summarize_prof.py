@@ -24,7 +24,7 @@ if log.exists():
 
 
 def short(n):
-    for k in ("estep_diag_kernel", "suffstat_diag_kernel", "estep_kernel", "suffstat_kernel"):
+    for k in ("estep_diag_mfma_kernel", "estep_diag_kernel", "suffstat_diag_kernel", "estep_kernel", "suffstat_kernel"):
         if k in n:
             return k
     return None
