@@ -8,7 +8,7 @@ tag=$1; shift
 out=gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp 2>/dev/null && export TMPDIR=/tmp && cd - >/dev/null
-args="--steps 5 --warmup 1 --no-cpu-baseline --no-parity $*"
+args="--steps 5 --warmup 1 --no-cpu-baseline --no-parity --no-other-configs $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- python3 bench.py $args > $out/kt.log 2>&1
 rocprofv3 --kernel-trace --output-format csv -d $out/p1 -o p1 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -- python3 bench.py $args > $out/p1.log 2>&1
 rocprofv3 --kernel-trace --output-format csv -d $out/p2 -o p2 --pmc FETCH_SIZE SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -- python3 bench.py $args > $out/p2.log 2>&1

@@ -24,9 +24,13 @@ if log.exists():
 
 
 def short(n):
-    for k in ("estep_diag_mfma_kernel", "estep_diag_kernel", "suffstat_diag_kernel", "estep_kernel", "suffstat_kernel"):
-        if k in n:
-            return k
+    """Kernel family + template arguments (every instantiation is reported on its own)."""
+    for k in ("estep_diag_mfma_kernel", "estep_diag_kernel", "suffstat_diag_kernel", "estep_wide_kernel", "estep_kernel",
+              "suffstat_kernel"):
+        i = n.find(k)
+        if i >= 0:
+            j = n.find("(", i)
+            return n[i:j if j > 0 else None].strip()
     return None
 
 
