@@ -74,8 +74,12 @@ inline double run(int algo, const vMatrixXd& X, vMatrixXd& qZ, std::vector<W>& w
   for (int j = 0; j < J; ++j) n[j] = (int64_t)X[j].rows();
   ModelGuard g;
   double F = 0.0;
-  check(lc_learn(algo, J, ptr.data(), n.data(), D, rs, cs, wprior, clusterprior, maxclusters, sparse ? 1 : 0,
-                 verbose ? 1 : 0, nthreads, 0, &g.m, &F));
+  /* the priors the caller's weight objects carry: vbem's weights.resize(J, W()) keeps existing elements and
+   * default-constructs the rest (cluster.cpp:192) */
+  std::vector<double> wpj(J, W().prior());
+  for (int j = 0; j < J && j < (int)weights.size(); ++j) wpj[j] = weights[j].prior();
+  check(lc_learn_w(algo, J, ptr.data(), n.data(), D, rs, cs, wprior, wpj.data(), clusterprior, maxclusters,
+                   sparse ? 1 : 0, verbose ? 1 : 0, nthreads, 0, &g.m, &F));
   int K = 0;
   check(lc_model_dims(g.m, 0, &K, 0));
   /* qZ, weights, clusters are overwritten exactly as the reference does (cluster.cpp:583-585, 192-193) */

@@ -226,6 +226,13 @@ int lc_learn(int algo, int J, const double* const* Xj, const int64_t* Nj, int D,
              int64_t col_stride, double wprior, double clusterprior, int maxclusters, int sparse, int verbose,
              unsigned nthreads, int device, lc_model** out, double* F);
 
+/* The same with the prior of EVERY group's weight distribution (wprior_j[J], NULL = defaults): what the caller's
+ * `std::vector<Dirichlet>& weights` carries into learnSGMC (vbem's weights.resize(J, W()) keeps existing elements,
+ * cluster.cpp:192).  GDirichlet has no parameter (ignored there); single-matrix learners use `wprior`. */
+int lc_learn_w(int algo, int J, const double* const* Xj, const int64_t* Nj, int D, int64_t row_stride,
+               int64_t col_stride, double wprior, const double* wprior_j, double clusterprior, int maxclusters,
+               int sparse, int verbose, unsigned nthreads, int device, lc_model** out, double* F);
+
 /* The same model-selection loop (cluster(), cluster.cpp:564-629) on observations that already live in
  * a context (lc_ctx_set_data or lc_ctx_synth): nothing but the M-step statistics crosses PCIe, the
  * split search (partobs / splitobs / auglabels, cluster.cpp:438-470) runs on the device too.

@@ -165,6 +165,9 @@ def lib() -> C.CDLL:
     L.lc_learn.argtypes = [C.c_int, C.c_int, C.POINTER(c_double_p), c_int64_p, C.c_int, C.c_int64, C.c_int64,
                            C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_int,
                            C.POINTER(C.c_void_p), c_double_p]
+    L.lc_learn_w.argtypes = [C.c_int, C.c_int, C.POINTER(c_double_p), c_int64_p, C.c_int, C.c_int64, C.c_int64,
+                             C.c_double, c_double_p, C.c_double, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_int,
+                             C.POINTER(C.c_void_p), c_double_p]
     L.lc_cluster.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int,
                              C.c_uint, C.POINTER(C.c_void_p), c_double_p]
     L.lc_model_free.argtypes = [C.c_void_p]
@@ -603,15 +606,23 @@ class Model:
         return Fw, Fc
 
 
-def learn(algo, X, wprior=1.0, clusterprior=1.0, maxclusters=-1, sparse=False, verbose=False, nthreads=1, device=0):
+def learn(algo, X, wprior=1.0, clusterprior=1.0, maxclusters=-1, sparse=False, verbose=False, nthreads=1, device=0,
+          wprior_j=None):
+    """wprior_j: one weight prior per group (the priors the caller's weight objects carry into the multi-group
+    learners: learnSGMC's Dirichlet alphas); None = defaults."""
     Xs = [X] if isinstance(X, np.ndarray) else list(X)
     Xs = [np.ascontiguousarray(x, dtype=np.float64) for x in Xs]
     J, D = len(Xs), Xs[0].shape[1]
     ptrs = (c_double_p * J)(*[dptr(x) for x in Xs])
     Nj = (C.c_int64 * J)(*[x.shape[0] for x in Xs])
     mh, F = C.c_void_p(), C.c_double()
-    check(lib().lc_learn(algo, J, ptrs, Nj, D, D, 1, wprior, clusterprior, maxclusters, int(sparse), int(verbose),
-                         nthreads, device, C.byref(mh), C.byref(F)))
+    wj = None
+    if wprior_j is not None:
+        wj = np.ascontiguousarray(wprior_j, dtype=np.float64)
+        if wj.shape != (J,):
+            raise ValueError("wprior_j needs one value per group")
+    check(lib().lc_learn_w(algo, J, ptrs, Nj, D, D, 1, wprior, dptr(wj), clusterprior, maxclusters, int(sparse),
+                           int(verbose), nthreads, device, C.byref(mh), C.byref(F)))
     return F.value, Model(mh), [x.shape[0] for x in Xs]
 
 

@@ -198,7 +198,7 @@ std::vector<std::vector<int>> assign_groups(int J, const int64_t* Nj, int W) {
 }
 
 double learn_sharded(int algo, int J, const double* const* Xj, const int64_t* Nj, int D, int64_t rs, int64_t cs,
-                     double wprior, double clusterprior, int maxclusters, int sparse, int verbose, unsigned nthreads,
+                     double wprior, const double* wprior_j, double clusterprior, int maxclusters, int sparse, int verbose, unsigned nthreads,
                      int device, int W, bool same_device, lc_model* m) {
   const bool single = algo_single(algo);
   if (single) W = (int)std::max<int64_t>(1, std::min<int64_t>(W, Nj[0] / 64));  // at least a few row groups per shard
@@ -250,6 +250,8 @@ double learn_sharded(int algo, int J, const double* const* Xj, const int64_t* Nj
         }
         ctx.set_data((int)xp.size(), xp.data(), nn.data(), D, rs, cs);
         ctx.set_group_sharded(true);
+        if (wprior_j)  // the priors the caller's weight objects carry (weights.resize(J, W()) keeps them, cluster.cpp:192)
+          for (int j : sh.groups) model.weights.emplace_back(model.wkind, wprior_j[j]);
       }
       lce::ClusterOptions co;
       co.clusterprior = clusterprior;
@@ -281,7 +283,7 @@ double learn_sharded(int algo, int J, const double* const* Xj, const int64_t* Nj
   if (!single) {
     std::vector<lch::WeightState> w;
     w.reserve((size_t)J);
-    for (int j = 0; j < J; ++j) w.emplace_back(out.wkind, lch::ALPHA1PRIOR);
+    for (int j = 0; j < J; ++j) w.emplace_back(out.wkind, wprior_j ? wprior_j[j] : lch::ALPHA1PRIOR);
     for (int r = 0; r < W; ++r) {
       lce::Model& mr = r == 0 ? out : models[(size_t)r];
       for (size_t l = 0; l < m->shards[(size_t)r]->groups.size(); ++l)
@@ -480,13 +482,13 @@ int lc_estep_posterior(lc_ctx* ctx, int K, const double* nu, const double* beta,
     std::vector<double> ll(K);
     ctx->impl.estep(K, A.data(), m, c.data(), Fz, ll.data());
     if (LLk) {
-      std::vector<double> Njk((size_t)J * K);
+      std::vector<double> Njk((size_t)J * K), nks((size_t)K, 0.0);
       ctx->impl.colsums(Njk.data());
-      for (int k = 0; k < K; ++k) {
-        double nk = 0.0;
-        for (int j = 0; j < J; ++j) nk += Njk[(size_t)j * K + k];
-        LLk[k] = ll[k] + cst[k] * nk;
-      }
+      for (int k = 0; k < K; ++k)
+        for (int j = 0; j < J; ++j) nks[(size_t)k] += Njk[(size_t)j * K + k];
+      // whole groups per rank: the counts above are this rank's groups only, while ll is already summed over ranks
+      if (ctx->impl.group_sharded()) ctx->impl.allreduce_values(nks.data(), K);
+      for (int k = 0; k < K; ++k) LLk[k] = ll[k] + cst[k] * nks[(size_t)k];
     }
   });
 }
@@ -708,6 +710,13 @@ int lc_vbem(lc_ctx* ctx, lc_model** model, int wkind, int ckind, double wprior, 
 int lc_learn(int algo, int J, const double* const* Xj, const int64_t* Nj, int D, int64_t rs, int64_t cs,
              double wprior, double clusterprior, int maxclusters, int sparse, int verbose, unsigned nthreads,
              int device, lc_model** out, double* F) {
+  return lc_learn_w(algo, J, Xj, Nj, D, rs, cs, wprior, nullptr, clusterprior, maxclusters, sparse, verbose, nthreads,
+                    device, out, F);
+}
+
+int lc_learn_w(int algo, int J, const double* const* Xj, const int64_t* Nj, int D, int64_t rs, int64_t cs,
+               double wprior, const double* wprior_j, double clusterprior, int maxclusters, int sparse, int verbose,
+               unsigned nthreads, int device, lc_model** out, double* F) {
   return guarded([&] {
     need(Xj, "Xj");
     need(Nj, "Nj");
@@ -730,8 +739,8 @@ int lc_learn(int algo, int J, const double* const* Xj, const int64_t* Nj, int D,
     const int ngpu = requested_gpus(&same_device);
     if (ngpu > 1 && (single ? Nj[0] >= 128 : J >= 2)) {
       for (int j = 0; j < J; ++j) need(Xj[j], "Xj[j]");
-      const double f = learn_sharded(algo, J, Xj, Nj, D, rs, cs, wprior, clusterprior, maxclusters, sparse, verbose,
-                                     nthreads, device, ngpu, same_device, m.get());
+      const double f = learn_sharded(algo, J, Xj, Nj, D, rs, cs, wprior, single ? nullptr : wprior_j, clusterprior,
+                                     maxclusters, sparse, verbose, nthreads, device, ngpu, same_device, m.get());
       if (F) *F = f;
       *out = m.release();
       return;
@@ -742,6 +751,8 @@ int lc_learn(int algo, int J, const double* const* Xj, const int64_t* Nj, int D,
     ctx.set_data(J, Xj, Nj, D, rs, cs);
     algo_configure(algo, m->model, verbose != 0, sparse != 0);
     if (single) m->model.weights.emplace_back(m->model.wkind, wprior);  // vecweights(1, weights), :653/:684/:715/:752
+    else if (wprior_j)  // the caller's weight objects keep their priors (weights.resize(J, W()), cluster.cpp:192)
+      for (int j = 0; j < J; ++j) m->model.weights.emplace_back(m->model.wkind, wprior_j[j]);
     lce::ClusterOptions co;
     co.clusterprior = clusterprior;
     co.maxclusters = maxclusters;
@@ -1067,16 +1078,26 @@ int lc_learn_topic_dist(int J, const int* Ij, const double* const* Xji, const in
                         double prior_k, unsigned maxT, int maxK, int verbose, unsigned nthreads, int device,
                         void* stream, lc_allreduce_fn fn, void* user, lc_tmodel** out, double* F) {
   return guarded([&] {
-    need(Ij, "Ij");
-    need(Xji, "Xji");
-    need(Nji, "Nji");
     need(out, "out");
-    if (nthreads < 1) throw std::invalid_argument("Must specify at least one thread for execution!");
-    if (J < 1) throw std::invalid_argument("need at least one group of observations");
-    if (maxT < 1) throw std::invalid_argument("maxT must be at least 1");
     const bool mcm = Wj != nullptr;
     std::unique_ptr<lc_tmodel> m(new lc_tmodel());
     lce::TopicData& d = m->data;
+    // A rank that rejects its input must not leave the others waiting in the first collective: the communicator is set
+    // up first, every rank validates and prepares locally, and the ranks agree on the outcome before anybody returns.
+    m->D = D;
+    if (fn) {  // whole groups (with all their documents) per rank: cluster statistics, N_tk, Fyz, Fz are summed
+      m->ctx.reset(new lc_ctx(device, static_cast<hipStream_t>(stream)));
+      m->ctx->impl.set_allreduce(fn, user);
+      m->ctx->impl.set_group_sharded(true);
+    }
+    std::exception_ptr bad;
+    try {
+    need(Ij, "Ij");
+    need(Xji, "Xji");
+    need(Nji, "Nji");
+    if (nthreads < 1) throw std::invalid_argument("Must specify at least one thread for execution!");
+    if (J < 1) throw std::invalid_argument("need at least one group of observations");
+    if (maxT < 1) throw std::invalid_argument("maxT must be at least 1");
     d.J = J;
     d.Ij.assign(Ij, Ij + J);
     m->doc0.assign(1, 0);
@@ -1097,7 +1118,6 @@ int lc_learn_topic_dist(int J, const int* Ij, const double* const* Xji, const in
       d.W = m->W.data();
       d.Dt = Dt;
     }
-    if (verbose) std::cout << (mcm ? "Learning MCM..." : "Learning SCM...") << std::endl;  // scluster.cpp:595-596
     // qY: |U(-1,1)| rows, normalised (scluster.cpp:519-521 / mcluster.cpp:559-561).  The reference draws from Eigen's
     // Random(), i.e. std::rand() per coefficient in column-major order; the same sequence is consumed here.
     m->model.T = (int)maxT;
@@ -1120,12 +1140,17 @@ int lc_learn_topic_dist(int J, const int* Ij, const double* const* Xji, const in
         }
       }
     }
-    m->ctx.reset(new lc_ctx(device, static_cast<hipStream_t>(stream)));
-    m->D = D;
-    if (fn) {  // whole groups (with all their documents) per rank: cluster statistics, N_tk, Fyz, Fz are summed
-      m->ctx->impl.set_allreduce(fn, user);
-      m->ctx->impl.set_group_sharded(true);
+    } catch (...) {
+      bad = std::current_exception();
     }
+    if (!fn) {  // one rank: argument errors come before the device is touched, as in the reference
+      if (bad) std::rethrow_exception(bad);
+      m->ctx.reset(new lc_ctx(device, static_cast<hipStream_t>(stream)));
+    } else if (m->ctx->impl.allreduce_value(bad ? 1.0 : 0.0) > 0.0) {
+      if (bad) std::rethrow_exception(bad);
+      throw std::invalid_argument("another rank rejected its input");
+    }
+    if (verbose) std::cout << (mcm ? "Learning MCM..." : "Learning SCM...") << std::endl;  // scluster.cpp:595-596
     const double docs = m->ctx->impl.allreduce_value((double)d.Itot);
     if (!mcm && (double)maxT > docs)  // scluster.cpp:531-533 (sic: no space before X)
       throw std::invalid_argument("maxT must be less than the number of documents ofX!");

@@ -185,3 +185,37 @@ def test_rccl_world_of_one_inside_the_em_loop(lib):
                 assert ctx.comm_info()["kind"] == "none"
         traces.append(tr)
     np.testing.assert_array_equal(traces[0], traces[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shards", [0, 2])
+def test_per_group_weight_priors_reach_the_learner(lib, sharded_env, shards):
+    """learnSGMC with Dirichlet(alpha_j) objects in the caller's `weights` vector: vbem's weights.resize(J, W()) keeps
+    them (cluster.cpp:192), so group j learns with ITS alpha.  lc_learn_w carries the priors; equal to the oracle's
+    cluster() with the same weight objects, unsharded and sharded over whole groups."""
+    import lc_oracle as o
+    from libcluster_amd import capi
+
+    sizes = [300, 500, 200, 400]
+    X = [_blobs(100 + (j % 2), n, 3, 3, 10.0) for j, n in enumerate(sizes)]
+    alphas = [0.1, 2.5, 1.0, 0.4]
+    w = [o.Dirichlet(a) for a in alphas]
+    cl = []
+    Fo, qo = o.cluster(X, w, cl, 1.0, -1, False, False, o.Dirichlet)
+    sharded_env(shards)
+    F, m, rows = capi.learn(capi.ALGO_SGMC, X, 1.0, 1.0, -1, False, False, 4, 0, wprior_j=alphas)
+    q = m.qz_all(rows)
+    K = m.dims()[1]
+    el = [m.weights(j)[0] for j in range(len(X))]
+    m.close()
+    assert K == len(cl)
+    assert abs(F - Fo) <= 1e-9 * abs(Fo)
+    for a, b in zip(q, qo):
+        np.testing.assert_allclose(a, b, atol=1e-8)
+    for j in range(len(X)):
+        np.testing.assert_allclose(el[j], w[j].Elogweight(), rtol=1e-8, atol=1e-10)
+    # and they matter: the default priors give another free energy
+    sharded_env(0)
+    F1, m1, _ = capi.learn(capi.ALGO_SGMC, X, 1.0, 1.0, -1, False, False, 4, 0)
+    m1.close()
+    assert abs(F1 - F) > 1e-6 * abs(F)
