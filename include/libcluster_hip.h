@@ -197,6 +197,8 @@ int lc_ctx_timing_enable(lc_ctx* ctx, int on);
 int lc_ctx_timing_reset(lc_ctx* ctx);
 int lc_ctx_timing_get(lc_ctx* ctx, double* estep_ms, int64_t* estep_calls, double* suffstat_ms,
                       int64_t* suffstat_calls);
+/* launches of the fused pass (small observations, D <= 16: vbexpectation + the next iteration's updateSS in one kernel) */
+int lc_ctx_timing_get_fused(lc_ctx* ctx, double* fused_ms, int64_t* fused_calls);
 
 /* ======================================================================== *
  * Variational Bayes EM on a context (vbem, cluster.cpp:177-239).

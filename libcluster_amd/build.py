@@ -24,7 +24,8 @@ ARCH = "gfx950"
 # north-star shape, other kernels unchanged (measured; max-ilp / iterative-ilp / max-memory-clause are slower).
 DEVICE_FLAGS = ["-mllvm", "-amdgpu-use-amdgpu-trackers=1", "-mllvm", "-amdgpu-disable-unclustered-high-rp-reschedule=1"]
 
-SOURCES = ["lc_kernels_estep.hip", "lc_kernels_suffstat.hip", "lc_kernels_diag.hip", "lc_kernels_aux.hip", "lc_ctx.cpp",
+SOURCES = ["lc_kernels_estep.hip", "lc_kernels_suffstat.hip", "lc_kernels_diag.hip", "lc_kernels_aux.hip", "lc_kernels_fused.hip",
+           "lc_ctx.cpp",
            "lc_comm.cpp", "lc_engine.cpp", "lc_topic.cpp", "lc_capi.cpp"]
 HEADERS = ["lc_kernels.h", "lc_device.hpp", "lc_ctx.hpp", "lc_comm.hpp", "lc_engine.hpp", "lc_topic.hpp", "lc_host.hpp",
            "../../include/libcluster_hip.h"]

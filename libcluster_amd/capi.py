@@ -492,7 +492,12 @@ class Context:
         a, b = C.c_double(), C.c_double()
         na, nb = C.c_int64(), C.c_int64()
         check(lib().lc_ctx_timing_get(self._h, C.byref(a), C.byref(na), C.byref(b), C.byref(nb)))
-        return {"estep_ms": a.value, "estep_calls": na.value, "suffstat_ms": b.value, "suffstat_calls": nb.value}
+        f, nf = C.c_double(), C.c_int64()
+        fn = lib().lc_ctx_timing_get_fused
+        fn.argtypes = [C.c_void_p, c_double_p, c_int64_p]
+        check(fn(self._h, C.byref(f), C.byref(nf)))
+        return {"estep_ms": a.value, "estep_calls": na.value, "suffstat_ms": b.value, "suffstat_calls": nb.value,
+                "fused_ms": f.value, "fused_calls": nf.value}
 
     def synchronize(self):
         check(lib().lc_ctx_synchronize(self._h))

@@ -665,6 +665,15 @@ int lc_ctx_timing_get(lc_ctx* ctx, double* estep_ms, int64_t* estep_calls, doubl
   });
 }
 
+int lc_ctx_timing_get_fused(lc_ctx* ctx, double* fused_ms, int64_t* fused_calls) {
+  return guarded([&] {
+    need(ctx, "ctx");
+    const lcc::KernelTimes t = ctx->impl.timing_get();
+    if (fused_ms) *fused_ms = t.fused_ms;
+    if (fused_calls) *fused_calls = t.fused_calls;
+  });
+}
+
 // ---------------------------------------------------------------------------
 int lc_vbem(lc_ctx* ctx, lc_model** model, int wkind, int ckind, double wprior, double clusterprior, int maxit,
             int sparse, int fixed_iters, int verbose, unsigned nthreads, double* F, int* niter, double* Ftrace,

@@ -736,16 +736,7 @@ void Context::allreduce_values(double* v, int n) {
   LC_HIP(hipStreamSynchronize(stream_));
 }
 
-void Context::estep(int K, const double* A, const double* m, const double* c, double* Fz, double* LLk, bool raw) {
-  if (K < 1) throw std::invalid_argument("K must be >= 1");
-  require_gw_width();  // (an upper limit only: wide observations stream through estep_wide_kernel)
-  if (NP_ == 0 && !distributed()) {
-    if (Fz) *Fz = -0.0;
-    if (LLk) std::fill(LLk, LLk + K, 0.0);
-    qz_[cur_].K = K;
-    return;
-  }
-  LC_HIP(hipSetDevice(device_));
+void Context::pack_estep_params(int K, const double* A, const double* m, const double* c) {
   const int D = D_, DP = DP_, NT = DP / 4;
   const bool wide = DP > 128;
   const int NTILES = wide ? 0 : lck::ntiles(DP);
@@ -786,6 +777,22 @@ void Context::estep(int K, const double* A, const double* m, const double* c, do
     }
   }
   std::memcpy(hpack_.data() + (size_t)K * PS, c, (size_t)J_ * K * sizeof(double));
+}
+
+void Context::estep(int K, const double* A, const double* m, const double* c, double* Fz, double* LLk, bool raw) {
+  if (K < 1) throw std::invalid_argument("K must be >= 1");
+  require_gw_width();  // (an upper limit only: wide observations stream through estep_wide_kernel)
+  if (NP_ == 0 && !distributed()) {
+    if (Fz) *Fz = -0.0;
+    if (LLk) std::fill(LLk, LLk + K, 0.0);
+    qz_[cur_].K = K;
+    return;
+  }
+  LC_HIP(hipSetDevice(device_));
+  const int DP = DP_;
+  const bool wide = DP > 128;
+  const int64_t PS = wide ? (int64_t)lck::wide_chunks(DP) * lck::WIDE_CHUNK : lck::pstride(DP);
+  pack_estep_params(K, A, m, c);
   params_.reserve(hpack_.size());
   LC_HIP(hipMemcpyAsync(params_.p, hpack_.data(), hpack_.size() * sizeof(double), hipMemcpyHostToDevice, stream_));
 
@@ -843,6 +850,106 @@ void Context::estep(int K, const double* A, const double* m, const double* c, do
   LC_HIP(hipStreamSynchronize(stream_));
   if (Fz) *Fz = hred_[0];
   if (LLk) std::copy(hred_.begin() + 1, hred_.end(), LLk);
+}
+
+bool Context::estep_suffstat_fused(int K, const double* A, const double* m, const double* c, double* Fz, double* LLk,
+                                   double* Nk, double* xs, double* xxs, double* Njk) {
+  if (K < 1) throw std::invalid_argument("K must be >= 1");
+  const int D = D_, DP = DP_;
+  const int64_t nrg = NP_ / lck::RG;
+  if (!lck::fused_eligible(DP, K)) return false;
+  const int grid = NP_ > 0 ? lck::fused_plan(DP, nrg, K) : 0;  // (0: this rank holds no rows; it still joins the sums)
+  LC_HIP(hipSetDevice(device_));
+  const int64_t PS = lck::pstride(DP), SS = lck::stat_stride(DP);
+  pack_estep_params(K, A, m, c);
+  params_.reserve(hpack_.size());
+  LC_HIP(hipMemcpyAsync(params_.p, hpack_.data(), hpack_.size() * sizeof(double), hipMemcpyHostToDevice, stream_));
+  ensure_qz(qz_[cur_], K, false);  // the E-step overwrites every column
+  qz_[cur_].K = K;
+  fzpart_.reserve((size_t)std::max(grid, 1));
+  llpart_.reserve((size_t)std::max(grid, 1) * K);
+  sspart_.reserve((size_t)std::max(grid, 1) * K * SS);
+  // one buffer for everything that is summed over ranks and copied back: [K records | J x K counts | Fz | LL_k]
+  const size_t nstat = (size_t)K * SS + (size_t)J_ * K, nout = nstat + 1 + (size_t)K;
+  ssout_.reserve(nout);
+  double* njk_d = ssout_.p + (size_t)K * SS;
+  double* fz_d = ssout_.p + nstat;
+  lck::FusedLaunch a;
+  a.DP = DP;
+  a.X = X_.p;
+  a.nrg = nrg;
+  a.rginfo = J_ > 1 ? rginfo_.p : nullptr;
+  a.nrows = Nj_[0];
+  a.params = params_.p;
+  a.ctab = params_.p + (size_t)K * PS;
+  a.K = K;
+  a.qZ = qz_[cur_].buf.p;
+  a.ldq = NP_;
+  a.fz_part = fzpart_.p;
+  a.ll_part = LLk ? llpart_.p : nullptr;
+  a.partial = sspart_.p;
+  a.grid = grid;
+  EvPair ev{};
+  if (timing_) {
+    LC_HIP(hipEventCreate(&ev.a));
+    LC_HIP(hipEventCreate(&ev.b));
+    ev.kind = 2;
+    LC_HIP(hipEventRecord(ev.a, stream_));
+  }
+  if (grid > 0) LC_HIP(lck::launch_fused(a, stream_));
+  if (timing_) {
+    LC_HIP(hipEventRecord(ev.b, stream_));
+    pending_.push_back(ev);
+  }
+  redtmp_.reserve((size_t)lck::REDUCE_TMP_ELEMS * 64);
+  if (grid > 0) {
+    LC_HIP(lck::launch_reduce_partials(sspart_.p, grid, (int64_t)K * SS, ssout_.p, stream_));
+    LC_HIP(lck::launch_reduce_partials(fzpart_.p, grid, 1, fz_d, stream_, redtmp_.p));
+    if (LLk) LC_HIP(lck::launch_reduce_partials(llpart_.p, grid, K, fz_d + 1, stream_, redtmp_.p));
+    else LC_HIP(hipMemsetAsync(fz_d + 1, 0, (size_t)K * sizeof(double), stream_));
+  } else {
+    LC_HIP(hipMemsetAsync(ssout_.p, 0, nout * sizeof(double), stream_));
+  }
+  const bool own_counts = J_ > 1 || group_sharded();
+  if (grid <= 0) {
+    // nothing to count
+  } else if (own_counts)
+    LC_HIP(lck::launch_group_colsum(qz_[cur_].buf.p, NP_, K, goff_d_.p, J_, njk_d, stream_, redtmp_.p, NP_));
+  else
+    LC_HIP(hipMemsetAsync(njk_d, 0, (size_t)K * sizeof(double), stream_));
+  if (group_sharded_) {  // whole groups per rank: the per-group counts stay local (two sums around them)
+    allreduce(ssout_.p, (int64_t)K * SS);
+    allreduce(fz_d, 1 + K);
+  } else {
+    allreduce(ssout_.p, (int64_t)nout);
+  }
+  hss_.resize(nout);
+  LC_HIP(hipMemcpyAsync(hss_.data(), ssout_.p, nout * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  LC_HIP(hipStreamSynchronize(stream_));
+  for (int k = 0; k < K; ++k) {
+    const double* rec = hss_.data() + (size_t)k * SS;
+    if (Nk) Nk[k] = rec[0];
+    if (xs)
+      for (int d = 0; d < D; ++d) xs[(size_t)k * D + d] = rec[1 + d];
+    if (xxs) {
+      const double* S = rec + 1 + DP;
+      double* o = xxs + (size_t)k * D * D;
+      for (int i = 0; i < D; ++i)
+        for (int j = 0; j <= i; ++j) {  // the lower triangle is authoritative
+          o[(size_t)i * D + j] = S[(size_t)i * DP + j];
+          o[(size_t)j * D + i] = S[(size_t)i * DP + j];
+        }
+    }
+  }
+  if (Njk) {
+    if (!own_counts)
+      for (int k = 0; k < K; ++k) Njk[k] = hss_[(size_t)k * SS];
+    else
+      std::copy(hss_.begin() + (size_t)K * SS, hss_.begin() + nstat, Njk);
+  }
+  if (Fz) *Fz = hss_[nstat];
+  if (LLk) std::copy(hss_.begin() + nstat + 1, hss_.begin() + nout, LLk);
+  return true;
 }
 
 // Sparse statistics (cluster.cpp:67-79): turn the J x K activity mask into a work list of
@@ -1341,7 +1448,10 @@ KernelTimes Context::timing_get() {
   for (auto& p : pending_) {
     float ms = 0.f;
     LC_HIP(hipEventElapsedTime(&ms, p.a, p.b));
-    if (p.kind == 0) {
+    if (p.kind == 2) {
+      times_.fused_ms += ms;
+      times_.fused_calls += 1;
+    } else if (p.kind == 0) {
       times_.estep_ms += ms;
       times_.estep_calls += 1;
     } else {

@@ -72,8 +72,8 @@ void trim_cache();
 void cache_release_thread();
 
 struct KernelTimes {
-  double estep_ms = 0, suffstat_ms = 0;
-  int64_t estep_calls = 0, suffstat_calls = 0;
+  double estep_ms = 0, suffstat_ms = 0, fused_ms = 0;  // fused: E-step + statistics in one launch (small observations)
+  int64_t estep_calls = 0, suffstat_calls = 0, fused_calls = 0;
 };
 
 class Context {
@@ -168,6 +168,11 @@ class Context {
   // sum_n q_nk (log q~_nk - c_jk)  (the data term of cluster.cpp:409-410).
   // raw = true stops after log q~ (c_jk - 0.5 d^2) has been written to qZ: GaussWish::Eloglike.
   void estep(int K, const double* A, const double* m, const double* c, double* Fz, double* LLk, bool raw = false);
+  // Small observations (D <= 16, K <= 16, Gauss-Wishart, dense): the E-step AND the statistics of the responsibilities it
+  // produces, in one pass (lc_kernels_fused.hip).  Same outputs as estep() followed by suffstat(nullptr, ...).
+  // Returns false, having done nothing, when the shape has no fused path.
+  bool estep_suffstat_fused(int K, const double* A, const double* m, const double* c, double* Fz, double* LLk,
+                            double* Nk, double* xs, double* xxs, double* Njk);
   // Sufficient statistics of the current qZ.  smask: J x K (1 = accumulate) or null.
   // Nk[K], xs[K*D], xxs[K*D*D] (row-major, symmetric), Njk[J*K].
   void suffstat(const unsigned char* smask, double* Nk, double* xs, double* xxs, double* Njk);
@@ -196,6 +201,8 @@ class Context {
   void ensure_qz(QZ& q, int K, bool preserve);
   void build_layout(int J, const int64_t* Nj, int D);
   void allreduce(double* dbuf, int64_t count);
+  // pack the E-step parameter stream (tiles of A_k in consumption order, -b_k; then the J x K table c) into hpack_
+  void pack_estep_params(int K, const double* A, const double* m, const double* c);
   void use_device() const;         // hipSetDevice(device_): every method that allocates, launches or copies starts here
   void require_gw_width() const;  // throws for DP > 128 (full-covariance kernels)
   int build_sparse_worklist(const unsigned char* smask, int K, int64_t SS, lck::SuffstatLaunch& a);

@@ -23,6 +23,20 @@ __device__ __forceinline__ double mfma4(double a, double b, double c) {
   return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
 }
 
+// n-th read of a cluster's parameter stream (for it: -b[it], tile(it,0), ..., tile(it,it)):
+// .jt < 0: element of the -b vector (offset in doubles from Pb), else of tile (it,jt) (from Pt)
+struct RdInfo {
+  int it, jt, off;
+};
+__host__ __device__ constexpr RdInfo rd_info(int n) {
+  int it = 0;
+  while (n >= it + 2) {
+    n -= it + 2;
+    ++it;
+  }
+  return n == 0 ? RdInfo{it, -1, 4 * it} : RdInfo{it, n - 1, (it * (it + 1) / 2 + (n - 1)) * 16};
+}
+
 // compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(<N-1>)
 template <typename F, int... I>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {

@@ -187,6 +187,8 @@ double vbem(lcc::Context& ctx, Model& model, const VbemOptions& opt) {
   std::vector<double> cst(K);
   std::vector<unsigned char> mask;
   model.LLk.assign(K, 0.0);
+  std::vector<double> nNk, nxs, nxxs, nNjk;  // statistics of the responsibilities the last (fused) E-step produced
+  bool have_next = false;
 
   double F = std::numeric_limits<double>::max(), Fold;
   int i = 0, done = 0;
@@ -210,7 +212,14 @@ double vbem(lcc::Context& ctx, Model& model, const VbemOptions& opt) {
       for (size_t t = 0; t < mask.size(); ++t) mask[t] = Njk[t] >= lch::ZEROCUTOFF ? 1 : 0;
       maskp = mask.data();
     }
-    if (done == 0 && opt.preset && opt.preset->K == K && !opt.sparse) {
+    if (have_next) {
+      // the fused pass of the previous iteration already produced the statistics of its responsibilities
+      Nk.swap(nNk);
+      xs.swap(nxs);
+      xxs.swap(nxxs);
+      Njk.swap(nNjk);
+      have_next = false;
+    } else if (done == 0 && opt.preset && opt.preset->K == K && !opt.sparse) {
       Nk = opt.preset->Nk;
       xs = opt.preset->xs;
       xxs = opt.preset->xxs;
@@ -267,7 +276,17 @@ double vbem(lcc::Context& ctx, Model& model, const VbemOptions& opt) {
     }
     double Fz = 0.0;
     const auto t2 = now();
-    run_estep(ctx, model, K, &Fz, opt.want_ll ? model.LLk.data() : nullptr);
+    // small observations: the E-step and the statistics the NEXT iteration starts from in one pass (updateSS runs at
+    // the top of the next iteration on exactly these responsibilities, cluster.cpp:198-212)
+    if (full && !opt.sparse) {
+      nNk.resize(K);
+      nxs.resize((size_t)K * D);
+      nxxs.resize((size_t)K * std::max<size_t>(XX, 1));
+      nNjk.resize((size_t)J * K);
+      have_next = ctx.estep_suffstat_fused(K, A.data(), m.data(), c.data(), &Fz, opt.want_ll ? model.LLk.data() : nullptr,
+                                           nNk.data(), nxs.data(), nxxs.data(), nNjk.data());
+    }
+    if (!have_next) run_estep(ctx, model, K, &Fz, opt.want_ll ? model.LLk.data() : nullptr);
     const auto t3 = now();
 
     // fenergy (:145-165)

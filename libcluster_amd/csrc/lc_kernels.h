@@ -75,6 +75,27 @@ int estep_rows_per_block(int DP);
 int64_t estep_grid(int DP, int64_t nrg);
 hipError_t launch_estep(const EstepLaunch& a, hipStream_t stream);
 
+// ---- small observations: E-step + the next iteration's statistics in one persistent pass (lc_kernels_fused.hip) ----
+struct FusedLaunch {
+  int DP;
+  const double* X;       // [NP x DP]
+  int64_t nrg;           // row groups (NP / 16)
+  const int* rginfo;     // [nrg] or nullptr (single group)
+  int64_t nrows;         // valid rows when rginfo == nullptr
+  const double* params;  // [K x pstride(DP)] as for estep_kernel
+  const double* ctab;    // [J x K]
+  int K;
+  double* qZ;            // [K x ldq]: written once (the new responsibilities)
+  int64_t ldq;
+  double* fz_part;       // [grid]
+  double* ll_part;       // [grid x K] or nullptr
+  double* partial;       // [grid x K x stat_stride(DP)] statistics of the NEW responsibilities
+  int grid;              // fused_plan(...)
+};
+bool fused_eligible(int DP, int K);          // a property of the shape alone (identical on every rank)
+int fused_plan(int DP, int64_t nrg, int K);  // persistent blocks for nrg row groups (0 when there are none)
+hipError_t launch_fused(const FusedLaunch& a, hipStream_t stream);
+
 // sparse work item of suffstat_kernel: rows [r0, r1) of one group x clusters klist[kofs .. kofs + kcnt)
 struct SSItem {
   int64_t r0, r1;

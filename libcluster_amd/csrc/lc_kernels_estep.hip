@@ -45,20 +45,6 @@ namespace lck {
 // log q~ is written to the qZ buffer as scratch, then normalised in place in
 // the same arithmetic order as the reference: max, sum exp(x-max), log+max,
 // exp(x - logZ).
-// n-th read of a cluster's parameter stream (for it: -b[it], tile(it,0), ..., tile(it,it)):
-// .jt < 0: element of the -b vector (offset in doubles from Pb), else of tile (it,jt) (from Pt)
-struct RdInfo {
-  int it, jt, off;
-};
-__host__ __device__ constexpr RdInfo rd_info(int n) {
-  int it = 0;
-  while (n >= it + 2) {
-    n -= it + 2;
-    ++it;
-  }
-  return n == 0 ? RdInfo{it, -1, 4 * it} : RdInfo{it, n - 1, (it * (it + 1) / 2 + (n - 1)) * 16};
-}
-
 // blocks per CU the register budget is set for.  D = 64: three row groups per wave (96 VGPRs of X fragments) at
 // three waves per SIMD measured 22.2 ms against 22.6 for four row groups at two waves per SIMD (N=10M, K=32).
 template <int DP>
