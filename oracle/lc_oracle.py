@@ -17,7 +17,11 @@ citing the reference file:line it follows.  What pins it instead:
   * ``scipy.special.digamma/gammaln`` for the special functions Boost.Math
     provides in the reference;
   * the reference's own test data (test/testdata.h, re-typed as
-    tests/golden/xcat.json) with end-to-end traces committed as fixtures.
+    tests/golden/xcat.json) with end-to-end traces committed as fixtures;
+  * an independent textbook derivation of the free energy (negative ELBO from
+    Bishop PRML 10.71-10.77 and the Beta / Gamma / Normal-Gamma KL divergences,
+    written without any of this file's code): equal to ``fenergy`` for all three
+    weight and all three cluster families (tests/test_oracle_elbo.py).
 
 All arithmetic is IEEE double, like the reference.  Matrices are numpy
 row-major ``(N, D)`` arrays; groups are python lists of such arrays.
