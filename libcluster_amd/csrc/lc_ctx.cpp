@@ -779,13 +779,15 @@ void Context::pack_estep_params(int K, const double* A, const double* m, const d
   std::memcpy(hpack_.data() + (size_t)K * PS, c, (size_t)J_ * K * sizeof(double));
 }
 
-void Context::estep(int K, const double* A, const double* m, const double* c, double* Fz, double* LLk, bool raw) {
+void Context::estep(int K, const double* A, const double* m, const double* c, double* Fz, double* LLk, bool raw,
+                    double* target) {
   if (K < 1) throw std::invalid_argument("K must be >= 1");
+  if (target && !raw) throw std::invalid_argument("a target buffer needs raw mode");
   require_gw_width();  // (an upper limit only: wide observations stream through estep_wide_kernel)
   if (NP_ == 0 && !distributed()) {
     if (Fz) *Fz = -0.0;
     if (LLk) std::fill(LLk, LLk + K, 0.0);
-    qz_[cur_].K = K;
+    if (!target) qz_[cur_].K = K;
     return;
   }
   LC_HIP(hipSetDevice(device_));
@@ -796,8 +798,10 @@ void Context::estep(int K, const double* A, const double* m, const double* c, do
   params_.reserve(hpack_.size());
   LC_HIP(hipMemcpyAsync(params_.p, hpack_.data(), hpack_.size() * sizeof(double), hipMemcpyHostToDevice, stream_));
 
-  ensure_qz(qz_[cur_], K, false);  // E-step overwrites every column
-  qz_[cur_].K = K;
+  if (!target) {
+    ensure_qz(qz_[cur_], K, false);  // E-step overwrites every column
+    qz_[cur_].K = K;
+  }
   const int64_t nrg = NP_ / lck::RG;
   const int64_t grid = lck::estep_grid(DP, nrg);
   fzpart_.reserve((size_t)std::max<int64_t>(grid, 1));
@@ -813,7 +817,7 @@ void Context::estep(int K, const double* A, const double* m, const double* c, do
   a.params = params_.p;
   a.ctab = params_.p + (size_t)K * PS;
   a.K = K;
-  a.qZ = qz_[cur_].buf.p;
+  a.qZ = target ? target : qz_[cur_].buf.p;
   a.ldq = NP_;
   a.fz_part = fzpart_.p;
   a.ll_part = LLk ? llpart_.p : nullptr;
@@ -1149,6 +1153,95 @@ void Context::suffstat(const unsigned char* smask, double* Nk, double* xs, doubl
     else
       std::copy(hss_.begin() + (size_t)K * SS, hss_.end(), Njk);
   }
+}
+
+bool Context::dcache_eligible(int K) const {
+  static const bool off = std::getenv("LC_SPLIT_NO_DCACHE") != nullptr;
+  return !off && DP_ <= 128 && K >= 1 && !lck::fused_eligible(DP_, K + 1);
+}
+
+void Context::dcache_build(int K, const double* A, const double* m) {
+  use_device();
+  dcache_K_ = 0;
+  dcache_.reserve((size_t)std::max<int64_t>(NP_, 1) * K);
+  const std::vector<double> zero((size_t)J_ * K, 0.0);  // c = 0: the raw columns are -0.5 d^2
+  double fz = 0.0;
+  if (NP_ > 0) estep(K, A, m, zero.data(), &fz, nullptr, true, dcache_.p);
+  dcache_K_ = K;
+}
+
+void Context::estep_cached(int K1, const double* A, const double* m, const double* c, const int* changed, int nchanged,
+                           double* Fz) {
+  use_device();
+  if (dcache_K_ < 1 || K1 < 1 || nchanged < 1) throw std::invalid_argument("no cached distances");
+  const int D = D_;
+  std::vector<int> colmap((size_t)K1, 0);
+  for (int j = 0; j < K1; ++j) colmap[(size_t)j] = j;
+  for (int t = 0; t < nchanged; ++t) {
+    if (changed[t] < 0 || changed[t] >= K1) throw std::invalid_argument("changed column out of range");
+    colmap[(size_t)changed[t]] = -(t + 1);
+  }
+  for (int j = 0; j < K1; ++j)
+    if (colmap[(size_t)j] >= dcache_K_) throw std::invalid_argument("a column without cached distances must be recomputed");
+  // the changed clusters: raw E-step (c = 0) into the fresh columns
+  std::vector<double> A2((size_t)nchanged * D * D), m2((size_t)nchanged * D);
+  for (int t = 0; t < nchanged; ++t) {
+    std::copy(A + (size_t)changed[t] * D * D, A + (size_t)(changed[t] + 1) * D * D, A2.begin() + (size_t)t * D * D);
+    std::copy(m + (size_t)changed[t] * D, m + (size_t)(changed[t] + 1) * D, m2.begin() + (size_t)t * D);
+  }
+  dfresh_.reserve((size_t)std::max<int64_t>(NP_, 1) * nchanged);
+  const std::vector<double> zero((size_t)J_ * nchanged, 0.0);
+  double fz0 = 0.0;
+  if (NP_ > 0) estep(nchanged, A2.data(), m2.data(), zero.data(), &fz0, nullptr, true, dfresh_.p);
+  // constants + normalisation
+  ensure_qz(qz_[cur_], K1, false);
+  qz_[cur_].K = K1;
+  const int64_t grid = lck::softmax_cached_grid(NP_);
+  fzpart_.reserve((size_t)std::max<int64_t>(grid, 1));
+  red_.reserve((size_t)1 + K1);
+  if (NP_ > 0) {
+    hpack_.assign((size_t)J_ * K1, 0.0);
+    std::memcpy(hpack_.data(), c, (size_t)J_ * K1 * sizeof(double));
+    params_.reserve(hpack_.size());
+    LC_HIP(hipMemcpyAsync(params_.p, hpack_.data(), hpack_.size() * sizeof(double), hipMemcpyHostToDevice, stream_));
+    dcolmap_.reserve((size_t)K1);
+    LC_HIP(hipMemcpyAsync(dcolmap_.p, colmap.data(), (size_t)K1 * sizeof(int), hipMemcpyHostToDevice, stream_));
+    lck::CachedNormLaunch a;
+    a.dcache = dcache_.p;
+    a.ldc = NP_;
+    a.fresh = dfresh_.p;
+    a.ldf = NP_;
+    a.colmap = dcolmap_.p;
+    a.ctab = params_.p;
+    a.K = K1;
+    a.rginfo = J_ > 1 ? rginfo_.p : nullptr;
+    a.nrows = Nj_[0];
+    a.NP = NP_;
+    a.qZ = qz_[cur_].buf.p;
+    a.ldq = NP_;
+    a.fz_part = fzpart_.p;
+    EvPair ev{};
+    if (timing_) {
+      LC_HIP(hipEventCreate(&ev.a));
+      LC_HIP(hipEventCreate(&ev.b));
+      ev.kind = 0;
+      LC_HIP(hipEventRecord(ev.a, stream_));
+    }
+    LC_HIP(lck::launch_softmax_cached(a, stream_));
+    if (timing_) {
+      LC_HIP(hipEventRecord(ev.b, stream_));
+      pending_.push_back(ev);
+    }
+    redtmp_.reserve((size_t)lck::REDUCE_TMP_ELEMS * 64);
+    LC_HIP(lck::launch_reduce_partials(fzpart_.p, (int)grid, 1, red_.p, stream_, redtmp_.p));
+  } else {
+    LC_HIP(hipMemsetAsync(red_.p, 0, sizeof(double), stream_));
+  }
+  allreduce(red_.p, 1);
+  hred_.resize(1);
+  LC_HIP(hipMemcpyAsync(hred_.data(), red_.p, sizeof(double), hipMemcpyDeviceToHost, stream_));
+  LC_HIP(hipStreamSynchronize(stream_));  // (also covers the host vectors the asynchronous copies read)
+  if (Fz) *Fz = hred_[0];
 }
 
 void Context::suffstat_columns(const int* cols, int n, bool diag, double* Nk, double* xs, double* xxs, double* Njk) {

@@ -167,7 +167,16 @@ class Context {
   // Writes new responsibilities into qZ (K columns).  Fz = -sum logZ; LLk[k] =
   // sum_n q_nk (log q~_nk - c_jk)  (the data term of cluster.cpp:409-410).
   // raw = true stops after log q~ (c_jk - 0.5 d^2) has been written to qZ: GaussWish::Eloglike.
-  void estep(int K, const double* A, const double* m, const double* c, double* Fz, double* LLk, bool raw = false);
+  // target (raw mode only): write the K columns of c_jk - 0.5 d^2 there (leading dimension NP) instead of into qZ
+  void estep(int K, const double* A, const double* m, const double* c, double* Fz, double* LLk, bool raw = false,
+             double* target = nullptr);
+  // Split search (cluster.cpp:473): distances of the round's K clusters, cached once per round ...
+  bool dcache_eligible(int K) const;  // a property of the shape (identical on every rank)
+  void dcache_build(int K, const double* A, const double* m);
+  // ... and the E-step of a candidate's K1 clusters that recomputes only `changed` (a column >= the cached K is
+  // necessarily among them): same outputs as estep() without LLk.
+  void estep_cached(int K1, const double* A, const double* m, const double* c, const int* changed, int nchanged,
+                    double* Fz);
   // Small observations (D <= 16, K <= 16, Gauss-Wishart, dense): the E-step AND the statistics of the responsibilities it
   // produces, in one pass (lc_kernels_fused.hip).  Same outputs as estep() followed by suffstat(nullptr, ...).
   // Returns false, having done nothing, when the shape has no fused path.
@@ -227,6 +236,9 @@ class Context {
   const int* sskrec_ = nullptr;
   QZ qz_[2];
   QZ qzcols_;  // scratch: the columns suffstat_columns works on
+  DevBuf<double> dcache_, dfresh_;  // split search: cached -0.5 d^2 of the round's clusters [K x NP], recomputed columns
+  DevBuf<int> dcolmap_;
+  int dcache_K_ = 0;
   int cur_ = 0;
 
   DevBuf<double> params_, ctab_, fzpart_, llpart_, red_, redtmp_, sspart_, ssout_, ssext_;

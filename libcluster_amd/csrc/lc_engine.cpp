@@ -286,7 +286,12 @@ double vbem(lcc::Context& ctx, Model& model, const VbemOptions& opt) {
       have_next = ctx.estep_suffstat_fused(K, A.data(), m.data(), c.data(), &Fz, opt.want_ll ? model.LLk.data() : nullptr,
                                            nNk.data(), nxs.data(), nxxs.data(), nNjk.data());
     }
-    if (!have_next) run_estep(ctx, model, K, &Fz, opt.want_ll ? model.LLk.data() : nullptr);
+    if (have_next) {
+    } else if (done == 0 && full && opt.cached_changed && !opt.want_ll) {
+      ctx.estep_cached(K, A.data(), m.data(), c.data(), opt.cached_changed, opt.cached_nchanged, &Fz);
+    } else {
+      run_estep(ctx, model, K, &Fz, opt.want_ll ? model.LLk.data() : nullptr);
+    }
     const auto t3 = now();
 
     // fenergy (:145-165)
@@ -388,6 +393,10 @@ static bool split_gr(lcc::Context& ctx, Model& model, std::vector<int>& tally, d
   static const bool no_incremental = env_on("LC_SPLIT_FULL_STATS");
   StatsBlock round_stats;
   const size_t XX = ClusterAny::xx_size(model.ckind, D), XS = std::max<size_t>(XX, 1);
+  // ... and, from the third candidate of a round on, only those two clusters' distances: the other clusters' posteriors
+  // (hence their -0.5 d^2 for every row) are the same for every candidate of the round and are cached once
+  int preset_candidates = 0;
+  bool dcache_built = false;
 
   static const bool trace_phases = env_on("LC_TRACE_PHASES");
   auto now = [] { return std::chrono::steady_clock::now(); };
@@ -462,10 +471,10 @@ static bool split_gr(lcc::Context& ctx, Model& model, std::vector<int>& tally, d
     vo.nthreads = opt.nthreads;
     StatsBlock first;  // statistics of the augmented qZ (K + 1 columns) for the first of the two iterations
     const bool incremental = !opt.sparse && !no_incremental;
+    const int cols[2] = {k, K};  // the two columns this candidate changes
     double Fsplit;
     try {
       if (incremental && round_stats.K == K) {
-        const int cols[2] = {k, K};
         std::vector<double> n2(2), x2((size_t)2 * D), xx2((size_t)2 * XS), nj2((size_t)J * 2);
         ctx.suffstat_columns(cols, 2, model.ckind != lch::C_GAUSSWISH, n2.data(), x2.data(), XX ? xx2.data() : nullptr,
                              nj2.data());
@@ -487,6 +496,26 @@ static bool split_gr(lcc::Context& ctx, Model& model, std::vector<int>& tally, d
           for (int j = 0; j < J; ++j) first.Njk[(size_t)j * (K + 1) + c] = nj2[(size_t)j * 2 + t];
         }
         vo.preset = &first;
+        ++preset_candidates;
+        if (model.ckind == lch::C_GAUSSWISH && preset_candidates >= 2 && ctx.dcache_eligible(K)) {
+          if (!dcache_built) {
+            // the posteriors every later candidate's M-step will reproduce for its unchanged clusters
+            std::vector<double> Ac((size_t)K * D * D), mc((size_t)K * D);
+            for (int c2 = 0; c2 < K; ++c2) {
+              ClusterAny cl(model.ckind, prior, D);
+              cl.addstats(round_stats.Nk[(size_t)c2], round_stats.xs.data() + (size_t)c2 * D,
+                          round_stats.xxs.data() + (size_t)c2 * XX);
+              cl.update();
+              const std::vector<double> Ak = cl.gw.whitener();
+              std::copy(Ak.begin(), Ak.end(), Ac.begin() + (size_t)c2 * D * D);
+              std::copy(cl.gw.m.begin(), cl.gw.m.end(), mc.begin() + (size_t)c2 * D);
+            }
+            ctx.dcache_build(K, Ac.data(), mc.data());
+            dcache_built = true;
+          }
+          vo.cached_changed = cols;
+          vo.cached_nchanged = 2;
+        }
       } else if (incremental) {
         vo.capture = &first;
       }

@@ -48,6 +48,9 @@ struct VbemOptions {
   // per candidate (cluster.cpp:473 prescribes a full vbem; the statistics are a pure function of (X, qZ)).
   const StatsBlock* preset = nullptr;
   StatsBlock* capture = nullptr;
+  // first iteration: the context holds cached distances of every cluster but these (Context::estep_cached)
+  const int* cached_changed = nullptr;
+  int cached_nchanged = 0;
 };
 
 // fn(c) for c in [0, nchunks) on the persistent worker pool (inline when the work is small or the pool is busy)

@@ -213,6 +213,24 @@ hipError_t launch_aug_from_sub(double* q, int64_t ldq, int k, int K, const int64
                                const int64_t* starts, const int64_t* goff_sub, int J, const double* qsub1,
                                hipStream_t stream);
 
+// split search: normalise K columns of log q~ = c_jk + (cached | freshly computed) -0.5 d^2 (softmax_cached_kernel)
+struct CachedNormLaunch {
+  const double* dcache;  // [Kc x ldc] cached -0.5 d^2 of the round's clusters
+  int64_t ldc;
+  const double* fresh;   // [nfresh x ldf] the recomputed columns
+  int64_t ldf;
+  const int* colmap;     // [K] device: >= 0 cache column, < 0 fresh column -(v + 1)
+  const double* ctab;    // [J x K]
+  int K;
+  const int* rginfo;     // or nullptr (single group)
+  int64_t nrows, NP;
+  double* qZ;
+  int64_t ldq;
+  double* fz_part;       // [softmax_cached_grid(NP)]
+};
+int64_t softmax_cached_grid(int64_t NP);
+hipError_t launch_softmax_cached(const CachedNormLaunch& a, hipStream_t stream);
+
 // synthetic mixture generator (bench): Philox4x32-10, counter = global row.
 struct SynthLaunch {
   int DP, D, K;

@@ -554,4 +554,64 @@ hipError_t launch_transpose_qz(const double* qZ, int64_t ldq, int K, int64_t NP,
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Split search: the first full-data E-step of a candidate (cluster.cpp:473) from cached distances.
+// Within one round every candidate's unchanged clusters have the same posterior (their statistics are those of the
+// round's converged qZ), hence the same -0.5 d^2_j(x_n); only the two clusters the candidate changes are recomputed
+// (estep_kernel, raw mode, into `fresh`).  This kernel adds the constants c_jk, which DO change with the weights, and
+// normalises: logsumexp in the reference's operation order (probutils.cpp:141-150), q = exp(x - logZ)
+// (cluster.cpp:130-131), F_z partials.  One block = 256 rows; the K values of a row wait in LDS ([K][256]).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) softmax_cached_kernel(CachedNormLaunch a) {
+  extern __shared__ double tile[];  // [K][256]
+  __shared__ double fzw[4];
+  const int tid = threadIdx.x, K = a.K;
+  const int64_t row = (int64_t)blockIdx.x * 256 + tid;
+  const bool inb = row < a.NP;
+  int grp = 0;
+  bool ok = false;
+  if (inb) {
+    if (a.rginfo) {
+      const int info = a.rginfo[row >> 4];
+      grp = info >> 5;
+      ok = (int)(row & 15) < (info & 31);
+    } else {
+      ok = row < a.nrows;
+    }
+  }
+  const double* crow = a.ctab + (int64_t)grp * K;
+  double mx = -INFINITY;
+  for (int j = 0; j < K; ++j) {
+    const int cm = a.colmap[j];
+    double v = 0.0;
+    if (inb) v = crow[j] + (cm >= 0 ? a.dcache[(int64_t)cm * a.ldc + row] : a.fresh[(int64_t)(-cm - 1) * a.ldf + row]);
+    tile[j * 256 + tid] = v;
+    mx = fmax(mx, v);
+  }
+  double s = 0.0;
+  for (int j = 0; j < K; ++j) s += exp(tile[j * 256 + tid] - mx);
+  const double logZ = log(s) + mx;
+  if (inb)
+    for (int j = 0; j < K; ++j) {
+      double q = exp(tile[j * 256 + tid] - logZ);
+      if (!ok) q = 0.0;
+      a.qZ[(int64_t)j * a.ldq + row] = q;
+    }
+  const double fz = wave_sum(ok ? logZ : 0.0);
+  if ((tid & 63) == 0) fzw[tid >> 6] = fz;
+  __syncthreads();
+  if (tid == 0) a.fz_part[blockIdx.x] = -(fzw[0] + fzw[1] + fzw[2] + fzw[3]);  // cluster.cpp:137 returns -sum(logZ)
+}
+int64_t softmax_cached_grid(int64_t NP) { return (NP + 255) / 256; }
+hipError_t launch_softmax_cached(const CachedNormLaunch& a, hipStream_t stream) {
+  const int64_t grid = softmax_cached_grid(a.NP);
+  if (grid <= 0 || a.K <= 0) return hipSuccess;
+  const size_t shmem = (size_t)a.K * 256 * sizeof(double);
+  static LdsGrant grant;
+  if (hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(softmax_cached_kernel), shmem, grant); e != hipSuccess)
+    return e;
+  hipLaunchKernelGGL(softmax_cached_kernel, dim3((unsigned)grid), dim3(256), shmem, stream, a);
+  return hipGetLastError();
+}
+
 }  // namespace lck
