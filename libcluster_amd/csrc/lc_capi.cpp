@@ -746,7 +746,9 @@ int lc_learn_w(int algo, int J, const double* const* Xj, const int64_t* Nj, int 
     m->D = D;
     bool same_device = false;
     const int ngpu = requested_gpus(&same_device);
-    if (ngpu > 1 && (single ? Nj[0] >= 128 : J >= 2)) {
+    // LIBCLUSTER_FORCE_SHARDED=1 (tests): take the sharded path with a single shard too (ncclCommInitAll on one device)
+    static const bool force_sharded = std::getenv("LIBCLUSTER_FORCE_SHARDED") != nullptr;
+    if ((ngpu > 1 || (force_sharded && std::getenv("LIBCLUSTER_GPUS"))) && (single ? Nj[0] >= 128 : J >= 2)) {
       for (int j = 0; j < J; ++j) need(Xj[j], "Xj[j]");
       const double f = learn_sharded(algo, J, Xj, Nj, D, rs, cs, wprior, single ? nullptr : wprior_j, clusterprior,
                                      maxclusters, sparse, verbose, nthreads, device, ngpu, same_device, m.get());

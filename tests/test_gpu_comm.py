@@ -219,3 +219,37 @@ def test_per_group_weight_priors_reach_the_learner(lib, sharded_env, shards):
     F1, m1, _ = capi.learn(capi.ALGO_SGMC, X, 1.0, 1.0, -1, False, False, 4, 0)
     m1.close()
     assert abs(F1 - F) > 1e-6 * abs(F)
+
+
+@pytest.mark.gpu
+def test_libcluster_gpus_rccl_init_all_with_one_device(lib):
+    """The in-process multi-GPU path with its RCCL transport (ncclCommInitAll, one host thread per shard, all-reduce
+    on the shard's own stream) -- on a one-GPU box with a world of one (LIBCLUSTER_FORCE_SHARDED lets a single shard
+    take the sharded path): equal to the ordinary call.  More than one RCCL rank needs more than one GPU."""
+    import json
+    import subprocess
+    import sys
+
+    code = (
+        "import numpy as np, json, sys\n"
+        f"sys.path.insert(0, {str(ROOT)!r})\n"
+        "import libcluster_amd as lc\n"
+        "rng = np.random.default_rng(5)\n"
+        "mu = rng.normal(0, 6.0, (4, 5)); z = rng.integers(0, 4, 6001)\n"
+        "X = mu[z] + rng.normal(size=(6001, 5))\n"
+        "F, q, w, m, c, info = lc.learnVDP(X, return_info=True)\n"
+        "print('RESULT ' + json.dumps({'F': F, 'K': info['K'], 'rounds': [k for k, _ in info['rounds']], 'qsum': float(q.sum()),"
+        " 'q0': q[:5].tolist()}))\n")
+    outs = []
+    for env in ({}, {"LIBCLUSTER_GPUS": "1", "LIBCLUSTER_FORCE_SHARDED": "1"}):
+        e = dict(os.environ)
+        for k in ("LIBCLUSTER_GPUS", "LIBCLUSTER_GPUS_SAME_DEVICE", "LIBCLUSTER_FORCE_SHARDED", "LIBCLUSTER_COMM"):
+            e.pop(k, None)
+        e.update(env)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=e, cwd=str(ROOT))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs.append(json.loads([x for x in r.stdout.splitlines() if x.startswith("RESULT ")][-1][7:]))
+    a, b = outs
+    assert a["K"] == b["K"] and a["rounds"] == b["rounds"]
+    assert abs(a["F"] - b["F"]) <= 1e-12 * abs(a["F"])
+    np.testing.assert_allclose(a["q0"], b["q0"], atol=1e-12)

@@ -2,7 +2,9 @@
 // (suffstat_kernel's step for two clusters) in 18 groups of four; after each of the first NV groups ONE extra
 // operation of type T is issued.  Prints cycles per MFMA per SIMD and the price of the extra operation in cycles.
 //   T: 1 v_mul_f64   2 v_add_f64   3 v_fma_f64   4 2 x v_mov_b32 (64-bit copy)   5 2 x v_mov_b32_dpp (bank-masked)
-//      6 2 x v_cndmask_b32   7 ds_read_b64   8 v_add_u32   9 v_mul_f64 feeding the NEXT group's MFMAs (dependent)
+//      6 2 x v_cndmask_b32   7 ds_read_b64 (used at once)   8 v_add_u32   9 v_mul_f64 feeding the NEXT group's MFMAs
+//      10 ds_read_b64 whose value is used four groups later (software-pipelined, as the kernels do)
+//      11 ds_read_b128 used four groups later (two operands per instruction)
 // Build: hipcc --offload-arch=gfx950 -O3 tools/mfma_valu_price.hip -o tools/bin/mfma_valu_price
 #include <hip/hip_runtime.h>
 
@@ -13,7 +15,7 @@ __device__ __forceinline__ double mfma4(double a, double b, double c) { return _
 
 template <int T, int NV, int WPS>
 __global__ void __launch_bounds__(256, WPS) k(double* out, int iters, double seed) {
-  __shared__ double lds[1024];
+  __shared__ __attribute__((aligned(16))) double lds[1024];
   const int tid = threadIdx.x, lane = tid & 63;
   for (int i = tid; i < 1024; i += 256) lds[i] = 0.001 * i;
   __syncthreads();
@@ -24,6 +26,8 @@ __global__ void __launch_bounds__(256, WPS) k(double* out, int iters, double see
 #pragma unroll
   for (int i = 0; i < 4; ++i) a[i] = seed + lane * 0.01 + i, b[i] = seed * 0.5 + i, y[i] = b[i];
   double q = seed * 0.25;
+  double ringv[4] = {1.0, 2.0, 3.0, 4.0};
+  double2 ring2[4] = {{1.0, 2.0}, {3.0, 4.0}, {5.0, 6.0}, {7.0, 8.0}};
   int iv = lane;
   const bool sel = (lane & 8) != 0;
   for (int it = 0; it < iters; ++it) {
@@ -49,7 +53,15 @@ __global__ void __launch_bounds__(256, WPS) k(double* out, int iters, double see
         if (T == 7) y[r] = lds[(lane + 64 * r + it) & 1023];
         if (T == 8) iv += lane + g;
         if (T == 9) y[(g + 1) & 3] = q * a[(g + 1) & 3];  // consumed by the MFMAs of the next group
-        asm volatile("" : "+v"(y[r]), "+v"(s[r]));
+        if (T == 10) {  // the value read now replaces an MFMA operand four groups from now (ring of four)
+          b[(g + 0) & 3] = ringv[g & 3];
+          ringv[g & 3] = lds[(lane + 64 * r + it) & 1023];
+        }
+        if (T == 11) {
+          b[(g + 0) & 3] = ring2[g & 3].x + ring2[g & 3].y;
+          ring2[g & 3] = *reinterpret_cast<const double2*>(&lds[(2 * lane + 128 * r + 2 * it) & 1022]);
+        }
+        if (T < 10) asm volatile("" : "+v"(y[r]), "+v"(s[r]));
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -59,7 +71,7 @@ __global__ void __launch_bounds__(256, WPS) k(double* out, int iters, double see
 #pragma unroll
   for (int i = 0; i < 72; ++i) t += acc[i];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) t += y[i] + s[i];
+  for (int i = 0; i < 4; ++i) t += y[i] + s[i] + ringv[i] + ring2[i].x;
   out[blockIdx.x * 256 + threadIdx.x] = t;
 }
 
@@ -114,5 +126,7 @@ int main() {
   sweep<7>("ds_read_b64", out, cus);
   sweep<8>("v_add_u32", out, cus);
   sweep<9>("v_mul_f64 -> next MFMA operand", out, cus);
+  sweep<10>("ds_read_b64, used 4 groups later", out, cus);
+  sweep<11>("ds_read_b128, used 4 groups later", out, cus);
   return 0;
 }
