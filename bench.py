@@ -297,7 +297,7 @@ def measure(capi, cfg, steps, warmup, rank, world, local_rank, stream, nthreads,
         ctx.synth_groups([N // J] * J, D, K, mu, L, cfg["seed"], mix=group_mix(cfg, gids), group_ids=gids)
         ctx.set_sharding(True)
     comm_kind = comm_note = None
-    if world > 1:
+    if world > 1 or (dist is not None and comm is not None):
         comm_kind, comm_note = comm(ctx)
 
     model = None
@@ -402,7 +402,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # LC_BENCH_FORCE_DIST=1: walk the multi-rank code path (process group, RCCL unique-id broadcast, native communicator,
+    # self-check, barriers) with a world of one -- the only way to exercise it on a one-GPU box
+    force_dist = bool(os.environ.get("LC_BENCH_FORCE_DIST")) and "RANK" in os.environ
+    if world > 1 or force_dist:
         import torch.distributed as dist
 
         backend = os.environ.get("LC_DIST_BACKEND", "nccl")  # "gloo": test several ranks on one GPU

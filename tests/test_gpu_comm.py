@@ -253,3 +253,45 @@ def test_libcluster_gpus_rccl_init_all_with_one_device(lib):
     assert a["K"] == b["K"] and a["rounds"] == b["rounds"]
     assert abs(a["F"] - b["F"]) <= 1e-12 * abs(a["F"])
     np.testing.assert_allclose(a["q0"], b["q0"], atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_path_with_a_world_of_one(lib):
+    """bench.py's N > 1 path end to end -- torch.distributed process group on RCCL, broadcast of the unique id,
+    lc_ctx_comm_init_rccl, the self-check sum, barriers, max-over-ranks -- with one rank (LC_BENCH_FORCE_DIST): the line
+    names the library's own collective."""
+    import json
+    import socket
+    import sys
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    e = dict(os.environ)
+    e["LC_BENCH_FORCE_DIST"] = "1"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "1",
+                        "--config", "tiny", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-parity"],
+                       capture_output=True, text=True, timeout=600, env=e, cwd=str(ROOT))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["config"]["collective"] == "rccl"
+    assert line["value"] > 0 and np.isfinite(line["free_energy"])
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks(lib):
+    """`python bench.py --gpus 2` without a launcher: two child ranks (both on GPU 0 here, gloo rendezvous, the library's
+    host-staged collective), rank 0's line on stdout, exit status 0."""
+    import json
+    import sys
+
+    e = dict(os.environ)
+    e.update({"LC_DIST_BACKEND": "gloo", "LC_ALL_RANKS_ON_GPU0": "1"})
+    e.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--config", "tiny", "--steps", "3",
+                        "--warmup", "1"], capture_output=True, text=True, timeout=900, env=e, cwd=str(ROOT))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["collective"] == "host-shm"
+    assert line["config"]["rows_per_gpu"] == 200_000 and line["value"] > 0
