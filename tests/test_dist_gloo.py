@@ -118,7 +118,7 @@ def test_allreduce_hook_on_device_buffers():
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         rng = np.random.default_rng(4)
-        X = rng.normal(size=(5000, 16)) + rng.integers(0, 4, (5000, 1))
+        X = rng.normal(size=(5000, 24)) + rng.integers(0, 4, (5000, 1))  # (D > 16: the two-kernel iteration)
         q = rng.dirichlet(np.ones(4), 5000)
         res = []
         for hook in (False, True):
@@ -138,8 +138,8 @@ def test_allreduce_hook_on_device_buffers():
                 res.append((tr, ctx.get_qz([5000])[0]))
                 m.close()
                 if hook:
-                    K, D = 4, 16
-                    assert calls.count(K * (1 + 16 * 16 + 16) + K) == 3  # packed stats (DP = 16) + counts
+                    K, DP = 4, 32
+                    assert calls.count(K * (1 + DP * DP + DP) + K) == 3  # packed stats (D = 24 -> DP = 32) + counts
                     assert calls.count(1 + K) == 3                        # [Fz; LLk]
         np.testing.assert_array_equal(res[0][0], res[1][0])
         np.testing.assert_array_equal(res[0][1], res[1][1])
