@@ -100,7 +100,9 @@ for case in range(cases):
         def near_tie(nk):
             v = np.sort(np.asarray(nk, dtype=float))[::-1]
             a, b = v[:-1], v[1:]
-            return bool(np.any((a != b) & (np.abs(a - b) <= 1e-9 * np.maximum(np.abs(a), 1e-300)) & (a > 1e-12)))
+            # (exactly equal non-zero counts included: the two sides' exponentials differ by an ulp, so counts that
+            # round to the same double in the oracle need not on the device -- seed 41 cases 972 and 2183)
+            return bool(np.any((np.abs(a - b) <= 1e-9 * np.maximum(np.abs(a), 1e-300)) & (a > 1e-12)))
         if any(near_tie(w.Nk) for w in wo):
             skipped_ties += 1
             continue
