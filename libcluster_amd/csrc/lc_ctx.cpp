@@ -870,14 +870,16 @@ bool Context::estep_suffstat_fused(int K, const double* A, const double* m, cons
   LC_HIP(hipMemcpyAsync(params_.p, hpack_.data(), hpack_.size() * sizeof(double), hipMemcpyHostToDevice, stream_));
   ensure_qz(qz_[cur_], K, false);  // the E-step overwrites every column
   qz_[cur_].K = K;
-  fzpart_.reserve((size_t)std::max(grid, 1));
-  llpart_.reserve((size_t)std::max(grid, 1) * K);
-  sspart_.reserve((size_t)std::max(grid, 1) * K * SS);
-  // one buffer for everything that is summed over ranks and copied back: [K records | J x K counts | Fz | LL_k]
-  const size_t nstat = (size_t)K * SS + (size_t)J_ * K, nout = nstat + 1 + (size_t)K;
+  const int64_t W = lck::fused_record(DP, K);
+  sspart_.reserve((size_t)std::max(grid, 1) * W);
+  // one buffer for everything that is summed over ranks and copied back: [K records | Fz | LL_k | J x K counts]
+  // (the first three are the fold of the kernel's per-block records: one reduction launch)
+  // (single group without group sharding: the counts ARE the N_k of the records -- no count block at all)
+  const bool own_counts = J_ > 1 || group_sharded();
+  const size_t nrec = (size_t)W, nout = nrec + (own_counts ? (size_t)J_ * K : 0);
+  const size_t ofz = (size_t)K * SS, oll = ofz + 1;
   ssout_.reserve(nout);
-  double* njk_d = ssout_.p + (size_t)K * SS;
-  double* fz_d = ssout_.p + nstat;
+  double* njk_d = ssout_.p + nrec;
   lck::FusedLaunch a;
   a.DP = DP;
   a.X = X_.p;
@@ -889,9 +891,8 @@ bool Context::estep_suffstat_fused(int K, const double* A, const double* m, cons
   a.K = K;
   a.qZ = qz_[cur_].buf.p;
   a.ldq = NP_;
-  a.fz_part = fzpart_.p;
-  a.ll_part = LLk ? llpart_.p : nullptr;
   a.partial = sspart_.p;
+  a.want_ll = LLk != nullptr;
   a.grid = grid;
   EvPair ev{};
   if (timing_) {
@@ -905,30 +906,27 @@ bool Context::estep_suffstat_fused(int K, const double* A, const double* m, cons
     LC_HIP(hipEventRecord(ev.b, stream_));
     pending_.push_back(ev);
   }
-  redtmp_.reserve((size_t)lck::REDUCE_TMP_ELEMS * 64);
+  hss_.resize(nout);
+  // nothing to sum over ranks: the fold writes straight into the pinned host buffer (coherent, device-visible
+  // memory; visible after the stream synchronises) and the copy-back command drops off the iteration's critical path
+  static const bool direct_env = [] { const char* e = std::getenv("LC_FUSED_DIRECT_HOST"); return !e || std::atoi(e) != 0; }();
+  const bool direct = direct_env && !distributed() && grid > 0;
+  double* dst = direct ? hss_.data() : ssout_.p;
   if (grid > 0) {
-    LC_HIP(lck::launch_reduce_partials(sspart_.p, grid, (int64_t)K * SS, ssout_.p, stream_));
-    LC_HIP(lck::launch_reduce_partials(fzpart_.p, grid, 1, fz_d, stream_, redtmp_.p));
-    if (LLk) LC_HIP(lck::launch_reduce_partials(llpart_.p, grid, K, fz_d + 1, stream_, redtmp_.p));
-    else LC_HIP(hipMemsetAsync(fz_d + 1, 0, (size_t)K * sizeof(double), stream_));
+    LC_HIP(lck::launch_reduce_partials(sspart_.p, grid, W, dst, stream_));
+    if (own_counts) {
+      redtmp_.reserve((size_t)lck::REDUCE_TMP_ELEMS * 64);
+      LC_HIP(lck::launch_group_colsum(qz_[cur_].buf.p, NP_, K, goff_d_.p, J_, direct ? dst + nrec : njk_d, stream_,
+                                      redtmp_.p, NP_));
+    }
   } else {
     LC_HIP(hipMemsetAsync(ssout_.p, 0, nout * sizeof(double), stream_));
   }
-  const bool own_counts = J_ > 1 || group_sharded();
-  if (grid <= 0) {
-    // nothing to count
-  } else if (own_counts)
-    LC_HIP(lck::launch_group_colsum(qz_[cur_].buf.p, NP_, K, goff_d_.p, J_, njk_d, stream_, redtmp_.p, NP_));
-  else
-    LC_HIP(hipMemsetAsync(njk_d, 0, (size_t)K * sizeof(double), stream_));
-  if (group_sharded_) {  // whole groups per rank: the per-group counts stay local (two sums around them)
-    allreduce(ssout_.p, (int64_t)K * SS);
-    allreduce(fz_d, 1 + K);
-  } else {
-    allreduce(ssout_.p, (int64_t)nout);
+  if (!direct) {
+    // whole groups per rank: the per-group counts stay local; rows sharded: they are summed with the rest
+    allreduce(ssout_.p, (int64_t)(group_sharded_ ? nrec : nout));
+    LC_HIP(hipMemcpyAsync(hss_.data(), ssout_.p, nout * sizeof(double), hipMemcpyDeviceToHost, stream_));
   }
-  hss_.resize(nout);
-  LC_HIP(hipMemcpyAsync(hss_.data(), ssout_.p, nout * sizeof(double), hipMemcpyDeviceToHost, stream_));
   LC_HIP(hipStreamSynchronize(stream_));
   for (int k = 0; k < K; ++k) {
     const double* rec = hss_.data() + (size_t)k * SS;
@@ -949,10 +947,10 @@ bool Context::estep_suffstat_fused(int K, const double* A, const double* m, cons
     if (!own_counts)
       for (int k = 0; k < K; ++k) Njk[k] = hss_[(size_t)k * SS];
     else
-      std::copy(hss_.begin() + (size_t)K * SS, hss_.begin() + nstat, Njk);
+      std::copy(hss_.begin() + nrec, hss_.begin() + nout, Njk);
   }
-  if (Fz) *Fz = hss_[nstat];
-  if (LLk) std::copy(hss_.begin() + nstat + 1, hss_.begin() + nout, LLk);
+  if (Fz) *Fz = hss_[ofz];
+  if (LLk) std::copy(hss_.begin() + oll, hss_.begin() + oll + K, LLk);
   return true;
 }
 

@@ -87,11 +87,13 @@ struct FusedLaunch {
   int K;
   double* qZ;            // [K x ldq]: written once (the new responsibilities)
   int64_t ldq;
-  double* fz_part;       // [grid]
-  double* ll_part;       // [grid x K] or nullptr
-  double* partial;       // [grid x K x stat_stride(DP)] statistics of the NEW responsibilities
+  // ONE partial record per block, folded by a single reduce_partials launch:
+  //   [K x stat_stride(DP) statistics of the NEW responsibilities | Fz | LL_k (K; zeros when !want_ll)]
+  double* partial;       // [grid x fused_record(DP, K)]
+  bool want_ll;          // also the split-ordering data term
   int grid;              // fused_plan(...)
 };
+inline int64_t fused_record(int DP, int K) { return (int64_t)K * (1 + DP + (int64_t)DP * DP) + 1 + K; }
 bool fused_eligible(int DP, int K);          // a property of the shape alone (identical on every rank)
 int fused_plan(int DP, int64_t nrg, int K);  // persistent blocks for nrg row groups (0 when there are none)
 hipError_t launch_fused(const FusedLaunch& a, hipStream_t stream);

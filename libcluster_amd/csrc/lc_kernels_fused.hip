@@ -25,7 +25,8 @@ namespace lck {
 constexpr int FUSED_KMAX = 16;  // clusters per block-resident parameter set (four per wave in the statistics half)
 constexpr int FUSED_ROWS = 256; // rows per tile
 
-template <int DP>
+// CPW: clusters per wave in the statistics half (K <= 4 CPW)
+template <int DP, int CPW>
 __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a) {
   static_assert(DP == 16, "one 16 x 16 block of S_k (the general blocking lives in suffstat_kernel)");
   constexpr int NT = DP / 4;
@@ -34,7 +35,8 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a) {
   constexpr int PF = 6;
   constexpr int PS = NTILES * 16 + DP;
   constexpr int LD = DP + 2;  // row stride of the staged tile: conflict-free for both halves' fragment reads
-  constexpr int R = 4, CPW = FUSED_KMAX / 4;
+  constexpr int R = 4;
+  static_assert(4 * CPW <= FUSED_KMAX, "statistics accumulators");
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int K = a.K;
   double* xt = lds;                    // [256][LD]
@@ -170,7 +172,7 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a) {
         if (!myok || !myrow) q = 0.0;
         if (myok) qp[(int64_t)k * a.ldq] = q;
         qt[k * 256 + tid] = q;
-        if (a.ll_part) {  // wave-uniform
+        if (a.want_ll) {  // wave-uniform
           const double ll = wave_sum(q > 0.0 ? q * (lq - a.ctab[(int64_t)mygrp * K + k]) : 0.0);
           if (lane == 0) llw[wave * K + k] += ll;
         }
@@ -207,11 +209,12 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a) {
 
   // ---- one partial record per (block, cluster): [N_k, s_k(DP), S_k(DP x DP)]
   const int64_t SS = 1 + DP + DP * DP;
+  double* rec = a.partial + (int64_t)blockIdx.x * (K * SS + 1 + K);
 #pragma unroll
   for (int c = 0; c < CPW; ++c) {
     const int k = wave + 4 * c;
     if (k < K) {
-      double* out = a.partial + ((int64_t)blockIdx.x * K + k) * SS;
+      double* out = rec + (int64_t)k * SS;
       const double nsum = sum_over_hi(nacc[c]);
       if (lane == 0) out[0] = nsum;
       const double ssum = sum_over_hi(sacc[c]);
@@ -233,10 +236,9 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a) {
   fz = wave_sum(fz);
   if (lane == 0) fzw[wave] = fz;
   __syncthreads();
-  if (a.ll_part)
-    for (int k = tid; k < K; k += 256)
-      a.ll_part[(int64_t)blockIdx.x * K + k] = llw[k] + llw[K + k] + llw[2 * K + k] + llw[3 * K + k];
-  if (tid == 0) a.fz_part[blockIdx.x] = -(fzw[0] + fzw[1] + fzw[2] + fzw[3]);  // cluster.cpp:137 returns -sum(logZ)
+  for (int k = tid; k < K; k += 256)
+    rec[K * SS + 1 + k] = a.want_ll ? llw[k] + llw[K + k] + llw[2 * K + k] + llw[3 * K + k] : 0.0;
+  if (tid == 0) rec[K * SS] = -(fzw[0] + fzw[1] + fzw[2] + fzw[3]);  // cluster.cpp:137 returns -sum(logZ)
 }
 
 static size_t fused_lds_bytes(int DP, int K) {
@@ -262,18 +264,23 @@ int fused_plan(int DP, int64_t nrg, int K) {
     if (cus <= 0) cus = 256;
   }
   const int64_t ntile = (nrg * RG + FUSED_ROWS - 1) / FUSED_ROWS;
-  const int per_cu = fused_lds_bytes(DP, K) <= 80 * 1024 ? 2 : 1;
+  const size_t lds = fused_lds_bytes(DP, K);
+  const int per_cu = lds <= 80 * 1024 ? 2 : 1;
   return (int)std::min<int64_t>(ntile, (int64_t)cus * per_cu);
 }
 
 hipError_t launch_fused(const FusedLaunch& a, hipStream_t stream) {
   if (a.DP != 16 || a.grid <= 0) return hipErrorInvalidValue;
   const size_t shmem = fused_lds_bytes(a.DP, a.K);
-  auto kern = fused_small_kernel<16>;
-  static LdsGrant grant;
-  if (hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(kern), shmem, grant); e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3((unsigned)a.grid), dim3(256), shmem, stream, a);
-  return hipGetLastError();
+  static LdsGrant grants[3];
+  auto go = [&](auto kern, LdsGrant& g) {
+    if (hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(kern), shmem, g); e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)a.grid), dim3(256), shmem, stream, a);
+    return hipGetLastError();
+  };
+  if (a.K <= 4) return go(fused_small_kernel<16, 1>, grants[0]);
+  if (a.K <= 8) return go(fused_small_kernel<16, 2>, grants[1]);
+  return go(fused_small_kernel<16, 4>, grants[2]);
 }
 
 }  // namespace lck
