@@ -604,6 +604,10 @@ void Context::qz_swap_alt() { cur_ ^= 1; }
 void Context::select_rows(int k, double thresh, RowSelection& sel) {
   const QZ& q = qz_[cur_];
   if (k < 0 || k >= q.K) throw std::invalid_argument("qZ column out of range");
+  select_rows_col(q.buf.p + (size_t)k * NP_, thresh, sel);
+}
+
+void Context::select_rows_col(const double* col, double thresh, RowSelection& sel) {
   LC_HIP(hipSetDevice(device_));
   sel.M = 0;
   sel.starts.assign((size_t)J_ + 1, 0);
@@ -612,7 +616,6 @@ void Context::select_rows(int k, double thresh, RowSelection& sel) {
     LC_HIP(hipMemsetAsync(sel.starts_d.p, 0, (size_t)(J_ + 1) * sizeof(int64_t), stream_));
     return;
   }
-  const double* col = q.buf.p + (size_t)k * NP_;
   const int nb = lck::select_blocks(NP_);
   selcnt_.reserve((size_t)nb);
   seloff_.reserve((size_t)nb);
@@ -1168,10 +1171,24 @@ void Context::dcache_build(int K, const double* A, const double* m) {
   dcache_K_ = K;
 }
 
-void Context::estep_cached(int K1, const double* A, const double* m, const double* c, const int* changed, int nchanged,
-                           double* Fz) {
+void Context::dcache_patch(int col, const double* A1, const double* m1) {
   use_device();
-  if (dcache_K_ < 1 || K1 < 1 || nchanged < 1) throw std::invalid_argument("no cached distances");
+  if (col < 0 || col >= dcache_K_) throw std::invalid_argument("no such cached column");
+  const std::vector<double> zero((size_t)J_, 0.0);
+  double fz = 0.0;
+  if (NP_ > 0) estep(1, A1, m1, zero.data(), &fz, nullptr, true, dcache_.p + (size_t)col * NP_);
+}
+
+void Context::dcache_shrink(int K) {
+  if (K < 0 || K > dcache_K_) throw std::invalid_argument("cannot shrink the distance cache to more columns than it has");
+  dcache_K_ = K;
+}
+
+void Context::estep_cached(int K1, const double* A, const double* m, const double* c, const int* changed, int nchanged,
+                           double* Fz, bool keep_delta) {
+  use_device();
+  dq_K_ = 0;
+  if (dcache_K_ < 1 || K1 < 1 || nchanged < 0) throw std::invalid_argument("no cached distances");
   const int D = D_;
   std::vector<int> colmap((size_t)K1, 0);
   for (int j = 0; j < K1; ++j) colmap[(size_t)j] = j;
@@ -1187,11 +1204,12 @@ void Context::estep_cached(int K1, const double* A, const double* m, const doubl
     std::copy(A + (size_t)changed[t] * D * D, A + (size_t)(changed[t] + 1) * D * D, A2.begin() + (size_t)t * D * D);
     std::copy(m + (size_t)changed[t] * D, m + (size_t)(changed[t] + 1) * D, m2.begin() + (size_t)t * D);
   }
-  dfresh_.reserve((size_t)std::max<int64_t>(NP_, 1) * nchanged);
+  dfresh_.reserve((size_t)std::max<int64_t>(NP_, 1) * std::max(nchanged, 1));
   const std::vector<double> zero((size_t)J_ * nchanged, 0.0);
   double fz0 = 0.0;
-  if (NP_ > 0) estep(nchanged, A2.data(), m2.data(), zero.data(), &fz0, nullptr, true, dfresh_.p);
+  if (NP_ > 0 && nchanged > 0) estep(nchanged, A2.data(), m2.data(), zero.data(), &fz0, nullptr, true, dfresh_.p);
   // constants + normalisation
+  const bool have_old = qz_[cur_].K == K1;  // the buffer holds K1 columns of q_old
   ensure_qz(qz_[cur_], K1, false);
   qz_[cur_].K = K1;
   const int64_t grid = lck::softmax_cached_grid(NP_);
@@ -1218,6 +1236,13 @@ void Context::estep_cached(int K1, const double* A, const double* m, const doubl
     a.qZ = qz_[cur_].buf.p;
     a.ldq = NP_;
     a.fz_part = fzpart_.p;
+    if (keep_delta && have_old) {
+      dq_.reserve((size_t)NP_ * K1);
+      amax_.reserve((size_t)NP_);
+      a.dq = dq_.p;
+      a.ldd = NP_;
+      a.amax = amax_.p;
+    }
     EvPair ev{};
     if (timing_) {
       LC_HIP(hipEventCreate(&ev.a));
@@ -1240,6 +1265,33 @@ void Context::estep_cached(int K1, const double* A, const double* m, const doubl
   LC_HIP(hipMemcpyAsync(hred_.data(), red_.p, sizeof(double), hipMemcpyDeviceToHost, stream_));
   LC_HIP(hipStreamSynchronize(stream_));  // (also covers the host vectors the asynchronous copies read)
   if (Fz) *Fz = hred_[0];
+  if (keep_delta && have_old) dq_K_ = K1;  // (a rank without rows keeps an empty delta and still joins delta_suffstat's sums)
+}
+
+bool Context::delta_suffstat(int K1, double tau, double max_frac, double* dNk, double* dxs, double* dxxs, double* dNjk) {
+  use_device();
+  if (dq_K_ != K1 || K1 < 1) throw std::invalid_argument("no responsibilities delta of that width");
+  dq_K_ = 0;  // single use: the next E-step overwrites the responsibilities it refers to
+  RowSelection sel;
+  select_rows_col(amax_.p, tau, sel);
+  delta_rows_ = sel.M;
+  double cnt[2] = {(double)sel.M, (double)Ntot_};
+  allreduce_values(cnt, 2);  // every rank takes the same branch
+  if (cnt[0] > max_frac * cnt[1]) return false;
+  Context sub(device_, stream_);
+  sub.inherit_comm(*this);
+  sub.skip_zero_ = false;
+  sub.set_data_gather(*this, sel);
+  QZ& q = sub.qz_[sub.cur_];
+  sub.ensure_qz(q, K1, false);
+  q.K = K1;
+  if (sub.NP_ > 0) {
+    LC_HIP(hipMemsetAsync(q.buf.p, 0, (size_t)sub.NP_ * K1 * sizeof(double), stream_));  // padding rows carry nothing
+    LC_HIP(lck::launch_gather_cols(dq_.p, NP_, K1, sel.idx.p, sel.M, sel.starts_d.p, sub.goff_d_.p, J_, q.buf.p,
+                                   sub.NP_, stream_));
+  }
+  sub.suffstat(nullptr, dNk, dxs, dxxs, dNjk);
+  return true;
 }
 
 void Context::suffstat_columns(const int* cols, int n, bool diag, double* Nk, double* xs, double* xxs, double* Njk) {

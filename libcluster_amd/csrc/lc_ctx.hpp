@@ -152,6 +152,7 @@ class Context {
   // ---- split search on the device (partobs / splitobs / auglabels) ----------
   // rows with qZ[.,k] > thresh, in order (partobs' index part, comutils.cpp:56-72)
   void select_rows(int k, double thresh, RowSelection& sel);
+  void select_rows_col(const double* col, double thresh, RowSelection& sel);  // ... of any device column of NP values
   // this context := the selected rows of src, group structure kept (partobs' copy part)
   void set_data_gather(const Context& src, const RowSelection& sel);
   // qZ := [s, 1-s], s = ((x-m).v >= 0)   (splitobs + cluster.cpp:446-449); m, v: D host doubles
@@ -173,10 +174,23 @@ class Context {
   // Split search (cluster.cpp:473): distances of the round's K clusters, cached once per round ...
   bool dcache_eligible(int K) const;  // a property of the shape (identical on every rank)
   void dcache_build(int K, const double* A, const double* m);
+  void dcache_patch(int col, const double* A1, const double* m1);  // one column again, from one whitener / mean
+  void dcache_shrink(int K);                                       // forget the columns from K on
   // ... and the E-step of a candidate's K1 clusters that recomputes only `changed` (a column >= the cached K is
-  // necessarily among them): same outputs as estep() without LLk.
+  // necessarily among them; none at all when the cache was just built from these very clusters): same outputs as
+  // estep() without LLk.
+  // keep_delta: also leave q_new - q_old (against the responsibilities being overwritten) and every row's largest
+  // |q_new - q_old| on the device, for delta_suffstat()
   void estep_cached(int K1, const double* A, const double* m, const double* c, const int* changed, int nchanged,
-                    double* Fz);
+                    double* Fz, bool keep_delta = false);
+  // The CHANGE of the statistics caused by the last estep_cached(keep_delta): sum over the rows whose responsibilities
+  // moved by more than tau in some column of (q_new - q_old) x the usual terms -- the statistics are linear in q, so
+  // adding it to the statistics of q_old gives those of q_new up to tau * sum_n |x_n x_n^T| (rows that moved by <= tau
+  // are left out).  The rows are compacted in order and gathered into a sub-context (as partobs does), so the cost is
+  // proportional to the rows that moved.  Returns false, having computed nothing, when more than max_frac of all rows
+  // (summed over ranks) moved -- the caller then runs the ordinary pass.
+  bool delta_suffstat(int K1, double tau, double max_frac, double* dNk, double* dxs, double* dxxs, double* dNjk);
+  int64_t delta_rows() const { return delta_rows_; }  // rows the last delta_suffstat() found moved (this rank)
   // Small observations (D <= 16, K <= 16, Gauss-Wishart, dense): the E-step AND the statistics of the responsibilities it
   // produces, in one pass (lc_kernels_fused.hip).  Same outputs as estep() followed by suffstat(nullptr, ...).
   // Returns false, having done nothing, when the shape has no fused path.
@@ -239,6 +253,9 @@ class Context {
   DevBuf<double> dcache_, dfresh_;  // split search: cached -0.5 d^2 of the round's clusters [K x NP], recomputed columns
   DevBuf<int> dcolmap_;
   int dcache_K_ = 0;
+  DevBuf<double> dq_, amax_;  // estep_cached(keep_delta): q_new - q_old [K1 x NP], per-row max |.|
+  int dq_K_ = 0;
+  int64_t delta_rows_ = 0;
   int cur_ = 0;
 
   DevBuf<double> params_, ctab_, fzpart_, llpart_, red_, redtmp_, sspart_, ssout_, ssext_;

@@ -9,6 +9,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
+#include <cstring>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -189,6 +190,9 @@ double vbem(lcc::Context& ctx, Model& model, const VbemOptions& opt) {
   model.LLk.assign(K, 0.0);
   std::vector<double> nNk, nxs, nxxs, nNjk;  // statistics of the responsibilities the last (fused) E-step produced
   bool have_next = false;
+  bool cached_first = false, have_delta = false;  // split search: the first E-step came from cached distances / left its move
+  const double *cmpA = opt.cache_A, *cmpm = opt.cache_m;  // what the cached distances were computed from
+  int cmpK = opt.cache_K;
 
   double F = std::numeric_limits<double>::max(), Fold;
   int i = 0, done = 0;
@@ -225,6 +229,18 @@ double vbem(lcc::Context& ctx, Model& model, const VbemOptions& opt) {
       xxs = opt.preset->xxs;
       xxs.resize((size_t)K * std::max<size_t>(XX, 1));
       Njk = opt.preset->Njk;
+    } else if (done == 1 && have_delta) {
+      // Nk, xs, xxs, Njk still hold the statistics of the responsibilities the cached E-step overwrote
+      std::vector<double> dN(K), dx((size_t)K * D), dxx((size_t)K * XX), dNj((size_t)J * K);
+      if (ctx.delta_suffstat(K, opt.delta_tol, 0.5, dN.data(), dx.data(), dxx.data(), dNj.data())) {
+        for (int k = 0; k < K; ++k) Nk[k] += dN[k];
+        for (size_t t = 0; t < dx.size(); ++t) xs[t] += dx[t];
+        for (size_t t = 0; t < dxx.size(); ++t) xxs[t] += dxx[t];
+        for (size_t t = 0; t < dNj.size(); ++t) Njk[t] += dNj[t];
+      } else {
+        ctx.suffstat(maskp, Nk.data(), xs.data(), xxs.data(), Njk.data());
+      }
+      have_delta = false;
     } else if (full) ctx.suffstat(maskp, Nk.data(), xs.data(), xxs.data(), Njk.data());
     else ctx.suffstat_diag(maskp, Nk.data(), xs.data(), XX ? xxs.data() : nullptr, Njk.data());
     if (done == 0 && opt.capture) {
@@ -286,9 +302,35 @@ double vbem(lcc::Context& ctx, Model& model, const VbemOptions& opt) {
       have_next = ctx.estep_suffstat_fused(K, A.data(), m.data(), c.data(), &Fz, opt.want_ll ? model.LLk.data() : nullptr,
                                            nNk.data(), nxs.data(), nxxs.data(), nNjk.data());
     }
+    // second iteration after a cached first one: the clusters whose posterior is not bit for bit the cached one
+    std::vector<int> moved;
+    if (done == 1 && cached_first && opt.delta_second && cmpA && cmpm) {
+      for (int k = 0; k < K; ++k)
+        if (k >= cmpK ||
+            std::memcmp(A.data() + (size_t)k * D * D, cmpA + (size_t)k * D * D, (size_t)D * D * sizeof(double)) != 0 ||
+            std::memcmp(m.data() + (size_t)k * D, cmpm + (size_t)k * D, (size_t)D * sizeof(double)) != 0)
+          moved.push_back(k);
+      if ((int)moved.size() * 10 > K * 7) moved.clear();  // most of them: the ordinary E-step is cheaper
+    }
     if (have_next) {
     } else if (done == 0 && full && opt.cached_changed && !opt.want_ll) {
-      ctx.estep_cached(K, A.data(), m.data(), c.data(), opt.cached_changed, opt.cached_nchanged, &Fz);
+      const bool keep = opt.delta_second && !opt.sparse && opt.fixed_iters < 0;
+      ctx.estep_cached(K, A.data(), m.data(), c.data(), opt.cached_changed, opt.cached_nchanged, &Fz, keep);
+      cached_first = true;
+      have_delta = keep;
+    } else if (done == 0 && full && opt.build_cache && opt.delta_second && opt.built_A && opt.built_m && !opt.want_ll &&
+               !opt.sparse && opt.fixed_iters < 0) {
+      ctx.dcache_build(K, A.data(), m.data());
+      ctx.estep_cached(K, A.data(), m.data(), c.data(), nullptr, 0, &Fz, true);
+      *opt.built_A = A;
+      *opt.built_m = m;
+      cmpA = opt.built_A->data();
+      cmpm = opt.built_m->data();
+      cmpK = K;
+      cached_first = true;
+      have_delta = true;
+    } else if (!moved.empty()) {
+      ctx.estep_cached(K, A.data(), m.data(), c.data(), moved.data(), (int)moved.size(), &Fz);
     } else {
       run_estep(ctx, model, K, &Fz, opt.want_ll ? model.LLk.data() : nullptr);
     }
@@ -397,6 +439,14 @@ static bool split_gr(lcc::Context& ctx, Model& model, std::vector<int>& tally, d
   // (hence their -0.5 d^2 for every row) are the same for every candidate of the round and are cached once
   int preset_candidates = 0;
   bool dcache_built = false;
+  std::vector<double> cacheA, cachem;  // what the cache was built from
+  int cache_patch_col = -1;            // >= 0: a first candidate built it, this column still holds its half-cluster
+  // ... and the second iteration of such a candidate works on the rows / clusters the first one moved (VbemOptions)
+  static const bool no_delta = env_on("LC_SPLIT_NO_DELTA");
+  static const double delta_tol = [] {
+    const char* e = std::getenv("LC_SPLIT_DELTA_TOL");
+    return e ? std::atof(e) : 0x1p-50;
+  }();
 
   static const bool trace_phases = env_on("LC_TRACE_PHASES");
   auto now = [] { return std::chrono::steady_clock::now(); };
@@ -497,10 +547,31 @@ static bool split_gr(lcc::Context& ctx, Model& model, std::vector<int>& tally, d
         }
         vo.preset = &first;
         ++preset_candidates;
-        if (model.ckind == lch::C_GAUSSWISH && preset_candidates >= 2 && ctx.dcache_eligible(K)) {
+        if (cache_patch_col >= 0) {
+          // the cache a first candidate built: its column k belongs to half of that candidate's split cluster -- put
+          // the round's own cluster back (its posterior from the round's statistics, as every later M-step reproduces
+          // it), and forget the extra column
+          const int kc = cache_patch_col;
+          cache_patch_col = -1;
+          ClusterAny cl(model.ckind, prior, D);
+          cl.addstats(round_stats.Nk[(size_t)kc], round_stats.xs.data() + (size_t)kc * D,
+                      round_stats.xxs.data() + (size_t)kc * XX);
+          cl.update();
+          const std::vector<double> Ak = cl.gw.whitener();
+          ctx.dcache_patch(kc, Ak.data(), cl.gw.m.data());
+          ctx.dcache_shrink(K);
+          std::copy(Ak.begin(), Ak.end(), cacheA.begin() + (size_t)kc * D * D);
+          std::copy(cl.gw.m.begin(), cl.gw.m.end(), cachem.begin() + (size_t)kc * D);
+          cacheA.resize((size_t)K * D * D);
+          cachem.resize((size_t)K * D);
+          dcache_built = true;
+        }
+        if (model.ckind == lch::C_GAUSSWISH && (dcache_built || preset_candidates >= 2) && ctx.dcache_eligible(K)) {
           if (!dcache_built) {
             // the posteriors every later candidate's M-step will reproduce for its unchanged clusters
-            std::vector<double> Ac((size_t)K * D * D), mc((size_t)K * D);
+            std::vector<double>&Ac = cacheA, &mc = cachem;
+            Ac.assign((size_t)K * D * D, 0.0);
+            mc.assign((size_t)K * D, 0.0);
             for (int c2 = 0; c2 < K; ++c2) {
               ClusterAny cl(model.ckind, prior, D);
               cl.addstats(round_stats.Nk[(size_t)c2], round_stats.xs.data() + (size_t)c2 * D,
@@ -515,11 +586,30 @@ static bool split_gr(lcc::Context& ctx, Model& model, std::vector<int>& tally, d
           }
           vo.cached_changed = cols;
           vo.cached_nchanged = 2;
+          if (!no_delta) {
+            vo.delta_second = true;
+            vo.delta_tol = delta_tol;
+            vo.cache_A = cacheA.data();
+            vo.cache_m = cachem.data();
+            vo.cache_K = K;
+          }
         }
       } else if (incremental) {
         vo.capture = &first;
+        if (model.ckind == lch::C_GAUSSWISH && !no_delta && !dcache_built && ctx.dcache_eligible(K)) {
+          // the first candidate of the round builds the cache from its own K + 1 clusters; column k (this candidate's
+          // half of the split cluster) is put right before another candidate uses the cache
+          cacheA.clear();
+          cachem.clear();
+          vo.build_cache = true;
+          vo.built_A = &cacheA;
+          vo.built_m = &cachem;
+          vo.delta_second = true;
+          vo.delta_tol = delta_tol;
+        }
       }
       Fsplit = vbem(ctx, ms, vo);
+      if (vo.build_cache && cacheA.size() == (size_t)(K + 1) * D * D) cache_patch_col = k;
     } catch (...) {
       ctx.qz_swap_alt();
       throw;

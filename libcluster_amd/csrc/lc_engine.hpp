@@ -51,6 +51,22 @@ struct VbemOptions {
   // first iteration: the context holds cached distances of every cluster but these (Context::estep_cached)
   const int* cached_changed = nullptr;
   int cached_nchanged = 0;
+  // ... and the iteration after it (the second of a candidate's two, cluster.cpp:473 with the off-by-one of :235-236)
+  // works on what that E-step MOVED: its statistics are those of the first iteration plus the change over the rows
+  // whose responsibilities moved by more than delta_tol (Context::delta_suffstat; the ordinary pass when most rows
+  // moved), and its E-step recomputes the distances of the clusters whose posterior differs in any bit from the cached
+  // one (cache_A / cache_m: the cache_K whiteners and means the cache was built from)
+  bool delta_second = false;
+  double delta_tol = 0.0;
+  const double* cache_A = nullptr;
+  const double* cache_m = nullptr;
+  int cache_K = 0;
+  // first iteration: BUILD the cache from its own clusters (raw distances of all of them, then the normalisation
+  // sweep -- the same responsibilities as the ordinary E-step) and hand back what it was built from; the second
+  // iteration then works as above.  For the first candidate of a round (delta_second must be set too).
+  bool build_cache = false;
+  std::vector<double>* built_A = nullptr;
+  std::vector<double>* built_m = nullptr;
 };
 
 // fn(c) for c in [0, nchunks) on the persistent worker pool (inline when the work is small or the pool is busy)

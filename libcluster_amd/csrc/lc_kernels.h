@@ -206,6 +206,9 @@ hipError_t launch_group_starts(const int64_t* idx, int64_t M, const int64_t* gof
                                hipStream_t stream);
 // qT[row * K + k] = qZ[k * ldq + row]
 hipError_t launch_transpose_qz(const double* qZ, int64_t ldq, int K, int64_t NP, double* qT, hipStream_t stream);
+// dst[c, gathered row of p] = src[c, idx[p]] for K columns (column-major, leading dimensions lds / ldd)
+hipError_t launch_gather_cols(const double* src, int64_t lds, int K, const int64_t* idx, int64_t M, const int64_t* starts,
+                              const int64_t* goff_sub, int J, double* dst, int64_t ldd, hipStream_t stream);
 hipError_t launch_gather_rows(const double* X, int DP, const int64_t* idx, int64_t M, const int64_t* starts,
                               const int64_t* goff_sub, int J, double* Xdst, hipStream_t stream);
 hipError_t launch_split_init(const double* X, int DP, int D, int64_t NP, const int* rginfo, int64_t nrows,
@@ -229,6 +232,10 @@ struct CachedNormLaunch {
   double* qZ;
   int64_t ldq;
   double* fz_part;       // [softmax_cached_grid(NP)]
+  // optional (both or neither): how far this E-step moved the responsibilities it overwrites
+  double* dq = nullptr;    // [K x ldd] q_new - q_old
+  int64_t ldd = 0;
+  double* amax = nullptr;  // [NP] max_j |q_new - q_old| of the row
 };
 int64_t softmax_cached_grid(int64_t NP);
 hipError_t launch_softmax_cached(const CachedNormLaunch& a, hipStream_t stream);

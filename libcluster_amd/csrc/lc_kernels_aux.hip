@@ -334,6 +334,24 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const double* X, int D
   reinterpret_cast<double2*>(Xdst + dst * DP)[c2] = reinterpret_cast<const double2*>(X + idx[p] * DP)[c2];
 }
 
+// K columns of a column-major table for the selected rows, into the gathered layout; one thread per selected row
+__global__ void __launch_bounds__(256) gather_cols_kernel(const double* src, int64_t lds, int K, const int64_t* idx,
+                                                          int64_t M, const int64_t* starts, const int64_t* goff_sub, int J,
+                                                          double* dst, int64_t ldd) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= M) return;
+  const int64_t s = idx[p], d = sel_dst_row(p, starts, goff_sub, J);
+  for (int c = 0; c < K; ++c) dst[(int64_t)c * ldd + d] = src[(int64_t)c * lds + s];
+}
+
+hipError_t launch_gather_cols(const double* src, int64_t lds, int K, const int64_t* idx, int64_t M, const int64_t* starts,
+                              const int64_t* goff_sub, int J, double* dst, int64_t ldd, hipStream_t stream) {
+  if (M <= 0 || K <= 0) return hipSuccess;
+  hipLaunchKernelGGL(gather_cols_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, stream, src, lds, K, idx, M,
+                     starts, goff_sub, J, dst, ldd);
+  return hipGetLastError();
+}
+
 hipError_t launch_gather_rows(const double* X, int DP, const int64_t* idx, int64_t M, const int64_t* starts,
                               const int64_t* goff_sub, int J, double* Xdst, hipStream_t stream) {
   if (M <= 0) return hipSuccess;
@@ -591,7 +609,18 @@ __global__ void __launch_bounds__(256) softmax_cached_kernel(CachedNormLaunch a)
   double s = 0.0;
   for (int j = 0; j < K; ++j) s += exp(tile[j * 256 + tid] - mx);
   const double logZ = log(s) + mx;
-  if (inb)
+  if (inb && a.dq) {  // (launch-uniform) also report the move away from the responsibilities being overwritten
+    double am = 0.0;
+    for (int j = 0; j < K; ++j) {
+      double q = exp(tile[j * 256 + tid] - logZ);
+      if (!ok) q = 0.0;
+      const double d = q - a.qZ[(int64_t)j * a.ldq + row];
+      a.dq[(int64_t)j * a.ldd + row] = d;
+      am = fmax(am, fabs(d));
+      a.qZ[(int64_t)j * a.ldq + row] = q;
+    }
+    a.amax[row] = am;
+  } else if (inb)
     for (int j = 0; j < K; ++j) {
       double q = exp(tile[j * 256 + tid] - logZ);
       if (!ok) q = 0.0;
