@@ -211,6 +211,8 @@ void Context::build_layout(int J, const int64_t* Nj, int D) {
   if (J < 1) throw std::invalid_argument("need at least one group of observations");
   if (D < 1) throw std::invalid_argument("observations must have at least one dimension");
   const int DP = lck::padded_dim_wide(D);  // D > 128: diagonal / exponential families only (checked where it matters)
+  dcache_invalidate();  // new observations: no cached distance survives
+  dc_cap_ = 0;          // (the slab is re-allocated for the new row count)
   J_ = J;
   D_ = D;
   DP_ = DP;
@@ -1157,87 +1159,195 @@ void Context::suffstat(const unsigned char* smask, double* Nk, double* xs, doubl
 }
 
 bool Context::dcache_eligible(int K) const {
-  static const bool off = std::getenv("LC_SPLIT_NO_DCACHE") != nullptr;
-  return !off && DP_ <= 128 && K >= 1 && !lck::fused_eligible(DP_, K + 1);
+  static const bool off = std::getenv("LC_SPLIT_NO_DCACHE") != nullptr || std::getenv("LC_SPLIT_NO_DELTA") != nullptr;
+  // (the normalisation sweep keeps a row's K values in LDS: 2 KB per cluster and block)
+  return !off && DP_ <= 128 && K >= 1 && K <= 72 && !lck::fused_eligible(DP_, K);
 }
 
-void Context::dcache_build(int K, const double* A, const double* m) {
-  use_device();
-  dcache_K_ = 0;
-  dcache_.reserve((size_t)std::max<int64_t>(NP_, 1) * K);
-  const std::vector<double> zero((size_t)J_ * K, 0.0);  // c = 0: the raw columns are -0.5 d^2
-  double fz = 0.0;
-  if (NP_ > 0) estep(K, A, m, zero.data(), &fz, nullptr, true, dcache_.p);
-  dcache_K_ = K;
-}
-
-void Context::dcache_patch(int col, const double* A1, const double* m1) {
-  use_device();
-  if (col < 0 || col >= dcache_K_) throw std::invalid_argument("no such cached column");
-  const std::vector<double> zero((size_t)J_, 0.0);
-  double fz = 0.0;
-  if (NP_ > 0) estep(1, A1, m1, zero.data(), &fz, nullptr, true, dcache_.p + (size_t)col * NP_);
-}
-
-void Context::dcache_shrink(int K) {
-  if (K < 0 || K > dcache_K_) throw std::invalid_argument("cannot shrink the distance cache to more columns than it has");
-  dcache_K_ = K;
-}
-
-void Context::estep_cached(int K1, const double* A, const double* m, const double* c, const int* changed, int nchanged,
-                           double* Fz, bool keep_delta) {
-  use_device();
+void Context::dcache_invalidate() {
+  dc_K_ = 0;
+  dc_saved_.clear();
+  dc_journal_ = false;
   dq_K_ = 0;
-  if (dcache_K_ < 1 || K1 < 1 || nchanged < 0) throw std::invalid_argument("no cached distances");
+}
+
+void Context::dcache_release() {
+  dcache_invalidate();
+  dc_cap_ = 0;
+  dc_slab_.release();
+  dfresh_.release();
+  dq_.release();
+  amax_.release();
+  dc_tagA_.clear();
+  dc_tagm_.clear();
+}
+
+void Context::dcache_journal_begin() {
+  dc_saved_.clear();
+  dc_journal_ = true;
+  dc_jK0_ = dc_K_;
+}
+
+void Context::dcache_journal_end() {
+  dc_saved_.clear();
+  dc_journal_ = false;
+}
+
+void Context::dcache_rollback() {
+  if (!dc_journal_) return;
+  use_device();
+  for (auto& sv : dc_saved_) {
+    if (NP_ > 0)
+      LC_HIP(hipMemcpyAsync(dc_slab_.p + (size_t)sv->col * NP_, sv->buf.p, (size_t)NP_ * sizeof(double),
+                            hipMemcpyDeviceToDevice, stream_));
+    dc_tagA_[(size_t)sv->col].swap(sv->A);
+    dc_tagm_[(size_t)sv->col].swap(sv->m);
+  }
+  dc_K_ = dc_jK0_;
+  dc_saved_.clear();
+  dc_journal_ = false;
+}
+
+void Context::dcache_keep_columns(const std::vector<int>& keep) {
+  use_device();
+  dc_saved_.clear();
+  dc_journal_ = false;
+  int out = 0;
+  for (int k : keep) {
+    if (k < 0 || k >= dc_K_) {  // a column the cache never had: everything from here on is unknown
+      break;
+    }
+    if (k != out) {
+      if (NP_ > 0)
+        LC_HIP(hipMemcpyAsync(dc_slab_.p + (size_t)out * NP_, dc_slab_.p + (size_t)k * NP_, (size_t)NP_ * sizeof(double),
+                              hipMemcpyDeviceToDevice, stream_));  // (k > out: columns only move down, in order)
+      dc_tagA_[(size_t)out] = dc_tagA_[(size_t)k];
+      dc_tagm_[(size_t)out] = dc_tagm_[(size_t)k];
+    }
+    ++out;
+  }
+  dc_K_ = out;
+}
+
+int Context::estep_cache(int K, const double* A, const double* m, const double* c, double* Fz, double* LLk, bool keep_delta,
+                         int* stale_out) {
+  use_device();
+  if (K < 1) throw std::invalid_argument("K must be >= 1");
+  require_gw_width();
   const int D = D_;
-  std::vector<int> colmap((size_t)K1, 0);
-  for (int j = 0; j < K1; ++j) colmap[(size_t)j] = j;
-  for (int t = 0; t < nchanged; ++t) {
-    if (changed[t] < 0 || changed[t] >= K1) throw std::invalid_argument("changed column out of range");
-    colmap[(size_t)changed[t]] = -(t + 1);
+  const size_t AA = (size_t)D * D;
+  dq_K_ = 0;
+  // the columns whose tag is not, bit for bit, this cluster's whitener and mean
+  std::vector<int> changed;
+  int stale = 0;
+  for (int k = 0; k < K; ++k) {
+    const bool have = k < dc_K_ && dc_tagA_[(size_t)k].size() == AA && dc_tagm_[(size_t)k].size() == (size_t)D;
+    if (have && std::memcmp(dc_tagA_[(size_t)k].data(), A + (size_t)k * AA, AA * sizeof(double)) == 0 &&
+        std::memcmp(dc_tagm_[(size_t)k].data(), m + (size_t)k * D, (size_t)D * sizeof(double)) == 0)
+      continue;
+    changed.push_back(k);
+    stale += have ? 1 : 0;
   }
-  for (int j = 0; j < K1; ++j)
-    if (colmap[(size_t)j] >= dcache_K_) throw std::invalid_argument("a column without cached distances must be recomputed");
-  // the changed clusters: raw E-step (c = 0) into the fresh columns
-  std::vector<double> A2((size_t)nchanged * D * D), m2((size_t)nchanged * D);
-  for (int t = 0; t < nchanged; ++t) {
-    std::copy(A + (size_t)changed[t] * D * D, A + (size_t)(changed[t] + 1) * D * D, A2.begin() + (size_t)t * D * D);
-    std::copy(m + (size_t)changed[t] * D, m + (size_t)(changed[t] + 1) * D, m2.begin() + (size_t)t * D);
+  if (stale_out) *stale_out = stale;
+  const int nch = (int)changed.size();
+  const size_t NPs = (size_t)std::max<int64_t>(NP_, 1);
+  // room for K columns (the valid ones move along when the slab grows)
+  if (K > dc_cap_) {
+    const int newcap = K + std::max(8, K / 4);
+    DevBuf<double> nb;
+    nb.reserve(NPs * newcap);
+    if (dc_K_ > 0 && NP_ > 0)
+      LC_HIP(hipMemcpyAsync(nb.p, dc_slab_.p, (size_t)NP_ * dc_K_ * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+    LC_HIP(hipStreamSynchronize(stream_));
+    std::swap(dc_slab_.p, nb.p);
+    std::swap(dc_slab_.cap, nb.cap);
+    std::swap(dc_slab_.device, nb.device);
+    dc_cap_ = newcap;
   }
-  dfresh_.reserve((size_t)std::max<int64_t>(NP_, 1) * std::max(nchanged, 1));
-  const std::vector<double> zero((size_t)J_ * nchanged, 0.0);
-  double fz0 = 0.0;
-  if (NP_ > 0 && nchanged > 0) estep(nchanged, A2.data(), m2.data(), zero.data(), &fz0, nullptr, true, dfresh_.p);
+  if ((int)dc_tagA_.size() < K) {
+    dc_tagA_.resize((size_t)K);
+    dc_tagm_.resize((size_t)K);
+  }
+  // journal: what is about to be overwritten (a column is saved once per journal)
+  if (dc_journal_)
+    for (int k : changed) {
+      if (k >= dc_K_ || k >= dc_jK0_) continue;  // nothing valid there / not part of the state to return to
+      bool done = false;
+      for (auto& sv : dc_saved_) done = done || sv->col == k;
+      if (done) continue;
+      auto sv = std::make_unique<SavedColumn>();
+      sv->col = k;
+      sv->buf.reserve(NPs);
+      if (NP_ > 0)
+        LC_HIP(hipMemcpyAsync(sv->buf.p, dc_slab_.p + (size_t)k * NP_, (size_t)NP_ * sizeof(double), hipMemcpyDeviceToDevice,
+                              stream_));
+      sv->A = dc_tagA_[(size_t)k];
+      sv->m = dc_tagm_[(size_t)k];
+      dc_saved_.push_back(std::move(sv));
+    }
+  // recompute: raw E-step (c = 0: the columns are -0.5 d^2), straight into the slab when the columns are adjacent
+  if (nch > 0) {
+    const bool adjacent = changed.back() - changed.front() + 1 == nch;
+    std::vector<double> A2, m2;
+    const double *Ap = A + (size_t)changed.front() * AA, *mp = m + (size_t)changed.front() * D;
+    if (!adjacent) {
+      A2.resize((size_t)nch * AA);
+      m2.resize((size_t)nch * D);
+      for (int t = 0; t < nch; ++t) {
+        std::copy(A + (size_t)changed[t] * AA, A + (size_t)(changed[t] + 1) * AA, A2.begin() + (size_t)t * AA);
+        std::copy(m + (size_t)changed[t] * D, m + (size_t)(changed[t] + 1) * D, m2.begin() + (size_t)t * D);
+      }
+      Ap = A2.data();
+      mp = m2.data();
+      dfresh_.reserve(NPs * nch);
+    }
+    const std::vector<double> zero((size_t)J_ * nch, 0.0);
+    double fz0 = 0.0;
+    double* target = adjacent ? dc_slab_.p + (size_t)changed.front() * NP_ : dfresh_.p;
+    if (NP_ > 0) {
+      estep(nch, Ap, mp, zero.data(), &fz0, nullptr, true, target);
+      if (!adjacent)
+        for (int t = 0; t < nch; ++t)
+          LC_HIP(hipMemcpyAsync(dc_slab_.p + (size_t)changed[t] * NP_, dfresh_.p + (size_t)t * NP_,
+                                (size_t)NP_ * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+    }
+    for (int k : changed) {
+      dc_tagA_[(size_t)k].assign(A + (size_t)k * AA, A + (size_t)(k + 1) * AA);
+      dc_tagm_[(size_t)k].assign(m + (size_t)k * D, m + (size_t)(k + 1) * D);
+    }
+  }
+  dc_K_ = K;
   // constants + normalisation
-  const bool have_old = qz_[cur_].K == K1;  // the buffer holds K1 columns of q_old
-  ensure_qz(qz_[cur_], K1, false);
-  qz_[cur_].K = K1;
+  const bool have_old = qz_[cur_].K == K;  // the buffer holds K columns of q_old
+  ensure_qz(qz_[cur_], K, false);
+  qz_[cur_].K = K;
   const int64_t grid = lck::softmax_cached_grid(NP_);
   fzpart_.reserve((size_t)std::max<int64_t>(grid, 1));
-  red_.reserve((size_t)1 + K1);
+  if (LLk) llpart_.reserve((size_t)std::max<int64_t>(grid, 1) * K);
+  red_.reserve((size_t)1 + K);
+  const bool delta = keep_delta && have_old;
   if (NP_ > 0) {
-    hpack_.assign((size_t)J_ * K1, 0.0);
-    std::memcpy(hpack_.data(), c, (size_t)J_ * K1 * sizeof(double));
+    hpack_.assign((size_t)J_ * K, 0.0);
+    std::memcpy(hpack_.data(), c, (size_t)J_ * K * sizeof(double));
     params_.reserve(hpack_.size());
     LC_HIP(hipMemcpyAsync(params_.p, hpack_.data(), hpack_.size() * sizeof(double), hipMemcpyHostToDevice, stream_));
-    dcolmap_.reserve((size_t)K1);
-    LC_HIP(hipMemcpyAsync(dcolmap_.p, colmap.data(), (size_t)K1 * sizeof(int), hipMemcpyHostToDevice, stream_));
     lck::CachedNormLaunch a;
-    a.dcache = dcache_.p;
+    a.dcache = dc_slab_.p;
     a.ldc = NP_;
-    a.fresh = dfresh_.p;
-    a.ldf = NP_;
-    a.colmap = dcolmap_.p;
+    a.fresh = nullptr;
+    a.ldf = 0;
+    a.colmap = nullptr;
     a.ctab = params_.p;
-    a.K = K1;
+    a.K = K;
     a.rginfo = J_ > 1 ? rginfo_.p : nullptr;
     a.nrows = Nj_[0];
     a.NP = NP_;
     a.qZ = qz_[cur_].buf.p;
     a.ldq = NP_;
     a.fz_part = fzpart_.p;
-    if (keep_delta && have_old) {
-      dq_.reserve((size_t)NP_ * K1);
+    a.ll_part = LLk ? llpart_.p : nullptr;
+    if (delta) {
+      dq_.reserve((size_t)NP_ * K);
       amax_.reserve((size_t)NP_);
       a.dq = dq_.p;
       a.ldd = NP_;
@@ -1257,15 +1367,19 @@ void Context::estep_cached(int K1, const double* A, const double* m, const doubl
     }
     redtmp_.reserve((size_t)lck::REDUCE_TMP_ELEMS * 64);
     LC_HIP(lck::launch_reduce_partials(fzpart_.p, (int)grid, 1, red_.p, stream_, redtmp_.p));
+    if (LLk) LC_HIP(lck::launch_reduce_partials(llpart_.p, (int)grid, K, red_.p + 1, stream_, redtmp_.p));
   } else {
-    LC_HIP(hipMemsetAsync(red_.p, 0, sizeof(double), stream_));
+    LC_HIP(hipMemsetAsync(red_.p, 0, (size_t)(1 + K) * sizeof(double), stream_));
   }
-  allreduce(red_.p, 1);
-  hred_.resize(1);
-  LC_HIP(hipMemcpyAsync(hred_.data(), red_.p, sizeof(double), hipMemcpyDeviceToHost, stream_));
+  const int nred = LLk ? 1 + K : 1;
+  allreduce(red_.p, nred);
+  hred_.resize((size_t)nred);
+  LC_HIP(hipMemcpyAsync(hred_.data(), red_.p, (size_t)nred * sizeof(double), hipMemcpyDeviceToHost, stream_));
   LC_HIP(hipStreamSynchronize(stream_));  // (also covers the host vectors the asynchronous copies read)
   if (Fz) *Fz = hred_[0];
-  if (keep_delta && have_old) dq_K_ = K1;  // (a rank without rows keeps an empty delta and still joins delta_suffstat's sums)
+  if (LLk) std::copy(hred_.begin() + 1, hred_.begin() + 1 + K, LLk);
+  if (delta) dq_K_ = K;  // (a rank without rows keeps an empty delta and still joins delta_suffstat's sums)
+  return nch;
 }
 
 bool Context::delta_suffstat(int K1, double tau, double max_frac, double* dNk, double* dxs, double* dxxs, double* dNjk) {

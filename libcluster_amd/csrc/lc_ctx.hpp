@@ -171,25 +171,34 @@ class Context {
   // target (raw mode only): write the K columns of c_jk - 0.5 d^2 there (leading dimension NP) instead of into qZ
   void estep(int K, const double* A, const double* m, const double* c, double* Fz, double* LLk, bool raw = false,
              double* target = nullptr);
-  // Split search (cluster.cpp:473): distances of the round's K clusters, cached once per round ...
+  // Model selection (cluster.cpp:564-629): the distances -0.5 d^2_k(x_n) of the clusters, kept on the device
+  // [K x NP], every column tagged on the host with the whitener and mean it was computed from.  An E-step through the
+  // cache recomputes the columns whose tag differs IN ANY BIT from the cluster it is asked about (raw estep_kernel),
+  // then adds the constants c_jk and normalises over all K columns (softmax_cached_kernel): the same outputs as
+  // estep().  Between two iterations of a converging model, and between the candidates of a split round, most
+  // clusters' posteriors are bit for bit the same, so most columns are re-used.  Returns the number of recomputed
+  // columns; *stale = how many of them had a valid (but different) tag.
+  // keep_delta: also leave q_new - q_old (against the responsibilities being overwritten, when the buffer held K
+  // columns) and every row's largest |q_new - q_old| on the device, for delta_suffstat().
   bool dcache_eligible(int K) const;  // a property of the shape (identical on every rank)
-  void dcache_build(int K, const double* A, const double* m);
-  void dcache_patch(int col, const double* A1, const double* m1);  // one column again, from one whitener / mean
-  void dcache_shrink(int K);                                       // forget the columns from K on
-  // ... and the E-step of a candidate's K1 clusters that recomputes only `changed` (a column >= the cached K is
-  // necessarily among them; none at all when the cache was just built from these very clusters): same outputs as
-  // estep() without LLk.
-  // keep_delta: also leave q_new - q_old (against the responsibilities being overwritten) and every row's largest
-  // |q_new - q_old| on the device, for delta_suffstat()
-  void estep_cached(int K1, const double* A, const double* m, const double* c, const int* changed, int nchanged,
-                    double* Fz, bool keep_delta = false);
-  // The CHANGE of the statistics caused by the last estep_cached(keep_delta): sum over the rows whose responsibilities
+  int estep_cache(int K, const double* A, const double* m, const double* c, double* Fz, double* LLk, bool keep_delta,
+                  int* stale = nullptr);
+  // a split candidate works on the cache in place: from journal_begin() on, a column is copied aside before it is
+  // first overwritten; rollback() puts columns, tags and width back, journal_end() keeps the new state
+  void dcache_journal_begin();
+  void dcache_rollback();
+  void dcache_journal_end();
+  void dcache_invalidate();
+  void dcache_release();  // ... and give the memory back
+  void dcache_keep_columns(const std::vector<int>& keep);  // prune_clusters
+  // The CHANGE of the statistics caused by the last estep_cache(keep_delta): sum over the rows whose responsibilities
   // moved by more than tau in some column of (q_new - q_old) x the usual terms -- the statistics are linear in q, so
   // adding it to the statistics of q_old gives those of q_new up to tau * sum_n |x_n x_n^T| (rows that moved by <= tau
   // are left out).  The rows are compacted in order and gathered into a sub-context (as partobs does), so the cost is
   // proportional to the rows that moved.  Returns false, having computed nothing, when more than max_frac of all rows
   // (summed over ranks) moved -- the caller then runs the ordinary pass.
   bool delta_suffstat(int K1, double tau, double max_frac, double* dNk, double* dxs, double* dxxs, double* dNjk);
+  int delta_pending() const { return dq_K_; }  // width of the move the last estep_cache(keep_delta) left (0: none)
   int64_t delta_rows() const { return delta_rows_; }  // rows the last delta_suffstat() found moved (this rank)
   // Small observations (D <= 16, K <= 16, Gauss-Wishart, dense): the E-step AND the statistics of the responsibilities it
   // produces, in one pass (lc_kernels_fused.hip).  Same outputs as estep() followed by suffstat(nullptr, ...).
@@ -250,10 +259,19 @@ class Context {
   const int* sskrec_ = nullptr;
   QZ qz_[2];
   QZ qzcols_;  // scratch: the columns suffstat_columns works on
-  DevBuf<double> dcache_, dfresh_;  // split search: cached -0.5 d^2 of the round's clusters [K x NP], recomputed columns
-  DevBuf<int> dcolmap_;
-  int dcache_K_ = 0;
-  DevBuf<double> dq_, amax_;  // estep_cached(keep_delta): q_new - q_old [K1 x NP], per-row max |.|
+  // distance cache: slab [dc_cap_ x NP], dc_K_ valid columns, host tags; scratch for non-adjacent recomputed columns
+  DevBuf<double> dc_slab_, dfresh_;
+  int dc_cap_ = 0, dc_K_ = 0;
+  std::vector<std::vector<double>> dc_tagA_, dc_tagm_;
+  struct SavedColumn {
+    int col = -1;
+    DevBuf<double> buf;
+    std::vector<double> A, m;
+  };
+  std::vector<std::unique_ptr<SavedColumn>> dc_saved_;
+  bool dc_journal_ = false;
+  int dc_jK0_ = 0;
+  DevBuf<double> dq_, amax_;  // estep_cache(keep_delta): q_new - q_old [K x NP], per-row max |.|
   int dq_K_ = 0;
   int64_t delta_rows_ = 0;
   int cur_ = 0;

@@ -190,9 +190,13 @@ double vbem(lcc::Context& ctx, Model& model, const VbemOptions& opt) {
   model.LLk.assign(K, 0.0);
   std::vector<double> nNk, nxs, nxxs, nNjk;  // statistics of the responsibilities the last (fused) E-step produced
   bool have_next = false;
-  bool cached_first = false, have_delta = false;  // split search: the first E-step came from cached distances / left its move
-  const double *cmpA = opt.cache_A, *cmpm = opt.cache_m;  // what the cached distances were computed from
-  int cmpK = opt.cache_K;
+  // model selection on cached distances (VbemOptions::inc): the last E-step left how far it moved the responsibilities;
+  // `chain` = statistics updates from moved rows since the last full pass
+  bool have_delta = false;
+  int chain = 0;
+  constexpr int CHAIN_CAP = 16;
+  // LC_SPLIT_DELTA_FORCE=1 (tests): stay on the cache and on moved-row statistics however much moves
+  static const bool inc_force = env_on("LC_SPLIT_DELTA_FORCE");
 
   double F = std::numeric_limits<double>::max(), Fold;
   int i = 0, done = 0;
@@ -202,6 +206,18 @@ double vbem(lcc::Context& ctx, Model& model, const VbemOptions& opt) {
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
     return std::chrono::duration<double, std::milli>(b - a).count();
+  };
+  // statistics += their change over the rows the last E-step moved; false (nothing touched) when most rows moved
+  auto add_delta = [&]() {
+    std::vector<double> dN(K), dx((size_t)K * D), dxx((size_t)K * XX), dNj((size_t)J * K);
+    if (!ctx.delta_suffstat(K, opt.inc->tol, inc_force ? 2.0 : 0.5, dN.data(), dx.data(), dxx.data(), dNj.data()))
+      return false;
+    for (int k = 0; k < K; ++k) Nk[k] += dN[k];
+    for (size_t t = 0; t < dx.size(); ++t) xs[t] += dx[t];
+    for (size_t t = 0; t < dxx.size(); ++t) xxs[t] += dxx[t];
+    for (size_t t = 0; t < dNj.size(); ++t) Njk[t] += dNj[t];
+    ++chain;
+    return true;
   };
   do {
     Fold = F;
@@ -229,26 +245,21 @@ double vbem(lcc::Context& ctx, Model& model, const VbemOptions& opt) {
       xxs = opt.preset->xxs;
       xxs.resize((size_t)K * std::max<size_t>(XX, 1));
       Njk = opt.preset->Njk;
-    } else if (done == 1 && have_delta) {
-      // Nk, xs, xxs, Njk still hold the statistics of the responsibilities the cached E-step overwrote
-      std::vector<double> dN(K), dx((size_t)K * D), dxx((size_t)K * XX), dNj((size_t)J * K);
-      if (ctx.delta_suffstat(K, opt.delta_tol, 0.5, dN.data(), dx.data(), dxx.data(), dNj.data())) {
-        for (int k = 0; k < K; ++k) Nk[k] += dN[k];
-        for (size_t t = 0; t < dx.size(); ++t) xs[t] += dx[t];
-        for (size_t t = 0; t < dxx.size(); ++t) xxs[t] += dxx[t];
-        for (size_t t = 0; t < dNj.size(); ++t) Njk[t] += dNj[t];
-      } else {
-        ctx.suffstat(maskp, Nk.data(), xs.data(), xxs.data(), Njk.data());
-      }
-      have_delta = false;
-    } else if (full) ctx.suffstat(maskp, Nk.data(), xs.data(), xxs.data(), Njk.data());
-    else ctx.suffstat_diag(maskp, Nk.data(), xs.data(), XX ? xxs.data() : nullptr, Njk.data());
+      chain = opt.preset->chain;
+    } else if (have_delta && chain < CHAIN_CAP && add_delta()) {
+      // Nk, xs, xxs, Njk held the statistics of the responsibilities the last E-step overwrote
+    } else if (full) {
+      ctx.suffstat(maskp, Nk.data(), xs.data(), xxs.data(), Njk.data());
+      chain = 0;
+    } else ctx.suffstat_diag(maskp, Nk.data(), xs.data(), XX ? xxs.data() : nullptr, Njk.data());
+    have_delta = false;
     if (done == 0 && opt.capture) {
       opt.capture->K = K;
       opt.capture->Nk = Nk;
       opt.capture->xs = xs;
       opt.capture->xxs = xxs;
       opt.capture->Njk = Njk;
+      opt.capture->chain = chain;
     }
     for (int j = 0; j < J; ++j) model.weights[j].update(Njk.data() + (size_t)j * K, K);
     const auto t1 = now();
@@ -302,35 +313,13 @@ double vbem(lcc::Context& ctx, Model& model, const VbemOptions& opt) {
       have_next = ctx.estep_suffstat_fused(K, A.data(), m.data(), c.data(), &Fz, opt.want_ll ? model.LLk.data() : nullptr,
                                            nNk.data(), nxs.data(), nxxs.data(), nNjk.data());
     }
-    // second iteration after a cached first one: the clusters whose posterior is not bit for bit the cached one
-    std::vector<int> moved;
-    if (done == 1 && cached_first && opt.delta_second && cmpA && cmpm) {
-      for (int k = 0; k < K; ++k)
-        if (k >= cmpK ||
-            std::memcmp(A.data() + (size_t)k * D * D, cmpA + (size_t)k * D * D, (size_t)D * D * sizeof(double)) != 0 ||
-            std::memcmp(m.data() + (size_t)k * D, cmpm + (size_t)k * D, (size_t)D * sizeof(double)) != 0)
-          moved.push_back(k);
-      if ((int)moved.size() * 10 > K * 7) moved.clear();  // most of them: the ordinary E-step is cheaper
-    }
     if (have_next) {
-    } else if (done == 0 && full && opt.cached_changed && !opt.want_ll) {
-      const bool keep = opt.delta_second && !opt.sparse && opt.fixed_iters < 0;
-      ctx.estep_cached(K, A.data(), m.data(), c.data(), opt.cached_changed, opt.cached_nchanged, &Fz, keep);
-      cached_first = true;
-      have_delta = keep;
-    } else if (done == 0 && full && opt.build_cache && opt.delta_second && opt.built_A && opt.built_m && !opt.want_ll &&
-               !opt.sparse && opt.fixed_iters < 0) {
-      ctx.dcache_build(K, A.data(), m.data());
-      ctx.estep_cached(K, A.data(), m.data(), c.data(), nullptr, 0, &Fz, true);
-      *opt.built_A = A;
-      *opt.built_m = m;
-      cmpA = opt.built_A->data();
-      cmpm = opt.built_m->data();
-      cmpK = K;
-      cached_first = true;
-      have_delta = true;
-    } else if (!moved.empty()) {
-      ctx.estep_cached(K, A.data(), m.data(), c.data(), moved.data(), (int)moved.size(), &Fz);
+    } else if (opt.inc && opt.inc->on && full && !opt.sparse && opt.fixed_iters < 0 && ctx.dcache_eligible(K)) {
+      int stale = 0;
+      ctx.estep_cache(K, A.data(), m.data(), c.data(), &Fz, opt.want_ll ? model.LLk.data() : nullptr, true, &stale);
+      have_delta = ctx.delta_pending() == K;
+      // most clusters' posteriors moved since their distances were computed: the cache costs more than it saves
+      if (K >= 4 && stale * 10 > K * 7 && !inc_force) opt.inc->on = false;
     } else {
       run_estep(ctx, model, K, &Fz, opt.want_ll ? model.LLk.data() : nullptr);
     }
@@ -358,6 +347,17 @@ double vbem(lcc::Context& ctx, Model& model, const VbemOptions& opt) {
       again = (std::abs((Fold - F) / Fold) > lch::CONVERGE) && ((i++ < opt.maxit) || (opt.maxit < 0));  // :235-236
     }
   } while (again);
+  if (opt.capture_final) {
+    opt.capture_final->K = 0;
+    if (have_delta && chain < CHAIN_CAP && add_delta()) {
+      opt.capture_final->K = K;
+      opt.capture_final->Nk = Nk;
+      opt.capture_final->xs = xs;
+      opt.capture_final->xxs = xxs;
+      opt.capture_final->Njk = Njk;
+      opt.capture_final->chain = chain;
+    }
+  }
   return F;
 }
 
@@ -391,6 +391,8 @@ static bool prune_clusters(lcc::Context& ctx, Model& model, bool verbose) {
   model.clusters.swap(nc);
   model.LLk.swap(nll);
   ctx.qz_keep_columns(keep);
+  ctx.dcache_keep_columns(keep);
+  model.final_stats.K = 0;  // (their columns no longer line up)
   const int nK = (int)keep.size();
   std::vector<double> Njk((size_t)J * nK);
   ctx.colsums(Njk.data());
@@ -401,7 +403,8 @@ static bool prune_clusters(lcc::Context& ctx, Model& model, bool verbose) {
 // ---------------------------------------------------------------------------
 // cluster.cpp:366-495
 // ---------------------------------------------------------------------------
-static bool split_gr(lcc::Context& ctx, Model& model, std::vector<int>& tally, double F, const ClusterOptions& opt) {
+static bool split_gr(lcc::Context& ctx, Model& model, std::vector<int>& tally, double F, const ClusterOptions& opt,
+                     IncState* inc) {
   const int J = ctx.J(), K = (int)model.clusters.size(), D = ctx.D();
   if (K >= opt.maxclusters && opt.maxclusters >= 0) return false;
   tally.resize(K, 0);
@@ -433,20 +436,14 @@ static bool split_gr(lcc::Context& ctx, Model& model, std::vector<int>& tally, d
   // candidate changes two columns of qZ (auglabels moves mass from column k to the new column K), so every later
   // candidate recomputes those two only.  Not in sparse mode (the masks depend on all columns).
   static const bool no_incremental = env_on("LC_SPLIT_FULL_STATS");
+  // ... known already when the round's VBEM could follow the rows its last E-step moved (cluster())
   StatsBlock round_stats;
+  if (model.final_stats.K == K && !opt.sparse && !no_incremental) round_stats = model.final_stats;
   const size_t XX = ClusterAny::xx_size(model.ckind, D), XS = std::max<size_t>(XX, 1);
-  // ... and, from the third candidate of a round on, only those two clusters' distances: the other clusters' posteriors
-  // (hence their -0.5 d^2 for every row) are the same for every candidate of the round and are cached once
-  int preset_candidates = 0;
-  bool dcache_built = false;
-  std::vector<double> cacheA, cachem;  // what the cache was built from
-  int cache_patch_col = -1;            // >= 0: a first candidate built it, this column still holds its half-cluster
-  // ... and the second iteration of such a candidate works on the rows / clusters the first one moved (VbemOptions)
-  static const bool no_delta = env_on("LC_SPLIT_NO_DELTA");
-  static const double delta_tol = [] {
-    const char* e = std::getenv("LC_SPLIT_DELTA_TOL");
-    return e ? std::atof(e) : 0x1p-50;
-  }();
+  // Gauss-Wishart, dense: a candidate's E-steps go through the context's distance cache IN PLACE (only the split
+  // cluster's two halves, and whatever else its two iterations move, are recomputed); a journal puts the cache back
+  // when the candidate is rejected
+  const bool cache_trials = inc && model.ckind == lch::C_GAUSSWISH && !opt.sparse;
 
   static const bool trace_phases = env_on("LC_TRACE_PHASES");
   auto now = [] { return std::chrono::steady_clock::now(); };
@@ -520,15 +517,18 @@ static bool split_gr(lcc::Context& ctx, Model& model, std::vector<int>& tally, d
     vo.sparse = opt.sparse;
     vo.nthreads = opt.nthreads;
     StatsBlock first;  // statistics of the augmented qZ (K + 1 columns) for the first of the two iterations
+    StatsBlock fin;    // ... and of the responsibilities its last E-step leaves (next round's start when it is accepted)
     const bool incremental = !opt.sparse && !no_incremental;
     const int cols[2] = {k, K};  // the two columns this candidate changes
     double Fsplit;
+    bool journal = false;
     try {
       if (incremental && round_stats.K == K) {
         std::vector<double> n2(2), x2((size_t)2 * D), xx2((size_t)2 * XS), nj2((size_t)J * 2);
         ctx.suffstat_columns(cols, 2, model.ckind != lch::C_GAUSSWISH, n2.data(), x2.data(), XX ? xx2.data() : nullptr,
                              nj2.data());
         first.K = K + 1;
+        first.chain = round_stats.chain;
         first.Nk.assign(round_stats.Nk.begin(), round_stats.Nk.end());
         first.Nk.push_back(0.0);
         first.xs.assign(round_stats.xs.begin(), round_stats.xs.end());
@@ -546,71 +546,18 @@ static bool split_gr(lcc::Context& ctx, Model& model, std::vector<int>& tally, d
           for (int j = 0; j < J; ++j) first.Njk[(size_t)j * (K + 1) + c] = nj2[(size_t)j * 2 + t];
         }
         vo.preset = &first;
-        ++preset_candidates;
-        if (cache_patch_col >= 0) {
-          // the cache a first candidate built: its column k belongs to half of that candidate's split cluster -- put
-          // the round's own cluster back (its posterior from the round's statistics, as every later M-step reproduces
-          // it), and forget the extra column
-          const int kc = cache_patch_col;
-          cache_patch_col = -1;
-          ClusterAny cl(model.ckind, prior, D);
-          cl.addstats(round_stats.Nk[(size_t)kc], round_stats.xs.data() + (size_t)kc * D,
-                      round_stats.xxs.data() + (size_t)kc * XX);
-          cl.update();
-          const std::vector<double> Ak = cl.gw.whitener();
-          ctx.dcache_patch(kc, Ak.data(), cl.gw.m.data());
-          ctx.dcache_shrink(K);
-          std::copy(Ak.begin(), Ak.end(), cacheA.begin() + (size_t)kc * D * D);
-          std::copy(cl.gw.m.begin(), cl.gw.m.end(), cachem.begin() + (size_t)kc * D);
-          cacheA.resize((size_t)K * D * D);
-          cachem.resize((size_t)K * D);
-          dcache_built = true;
-        }
-        if (model.ckind == lch::C_GAUSSWISH && (dcache_built || preset_candidates >= 2) && ctx.dcache_eligible(K)) {
-          if (!dcache_built) {
-            // the posteriors every later candidate's M-step will reproduce for its unchanged clusters
-            std::vector<double>&Ac = cacheA, &mc = cachem;
-            Ac.assign((size_t)K * D * D, 0.0);
-            mc.assign((size_t)K * D, 0.0);
-            for (int c2 = 0; c2 < K; ++c2) {
-              ClusterAny cl(model.ckind, prior, D);
-              cl.addstats(round_stats.Nk[(size_t)c2], round_stats.xs.data() + (size_t)c2 * D,
-                          round_stats.xxs.data() + (size_t)c2 * XX);
-              cl.update();
-              const std::vector<double> Ak = cl.gw.whitener();
-              std::copy(Ak.begin(), Ak.end(), Ac.begin() + (size_t)c2 * D * D);
-              std::copy(cl.gw.m.begin(), cl.gw.m.end(), mc.begin() + (size_t)c2 * D);
-            }
-            ctx.dcache_build(K, Ac.data(), mc.data());
-            dcache_built = true;
-          }
-          vo.cached_changed = cols;
-          vo.cached_nchanged = 2;
-          if (!no_delta) {
-            vo.delta_second = true;
-            vo.delta_tol = delta_tol;
-            vo.cache_A = cacheA.data();
-            vo.cache_m = cachem.data();
-            vo.cache_K = K;
-          }
-        }
       } else if (incremental) {
         vo.capture = &first;
-        if (model.ckind == lch::C_GAUSSWISH && !no_delta && !dcache_built && ctx.dcache_eligible(K)) {
-          // the first candidate of the round builds the cache from its own K + 1 clusters; column k (this candidate's
-          // half of the split cluster) is put right before another candidate uses the cache
-          cacheA.clear();
-          cachem.clear();
-          vo.build_cache = true;
-          vo.built_A = &cacheA;
-          vo.built_m = &cachem;
-          vo.delta_second = true;
-          vo.delta_tol = delta_tol;
-        }
+      }
+      if (cache_trials && inc->on) {
+        ctx.dcache_journal_begin();
+        journal = true;
+        vo.inc = inc;
+        vo.capture_final = &fin;
       }
       Fsplit = vbem(ctx, ms, vo);
-      if (vo.build_cache && cacheA.size() == (size_t)(K + 1) * D * D) cache_patch_col = k;
     } catch (...) {
+      if (journal) ctx.dcache_rollback();
       ctx.qz_swap_alt();
       throw;
     }
@@ -618,6 +565,7 @@ static bool split_gr(lcc::Context& ctx, Model& model, std::vector<int>& tally, d
       // the converged qZ's statistics from this candidate's: columns other than k are untouched, column k gave its
       // moved mass to column K (q_t[:,k] = q_aug[:,k] + q_aug[:,K] row by row, and the statistics are linear in q)
       round_stats.K = K;
+      round_stats.chain = first.chain;
       round_stats.Nk.assign(first.Nk.begin(), first.Nk.begin() + K);
       round_stats.xs.assign(first.xs.begin(), first.xs.begin() + (size_t)K * D);
       round_stats.xxs.assign(first.xxs.begin(), first.xxs.begin() + (size_t)K * XS);
@@ -631,6 +579,7 @@ static bool split_gr(lcc::Context& ctx, Model& model, std::vector<int>& tally, d
       }
     }
     if (anyempty(ms.clusters)) {  // :476
+      if (journal) ctx.dcache_rollback();
       ctx.qz_swap_alt();
       continue;
     }
@@ -641,8 +590,11 @@ static bool split_gr(lcc::Context& ctx, Model& model, std::vector<int>& tally, d
                 << " ms" << std::endl;
     if ((Fsplit < F) && (std::abs((F - Fsplit) / F) > lch::CONVERGE)) {  // :484-489
       tally[k] = 0;
+      if (journal) ctx.dcache_journal_end();
+      model.next_stats = std::move(fin);  // (K = 0 when they could not be had from the moved rows)
       return true;  // the augmented qZ is now the current one
     }
+    if (journal) ctx.dcache_rollback();
     ctx.qz_swap_alt();
   }
   return false;
@@ -657,9 +609,33 @@ double cluster(lcc::Context& ctx, Model& model, const ClusterOptions& opt) {
   std::vector<int> tally;
   bool issplit = true;
   double F = 0.0;
+  // Gauss-Wishart, dense: E-steps through the distance cache, statistics from the moved rows (VbemOptions::inc);
+  // LC_SPLIT_NO_DELTA=1 restores full passes everywhere but the two-column statistics of the split candidates
+  static const bool no_delta = env_on("LC_SPLIT_NO_DELTA") || env_on("LC_SPLIT_NO_DCACHE");
+  static const double delta_tol = [] {
+    const char* e = std::getenv("LC_SPLIT_DELTA_TOL");
+    return e ? std::atof(e) : 0x1p-50;
+  }();
+  IncState inc;
+  inc.tol = delta_tol;
+  const bool inc_allowed = !no_delta && model.ckind == lch::C_GAUSSWISH && !opt.sparse;
+  model.final_stats.K = 0;
+  model.next_stats.K = 0;
+  ctx.dcache_invalidate();
+  struct CacheRelease {  // the cache is this call's: hand its memory back on every way out
+    lcc::Context& c;
+    ~CacheRelease() { c.dcache_release(); }
+  } cache_release{ctx};
   while (issplit) {
     std::vector<double> tr;
     VbemOptions vo;
+    inc.on = inc_allowed;  // (a round may switch it off for itself: its clusters overlap too much for the cache to pay)
+    if (inc_allowed) {
+      vo.inc = &inc;
+      vo.capture_final = &model.final_stats;
+      if (model.next_stats.K == ctx.K()) vo.preset = &model.next_stats;  // the accepted candidate's
+    }
+    model.final_stats.K = 0;
     vo.clusterprior = opt.clusterprior;
     vo.maxit = -1;
     vo.sparse = opt.sparse;
@@ -671,6 +647,7 @@ double cluster(lcc::Context& ctx, Model& model, const ClusterOptions& opt) {
     static const bool ll_extra_pass = env_on("LC_LL_EXTRA_PASS");  // (the round-1 behaviour, for A/B timing)
     vo.want_ll = !ll_extra_pass;
     F = vbem(ctx, model, vo);
+    model.next_stats.K = 0;
     if (opt.trace) opt.trace->emplace_back((int)model.clusters.size(), tr);
     int nkeep = 0;
     for (const auto& cl : model.clusters) nkeep += !(cl.N() < lch::ZEROCUTOFF);
@@ -680,7 +657,7 @@ double cluster(lcc::Context& ctx, Model& model, const ClusterOptions& opt) {
     prune_clusters(ctx, model, opt.verbose);
     const auto c1 = std::chrono::steady_clock::now();
     if (opt.verbose) std::cout << '<' << std::flush;
-    issplit = split_gr(ctx, model, tally, F, opt);
+    issplit = split_gr(ctx, model, tally, F, opt, inc_allowed ? &inc : nullptr);
     if (trace_phases)
       std::cerr << "[cluster K=" << model.clusters.size() << "] data_loglik+prune "
                 << std::chrono::duration<double, std::milli>(c1 - c0).count() << " ms, split search "

@@ -15,6 +15,20 @@
 
 namespace lce {
 
+// Sufficient statistics of one qZ: N_k [K], sum q x [K*D], second moments [K*XX] (XX = D*D / D / 0 by family), N_jk [J*K]
+struct StatsBlock {
+  int K = 0;
+  std::vector<double> Nk, xs, xxs, Njk;
+  int chain = 0;  // updates by moved rows (Context::delta_suffstat) since the last full pass over the data
+};
+
+// cluster(): the E-steps go through the context's distance cache and the statistics follow the rows an E-step moved
+// (VbemOptions::inc).  `on` is cleared when that stops paying (most clusters' posteriors change between E-steps).
+struct IncState {
+  bool on = true;
+  double tol = 0x1p-50;  // a row whose responsibilities all moved by <= tol does not count as moved (LC_SPLIT_DELTA_TOL)
+};
+
 struct Model {
   int wkind = lch::W_DIRICHLET;
   std::vector<lch::WeightState> weights;      // J
@@ -24,12 +38,9 @@ struct Model {
   // parameters of the last E-step: (A [K*D*D], m [K*D]) for Gauss-Wishart clusters, (a, w2, w1) [K*D each] in
   // lastA = [a | w2 | w1] for the diagonal families; c [J*K]
   std::vector<double> lastA, lastm, lastc;
-};
-
-// Sufficient statistics of one qZ: N_k [K], sum q x [K*D], second moments [K*XX] (XX = D*D / D / 0 by family), N_jk [J*K]
-struct StatsBlock {
-  int K = 0;
-  std::vector<double> Nk, xs, xxs, Njk;
+  // cluster(): statistics of the converged responsibilities of the round (K = 0: not known) / of the accepted
+  // candidate's responsibilities the next round starts from
+  StatsBlock final_stats, next_stats;
 };
 
 struct VbemOptions {
@@ -48,25 +59,16 @@ struct VbemOptions {
   // per candidate (cluster.cpp:473 prescribes a full vbem; the statistics are a pure function of (X, qZ)).
   const StatsBlock* preset = nullptr;
   StatsBlock* capture = nullptr;
-  // first iteration: the context holds cached distances of every cluster but these (Context::estep_cached)
-  const int* cached_changed = nullptr;
-  int cached_nchanged = 0;
-  // ... and the iteration after it (the second of a candidate's two, cluster.cpp:473 with the off-by-one of :235-236)
-  // works on what that E-step MOVED: its statistics are those of the first iteration plus the change over the rows
-  // whose responsibilities moved by more than delta_tol (Context::delta_suffstat; the ordinary pass when most rows
-  // moved), and its E-step recomputes the distances of the clusters whose posterior differs in any bit from the cached
-  // one (cache_A / cache_m: the cache_K whiteners and means the cache was built from)
-  bool delta_second = false;
-  double delta_tol = 0.0;
-  const double* cache_A = nullptr;
-  const double* cache_m = nullptr;
-  int cache_K = 0;
-  // first iteration: BUILD the cache from its own clusters (raw distances of all of them, then the normalisation
-  // sweep -- the same responsibilities as the ordinary E-step) and hand back what it was built from; the second
-  // iteration then works as above.  For the first candidate of a round (delta_second must be set too).
-  bool build_cache = false;
-  std::vector<double>* built_A = nullptr;
-  std::vector<double>* built_m = nullptr;
+  // Model selection on cached distances (Gauss-Wishart, dense): every E-step goes through Context::estep_cache --
+  // only the clusters whose posterior changed in any bit since their distances were last computed are recomputed --
+  // and leaves how far it moved the responsibilities; the next iteration's statistics are then the previous ones plus
+  // the change over the rows that moved by more than inc->tol (Context::delta_suffstat; the ordinary pass when most
+  // rows moved or the chain of such updates gets long).  cluster.cpp prescribes full passes; the statistics are a
+  // pure, linear function of (X, qZ) and the distances a pure function of (X, cluster posterior).
+  IncState* inc = nullptr;
+  // statistics of the responsibilities the LAST E-step produced, when they can be had from the moved rows (K = 0
+  // otherwise): the split search starts from them, and an accepted candidate hands them to the next round
+  StatsBlock* capture_final = nullptr;
 };
 
 // fn(c) for c in [0, nchunks) on the persistent worker pool (inline when the work is small or the pool is busy)

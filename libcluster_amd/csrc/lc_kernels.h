@@ -224,7 +224,7 @@ struct CachedNormLaunch {
   int64_t ldc;
   const double* fresh;   // [nfresh x ldf] the recomputed columns
   int64_t ldf;
-  const int* colmap;     // [K] device: >= 0 cache column, < 0 fresh column -(v + 1)
+  const int* colmap;     // [K] device: >= 0 cache column, < 0 fresh column -(v + 1); nullptr: cache column j for cluster j
   const double* ctab;    // [J x K]
   int K;
   const int* rginfo;     // or nullptr (single group)
@@ -233,6 +233,7 @@ struct CachedNormLaunch {
   int64_t ldq;
   double* fz_part;       // [softmax_cached_grid(NP)]
   // optional (both or neither): how far this E-step moved the responsibilities it overwrites
+  double* ll_part = nullptr;  // [softmax_cached_grid(NP) x K] or nullptr: sum_n q_nk (log q~_nk - c_jk) partials
   double* dq = nullptr;    // [K x ldd] q_new - q_old
   int64_t ldd = 0;
   double* amax = nullptr;  // [NP] max_j |q_new - q_old| of the row

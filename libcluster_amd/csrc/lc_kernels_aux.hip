@@ -581,9 +581,10 @@ hipError_t launch_transpose_qz(const double* qZ, int64_t ldq, int K, int64_t NP,
 // (cluster.cpp:130-131), F_z partials.  One block = 256 rows; the K values of a row wait in LDS ([K][256]).
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) softmax_cached_kernel(CachedNormLaunch a) {
-  extern __shared__ double tile[];  // [K][256]
+  extern __shared__ double tile[];  // [K][256], then [4][K] wave partials of LL_k
   __shared__ double fzw[4];
   const int tid = threadIdx.x, K = a.K;
+  double* llw = tile + (size_t)K * 256;
   const int64_t row = (int64_t)blockIdx.x * 256 + tid;
   const bool inb = row < a.NP;
   int grp = 0;
@@ -600,7 +601,7 @@ __global__ void __launch_bounds__(256) softmax_cached_kernel(CachedNormLaunch a)
   const double* crow = a.ctab + (int64_t)grp * K;
   double mx = -INFINITY;
   for (int j = 0; j < K; ++j) {
-    const int cm = a.colmap[j];
+    const int cm = a.colmap ? a.colmap[j] : j;
     double v = 0.0;
     if (inb) v = crow[j] + (cm >= 0 ? a.dcache[(int64_t)cm * a.ldc + row] : a.fresh[(int64_t)(-cm - 1) * a.ldf + row]);
     tile[j * 256 + tid] = v;
@@ -609,33 +610,39 @@ __global__ void __launch_bounds__(256) softmax_cached_kernel(CachedNormLaunch a)
   double s = 0.0;
   for (int j = 0; j < K; ++j) s += exp(tile[j * 256 + tid] - mx);
   const double logZ = log(s) + mx;
-  if (inb && a.dq) {  // (launch-uniform) also report the move away from the responsibilities being overwritten
-    double am = 0.0;
-    for (int j = 0; j < K; ++j) {
-      double q = exp(tile[j * 256 + tid] - logZ);
-      if (!ok) q = 0.0;
-      const double d = q - a.qZ[(int64_t)j * a.ldq + row];
-      a.dq[(int64_t)j * a.ldd + row] = d;
-      am = fmax(am, fabs(d));
+  // (a.dq, a.ll_part: launch-uniform)
+  double am = 0.0;
+  for (int j = 0; j < K; ++j) {
+    const double lq = tile[j * 256 + tid];
+    double q = exp(lq - logZ);
+    if (!ok) q = 0.0;
+    if (inb) {
+      if (a.dq) {  // also report the move away from the responsibilities being overwritten
+        const double d = q - a.qZ[(int64_t)j * a.ldq + row];
+        a.dq[(int64_t)j * a.ldd + row] = d;
+        am = fmax(am, fabs(d));
+      }
       a.qZ[(int64_t)j * a.ldq + row] = q;
     }
-    a.amax[row] = am;
-  } else if (inb)
-    for (int j = 0; j < K; ++j) {
-      double q = exp(tile[j * 256 + tid] - logZ);
-      if (!ok) q = 0.0;
-      a.qZ[(int64_t)j * a.ldq + row] = q;
+    if (a.ll_part) {  // the data term of the split ordering (cluster.cpp:407-410), as estep_kernel's sweep forms it
+      const double ll = wave_sum(q > 0.0 ? q * (lq - crow[j]) : 0.0);
+      if ((tid & 63) == 0) llw[(tid >> 6) * K + j] = ll;
     }
+  }
+  if (inb && a.dq) a.amax[row] = am;
   const double fz = wave_sum(ok ? logZ : 0.0);
   if ((tid & 63) == 0) fzw[tid >> 6] = fz;
   __syncthreads();
   if (tid == 0) a.fz_part[blockIdx.x] = -(fzw[0] + fzw[1] + fzw[2] + fzw[3]);  // cluster.cpp:137 returns -sum(logZ)
+  if (a.ll_part)
+    for (int j = tid; j < K; j += 256)
+      a.ll_part[(int64_t)blockIdx.x * K + j] = llw[j] + llw[K + j] + llw[2 * K + j] + llw[3 * K + j];
 }
 int64_t softmax_cached_grid(int64_t NP) { return (NP + 255) / 256; }
 hipError_t launch_softmax_cached(const CachedNormLaunch& a, hipStream_t stream) {
   const int64_t grid = softmax_cached_grid(a.NP);
   if (grid <= 0 || a.K <= 0) return hipSuccess;
-  const size_t shmem = (size_t)a.K * 256 * sizeof(double);
+  const size_t shmem = ((size_t)a.K * 256 + (size_t)4 * a.K) * sizeof(double);
   static LdsGrant grant;
   if (hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(softmax_cached_kernel), shmem, grant); e != hipSuccess)
     return e;

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Randomised parity sweep of the full learners (model selection: VBEM + prune + greedy split search) against the
-oracle: every round's K and free energies, final K and F.  Usage: tools/fuzz_learn.py [cases] [seed]"""
+oracle: every round's K and free energies, final K and F.  Usage: tools/fuzz_learn.py [cases] [seed]
+LC_FUZZ_CACHE=1: only the shapes whose model selection runs on cached distances and moved-row statistics (Gauss-Wishart
+learners, D > 16, dense), from well separated to heavily overlapping mixtures."""
 import os
 import sys
 import time
@@ -20,6 +22,9 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 FLAT = ["learnVDP", "learnBGMM", "learnDGMM", "learnBEMM"]
 GROUPED = ["learnGMC", "learnSGMC", "learnDGMC", "learnEGMC"]
+CACHE_ONLY = os.environ.get("LC_FUZZ_CACHE") == "1"
+if CACHE_ONLY:
+    FLAT, GROUPED = ["learnVDP", "learnBGMM"], ["learnGMC", "learnGMC", "learnSGMC"]
 fails, t0 = [], time.time()
 for case in range(cases):
     kind = rng.choice(["flat", "grouped", "topic"], p=[0.45, 0.4, 0.15])
@@ -27,6 +32,11 @@ for case in range(cases):
     Kt = int(rng.integers(1, 7))
     cent = rng.normal(0, 6.0, (Kt, D))
     spread = rng.uniform(0.4, 1.5)
+    if CACHE_ONLY:
+        kind = rng.choice(["flat", "grouped"], p=[0.6, 0.4])
+        D = int(rng.choice([17, 20, 23, 33, 40, 70]))
+        Kt = int(rng.integers(2, 9))
+        cent = rng.normal(0, float(rng.choice([6.0, 2.0, 0.7, 0.35])), (Kt, D))
 
     def draw(n, positive):
         z = rng.integers(0, Kt, n)
