@@ -652,6 +652,20 @@ void Context::set_data_gather(const Context& src, const RowSelection& sel) {
   LC_HIP(lck::launch_gather_rows(src.X_.p, DP_, sel.idx.p, sel.M, sel.starts_d.p, goff_d_.p, J_, X_.p, stream_));
 }
 
+void Context::qz_gather_column(const Context& src, const RowSelection& sel, int col) {
+  use_device();
+  if (src.device_ != device_ || src.J_ != J_) throw std::invalid_argument("not a sub-problem of that context");
+  const QZ& sq = src.qz_[src.cur_];
+  if (col < 0 || col >= sq.K) throw std::invalid_argument("qZ column out of range");
+  QZ& q = qz_[cur_];
+  ensure_qz(q, 1, false);
+  q.K = 1;
+  if (NP_ == 0) return;
+  LC_HIP(hipMemsetAsync(q.buf.p, 0, (size_t)NP_ * sizeof(double), stream_));  // padding rows carry nothing
+  LC_HIP(lck::launch_gather_cols(sq.buf.p + (size_t)col * src.NP_, src.NP_, 1, sel.idx.p, sel.M, sel.starts_d.p, goff_d_.p,
+                                 J_, q.buf.p, NP_, stream_));
+}
+
 void Context::qz_init_split(const double* m, const double* v) {
   use_device();
   ensure_qz(qz_[cur_], 2, false);
@@ -1160,8 +1174,8 @@ void Context::suffstat(const unsigned char* smask, double* Nk, double* xs, doubl
 
 bool Context::dcache_eligible(int K) const {
   static const bool off = std::getenv("LC_SPLIT_NO_DCACHE") != nullptr || std::getenv("LC_SPLIT_NO_DELTA") != nullptr;
-  // (the normalisation sweep keeps a row's K values in LDS: 2 KB per cluster and block)
-  return !off && DP_ <= 128 && K >= 1 && K <= 72 && !lck::fused_eligible(DP_, K);
+  // (the normalisation sweep keeps a row's K values in registers)
+  return !off && DP_ <= 128 && K >= 1 && K <= lck::softmax_cached_max_k() && !lck::fused_eligible(DP_, K);
 }
 
 void Context::dcache_invalidate() {
@@ -1229,7 +1243,7 @@ void Context::dcache_keep_columns(const std::vector<int>& keep) {
   dc_K_ = out;
 }
 
-int Context::estep_cache(int K, const double* A, const double* m, const double* c, double* Fz, double* LLk, bool keep_delta,
+int Context::estep_cache(int K, const double* A, const double* m, const double* c, double* Fz, double* LLk, double delta_tol,
                          int* stale_out) {
   use_device();
   if (K < 1) throw std::invalid_argument("K must be >= 1");
@@ -1325,7 +1339,7 @@ int Context::estep_cache(int K, const double* A, const double* m, const double* 
   fzpart_.reserve((size_t)std::max<int64_t>(grid, 1));
   if (LLk) llpart_.reserve((size_t)std::max<int64_t>(grid, 1) * K);
   red_.reserve((size_t)1 + K);
-  const bool delta = keep_delta && have_old;
+  const bool delta = delta_tol >= 0.0 && have_old;
   if (NP_ > 0) {
     hpack_.assign((size_t)J_ * K, 0.0);
     std::memcpy(hpack_.data(), c, (size_t)J_ * K * sizeof(double));
@@ -1352,6 +1366,8 @@ int Context::estep_cache(int K, const double* A, const double* m, const double* 
       a.dq = dq_.p;
       a.ldd = NP_;
       a.amax = amax_.p;
+      a.dq_tol = delta_tol;
+      dq_tol_ = delta_tol;
     }
     EvPair ev{};
     if (timing_) {
@@ -1382,12 +1398,12 @@ int Context::estep_cache(int K, const double* A, const double* m, const double* 
   return nch;
 }
 
-bool Context::delta_suffstat(int K1, double tau, double max_frac, double* dNk, double* dxs, double* dxxs, double* dNjk) {
+bool Context::delta_suffstat(int K1, double max_frac, double* dNk, double* dxs, double* dxxs, double* dNjk) {
   use_device();
   if (dq_K_ != K1 || K1 < 1) throw std::invalid_argument("no responsibilities delta of that width");
   dq_K_ = 0;  // single use: the next E-step overwrites the responsibilities it refers to
   RowSelection sel;
-  select_rows_col(amax_.p, tau, sel);
+  select_rows_col(amax_.p, dq_tol_, sel);
   delta_rows_ = sel.M;
   double cnt[2] = {(double)sel.M, (double)Ntot_};
   allreduce_values(cnt, 2);  // every rank takes the same branch

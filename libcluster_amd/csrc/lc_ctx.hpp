@@ -155,6 +155,8 @@ class Context {
   void select_rows_col(const double* col, double thresh, RowSelection& sel);  // ... of any device column of NP values
   // this context := the selected rows of src, group structure kept (partobs' copy part)
   void set_data_gather(const Context& src, const RowSelection& sel);
+  // qZ := the selected rows of column `col` of src's current qZ (one column; this context holds src's selected rows)
+  void qz_gather_column(const Context& src, const RowSelection& sel, int col);
   // qZ := [s, 1-s], s = ((x-m).v >= 0)   (splitobs + cluster.cpp:446-449); m, v: D host doubles
   void qz_init_split(const double* m, const double* v);
   // ExpGamma::splitobs (distributions.cpp:575-581): s = (x.v > mean over the group's rows of x.v)
@@ -178,10 +180,11 @@ class Context {
   // estep().  Between two iterations of a converging model, and between the candidates of a split round, most
   // clusters' posteriors are bit for bit the same, so most columns are re-used.  Returns the number of recomputed
   // columns; *stale = how many of them had a valid (but different) tag.
-  // keep_delta: also leave q_new - q_old (against the responsibilities being overwritten, when the buffer held K
-  // columns) and every row's largest |q_new - q_old| on the device, for delta_suffstat().
+  // delta_tol >= 0: also leave every row's largest |q_new - q_old| (against the responsibilities being overwritten,
+  // when the buffer held K columns) and, for the rows where it exceeds delta_tol, q_new - q_old, on the device for
+  // delta_suffstat(); rows that come out bit for bit as they were are not even written.
   bool dcache_eligible(int K) const;  // a property of the shape (identical on every rank)
-  int estep_cache(int K, const double* A, const double* m, const double* c, double* Fz, double* LLk, bool keep_delta,
+  int estep_cache(int K, const double* A, const double* m, const double* c, double* Fz, double* LLk, double delta_tol,
                   int* stale = nullptr);
   // a split candidate works on the cache in place: from journal_begin() on, a column is copied aside before it is
   // first overwritten; rollback() puts columns, tags and width back, journal_end() keeps the new state
@@ -191,14 +194,14 @@ class Context {
   void dcache_invalidate();
   void dcache_release();  // ... and give the memory back
   void dcache_keep_columns(const std::vector<int>& keep);  // prune_clusters
-  // The CHANGE of the statistics caused by the last estep_cache(keep_delta): sum over the rows whose responsibilities
-  // moved by more than tau in some column of (q_new - q_old) x the usual terms -- the statistics are linear in q, so
+  // The CHANGE of the statistics caused by the last estep_cache(delta_tol = tau): sum over the rows whose
+  // responsibilities moved by more than tau in some column of (q_new - q_old) x the usual terms -- the statistics are linear in q, so
   // adding it to the statistics of q_old gives those of q_new up to tau * sum_n |x_n x_n^T| (rows that moved by <= tau
   // are left out).  The rows are compacted in order and gathered into a sub-context (as partobs does), so the cost is
   // proportional to the rows that moved.  Returns false, having computed nothing, when more than max_frac of all rows
   // (summed over ranks) moved -- the caller then runs the ordinary pass.
-  bool delta_suffstat(int K1, double tau, double max_frac, double* dNk, double* dxs, double* dxxs, double* dNjk);
-  int delta_pending() const { return dq_K_; }  // width of the move the last estep_cache(keep_delta) left (0: none)
+  bool delta_suffstat(int K1, double max_frac, double* dNk, double* dxs, double* dxxs, double* dNjk);
+  int delta_pending() const { return dq_K_; }  // width of the move the last estep_cache(delta_tol >= 0) left (0: none)
   int64_t delta_rows() const { return delta_rows_; }  // rows the last delta_suffstat() found moved (this rank)
   // Small observations (D <= 16, K <= 16, Gauss-Wishart, dense): the E-step AND the statistics of the responsibilities it
   // produces, in one pass (lc_kernels_fused.hip).  Same outputs as estep() followed by suffstat(nullptr, ...).
@@ -271,7 +274,8 @@ class Context {
   std::vector<std::unique_ptr<SavedColumn>> dc_saved_;
   bool dc_journal_ = false;
   int dc_jK0_ = 0;
-  DevBuf<double> dq_, amax_;  // estep_cache(keep_delta): q_new - q_old [K x NP], per-row max |.|
+  DevBuf<double> dq_, amax_;  // estep_cache(delta_tol): q_new - q_old [K x NP] (moved rows), per-row max |.|
+  double dq_tol_ = 0.0;
   int dq_K_ = 0;
   int64_t delta_rows_ = 0;
   int cur_ = 0;

@@ -163,6 +163,9 @@ void parallel_chunks(int nchunks, unsigned nthreads, double work_per_chunk, cons
 // ---------------------------------------------------------------------------
 // cluster.cpp:177-239
 // ---------------------------------------------------------------------------
+// statistics updates from moved rows in a row before a full pass refreshes them
+constexpr int CHAIN_CAP = 64;
+
 double vbem(lcc::Context& ctx, Model& model, const VbemOptions& opt) {
   const int J = ctx.J(), K = ctx.K(), D = ctx.D();
   if (K < 1) throw std::invalid_argument("qZ must have at least one column");
@@ -194,7 +197,6 @@ double vbem(lcc::Context& ctx, Model& model, const VbemOptions& opt) {
   // `chain` = statistics updates from moved rows since the last full pass
   bool have_delta = false;
   int chain = 0;
-  constexpr int CHAIN_CAP = 16;
   // LC_SPLIT_DELTA_FORCE=1 (tests): stay on the cache and on moved-row statistics however much moves
   static const bool inc_force = env_on("LC_SPLIT_DELTA_FORCE");
 
@@ -210,8 +212,11 @@ double vbem(lcc::Context& ctx, Model& model, const VbemOptions& opt) {
   // statistics += their change over the rows the last E-step moved; false (nothing touched) when most rows moved
   auto add_delta = [&]() {
     std::vector<double> dN(K), dx((size_t)K * D), dxx((size_t)K * XX), dNj((size_t)J * K);
-    if (!ctx.delta_suffstat(K, opt.inc->tol, inc_force ? 2.0 : 0.5, dN.data(), dx.data(), dxx.data(), dNj.data()))
-      return false;
+    const bool okd = ctx.delta_suffstat(K, inc_force ? 2.0 : 0.5, dN.data(), dx.data(), dxx.data(), dNj.data());
+    if (trace_phases)
+      std::cerr << "[vbem] statistics from " << ctx.delta_rows() << " moved rows" << (okd ? "" : " (too many: full pass)")
+                << std::endl;
+    if (!okd) return false;
     for (int k = 0; k < K; ++k) Nk[k] += dN[k];
     for (size_t t = 0; t < dx.size(); ++t) xs[t] += dx[t];
     for (size_t t = 0; t < dxx.size(); ++t) xxs[t] += dxx[t];
@@ -316,12 +321,21 @@ double vbem(lcc::Context& ctx, Model& model, const VbemOptions& opt) {
     if (have_next) {
     } else if (opt.inc && opt.inc->on && full && !opt.sparse && opt.fixed_iters < 0 && ctx.dcache_eligible(K)) {
       int stale = 0;
-      ctx.estep_cache(K, A.data(), m.data(), c.data(), &Fz, opt.want_ll ? model.LLk.data() : nullptr, true, &stale);
+      const int nre = ctx.estep_cache(K, A.data(), m.data(), c.data(), &Fz, opt.want_ll ? model.LLk.data() : nullptr,
+                                      opt.inc->tol, &stale);
+      if (trace_phases)
+        std::cerr << "[vbem] cached E-step: K " << K << ", recomputed " << nre << " (stale " << stale << ")" << std::endl;
       have_delta = ctx.delta_pending() == K;
-      // most clusters' posteriors moved since their distances were computed: the cache costs more than it saves
-      if (K >= 4 && stale * 10 > K * 7 && !inc_force) opt.inc->on = false;
+      // most clusters' posteriors moved from one E-step to the next, twice in a row: the cache costs more than it
+      // saves (once is what a full refresh of the statistics looks like, and what the first E-step after the cache
+      // was left alone for a while looks like)
+      if (opt.inc->synced && K >= 4 && stale * 10 > K * 7) ++opt.inc->bad;
+      else opt.inc->bad = 0;
+      opt.inc->synced = true;
+      if (opt.inc->bad >= 2 && !inc_force) opt.inc->on = false;
     } else {
       run_estep(ctx, model, K, &Fz, opt.want_ll ? model.LLk.data() : nullptr);
+      if (opt.inc) opt.inc->synced = false;
     }
     const auto t3 = now();
 
@@ -349,16 +363,37 @@ double vbem(lcc::Context& ctx, Model& model, const VbemOptions& opt) {
   } while (again);
   if (opt.capture_final) {
     opt.capture_final->K = 0;
-    if (have_delta && chain < CHAIN_CAP && add_delta()) {
+    if (have_delta && chain < CHAIN_CAP) {
       opt.capture_final->K = K;
       opt.capture_final->Nk = Nk;
       opt.capture_final->xs = xs;
       opt.capture_final->xxs = xxs;
       opt.capture_final->Njk = Njk;
       opt.capture_final->chain = chain;
+      opt.capture_final->pending = true;
     }
   }
   return F;
+}
+
+bool finish_stats(lcc::Context& ctx, StatsBlock& s) {
+  if (s.K < 1) return false;
+  if (!s.pending) return true;
+  s.pending = false;
+  static const bool inc_force = env_on("LC_SPLIT_DELTA_FORCE");
+  const int K = s.K;
+  std::vector<double> dN(K), dx(s.xs.size()), dxx(s.xxs.size()), dNj(s.Njk.size());
+  if (ctx.delta_pending() != K || s.chain >= CHAIN_CAP ||
+      !ctx.delta_suffstat(K, inc_force ? 2.0 : 0.5, dN.data(), dx.data(), dxx.data(), dNj.data())) {
+    s.K = 0;
+    return false;
+  }
+  for (int k = 0; k < K; ++k) s.Nk[k] += dN[k];
+  for (size_t t = 0; t < dx.size(); ++t) s.xs[t] += dx[t];
+  for (size_t t = 0; t < dxx.size(); ++t) s.xxs[t] += dxx[t];
+  for (size_t t = 0; t < dNj.size(); ++t) s.Njk[t] += dNj[t];
+  ++s.chain;
+  return true;
 }
 
 // Data term of the split ordering (cluster.cpp:407-410): LLk[k] = sum_n q_nk (log q~_nk - c_jk).
@@ -519,31 +554,39 @@ static bool split_gr(lcc::Context& ctx, Model& model, std::vector<int>& tally, d
     StatsBlock first;  // statistics of the augmented qZ (K + 1 columns) for the first of the two iterations
     StatsBlock fin;    // ... and of the responsibilities its last E-step leaves (next round's start when it is accepted)
     const bool incremental = !opt.sparse && !no_incremental;
-    const int cols[2] = {k, K};  // the two columns this candidate changes
     double Fsplit;
     bool journal = false;
     try {
       if (incremental && round_stats.K == K) {
-        std::vector<double> n2(2), x2((size_t)2 * D), xx2((size_t)2 * XS), nj2((size_t)J * 2);
-        ctx.suffstat_columns(cols, 2, model.ckind != lch::C_GAUSSWISH, n2.data(), x2.data(), XX ? xx2.data() : nullptr,
-                             nj2.data());
+        // auglabels moved the mass of the selected rows labelled for the new cluster from column k to column K
+        // (comutils.cpp:75-104): the statistics of that mass, T, come from the sub-problem's own rows (1/K of the
+        // data, one column); column K's are T, column k's are the round's minus T, the others are the round's
+        std::vector<double> n1(1), x1((size_t)D), xx1(XS), nj1((size_t)J);
+        sub.qz_gather_column(ctx, sel, K);
+        if (model.ckind == lch::C_GAUSSWISH) sub.suffstat(nullptr, n1.data(), x1.data(), xx1.data(), nj1.data());
+        else sub.suffstat_diag(nullptr, n1.data(), x1.data(), XX ? xx1.data() : nullptr, nj1.data());
         first.K = K + 1;
         first.chain = round_stats.chain;
         first.Nk.assign(round_stats.Nk.begin(), round_stats.Nk.end());
-        first.Nk.push_back(0.0);
+        first.Nk.push_back(n1[0]);
+        first.Nk[(size_t)k] = std::max(0.0, first.Nk[(size_t)k] - n1[0]);
         first.xs.assign(round_stats.xs.begin(), round_stats.xs.end());
         first.xs.resize((size_t)(K + 1) * D, 0.0);
         first.xxs.assign(round_stats.xxs.begin(), round_stats.xxs.begin() + (size_t)K * XS);
         first.xxs.resize((size_t)(K + 1) * XS, 0.0);
+        for (int d = 0; d < D; ++d) {
+          first.xs[(size_t)K * D + d] = x1[(size_t)d];
+          first.xs[(size_t)k * D + d] -= x1[(size_t)d];
+        }
+        for (size_t e = 0; e < XX; ++e) {
+          first.xxs[(size_t)K * XX + e] = xx1[e];
+          first.xxs[(size_t)k * XX + e] -= xx1[e];
+        }
         first.Njk.assign((size_t)J * (K + 1), 0.0);
-        for (int j = 0; j < J; ++j)
+        for (int j = 0; j < J; ++j) {
           for (int c = 0; c < K; ++c) first.Njk[(size_t)j * (K + 1) + c] = round_stats.Njk[(size_t)j * K + c];
-        for (int t = 0; t < 2; ++t) {
-          const int c = cols[t];
-          first.Nk[(size_t)c] = n2[(size_t)t];
-          std::copy(x2.begin() + (size_t)t * D, x2.begin() + (size_t)(t + 1) * D, first.xs.begin() + (size_t)c * D);
-          if (XX) std::copy(xx2.begin() + (size_t)t * XX, xx2.begin() + (size_t)(t + 1) * XX, first.xxs.begin() + (size_t)c * XX);
-          for (int j = 0; j < J; ++j) first.Njk[(size_t)j * (K + 1) + c] = nj2[(size_t)j * 2 + t];
+          first.Njk[(size_t)j * (K + 1) + K] = nj1[(size_t)j];
+          first.Njk[(size_t)j * (K + 1) + k] = std::max(0.0, first.Njk[(size_t)j * (K + 1) + k] - nj1[(size_t)j]);
         }
         vo.preset = &first;
       } else if (incremental) {
@@ -591,6 +634,7 @@ static bool split_gr(lcc::Context& ctx, Model& model, std::vector<int>& tally, d
     if ((Fsplit < F) && (std::abs((F - Fsplit) / F) > lch::CONVERGE)) {  // :484-489
       tally[k] = 0;
       if (journal) ctx.dcache_journal_end();
+      finish_stats(ctx, fin);
       model.next_stats = std::move(fin);  // (K = 0 when they could not be had from the moved rows)
       return true;  // the augmented qZ is now the current one
     }
@@ -630,6 +674,7 @@ double cluster(lcc::Context& ctx, Model& model, const ClusterOptions& opt) {
     std::vector<double> tr;
     VbemOptions vo;
     inc.on = inc_allowed;  // (a round may switch it off for itself: its clusters overlap too much for the cache to pay)
+    inc.bad = 0;
     if (inc_allowed) {
       vo.inc = &inc;
       vo.capture_final = &model.final_stats;
@@ -648,6 +693,7 @@ double cluster(lcc::Context& ctx, Model& model, const ClusterOptions& opt) {
     vo.want_ll = !ll_extra_pass;
     F = vbem(ctx, model, vo);
     model.next_stats.K = 0;
+    finish_stats(ctx, model.final_stats);  // (before pruning touches the responsibilities)
     if (opt.trace) opt.trace->emplace_back((int)model.clusters.size(), tr);
     int nkeep = 0;
     for (const auto& cl : model.clusters) nkeep += !(cl.N() < lch::ZEROCUTOFF);

@@ -20,6 +20,9 @@ struct StatsBlock {
   int K = 0;
   std::vector<double> Nk, xs, xxs, Njk;
   int chain = 0;  // updates by moved rows (Context::delta_suffstat) since the last full pass over the data
+  // vbem()'s capture_final: these are the statistics of the responsibilities BEFORE its last E-step, and the context
+  // still holds that E-step's move -- finish_stats() adds it (only the caller knows whether it will be needed)
+  bool pending = false;
 };
 
 // cluster(): the E-steps go through the context's distance cache and the statistics follow the rows an E-step moved
@@ -27,6 +30,8 @@ struct StatsBlock {
 struct IncState {
   bool on = true;
   double tol = 0x1p-50;  // a row whose responsibilities all moved by <= tol does not count as moved (LC_SPLIT_DELTA_TOL)
+  bool synced = false;   // the previous E-step went through the cache (its tags describe the model as of then)
+  int bad = 0;           // E-steps in a row, each right after a synced one, that found most columns stale
 };
 
 struct Model {
@@ -67,9 +72,14 @@ struct VbemOptions {
   // pure, linear function of (X, qZ) and the distances a pure function of (X, cluster posterior).
   IncState* inc = nullptr;
   // statistics of the responsibilities the LAST E-step produced, when they can be had from the moved rows (K = 0
-  // otherwise): the split search starts from them, and an accepted candidate hands them to the next round
+  // otherwise; left `pending`, see StatsBlock): the split search starts from them, and an accepted candidate hands
+  // them to the next round
   StatsBlock* capture_final = nullptr;
 };
+
+// completes a block vbem() left pending (no other pass may have touched the context since); false and K = 0 when the
+// statistics cannot be had from the moved rows
+bool finish_stats(lcc::Context& ctx, StatsBlock& s);
 
 // fn(c) for c in [0, nchunks) on the persistent worker pool (inline when the work is small or the pool is busy)
 void parallel_chunks(int nchunks, unsigned nthreads, double work_per_chunk, const std::function<void(int)>& fn);

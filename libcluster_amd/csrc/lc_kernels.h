@@ -234,11 +234,13 @@ struct CachedNormLaunch {
   double* fz_part;       // [softmax_cached_grid(NP)]
   // optional (both or neither): how far this E-step moved the responsibilities it overwrites
   double* ll_part = nullptr;  // [softmax_cached_grid(NP) x K] or nullptr: sum_n q_nk (log q~_nk - c_jk) partials
-  double* dq = nullptr;    // [K x ldd] q_new - q_old
+  double* dq = nullptr;    // [K x ldd] q_new - q_old, written for the rows with amax > dq_tol only
+  double dq_tol = 0.0;
   int64_t ldd = 0;
   double* amax = nullptr;  // [NP] max_j |q_new - q_old| of the row
 };
 int64_t softmax_cached_grid(int64_t NP);
+int softmax_cached_max_k();  // widest K the sweep is built for
 hipError_t launch_softmax_cached(const CachedNormLaunch& a, hipStream_t stream);
 
 // synthetic mixture generator (bench): Philox4x32-10, counter = global row.

@@ -573,20 +573,22 @@ hipError_t launch_transpose_qz(const double* qZ, int64_t ldq, int K, int64_t NP,
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Split search: the first full-data E-step of a candidate (cluster.cpp:473) from cached distances.
-// Within one round every candidate's unchanged clusters have the same posterior (their statistics are those of the
-// round's converged qZ), hence the same -0.5 d^2_j(x_n); only the two clusters the candidate changes are recomputed
-// (estep_kernel, raw mode, into `fresh`).  This kernel adds the constants c_jk, which DO change with the weights, and
-// normalises: logsumexp in the reference's operation order (probutils.cpp:141-150), q = exp(x - logZ)
-// (cluster.cpp:130-131), F_z partials.  One block = 256 rows; the K values of a row wait in LDS ([K][256]).
+// Model selection: the E-step from cached distances (Context::estep_cache).
+// A cluster whose posterior has not changed in any bit since its column of -0.5 d^2_k(x_n) was computed keeps that
+// column (estep_kernel in raw mode recomputes the others).  This kernel adds the constants c_jk, which DO change with
+// the weights, and normalises: logsumexp in the reference's operation order (probutils.cpp:141-150), q = exp(x - logZ)
+// (cluster.cpp:130-131), F_z and (optionally) LL_k partials.  One lane = one row; its K values stay in registers
+// (KT >= K, statically unrolled: all loads of a row are in flight together, no LDS, full occupancy) -- the pass is a
+// pure stream of 8 K bytes per row in and, where something changed, out.
 // ---------------------------------------------------------------------------------------------------------------
+template <int KT>
 __global__ void __launch_bounds__(256) softmax_cached_kernel(CachedNormLaunch a) {
-  extern __shared__ double tile[];  // [K][256], then [4][K] wave partials of LL_k
   __shared__ double fzw[4];
+  __shared__ double llw[4 * KT];
   const int tid = threadIdx.x, K = a.K;
-  double* llw = tile + (size_t)K * 256;
   const int64_t row = (int64_t)blockIdx.x * 256 + tid;
   const bool inb = row < a.NP;
+  const int64_t rr = inb ? row : 0;  // (out-of-range lanes load row 0 and write nothing)
   int grp = 0;
   bool ok = false;
   if (inb) {
@@ -599,55 +601,101 @@ __global__ void __launch_bounds__(256) softmax_cached_kernel(CachedNormLaunch a)
     }
   }
   const double* crow = a.ctab + (int64_t)grp * K;
-  double mx = -INFINITY;
-  for (int j = 0; j < K; ++j) {
-    const int cm = a.colmap ? a.colmap[j] : j;
-    double v = 0.0;
-    if (inb) v = crow[j] + (cm >= 0 ? a.dcache[(int64_t)cm * a.ldc + row] : a.fresh[(int64_t)(-cm - 1) * a.ldf + row]);
-    tile[j * 256 + tid] = v;
-    mx = fmax(mx, v);
+  double v[KT];
+#pragma unroll
+  for (int j = 0; j < KT; ++j) {
+    v[j] = -INFINITY;
+    if (j < K) {
+      const int cm = a.colmap ? a.colmap[j] : j;
+      const double* col = cm >= 0 ? a.dcache + (int64_t)cm * a.ldc : a.fresh + (int64_t)(-cm - 1) * a.ldf;
+      v[j] = col[rr];
+    }
   }
+  double mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < KT; ++j)
+    if (j < K) {
+      v[j] += crow[j];
+      mx = fmax(mx, v[j]);
+    }
   double s = 0.0;
-  for (int j = 0; j < K; ++j) s += exp(tile[j * 256 + tid] - mx);
+#pragma unroll
+  for (int j = 0; j < KT; ++j)
+    if (j < K) s += exp(v[j] - mx);
   const double logZ = log(s) + mx;
   // (a.dq, a.ll_part: launch-uniform)
-  double am = 0.0;
-  for (int j = 0; j < K; ++j) {
-    const double lq = tile[j * 256 + tid];
-    double q = exp(lq - logZ);
-    if (!ok) q = 0.0;
-    if (inb) {
-      if (a.dq) {  // also report the move away from the responsibilities being overwritten
-        const double d = q - a.qZ[(int64_t)j * a.ldq + row];
-        a.dq[(int64_t)j * a.ldd + row] = d;
-        am = fmax(am, fabs(d));
+#pragma unroll
+  for (int j = 0; j < KT; ++j)
+    if (j < K) {
+      const double lq = v[j];
+      double q = exp(lq - logZ);
+      if (!ok) q = 0.0;
+      v[j] = q;
+      if (a.ll_part) {  // the data term of the split ordering (cluster.cpp:407-410), as estep_kernel's sweep forms it
+        const double ll = wave_sum(q > 0.0 ? q * (lq - crow[j]) : 0.0);
+        if ((tid & 63) == 0) llw[(tid >> 6) * KT + j] = ll;
       }
-      a.qZ[(int64_t)j * a.ldq + row] = q;
     }
-    if (a.ll_part) {  // the data term of the split ordering (cluster.cpp:407-410), as estep_kernel's sweep forms it
-      const double ll = wave_sum(q > 0.0 ? q * (lq - crow[j]) : 0.0);
-      if ((tid & 63) == 0) llw[(tid >> 6) * K + j] = ll;
+  if (a.dq) {
+    // Also report the move away from the responsibilities being overwritten -- and write only what changed: a row
+    // whose K values all come out bit for bit as they were is not written at all, its q_new - q_old only when some
+    // |.| exceeds dq_tol (delta_suffstat never looks at the other rows).  Between the candidates of a split round
+    // almost every row is of the first kind.
+    double d[KT];
+#pragma unroll
+    for (int j = 0; j < KT; ++j)
+      if (j < K) d[j] = a.qZ[(int64_t)j * a.ldq + rr];
+    double am = 0.0;
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < KT; ++j)
+      if (j < K) {
+        d[j] = v[j] - d[j];
+        am = fmax(am, fabs(d[j]));
+        any = any || d[j] != 0.0;
+      }
+    if (inb) {
+      a.amax[row] = am;
+      if (any) {
+        const bool moved = am > a.dq_tol;
+#pragma unroll
+        for (int j = 0; j < KT; ++j)
+          if (j < K) {
+            if (moved) a.dq[(int64_t)j * a.ldd + row] = d[j];
+            a.qZ[(int64_t)j * a.ldq + row] = v[j];
+          }
+      }
     }
+  } else if (inb) {
+#pragma unroll
+    for (int j = 0; j < KT; ++j)
+      if (j < K) a.qZ[(int64_t)j * a.ldq + row] = v[j];
   }
-  if (inb && a.dq) a.amax[row] = am;
   const double fz = wave_sum(ok ? logZ : 0.0);
   if ((tid & 63) == 0) fzw[tid >> 6] = fz;
   __syncthreads();
   if (tid == 0) a.fz_part[blockIdx.x] = -(fzw[0] + fzw[1] + fzw[2] + fzw[3]);  // cluster.cpp:137 returns -sum(logZ)
   if (a.ll_part)
     for (int j = tid; j < K; j += 256)
-      a.ll_part[(int64_t)blockIdx.x * K + j] = llw[j] + llw[K + j] + llw[2 * K + j] + llw[3 * K + j];
+      a.ll_part[(int64_t)blockIdx.x * K + j] = llw[j] + llw[KT + j] + llw[2 * KT + j] + llw[3 * KT + j];
 }
 int64_t softmax_cached_grid(int64_t NP) { return (NP + 255) / 256; }
+int softmax_cached_max_k() { return 72; }
 hipError_t launch_softmax_cached(const CachedNormLaunch& a, hipStream_t stream) {
   const int64_t grid = softmax_cached_grid(a.NP);
   if (grid <= 0 || a.K <= 0) return hipSuccess;
-  const size_t shmem = ((size_t)a.K * 256 + (size_t)4 * a.K) * sizeof(double);
-  static LdsGrant grant;
-  if (hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(softmax_cached_kernel), shmem, grant); e != hipSuccess)
-    return e;
-  hipLaunchKernelGGL(softmax_cached_kernel, dim3((unsigned)grid), dim3(256), shmem, stream, a);
-  return hipGetLastError();
+  if (a.K > softmax_cached_max_k()) return hipErrorInvalidValue;
+  auto go = [&](auto kern) {
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), 0, stream, a);
+    return hipGetLastError();
+  };
+  if (a.K <= 8) return go(softmax_cached_kernel<8>);
+  if (a.K <= 16) return go(softmax_cached_kernel<16>);
+  if (a.K <= 24) return go(softmax_cached_kernel<24>);
+  if (a.K <= 32) return go(softmax_cached_kernel<32>);
+  if (a.K <= 40) return go(softmax_cached_kernel<40>);
+  if (a.K <= 56) return go(softmax_cached_kernel<56>);
+  return go(softmax_cached_kernel<72>);
 }
 
 }  // namespace lck
