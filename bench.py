@@ -285,6 +285,28 @@ def setup_comm(ctx, capi, lcd, dist, torch, rank, world, local_rank, want):
     return kind, note
 
 
+def model_selection(capi, device, stream, N=10_000_000, D=64, Kt=32):
+    """The whole learnVDP loop (cluster.cpp:564-629: VBEM, prune, greedy split search) on device-resident synthetic
+    observations -- the caller of the hot path; tools/learn_bench.py is the same measurement."""
+    import numpy as np
+
+    rng = np.random.default_rng(5)
+    mu = rng.normal(0, 4.0, (Kt, D))
+    L = np.stack([np.linalg.cholesky((lambda B: B @ B.T / D + 0.5 * np.eye(D))(rng.normal(size=(D, D)))) for _ in range(Kt)])
+    with capi.Context(device, stream) as ctx:
+        ctx.synth(N, D, Kt, mu, L, 99, 0, 0.9)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        F, model = ctx.cluster(capi.W_STICKBREAK, nthreads=16)
+        dt = time.perf_counter() - t0
+        rounds = model.rounds()
+        K = model.dims()[1]
+        model.close()
+    return {"workload": f"learnVDP N={N} D={D}, {Kt} true clusters, from one cluster up (device-resident data)",
+            "seconds": dt, "K_found": K, "rounds": len(rounds), "main_vbem_iterations": sum(len(t) for _, t in rounds),
+            "free_energy": F}
+
+
 def measure(capi, cfg, steps, warmup, rank, world, local_rank, stream, nthreads, comm=None, dist=None, torch=None):
     """Synthesise the workload in HBM, run `warmup` untimed and `steps` timed VBEM iterations; returns everything the
     JSON line needs plus the live context / model (for the CPU baseline)."""
@@ -483,6 +505,7 @@ def main():
                     m2.close()
                 x2.close()
             line["other_configs"] = others
+            line["model_selection"] = model_selection(capi, local_rank, stream)
         print(json.dumps(line), flush=True)
     if model is not None:
         model.close()

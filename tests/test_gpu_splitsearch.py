@@ -1,9 +1,10 @@
 """The split search's shortcuts against the reference's literal schedule.
 
 `split_gr` (cluster.cpp:366-495) runs a full `vbem(..., 1)` on all data for every candidate.  The HIP path keeps the
-arithmetic and shares what is provably common between the candidates of a round: LL_k as a by-product of the last
-E-step (no extra pass), the statistics of the unchanged columns (two-column passes), the distances of the unchanged
-clusters (cached once per round).  Each shortcut has an environment switch that restores the literal schedule; the two
+arithmetic and shares what is provably common between E-steps: LL_k as a by-product of the last E-step (no extra
+pass), the statistics of the unchanged columns (a candidate's moved mass only), the distances of every cluster whose
+posterior has not changed in any bit (a journaled cache, rolled back when a candidate is rejected), statistics that
+follow the rows an E-step moved.  Each shortcut has an environment switch that restores the literal schedule; the two
 must walk the same rounds to the same K and F, and both must equal the oracle."""
 import os
 import re
@@ -62,3 +63,66 @@ def test_cached_first_estep_equals_the_oracle_on_a_many_candidate_round(lib):
         np.testing.assert_allclose(a, b, rtol=1e-9)
     assert abs(F - Fo) <= 1e-9 * abs(Fo)
     np.testing.assert_allclose(q, qo, atol=1e-8)
+
+
+_SNIPPET = r"""
+import json, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+import libcluster_amd as lc
+rng = np.random.default_rng({seed})
+K, D, N, J, scale = {K}, {D}, {N}, {J}, {scale}
+mu = rng.normal(0, scale, (K, D))
+Xs = [mu[rng.integers(0, K, N)] + rng.normal(size=(N, D)) for _ in range(J)]
+if J == 1:
+    F, q, w, means, covs, info = lc.learnVDP(Xs[0], return_info=True)
+else:
+    F, q, w, means, covs, info = lc.learnGMC(Xs, return_info=True)
+print(json.dumps(dict(F=F, K=info["K"], rounds=[[k, list(map(float, t))] for k, t in info["rounds"]])))
+"""
+
+
+def _run_snippet(env, **kw):
+    import json
+
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-c", _SNIPPET.format(root=str(ROOT), **kw)], capture_output=True, text=True,
+                       timeout=600, env=e, cwd=str(ROOT))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("kw", [dict(seed=5, K=5, D=20, N=6000, J=1, scale=0.8),    # heavy overlap: the cache stops paying
+                                dict(seed=6, K=6, D=24, N=5000, J=1, scale=2.0),    # some overlap
+                                dict(seed=7, K=7, D=33, N=4000, J=1, scale=6.0),    # well separated
+                                dict(seed=8, K=5, D=20, N=1500, J=3, scale=3.0)])   # groups (learnGMC)
+def test_cached_distances_and_moved_row_statistics_against_full_passes_and_the_oracle(lib, kw):
+    """cluster() on the journaled distance cache (Context::estep_cache) with statistics that follow the moved rows
+    (Context::delta_suffstat): the default policy, the cache forced on however much moves, a zero tolerance (every row
+    that moved at all counts) and full passes everywhere must walk the same rounds; the default must equal the oracle."""
+    import lc_oracle as o
+
+    runs = {name: _run_snippet(env, **kw) for name, env in
+            {"default": {}, "forced": {"LC_SPLIT_DELTA_FORCE": "1"},
+             "forced_tol0": {"LC_SPLIT_DELTA_FORCE": "1", "LC_SPLIT_DELTA_TOL": "0"},
+             "full": {"LC_SPLIT_NO_DELTA": "1"}}.items()}
+    ref = runs["full"]
+    for name, r in runs.items():
+        assert r["K"] == ref["K"] and [k for k, _ in r["rounds"]] == [k for k, _ in ref["rounds"]], (name, r, ref)
+        for (_, a), (_, b) in zip(r["rounds"], ref["rounds"]):
+            np.testing.assert_allclose(a, b, rtol=1e-10, err_msg=name)
+        assert abs(r["F"] - ref["F"]) <= 1e-10 * abs(ref["F"]), name
+    rng = np.random.default_rng(kw["seed"])
+    mu = rng.normal(0, kw["scale"], (kw["K"], kw["D"]))
+    Xs = [mu[rng.integers(0, kw["K"], kw["N"])] + rng.normal(size=(kw["N"], kw["D"])) for _ in range(kw["J"])]
+    tr = []
+    if kw["J"] == 1:
+        Fo, _, _, clo = o.learnVDP(Xs[0], trace=tr)
+    else:
+        Fo, _, _, clo = o.learnGMC(Xs, trace=tr)
+    d = runs["default"]
+    assert d["K"] == len(clo) and [k for k, _ in d["rounds"]] == [k for k, _ in tr]
+    for (_, a), (_, b) in zip(d["rounds"], tr):
+        np.testing.assert_allclose(a, b, rtol=1e-9)
+    assert abs(d["F"] - Fo) <= 1e-9 * abs(Fo)
