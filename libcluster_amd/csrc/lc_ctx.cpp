@@ -225,7 +225,9 @@ void Context::build_layout(int J, const int64_t* Nj, int D) {
     Ntot_ += Nj[j];
   }
   NP_ = goff_[J];
-  qz_[0].K = qz_[1].K = 0;
+  // (the responsibility buffers are sized by rows x columns: a new row count means new buffers)
+  qz_[0].K = qz_[1].K = qzcols_.K = 0;
+  qz_[0].cap = qz_[1].cap = qzcols_.cap = 0;
   LC_HIP(hipSetDevice(device_));
   X_.reserve((size_t)std::max<int64_t>(NP_, 1) * DP_);
   goff_d_.reserve(J + 1);

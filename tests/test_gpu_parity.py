@@ -509,3 +509,36 @@ def test_wide_gauss_wishart_learners():
     assert info["K"] == len(clo) and abs(F - Fo) <= 1e-8 * abs(Fo)
     for a, b in zip(qZ, qo):
         assert_q_close(a, b, rtol=1e-6)
+
+
+@pytest.mark.gpu
+def test_context_takes_new_observations_with_more_rows(lib):
+    """A context that has worked on N rows is handed 40x as many (lc_ctx_set_data again): every row-sized buffer must
+    follow (the responsibility buffers once kept their old size)."""
+    from libcluster_amd import capi
+
+    rng = np.random.default_rng(12)
+    res = []
+    for reuse in (False, True):
+        with capi.Context(0) as ctx:
+            if reuse:
+                Xs = rng.normal(size=(500, 24))
+                ctx.set_data(Xs)
+                ctx.set_qz(np.random.default_rng(1).dirichlet(np.ones(7), 500))
+                ctx.vbem(capi.W_DIRICHLET, fixed_iters=2)[2].close()
+                F0, m0 = ctx.cluster(capi.W_STICKBREAK)
+                m0.close()
+            r2 = np.random.default_rng(13)
+            X = r2.normal(size=(20000, 24)) + 3.0 * r2.integers(0, 3, (20000, 1))
+            q = r2.dirichlet(np.ones(7), 20000)
+            ctx.set_data(X)
+            ctx.set_qz(q)
+            F, tr, m = ctx.vbem(capi.W_DIRICHLET, fixed_iters=3)
+            m.close()
+            Fc, mc = ctx.cluster(capi.W_STICKBREAK)
+            K = mc.dims()[1]
+            mc.close()
+            res.append((tr, ctx.get_qz([20000])[0], Fc, K))
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    assert res[0][2] == res[1][2] and res[0][3] == res[1][3]
