@@ -213,6 +213,12 @@ int lc_vbem(lc_ctx* ctx, lc_model** model, int wkind, int ckind, double wprior, 
             int sparse, int fixed_iters, int verbose, unsigned nthreads, double* F, int* niter, double* Ftrace,
             int ntrace);
 
+/* prune_clusters (cluster.cpp:505-552) on a model lc_vbem produced and its context: clusters whose getN() is below
+ * ZEROCUTOFF leave the model and their columns leave qZ; every group's weights are then updated with the remaining
+ * columns' sums (not renormalised, cluster.cpp:546).  *removed (may be NULL) = how many went.  cluster() calls this
+ * between vbem and the split search (cluster.cpp:606). */
+int lc_prune(lc_ctx* ctx, lc_model* model, int verbose, int* removed);
+
 /* learnVDP / learnBGMM / learnDGMM / learnBEMM / learnGMC / learnSGMC / learnDGMC / learnEGMC
  * (cluster.cpp:636-873; lc_algo): uploads X,
  * runs the model-selection loop, returns the model (which owns its context so

@@ -170,6 +170,7 @@ def lib() -> C.CDLL:
                              C.POINTER(C.c_void_p), c_double_p]
     L.lc_cluster.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int,
                              C.c_uint, C.POINTER(C.c_void_p), c_double_p]
+    L.lc_prune.argtypes = [C.c_void_p, C.c_void_p, C.c_int, c_int_p]
     L.lc_model_free.argtypes = [C.c_void_p]
     L.lc_model_dims.argtypes = [C.c_void_p, c_int_p, c_int_p, c_int_p]
     L.lc_model_rounds.argtypes = [C.c_void_p, c_int_p]
@@ -513,6 +514,12 @@ class Context:
             model = Model(mh, ctx=self)
         return F.value, tr[: nit.value].copy(), model
 
+
+    def prune(self, model, verbose=False):
+        """prune_clusters (cluster.cpp:505-552) on `model` and this context's qZ -> number of clusters removed."""
+        n = C.c_int()
+        check(lib().lc_prune(self._h, model._h, int(verbose), C.byref(n)))
+        return n.value
 
     def cluster(self, wkind, wprior=1.0, clusterprior=1.0, maxclusters=-1, sparse=False, verbose=False, nthreads=1,
                 ckind=C_GAUSSWISH):

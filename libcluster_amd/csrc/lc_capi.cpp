@@ -716,6 +716,17 @@ int lc_vbem(lc_ctx* ctx, lc_model** model, int wkind, int ckind, double wprior, 
   });
 }
 
+int lc_prune(lc_ctx* ctx, lc_model* model, int verbose, int* removed) {
+  return guarded([&] {
+    need(ctx, "ctx");
+    need(model, "model");
+    const int K0 = (int)model->model.clusters.size();
+    if (K0 != ctx->impl.K()) throw std::invalid_argument("model and qZ have different numbers of clusters");
+    lce::prune_clusters(ctx->impl, model->model, verbose != 0);
+    if (removed) *removed = K0 - (int)model->model.clusters.size();
+  });
+}
+
 int lc_learn(int algo, int J, const double* const* Xj, const int64_t* Nj, int D, int64_t rs, int64_t cs,
              double wprior, double clusterprior, int maxclusters, int sparse, int verbose, unsigned nthreads,
              int device, lc_model** out, double* F) {

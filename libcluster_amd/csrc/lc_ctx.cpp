@@ -1224,27 +1224,6 @@ void Context::dcache_rollback() {
   dc_journal_ = false;
 }
 
-void Context::dcache_keep_columns(const std::vector<int>& keep) {
-  use_device();
-  dc_saved_.clear();
-  dc_journal_ = false;
-  int out = 0;
-  for (int k : keep) {
-    if (k < 0 || k >= dc_K_) {  // a column the cache never had: everything from here on is unknown
-      break;
-    }
-    if (k != out) {
-      if (NP_ > 0)
-        LC_HIP(hipMemcpyAsync(dc_slab_.p + (size_t)out * NP_, dc_slab_.p + (size_t)k * NP_, (size_t)NP_ * sizeof(double),
-                              hipMemcpyDeviceToDevice, stream_));  // (k > out: columns only move down, in order)
-      dc_tagA_[(size_t)out] = dc_tagA_[(size_t)k];
-      dc_tagm_[(size_t)out] = dc_tagm_[(size_t)k];
-    }
-    ++out;
-  }
-  dc_K_ = out;
-}
-
 int Context::estep_cache(int K, const double* A, const double* m, const double* c, double* Fz, double* LLk, double delta_tol,
                          int* stale_out) {
   use_device();

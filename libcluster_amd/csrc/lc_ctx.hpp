@@ -193,7 +193,6 @@ class Context {
   void dcache_journal_end();
   void dcache_invalidate();
   void dcache_release();  // ... and give the memory back
-  void dcache_keep_columns(const std::vector<int>& keep);  // prune_clusters
   // The CHANGE of the statistics caused by the last estep_cache(delta_tol = tau): sum over the rows whose
   // responsibilities moved by more than tau in some column of (q_new - q_old) x the usual terms -- the statistics are linear in q, so
   // adding it to the statistics of q_old gives those of q_new up to tau * sum_n |x_n x_n^T| (rows that moved by <= tau

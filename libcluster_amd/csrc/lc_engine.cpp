@@ -409,13 +409,15 @@ static void data_loglik(lcc::Context& ctx, Model& model) {
 // ---------------------------------------------------------------------------
 // cluster.cpp:505-552
 // ---------------------------------------------------------------------------
-static bool prune_clusters(lcc::Context& ctx, Model& model, bool verbose) {
+bool prune_clusters(lcc::Context& ctx, Model& model, bool verbose) {
   const int K = (int)model.clusters.size(), J = ctx.J();
   std::vector<int> keep;
   for (int k = 0; k < K; ++k)
     if (!(model.clusters[k].N() < lch::ZEROCUTOFF)) keep.push_back(k);
   if ((int)keep.size() == K) return false;
   if (verbose) std::cout << '*' << std::flush;
+  static const bool trace_phases = env_on("LC_TRACE_PHASES");
+  if (trace_phases) std::cerr << "[prune] " << keep.size() << " of " << K << " clusters kept" << std::endl;
   if (keep.empty()) throw std::runtime_error("all clusters are empty");
   std::vector<ClusterAny> nc;
   std::vector<double> nll;
@@ -426,7 +428,7 @@ static bool prune_clusters(lcc::Context& ctx, Model& model, bool verbose) {
   model.clusters.swap(nc);
   model.LLk.swap(nll);
   ctx.qz_keep_columns(keep);
-  ctx.dcache_keep_columns(keep);
+  ctx.dcache_invalidate();  // (rare: the next E-step recomputes every column)
   model.final_stats.K = 0;  // (their columns no longer line up)
   const int nK = (int)keep.size();
   std::vector<double> Njk((size_t)J * nK);

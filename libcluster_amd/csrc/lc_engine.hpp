@@ -87,6 +87,10 @@ void parallel_chunks(int nchunks, unsigned nthreads, double work_per_chunk, cons
 // cluster.cpp:177-239 on the context's current qZ.  Returns F.
 double vbem(lcc::Context& ctx, Model& model, const VbemOptions& opt);
 
+// cluster.cpp:505-552: drop the clusters with fewer than ZEROCUTOFF observations (model, qZ columns), then update the
+// weights with the remaining columns' sums (no renormalisation, as the reference).  True when something was removed.
+bool prune_clusters(lcc::Context& ctx, Model& model, bool verbose);
+
 struct ClusterOptions {
   double clusterprior = lch::PRIORVAL;
   int maxclusters = -1;

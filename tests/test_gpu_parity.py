@@ -542,3 +542,37 @@ def test_context_takes_new_observations_with_more_rows(lib):
     np.testing.assert_array_equal(res[0][0], res[1][0])
     np.testing.assert_array_equal(res[0][1], res[1][1])
     assert res[0][2] == res[1][2] and res[0][3] == res[1][3]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wkind,wname", [(capi.W_DIRICHLET, "Dirichlet"), (capi.W_STICKBREAK, "StickBreak")])
+def test_prune_clusters_drops_columns_and_updates_weights_like_the_reference(lib, wkind, wname):
+    """prune_clusters (cluster.cpp:505-552) through lc_prune: clusters that had no observations in the last M-step go
+    (model and qZ columns, the survivors' columns untouched and NOT renormalised), the weights are updated from the
+    remaining columns' sums."""
+    rng = np.random.default_rng(21)
+    N, D, K = 700, 5, 6
+    X = rng.normal(size=(N, D)) + 4.0 * rng.integers(0, 3, (N, 1))
+    q = np.zeros((N, K))
+    q[:, [0, 2, 5]] = rng.dirichlet(np.ones(3), N)  # clusters 1, 3 and 4 start (and stay, in the M-step) empty
+    _, _, qo, wo, co = o.vbem_fixed([X], [q], getattr(o, wname), 1.0, 1)
+    assert o.prune_clusters(qo, wo, co) and len(co) == 3
+    with capi.Context(0) as ctx:
+        ctx.set_data(X)
+        ctx.set_qz(q)
+        F, tr, m = ctx.vbem(wkind, fixed_iters=1)
+        assert ctx.prune(m) == 3
+        assert m.dims()[1] == 3
+        got = ctx.get_qz([N])[0]
+        np.testing.assert_allclose(got, qo[0], rtol=1e-10, atol=1e-300)
+        elog, nk = m.weights(0)
+        np.testing.assert_allclose(nk, wo[0].getNk(), rtol=1e-12)
+        np.testing.assert_allclose(elog, wo[0].Elogweight(), rtol=1e-10)
+        for k in range(3):
+            np.testing.assert_allclose(m.cluster(k)["N"], co[k].getN(), rtol=1e-12)
+        assert ctx.prune(m) == 0  # nothing left to drop
+        # the pruned model carries on: another iteration equals the oracle's on its pruned state
+        F2, tr2, m = ctx.vbem(wkind, fixed_iters=1, model=m)
+        Fo, _, _, _, _ = o.vbem_fixed([X], [qo[0]], getattr(o, wname), 1.0, 1)
+        np.testing.assert_allclose(tr2[0], Fo[0], rtol=1e-10)
+        m.close()
