@@ -1190,6 +1190,7 @@ void Context::dcache_invalidate() {
 void Context::dcache_release() {
   dcache_invalidate();
   dc_cap_ = 0;
+  dc_room_K_ = 0;
   dc_slab_.release();
   dfresh_.release();
   dq_.release();
@@ -1246,6 +1247,32 @@ int Context::estep_cache(int K, const double* A, const double* m, const double* 
   if (stale_out) *stale_out = stale;
   const int nch = (int)changed.size();
   const size_t NPs = (size_t)std::max<int64_t>(NP_, 1);
+  // Is there room?  Asked once per width (before anything is touched), and answered by ALL ranks together: a grown
+  // slab lives next to the old one for a moment, the move of the responsibilities takes K more columns, the journal
+  // a few.
+  if (K > dc_room_K_) {
+    const int newcap = K + std::max(8, K / 4);
+    size_t need = 0;
+    if (K > dc_cap_) need += NPs * (size_t)newcap * sizeof(double);
+    if (delta_tol >= 0.0 && dq_.cap < NPs * (size_t)K) need += NPs * (size_t)(K + 1) * sizeof(double);
+    bool ok = true;
+    size_t free_b = 0, total_b = 0;
+    if (need > 0) {
+      need += NPs * 4 * sizeof(double);
+      LC_HIP(hipMemGetInfo(&free_b, &total_b));
+      if (need > free_b) {
+        trim_cache();
+        LC_HIP(hipMemGetInfo(&free_b, &total_b));
+      }
+      ok = need <= free_b;
+    }
+    static const char* fake = std::getenv("LC_TEST_CACHE_NO_ROOM");  // tests: pretend the device is full from this K on
+    if (fake && K >= std::atoi(fake)) ok = false;
+    if (allreduce_value(ok ? 0.0 : 1.0) > 0.0)
+      throw CacheNoRoom("no room for the distance cache at K = " + std::to_string(K) + ": " + std::to_string(need) +
+                        " bytes needed, " + std::to_string(free_b) + " free on this rank");
+    dc_room_K_ = K;
+  }
   // room for K columns (the valid ones move along when the slab grows)
   if (K > dc_cap_) {
     const int newcap = K + std::max(8, K / 4);

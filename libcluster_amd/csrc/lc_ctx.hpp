@@ -18,6 +18,11 @@ namespace lcc {
 struct HipFailure : std::runtime_error {
   explicit HipFailure(const std::string& s) : std::runtime_error(s) {}
 };
+// Context::estep_cache: the device has no room for the distance cache at this width (nothing was changed; the caller
+// runs the ordinary E-step instead)
+struct CacheNoRoom : std::runtime_error {
+  explicit CacheNoRoom(const std::string& s) : std::runtime_error(s) {}
+};
 
 // all-reduce hook: sum `count` doubles in place across ranks (device buffer),
 // enqueued on / ordered with `stream`.  Returns 0 on success.
@@ -264,6 +269,7 @@ class Context {
   // distance cache: slab [dc_cap_ x NP], dc_K_ valid columns, host tags; scratch for non-adjacent recomputed columns
   DevBuf<double> dc_slab_, dfresh_;
   int dc_cap_ = 0, dc_K_ = 0;
+  int dc_room_K_ = 0;  // widest K for which all ranks found room
   std::vector<std::vector<double>> dc_tagA_, dc_tagm_;
   struct SavedColumn {
     int col = -1;

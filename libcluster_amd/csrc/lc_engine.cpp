@@ -320,19 +320,30 @@ double vbem(lcc::Context& ctx, Model& model, const VbemOptions& opt) {
     }
     if (have_next) {
     } else if (opt.inc && opt.inc->on && full && !opt.sparse && opt.fixed_iters < 0 && ctx.dcache_eligible(K)) {
-      int stale = 0;
-      const int nre = ctx.estep_cache(K, A.data(), m.data(), c.data(), &Fz, opt.want_ll ? model.LLk.data() : nullptr,
-                                      opt.inc->tol, &stale);
-      if (trace_phases)
-        std::cerr << "[vbem] cached E-step: K " << K << ", recomputed " << nre << " (stale " << stale << ")" << std::endl;
-      have_delta = ctx.delta_pending() == K;
-      // most clusters' posteriors moved from one E-step to the next, twice in a row: the cache costs more than it
-      // saves (once is what a full refresh of the statistics looks like, and what the first E-step after the cache
-      // was left alone for a while looks like)
-      if (opt.inc->synced && K >= 4 && stale * 10 > K * 7) ++opt.inc->bad;
-      else opt.inc->bad = 0;
-      opt.inc->synced = true;
-      if (opt.inc->bad >= 2 && !inc_force) opt.inc->on = false;
+      int stale = 0, nre = -1;
+      try {
+        nre = ctx.estep_cache(K, A.data(), m.data(), c.data(), &Fz, opt.want_ll ? model.LLk.data() : nullptr, opt.inc->tol,
+                              &stale);
+      } catch (const lcc::CacheNoRoom&) {
+        // (every rank holds the same number of rows within one, so every rank gets here at the same K)
+        ctx.dcache_release();
+        opt.inc->on = false;
+        opt.inc->no_room = true;
+        opt.inc->synced = false;
+        run_estep(ctx, model, K, &Fz, opt.want_ll ? model.LLk.data() : nullptr);
+      }
+      if (nre >= 0) {
+        if (trace_phases)
+          std::cerr << "[vbem] cached E-step: K " << K << ", recomputed " << nre << " (stale " << stale << ")" << std::endl;
+        have_delta = ctx.delta_pending() == K;
+        // most clusters' posteriors moved from one E-step to the next, twice in a row: the cache costs more than it
+        // saves (once is what a full refresh of the statistics looks like, and what the first E-step after the cache
+        // was left alone for a while looks like)
+        if (opt.inc->synced && K >= 4 && stale * 10 > K * 7) ++opt.inc->bad;
+        else opt.inc->bad = 0;
+        opt.inc->synced = true;
+        if (opt.inc->bad >= 2 && !inc_force) opt.inc->on = false;
+      }
     } else {
       run_estep(ctx, model, K, &Fz, opt.want_ll ? model.LLk.data() : nullptr);
       if (opt.inc) opt.inc->synced = false;
@@ -675,7 +686,7 @@ double cluster(lcc::Context& ctx, Model& model, const ClusterOptions& opt) {
   while (issplit) {
     std::vector<double> tr;
     VbemOptions vo;
-    inc.on = inc_allowed;  // (a round may switch it off for itself: its clusters overlap too much for the cache to pay)
+    inc.on = inc_allowed && !inc.no_room;  // (a round may switch it off for itself: its clusters overlap too much)
     inc.bad = 0;
     if (inc_allowed) {
       vo.inc = &inc;

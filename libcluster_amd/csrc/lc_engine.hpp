@@ -32,6 +32,7 @@ struct IncState {
   double tol = 0x1p-50;  // a row whose responsibilities all moved by <= tol does not count as moved (LC_SPLIT_DELTA_TOL)
   bool synced = false;   // the previous E-step went through the cache (its tags describe the model as of then)
   int bad = 0;           // E-steps in a row, each right after a synced one, that found most columns stale
+  bool no_room = false;  // the device ran out of room for the cache: off for the rest of this cluster() call
 };
 
 struct Model {

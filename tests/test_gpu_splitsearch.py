@@ -126,3 +126,14 @@ def test_cached_distances_and_moved_row_statistics_against_full_passes_and_the_o
     for (_, a), (_, b) in zip(d["rounds"], tr):
         np.testing.assert_allclose(a, b, rtol=1e-9)
     assert abs(d["F"] - Fo) <= 1e-9 * abs(Fo)
+
+
+def test_model_selection_carries_on_when_the_distance_cache_does_not_fit(lib):
+    """LC_TEST_CACHE_NO_ROOM=K pretends the device is full from K clusters on: cluster() must finish on the ordinary
+    kernels with the same rounds, K and F."""
+    kw = dict(seed=7, K=7, D=33, N=4000, J=1, scale=6.0)
+    a = _run_snippet({}, **kw)
+    b = _run_snippet({"LC_TEST_CACHE_NO_ROOM": "4"}, **kw)
+    assert a["K"] == b["K"] >= 6 and [k for k, _ in a["rounds"]] == [k for k, _ in b["rounds"]]
+    for (_, x), (_, y) in zip(a["rounds"], b["rounds"]):
+        np.testing.assert_allclose(x, y, rtol=1e-10)
