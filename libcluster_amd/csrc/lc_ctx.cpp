@@ -2,7 +2,9 @@
 #include "lc_engine.hpp"  // the host worker pool (parallel_chunks)
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <iostream>
 #include <cstring>
 #include <limits>
 #include <mutex>
@@ -61,7 +63,19 @@ struct BlockCache {
     return p;
   }
 };
-constexpr size_t DEV_CACHE_LIMIT = (size_t)16 << 30, DEV_BLOCK_LIMIT = (size_t)8 << 30;
+// Released device blocks are kept for re-use up to this much (LC_BLOCK_CACHE_GB, default 64: a fresh block of tens of
+// gigabytes costs seconds to map, and at tens of millions of rows every sub-problem of the split search takes and
+// returns such blocks); a failed allocation trims the cache and retries (DevBuf::reserve).
+static size_t dev_cache_limit() {
+  static const size_t v = [] {
+    const char* e = std::getenv("LC_BLOCK_CACHE_GB");
+    const double gb = e ? std::atof(e) : 64.0;
+    return (size_t)(std::max(0.0, gb) * (double)((size_t)1 << 30));
+  }();
+  return v;
+}
+#define DEV_CACHE_LIMIT dev_cache_limit()
+#define DEV_BLOCK_LIMIT (dev_cache_limit() / 4 * 3)
 int current_device() {
   int d = 0;
   (void)hipGetDevice(&d);
@@ -1250,11 +1264,14 @@ int Context::estep_cache(int K, const double* A, const double* m, const double* 
   // Is there room?  Asked once per width (before anything is touched), and answered by ALL ranks together: a grown
   // slab lives next to the old one for a moment, the move of the responsibilities takes K more columns, the journal
   // a few.
+  // (capacities grow geometrically and together: at tens of millions of rows every one of these blocks is past the
+  // block cache's limit, and a hipMalloc / hipFree of ten gigabytes costs seconds)
+  const int grown_cap = std::max(K + 8, 2 * dc_cap_);
   if (K > dc_room_K_) {
-    const int newcap = K + std::max(8, K / 4);
+    const int newcap = K > dc_cap_ ? grown_cap : dc_cap_;
     size_t need = 0;
     if (K > dc_cap_) need += NPs * (size_t)newcap * sizeof(double);
-    if (delta_tol >= 0.0 && dq_.cap < NPs * (size_t)K) need += NPs * (size_t)(K + 1) * sizeof(double);
+    if (delta_tol >= 0.0 && dq_.cap < NPs * (size_t)newcap) need += NPs * (size_t)(newcap + 1) * sizeof(double);
     bool ok = true;
     size_t free_b = 0, total_b = 0;
     if (need > 0) {
@@ -1275,7 +1292,9 @@ int Context::estep_cache(int K, const double* A, const double* m, const double* 
   }
   // room for K columns (the valid ones move along when the slab grows)
   if (K > dc_cap_) {
-    const int newcap = K + std::max(8, K / 4);
+    const int newcap = grown_cap;
+    static const bool trace = std::getenv("LC_TRACE_PHASES") != nullptr;
+    if (trace) std::cerr << "[cache] slab " << dc_cap_ << " -> " << newcap << " columns" << std::endl;
     DevBuf<double> nb;
     nb.reserve(NPs * newcap);
     if (dc_K_ > 0 && NP_ > 0)
@@ -1369,7 +1388,7 @@ int Context::estep_cache(int K, const double* A, const double* m, const double* 
     a.fz_part = fzpart_.p;
     a.ll_part = LLk ? llpart_.p : nullptr;
     if (delta) {
-      dq_.reserve((size_t)NP_ * K);
+      dq_.reserve((size_t)NP_ * std::max(K, dc_cap_));  // (as wide as the slab: re-allocated only when that grows)
       amax_.reserve((size_t)NP_);
       a.dq = dq_.p;
       a.ldd = NP_;
