@@ -240,8 +240,8 @@ void Context::build_layout(int J, const int64_t* Nj, int D) {
   }
   NP_ = goff_[J];
   // (the responsibility buffers are sized by rows x columns: a new row count means new buffers)
-  qz_[0].K = qz_[1].K = qzcols_.K = 0;
-  qz_[0].cap = qz_[1].cap = qzcols_.cap = 0;
+  qz_[0].K = qz_[1].K = 0;
+  qz_[0].cap = qz_[1].cap = 0;
   LC_HIP(hipSetDevice(device_));
   X_.reserve((size_t)std::max<int64_t>(NP_, 1) * DP_);
   goff_d_.reserve(J + 1);
@@ -1449,36 +1449,6 @@ bool Context::delta_suffstat(int K1, double max_frac, double* dNk, double* dxs, 
   }
   sub.suffstat(nullptr, dNk, dxs, dxxs, dNjk);
   return true;
-}
-
-void Context::suffstat_columns(const int* cols, int n, bool diag, double* Nk, double* xs, double* xxs, double* Njk) {
-  use_device();
-  QZ& cur = qz_[cur_];
-  if (n < 1) throw std::invalid_argument("need at least one column");
-  for (int t = 0; t < n; ++t)
-    if (cols[t] < 0 || cols[t] >= cur.K) throw std::invalid_argument("qZ column out of range");
-  ensure_qz(qzcols_, n, false);
-  qzcols_.K = n;
-  for (int t = 0; t < n && NP_ > 0; ++t)
-    LC_HIP(hipMemcpyAsync(qzcols_.buf.p + (size_t)t * NP_, cur.buf.p + (size_t)cols[t] * NP_, (size_t)NP_ * sizeof(double),
-                          hipMemcpyDeviceToDevice, stream_));
-  // run the ordinary pass with the scratch columns standing in for qZ (the buffers trade places, nothing is copied)
-  auto swap_qz = [](QZ& a, QZ& b) {
-    std::swap(a.buf.p, b.buf.p);
-    std::swap(a.buf.cap, b.buf.cap);
-    std::swap(a.buf.device, b.buf.device);
-    std::swap(a.cap, b.cap);
-    std::swap(a.K, b.K);
-  };
-  swap_qz(cur, qzcols_);
-  try {
-    if (diag) suffstat_diag(nullptr, Nk, xs, xxs, Njk);
-    else suffstat(nullptr, Nk, xs, xxs, Njk);
-  } catch (...) {
-    swap_qz(cur, qzcols_);
-    throw;
-  }
-  swap_qz(cur, qzcols_);
 }
 
 void Context::colsums(double* Njk) {

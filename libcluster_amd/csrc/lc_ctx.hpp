@@ -216,9 +216,6 @@ class Context {
   // Nk[K], xs[K*D], xxs[K*D*D] (row-major, symmetric), Njk[J*K].
   void suffstat(const unsigned char* smask, double* Nk, double* xs, double* xxs, double* Njk);
   void colsums(double* Njk);  // J x K column sums of the current qZ
-  // the same statistics for `n` chosen columns of the current qZ only (record t belongs to column cols[t]); diag selects
-  // suffstat_diag.  The split search recomputes the two columns a candidate changes (cluster.cpp:468-473).
-  void suffstat_columns(const int* cols, int n, bool diag, double* Nk, double* xs, double* xxs, double* Njk);
   // Diagonal / exponential families: log q~[n,k] = c_jk + sum_d (w2_kd (x_nd - a_kd)^2 + w1_kd x_nd);
   // a, w2, w1: K x D host arrays.  Same outputs as estep().
   void estep_diag(int K, const double* a, const double* w2, const double* w1, const double* c, double* Fz,
@@ -265,7 +262,6 @@ class Context {
   const int* sskptr_ = nullptr;
   const int* sskrec_ = nullptr;
   QZ qz_[2];
-  QZ qzcols_;  // scratch: the columns suffstat_columns works on
   // distance cache: slab [dc_cap_ x NP], dc_K_ valid columns, host tags; scratch for non-adjacent recomputed columns
   DevBuf<double> dc_slab_, dfresh_;
   int dc_cap_ = 0, dc_K_ = 0;
