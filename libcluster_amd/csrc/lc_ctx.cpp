@@ -1191,7 +1191,7 @@ void Context::suffstat(const unsigned char* smask, double* Nk, double* xs, doubl
 bool Context::dcache_eligible(int K) const {
   static const bool off = std::getenv("LC_SPLIT_NO_DCACHE") != nullptr || std::getenv("LC_SPLIT_NO_DELTA") != nullptr;
   // (the normalisation sweep keeps a row's K values in registers)
-  return !off && DP_ <= 128 && K >= 1 && K <= lck::softmax_cached_max_k() && !lck::fused_eligible(DP_, K);
+  return !off && DP_ <= lck::GW_MAX_DP && K >= 1 && K <= lck::softmax_cached_max_k() && !lck::fused_eligible(DP_, K);
 }
 
 void Context::dcache_invalidate() {

@@ -34,7 +34,7 @@ for case in range(cases):
     spread = rng.uniform(0.4, 1.5)
     if CACHE_ONLY:
         kind = rng.choice(["flat", "grouped"], p=[0.6, 0.4])
-        D = int(rng.choice([17, 20, 23, 33, 40, 70]))
+        D = int(rng.choice([17, 20, 23, 33, 40, 70, 130, 200], p=[0.16, 0.16, 0.16, 0.16, 0.14, 0.12, 0.06, 0.04]))
         Kt = int(rng.integers(2, 9))
         cent = rng.normal(0, float(rng.choice([6.0, 2.0, 0.7, 0.35])), (Kt, D))
 
