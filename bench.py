@@ -498,9 +498,11 @@ def main():
             others = []
             for name in OTHER_CONFIGS:
                 c2 = dict(CONFIGS[name])
-                r2, x2, m2, _ = measure(capi, c2, 5, 1, 0, 1, local_rank, stream, nthreads, None, None, torch)
+                # (the 0.25 ms iteration of the small configuration needs more steps for a steady number)
+                st, wu = (200, 20) if c2["N"] * c2["D"] * c2["K"] < 1e9 else (5, 1)
+                r2, x2, m2, _ = measure(capi, c2, st, wu, 0, 1, local_rank, stream, nthreads, None, None, torch)
                 r2["roofline"]["traffic"] = traffic.get(name, {}).get(r2["roofline"]["kernel"])
-                others.append({"config": name, "workload": c2["label"], "steps": 5, "warmup": 1,
+                others.append({"config": name, "workload": c2["label"], "steps": st, "warmup": wu,
                                "value": r2["value"], "ms_per_step": r2["ms_per_step"], "kernels": r2["kernels"],
                                "roofline": r2["roofline"]})
                 if m2 is not None:
