@@ -676,6 +676,8 @@ double cluster(lcc::Context& ctx, Model& model, const ClusterOptions& opt) {
   IncState inc;
   inc.tol = delta_tol;
   const bool inc_allowed = !no_delta && model.ckind == lch::C_GAUSSWISH && !opt.sparse;
+  int round_no = 0, failed_rounds = 0, skip_rounds = 0, backoff = 4;
+  bool inc_tried = false;
   model.final_stats.K = 0;
   model.next_stats.K = 0;
   ctx.dcache_invalidate();
@@ -686,7 +688,25 @@ double cluster(lcc::Context& ctx, Model& model, const ClusterOptions& opt) {
   while (issplit) {
     std::vector<double> tr;
     VbemOptions vo;
-    inc.on = inc_allowed && !inc.no_room;  // (a round may switch it off for itself: its clusters overlap too much)
+    // A round may switch the cache off for itself (its clusters overlap too much for it to pay).  After two such rounds
+    // in a row the next ones do not even try -- 4 of them, then 8, ... -- and the memory goes back meanwhile.
+    if (round_no > 0) {
+      if (inc_tried && !inc.on && !inc.no_room) {
+        if (++failed_rounds >= 2) {
+          skip_rounds = backoff;
+          backoff *= 2;
+          failed_rounds = 0;
+          ctx.dcache_release();
+        }
+      } else if (inc_tried) {
+        failed_rounds = 0;
+        backoff = 4;
+      }
+    }
+    ++round_no;
+    inc_tried = inc_allowed && !inc.no_room && skip_rounds == 0;
+    if (skip_rounds > 0) --skip_rounds;
+    inc.on = inc_tried;
     inc.bad = 0;
     if (inc_allowed) {
       vo.inc = &inc;

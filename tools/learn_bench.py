@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Wall time of the full model-selection loop (cluster(): VBEM + prune + greedy split search) on
 device-resident synthetic data.  Usage: tools/learn_bench.py N D Ktrue [StickBreak|Dirichlet] [GaussWish|NormGamma|ExpGamma]"""
+import os
 import sys
 import time
 from pathlib import Path
@@ -16,7 +17,8 @@ wk = capi.W_STICKBREAK if len(sys.argv) < 5 or sys.argv[4] == "StickBreak" else 
 fam = sys.argv[5] if len(sys.argv) > 5 else "GaussWish"
 ck = {"GaussWish": capi.C_GAUSSWISH, "NormGamma": capi.C_NORMGAMMA, "ExpGamma": capi.C_EXPGAMMA}[fam]
 rng = np.random.default_rng(5)
-mu = rng.normal(0, 4.0, (Kt, D)) if fam != "ExpGamma" else rng.uniform(20.0, 60.0, (Kt, D))
+scale = float(os.environ.get("LC_LB_SCALE", "4.0"))  # spread of the cluster centres (small: overlapping clusters)
+mu = rng.normal(0, scale, (Kt, D)) if fam != "ExpGamma" else rng.uniform(20.0, 60.0, (Kt, D))
 if fam == "GaussWish":
     L = np.stack([np.linalg.cholesky((lambda B: B @ B.T / D + 0.5 * np.eye(D))(rng.normal(size=(D, D)))) for _ in range(Kt)])
 else:
