@@ -1318,7 +1318,11 @@ int Context::estep_cache(int K, const double* A, const double* m, const double* 
       if (done) continue;
       auto sv = std::make_unique<SavedColumn>();
       sv->col = k;
-      sv->buf.reserve(NPs);
+      try {
+        sv->buf.reserve(NPs);
+      } catch (const HipFailure& e) {  // (nothing has been overwritten yet)
+        throw CacheNoRoom(std::string("no room for the distance cache's journal: ") + e.what());
+      }
       if (NP_ > 0)
         LC_HIP(hipMemcpyAsync(sv->buf.p, dc_slab_.p + (size_t)k * NP_, (size_t)NP_ * sizeof(double), hipMemcpyDeviceToDevice,
                               stream_));
