@@ -641,19 +641,23 @@ __global__ void __launch_bounds__(256) softmax_cached_kernel(CachedNormLaunch a)
     // whose K values all come out bit for bit as they were is not written at all, its q_new - q_old only when some
     // |.| exceeds dq_tol (delta_suffstat never looks at the other rows).  Between the candidates of a split round
     // almost every row is of the first kind.
-    double d[KT];
-#pragma unroll
-    for (int j = 0; j < KT; ++j)
-      if (j < K) d[j] = a.qZ[(int64_t)j * a.ldq + rr];
+    // (the old values pass through eight registers at a time: the new ones already hold 2 KT)
     double am = 0.0;
     bool any = false;
 #pragma unroll
-    for (int j = 0; j < KT; ++j)
-      if (j < K) {
-        d[j] = v[j] - d[j];
-        am = fmax(am, fabs(d[j]));
-        any = any || d[j] != 0.0;
-      }
+    for (int jb = 0; jb < KT; jb += 8) {
+      double o[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (jb + u < KT && jb + u < K) o[u] = a.qZ[(int64_t)(jb + u) * a.ldq + rr];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (jb + u < KT && jb + u < K) {
+          const double dd = v[jb + u] - o[u];
+          am = fmax(am, fabs(dd));
+          any = any || dd != 0.0;
+        }
+    }
     if (inb) {
       a.amax[row] = am;
       if (any) {
@@ -661,7 +665,7 @@ __global__ void __launch_bounds__(256) softmax_cached_kernel(CachedNormLaunch a)
 #pragma unroll
         for (int j = 0; j < KT; ++j)
           if (j < K) {
-            if (moved) a.dq[(int64_t)j * a.ldd + row] = d[j];
+            if (moved) a.dq[(int64_t)j * a.ldd + row] = v[j] - a.qZ[(int64_t)j * a.ldq + row];
             a.qZ[(int64_t)j * a.ldq + row] = v[j];
           }
       }
