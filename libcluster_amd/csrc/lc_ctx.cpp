@@ -225,8 +225,7 @@ void Context::build_layout(int J, const int64_t* Nj, int D) {
   if (J < 1) throw std::invalid_argument("need at least one group of observations");
   if (D < 1) throw std::invalid_argument("observations must have at least one dimension");
   const int DP = lck::padded_dim_wide(D);  // D > 128: diagonal / exponential families only (checked where it matters)
-  dcache_invalidate();  // new observations: no cached distance survives
-  dc_cap_ = 0;          // (the slab is re-allocated for the new row count)
+  dcache_release();  // new observations: no cached distance survives, and the buffers are sized by the row count
   J_ = J;
   D_ = D;
   DP_ = DP;
