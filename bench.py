@@ -452,6 +452,7 @@ def main():
     if args.rows:
         cfg["N"] = args.rows
     nthreads = max(1, min(32, len(os.sched_getaffinity(0)) // max(1, world)))  # host M-step threads of this rank
+    nthreads = int(os.environ.get("LC_BENCH_THREADS", nthreads))
     stream = torch.cuda.current_stream().cuda_stream
 
     def comm(ctx):

@@ -1,11 +1,13 @@
 #include "lc_engine.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <cmath>
 #include <exception>
 #include <iostream>
 #include <limits>
+#include <memory>
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
@@ -23,8 +25,10 @@ namespace {
 
 // A small persistent pool for the M-step's loop over clusters (the reference's "omp parallel for",
 // cluster.cpp:215-217).  Spawning 32 std::threads per iteration cost ~1 ms of a 50 ms iteration; the pool's
-// workers sleep on a condition variable between calls.  One parallel_for runs at a time (callers on other host
-// threads fall back to running their loop inline).
+// workers sleep on a condition variable between calls.  Items are handed out one by one from an atomic counter and the
+// caller starts on them at once, so workers that wake late (waking 31 sleepers takes longer than a D = 64 M-step)
+// simply find less, or nothing, left -- the call returns when the ITEMS are done, not when every worker has reported.
+// One parallel_for runs at a time (callers on other host threads fall back to running their loop inline).
 class Pool {
  public:
   // one pool per calling host thread: with LIBCLUSTER_GPUS every shard's thread runs its own (replicated) M-step
@@ -37,33 +41,51 @@ class Pool {
     std::unique_lock<std::mutex> busy(busy_, std::try_to_lock);
     if (!busy.owns_lock()) return false;
     grow(nt - 1);
-    std::vector<std::exception_ptr> errs(nt);
+    auto job = std::make_shared<Job>();
+    job->n = n;
+    job->call = [&fn](int k) { fn(k); };
     {
       std::lock_guard<std::mutex> g(m_);
-      job_ = [&](unsigned t) {
-        try {
-          for (int k = (int)t; k < n; k += (int)nt) fn(k);
-        } catch (...) {
-          errs[t] = std::current_exception();
-        }
-      };
+      cur_ = job;
       nworkers_ = nt - 1;
-      pending_ = nt - 1;
       ++gen_;
     }
     cv_.notify_all();
-    job_(nt - 1);  // the caller is the last worker
+    work(*job);
     {
-      std::unique_lock<std::mutex> g(m_);
-      done_.wait(g, [&] { return pending_ == 0; });
-      job_ = nullptr;
+      std::unique_lock<std::mutex> g(job->dm);
+      job->dcv.wait(g, [&] { return job->done.load(std::memory_order_acquire) >= n; });
     }
-    for (auto& e : errs)
-      if (e) std::rethrow_exception(e);
+    // (a worker that wakes from now on sees next >= n and never touches `call`, whose captures die with this frame)
+    if (job->err) std::rethrow_exception(job->err);
     return true;
   }
 
  private:
+  struct Job {
+    int n = 0;
+    std::function<void(int)> call;
+    std::atomic<int> next{0}, done{0};
+    std::mutex dm;
+    std::condition_variable dcv;
+    std::exception_ptr err;  // the first one (guarded by dm)
+  };
+  static void work(Job& j) {
+    for (;;) {
+      const int k = j.next.fetch_add(1, std::memory_order_relaxed);
+      if (k >= j.n) return;
+      try {
+        j.call(k);
+      } catch (...) {
+        std::lock_guard<std::mutex> g(j.dm);
+        if (!j.err) j.err = std::current_exception();
+      }
+      if (j.done.fetch_add(1, std::memory_order_acq_rel) + 1 >= j.n) {
+        std::lock_guard<std::mutex> g(j.dm);
+        j.dcv.notify_all();
+      }
+    }
+  }
   Pool() = default;
   ~Pool() {
     {
@@ -83,29 +105,25 @@ class Pool {
       }
       th_.emplace_back([this, id, seen]() mutable {
         for (;;) {
-          std::function<void(unsigned)> job;
+          std::shared_ptr<Job> job;
           {
             std::unique_lock<std::mutex> g(m_);
             cv_.wait(g, [&] { return stop_ || gen_ != seen; });
             if (stop_) return;
             seen = gen_;
             if (id >= nworkers_) continue;  // not needed for this job
-            job = job_;
+            job = cur_;
           }
-          job(id);
-          {
-            std::lock_guard<std::mutex> g(m_);
-            if (--pending_ == 0) done_.notify_one();
-          }
+          work(*job);
         }
       });
     }
   }
   std::mutex busy_, m_;
-  std::condition_variable cv_, done_;
+  std::condition_variable cv_;
   std::vector<std::thread> th_;
-  std::function<void(unsigned)> job_;
-  unsigned nworkers_ = 0, pending_ = 0;
+  std::shared_ptr<Job> cur_;
+  unsigned nworkers_ = 0;
   uint64_t gen_ = 0;
   bool stop_ = false;
 };
