@@ -66,32 +66,47 @@ inline double lgam(double x) {
 // In-place lower Cholesky A = L L^T (only the lower triangle is read/written,
 // the strict upper triangle is zeroed).  Returns false if not positive definite.
 inline bool cholesky(std::vector<double>& A, int n) {
+  // Works on U = L^T (row j of U = column j of L, contiguous): every element still receives its terms
+  // s -= L[i][k] * L[j][k] for k = 0 .. j-1 in that order -- bit for bit the row-by-row dot-product form -- but the
+  // inner loop runs over i (independent elements, unit stride), which the compiler vectorises; a dot product is a
+  // serial chain it may not reorder.  32 clusters at D = 64 are one M-step of the headline configuration.
+  std::vector<double> U((size_t)n * n, 0.0);
+  for (int j = 0; j < n; ++j)
+    for (int i = j; i < n; ++i) U[(size_t)j * n + i] = A[(size_t)i * n + j];
   for (int j = 0; j < n; ++j) {
-    double d = A[(size_t)j * n + j];
-    for (int k = 0; k < j; ++k) d -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
-    if (!(d > 0.0)) return false;
-    const double ljj = std::sqrt(d);
-    A[(size_t)j * n + j] = ljj;
-    for (int i = j + 1; i < n; ++i) {
-      double s = A[(size_t)i * n + j];
-      for (int k = 0; k < j; ++k) s -= A[(size_t)i * n + k] * A[(size_t)j * n + k];
-      A[(size_t)i * n + j] = s / ljj;
+    double* uj = U.data() + (size_t)j * n;
+    for (int k = 0; k < j; ++k) {
+      const double* uk = U.data() + (size_t)k * n;
+      const double ukj = uk[j];
+      for (int i = j; i < n; ++i) uj[i] -= uk[i] * ukj;
     }
-    for (int i = 0; i < j; ++i) A[(size_t)i * n + j] = 0.0;
+    if (!(uj[j] > 0.0)) return false;
+    const double ljj = std::sqrt(uj[j]);
+    uj[j] = ljj;
+    for (int i = j + 1; i < n; ++i) uj[i] /= ljj;
+  }
+  for (int i = 0; i < n; ++i) {
+    for (int j = 0; j <= i; ++j) A[(size_t)i * n + j] = U[(size_t)j * n + i];
+    for (int j = i + 1; j < n; ++j) A[(size_t)i * n + j] = 0.0;
   }
   return true;
 }
 
-// Inverse of a lower-triangular matrix (row-major), result lower-triangular.
+// Inverse of a lower-triangular matrix (row-major), result lower-triangular.  Row i accumulates
+// L[i][k] * (row k of the inverse) for k = 0 .. i-1 (unit stride, vectorisable); element j receives its terms for
+// k = j .. i-1 in increasing k, exactly as the element-by-element sum does.
 inline std::vector<double> tril_inverse(const std::vector<double>& L, int n) {
   std::vector<double> Li((size_t)n * n, 0.0);
-  for (int j = 0; j < n; ++j) {
-    Li[(size_t)j * n + j] = 1.0 / L[(size_t)j * n + j];
-    for (int i = j + 1; i < n; ++i) {
-      double s = 0.0;
-      for (int k = j; k < i; ++k) s += L[(size_t)i * n + k] * Li[(size_t)k * n + j];
-      Li[(size_t)i * n + j] = -s / L[(size_t)i * n + i];
+  for (int i = 0; i < n; ++i) {
+    double* ri = Li.data() + (size_t)i * n;
+    for (int k = 0; k < i; ++k) {
+      const double lik = L[(size_t)i * n + k];
+      const double* rk = Li.data() + (size_t)k * n;
+      for (int j = 0; j <= k; ++j) ri[j] += lik * rk[j];
     }
+    const double lii = L[(size_t)i * n + i];
+    for (int j = 0; j < i; ++j) ri[j] = -ri[j] / lii;
+    ri[i] = 1.0 / lii;
   }
   return Li;
 }
