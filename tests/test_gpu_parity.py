@@ -576,3 +576,28 @@ def test_prune_clusters_drops_columns_and_updates_weights_like_the_reference(lib
         Fo, _, _, _, _ = o.vbem_fixed([X], [qo[0]], getattr(o, wname), 1.0, 1)
         np.testing.assert_allclose(tr2[0], Fo[0], rtol=1e-10)
         m.close()
+
+
+@pytest.mark.gpu
+def test_mstep_failure_on_a_pool_thread_reaches_the_caller(lib):
+    """A NaN observation poisons one cluster's scatter matrix: GaussWish::update's log-determinant throws
+    (distributions.cpp:335-336) on whichever pool thread runs that cluster, and the caller sees the reference's
+    runtime_error -- also on the next call (the pool survives)."""
+    rng = np.random.default_rng(31)
+    N, D, K = 4000, 64, 8
+    X = rng.normal(size=(N, D)) + 2.0 * rng.integers(0, K, (N, 1))
+    q = rng.dirichlet(np.ones(K), N)
+    with capi.Context(0) as ctx:
+        Xbad = X.copy()
+        Xbad[17, 3] = np.nan
+        ctx.set_data(Xbad)
+        ctx.set_qz(q)
+        for _ in range(2):
+            with pytest.raises(RuntimeError, match="not positive definite"):
+                ctx.vbem(capi.W_DIRICHLET, fixed_iters=2, nthreads=8)
+            ctx.set_qz(q)
+        ctx.set_data(X)
+        ctx.set_qz(q)
+        F, tr, m = ctx.vbem(capi.W_DIRICHLET, fixed_iters=2, nthreads=8)
+        m.close()
+        assert np.isfinite(F)
