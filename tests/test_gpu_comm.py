@@ -295,3 +295,33 @@ def test_bench_starts_its_own_ranks(lib):
     line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["collective"] == "host-shm"
     assert line["config"]["rows_per_gpu"] == 200_000 and line["value"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("learner,shards,sep", [("learnVDP", 3, 6.0), ("learnBGMM", 2, 0.6), ("learnGMC", 3, 5.0)])
+def test_sharded_model_selection_on_cached_distances_equals_one_gpu(lib, sharded_env, learner, shards, sep):
+    """D = 20: cluster() runs on the journaled distance cache with statistics that follow the moved rows.
+    Sharded over contexts, every decision of that machinery (which columns to recompute, whether the moved rows are few
+    enough, whether the cache still pays, whether there is room) must come out the same on every shard: same rounds, K,
+    F and responsibilities as one context, for separated and for overlapping clusters."""
+    import libcluster_amd as lc
+
+    if learner == "learnGMC":
+        X = [_blobs(60, n, 20, 5, sep) for n in (1500, 900, 2100, 600)]
+    else:
+        X = _blobs(61, 7001, 20, 5, sep)
+    fn = getattr(lc, learner)
+    sharded_env(0)
+    F1, q1, w1, *rest1, info1 = fn(X, return_info=True)
+    sharded_env(shards)
+    F2, q2, w2, *rest2, info2 = fn(X, return_info=True)
+    assert info1["K"] == info2["K"] and info1["K"] >= 2
+    assert [k for k, _ in info1["rounds"]] == [k for k, _ in info2["rounds"]]
+    for (_, a), (_, b) in zip(info1["rounds"], info2["rounds"]):
+        np.testing.assert_allclose(b, a, rtol=1e-10)
+    assert abs(F1 - F2) <= 1e-10 * abs(F1)
+    if learner == "learnGMC":
+        for a, b in zip(q1, q2):
+            np.testing.assert_allclose(b, a, atol=1e-9)
+    else:
+        np.testing.assert_allclose(q2, q1, atol=1e-9)
