@@ -23,9 +23,11 @@ def _run(cmd, env=None):
     return json.loads(line[len("RESULT "):])
 
 
-@pytest.mark.parametrize("mode,family", [("rows", "GaussWish"), ("groups", "GaussWish"), ("rows", "NormGamma"),
-                                         ("groups", "ExpGamma"), ("rows", "ExpGamma")])
-def test_two_rank_cluster_equals_single_rank(lib, mode, family):
+@pytest.mark.parametrize("mode,family,D", [("rows", "GaussWish", 6), ("groups", "GaussWish", 6), ("rows", "NormGamma", 6),
+                                           ("groups", "ExpGamma", 6), ("rows", "ExpGamma", 6),
+                                           # D = 24: cluster() on the journaled distance cache
+                                           ("rows", "GaussWish", 24), ("groups", "GaussWish", 24)])
+def test_two_rank_cluster_equals_single_rank(lib, mode, family, D):
     """cluster() (VBEM + prune + split search) sharded over two ranks -- by row blocks (BGMM) or by whole
     groups (GMC: per-group counts and weights stay local) -- with all-reduced statistics, Fz, LL_k and
     decision counts takes the same decisions and reaches the same F as one rank.  Also for the diagonal and the
@@ -34,7 +36,7 @@ def test_two_rank_cluster_equals_single_rank(lib, mode, family):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     script = str(ROOT / "tools" / "dist_cluster_check.py")
-    args = ["30000", "6", "5", mode, family]
+    args = ["30000", str(D), "5", mode, family]
     one = _run([sys.executable, script, *args])
     two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                 "--master-addr", "127.0.0.1", "--master-port", str(port), script, *args],
