@@ -61,10 +61,10 @@ def _run_group(cmd, timeout):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["host", "rccl"])
-def test_two_ranks_through_the_c_abi(lib, mode):
+@pytest.mark.parametrize("mode,D", [("host", 8), ("rccl", 8), ("host", 24)])  # (D = 24: on the distance cache)
+def test_two_ranks_through_the_c_abi(lib, mode, D):
     exe = _compile()
-    rc, out = _run_group([str(exe), mode, "40000", "8", "4"], 300)
+    rc, out = _run_group([str(exe), mode, "40000", str(D), "4"], 300)
     assert rc == 0, out[-3000:]
     assert f"dist_test {mode} OK" in out, out[-3000:]
     if mode == "host":
