@@ -46,12 +46,20 @@ struct BlockCache {
     static BlockCache* c = new BlockCache();  // intentionally leaked
     return *c;
   }
+  static int& relaxed_fit() {
+    static thread_local int depth = 0;
+    return depth;
+  }
   void* take(std::vector<Block>& v, size_t need, int device, size_t* got) {
     std::lock_guard<std::mutex> g(m);
     const size_t me = thread_tag();
     int best = -1;
+    // (a block up to twice the request -- up to 16 times for short-lived sub-problem buffers, RelaxedFit: the split
+    // search's sub-problems halve from round to round, and mapping a fresh block of tens of gigabytes costs more than
+    // lending a big one for a few milliseconds)
+    const size_t slack = relaxed_fit() > 0 ? 16 : 2;
     for (int i = 0; i < (int)v.size(); ++i)
-      if (v[i].device == device && v[i].bytes >= need && v[i].bytes <= 2 * need + 4096 &&
+      if (v[i].device == device && v[i].bytes >= need && v[i].bytes <= slack * need + 4096 &&
           (v[i].owner == 0 || v[i].owner == me) && (best < 0 || v[i].bytes < v[best].bytes))
         best = i;
     if (best < 0) return nullptr;
@@ -82,6 +90,9 @@ int current_device() {
   return d;
 }
 }  // namespace
+
+RelaxedFit::RelaxedFit() { ++BlockCache::relaxed_fit(); }
+RelaxedFit::~RelaxedFit() { --BlockCache::relaxed_fit(); }
 
 void cache_release_thread() {
   BlockCache& c = BlockCache::get();
@@ -661,7 +672,10 @@ void Context::set_data_gather(const Context& src, const RowSelection& sel) {
   if (src.device_ != device_) throw std::invalid_argument("contexts live on different devices");
   std::vector<int64_t> mj((size_t)src.J_);
   for (int j = 0; j < src.J_; ++j) mj[(size_t)j] = sel.starts[(size_t)j + 1] - sel.starts[(size_t)j];
-  build_layout(src.J_, mj.data(), src.D_);
+  {
+    RelaxedFit lend;  // (a sub-problem: short-lived buffers)
+    build_layout(src.J_, mj.data(), src.D_);
+  }
   if (NP_ == 0) return;
   LC_HIP(hipMemsetAsync(X_.p, 0, (size_t)NP_ * DP_ * sizeof(double), stream_));
   LC_HIP(lck::launch_gather_rows(src.X_.p, DP_, sel.idx.p, sel.M, sel.starts_d.p, goff_d_.p, J_, X_.p, stream_));
@@ -1443,7 +1457,10 @@ bool Context::delta_suffstat(int K1, double max_frac, double* dNk, double* dxs, 
   sub.skip_zero_ = false;
   sub.set_data_gather(*this, sel);
   QZ& q = sub.qz_[sub.cur_];
-  sub.ensure_qz(q, K1, false);
+  {
+    RelaxedFit lend;
+    sub.ensure_qz(q, K1, false);
+  }
   q.K = K1;
   if (sub.NP_ > 0) {
     LC_HIP(hipMemsetAsync(q.buf.p, 0, (size_t)sub.NP_ * K1 * sizeof(double), stream_));  // padding rows carry nothing

@@ -72,6 +72,14 @@ struct RowSelection {
 
 // return every cached device / page-locked block to the driver
 void trim_cache();
+// while one of these lives on the calling thread, a device allocation may be served by a cached block up to 16 times
+// the request (2 otherwise): for the short-lived buffers of sub-problems
+struct RelaxedFit {
+  RelaxedFit();
+  ~RelaxedFit();
+  RelaxedFit(const RelaxedFit&) = delete;
+  RelaxedFit& operator=(const RelaxedFit&) = delete;
+};
 // Cached blocks are handed back only to the host thread that released them (one thread = one stream = ordered re-use).
 // A thread that is about to end calls this AFTER synchronising its stream: its blocks become available to everybody.
 void cache_release_thread();
