@@ -296,21 +296,20 @@ def test_config4_full_80M_rows_on_one_gpu():
     assert abs(tFz - Fz) <= 1e-11 * abs(Fz)
 
 
-def test_config5_per_gpu_size_gmc():
-    """BASELINE configs[4] at the size ONE of its eight GPUs holds: GMC (one GDirichlet per group), 8 groups x 500k
-    rows, D = 128, K = 64.  The property set of test_full_size_properties for grouped data: per-group counts add up to
-    the group sizes, statistics exactly symmetric, unit row sums, a 512-row prefix of EVERY group (4096 rows) equal to
-    the oracle's vbexpectation with that group's GDirichlet weights and bit-identical to a stand-alone run,
-    additivity over whole-group shards (the multi-GPU partition of SURVEY 8(e): N_jk stay local, cluster statistics
-    and F_z add up), non-increasing F."""
-    J, NJ, D, K, seed = 8, 500_000, 128, 64, 1005
+def _config5_gmc(J, shards, P, iters):
+    """GMC (one GDirichlet per group), J groups x 500k rows, D = 128, K = 64 of BASELINE configs[4]'s Philox stream.  The
+    property set of test_full_size_properties for grouped data: per-group counts add up to the group sizes, statistics
+    exactly symmetric, unit row sums, a P-row prefix of EVERY group equal to the oracle's vbexpectation with that
+    group's GDirichlet weights and bit-identical to a stand-alone run, additivity over whole-group shards (the
+    multi-GPU partition of SURVEY 8(e): N_jk stay local, cluster statistics and F_z add up), non-increasing F."""
+    NJ, D, K, seed = 500_000, 128, 64, 1005
     mu, L = _mixture(D, K, seed)
     mix = np.stack([np.random.default_rng([seed, g]).dirichlet(np.full(K, 0.5)) for g in range(J)])
-    P = 512
     with capi.Context(0) as ctx:
         ctx.synth_groups([NJ] * J, D, K, mu, L, seed, mix=mix, group_ids=list(range(J)))
         Xp = [ctx.get_rows(j, 0, P) for j in range(J)]
         Nk, xs, xxs, Njk = ctx.suffstat()
+        assert Njk.shape == (J, K)
         np.testing.assert_allclose(Njk.sum(axis=1), NJ, rtol=1e-9)      # rows of the initial qZ sum to 1, per group
         np.testing.assert_allclose(Njk.sum(axis=0), Nk, rtol=1e-12)
         assert np.array_equal(xxs, np.transpose(xxs, (0, 2, 1)))
@@ -320,19 +319,25 @@ def test_config5_per_gpu_size_gmc():
                 np.stack([p["iW"] for p in post]), [p["logdW"] for p in post], elog)
         Fz, _ = ctx.estep_posterior(*args, want_ll=False)
         qp = [ctx.get_qz_rows(j, 0, P) for j in range(J)]
+        qlast = ctx.get_qz_rows(J - 1, NJ - P, P)                        # the very last rows of the data set
+        Xlast = ctx.get_rows(J - 1, NJ - P, P)
         cols = ctx.colsums()
-        F, tr, m = ctx.vbem(capi.W_GDIRICHLET, fixed_iters=3, nthreads=16)
+        F, tr, m = ctx.vbem(capi.W_GDIRICHLET, fixed_iters=iters, nthreads=16)
         m.close()
     np.testing.assert_allclose(cols.sum(axis=1), NJ, rtol=1e-9)
-    for q in qp:
+    for q in qp + [qlast]:
         np.testing.assert_allclose(q.sum(axis=1), 1.0, rtol=1e-12)
     assert np.all(np.diff(tr) <= 1e-9 * abs(tr[0]))
 
-    with capi.Context(0) as c2:  # the 8 x 512 prefix rows as a data set of their own: identical rows
+    with capi.Context(0) as c2:  # the J x P prefix rows as a data set of their own: identical rows
         c2.set_data(Xp)
         c2.estep_posterior(*args, want_ll=False)
         for a, b in zip(qp, c2.get_qz([P] * J)):
             np.testing.assert_array_equal(a, b)
+    with capi.Context(0) as c3:  # and the tail of the last group, with that group's weights
+        c3.set_data(Xlast)
+        c3.estep_posterior(*(args[:5] + (elog[J - 1:J],)), want_ll=False)
+        np.testing.assert_array_equal(qlast, c3.get_qz([P])[0])
     cl = []
     for k in range(K):
         g = o.GaussWish(1.0, D)
@@ -348,7 +353,7 @@ def test_config5_per_gpu_size_gmc():
         assert np.max(np.abs(qp[j][big] - qref[big]) / qref[big]) < 1e-9
 
     tot, tFz = None, 0.0
-    for gs in ([0, 1, 2], [3, 4], [5, 6, 7]):  # whole groups per shard
+    for gs in shards:  # whole groups per shard
         with capi.Context(0) as cs:
             cs.synth_groups([NJ] * len(gs), D, K, mu, L, seed, mix=mix[gs], group_ids=gs)
             st = cs.suffstat()
@@ -361,3 +366,17 @@ def test_config5_per_gpu_size_gmc():
     np.testing.assert_allclose(tot[1], xs, rtol=1e-9, atol=1e-5)
     np.testing.assert_allclose(tot[2], xxs, rtol=1e-9, atol=1e-4)
     assert abs(tFz - Fz) <= 1e-11 * abs(Fz)
+
+
+def test_config5_per_gpu_size_gmc():
+    """BASELINE configs[4] at the size ONE of its eight GPUs holds: 8 groups x 500k rows, D = 128, K = 64; a 512-row
+    prefix of every group against the oracle; three uneven whole-group shards."""
+    _config5_gmc(8, ([0, 1, 2], [3, 4], [5, 6, 7]), 512, 3)
+
+
+def test_config5_full_size_gmc_on_one_gpu():
+    """BASELINE configs[4] at its FULL size on one GPU: GMC, J = 64 groups x 500k rows = 32M rows, D = 128, K = 64 --
+    32.8 GB of X and 16.4 GB of qZ resident, 64 GDirichlet weight objects, a J x K = 4096 count block.  The shards are
+    the eight 8-group blocks the 8-GPU run would hold (whole groups per GPU); a 128-row prefix of every
+    group (8192 rows) goes against the oracle with that group's weights."""
+    _config5_gmc(64, [list(range(8 * r, 8 * r + 8)) for r in range(8)], 128, 2)

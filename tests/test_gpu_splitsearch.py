@@ -44,6 +44,35 @@ def test_shortcuts_walk_the_same_rounds_as_the_literal_schedule(lib, args):
     assert fast[0] >= int(args[2]) - 1  # the final round tries (and rejects) every cluster: many candidates per round
 
 
+def _learn_trace(args, env):
+    import json
+
+    e = dict(os.environ)
+    e.update(env)
+    e["LC_LB_TRACE"] = "1"
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / "learn_bench.py"), *args], capture_output=True, text=True,
+                       timeout=900, env=e, cwd=str(ROOT))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("TRACE ")][-1]
+    return json.loads(line[6:])
+
+
+@pytest.mark.parametrize("args,scale", [(("2000000", "64", "10"), "4.0"),       # well separated: the cache carries the loop
+                                        (("1500000", "32", "8", "Dirichlet"), "1.0")])  # overlapping: rows keep moving
+def test_mid_size_model_selection_cache_against_full_passes(lib, args, scale):
+    """The sizes at which the distance cache and the moved-row statistics matter (millions of rows; the oracle cannot
+    follow there): the default policy (tau = 2^-50, chained moved-row updates) against LC_SPLIT_NO_DELTA=1 (full
+    E-step and statistics passes everywhere, the reference's schedule, cluster.cpp:473, 594-606) -- the same rounds,
+    the same K per round, the same number of VBEM iterations per round and EVERY free energy of every round to 1e-10."""
+    fast = _learn_trace(list(args), {"LC_LB_SCALE": scale})
+    full = _learn_trace(list(args), {"LC_LB_SCALE": scale, "LC_SPLIT_NO_DELTA": "1"})
+    assert [k for k, _ in fast] == [k for k, _ in full]
+    assert fast[-1][0] >= int(args[2]) - 1
+    for (k, a), (_, b) in zip(fast, full):
+        assert len(a) == len(b), (k, a, b)
+        np.testing.assert_allclose(a, b, rtol=1e-10, err_msg=f"round with K={k}")
+
+
 def test_cached_first_estep_equals_the_oracle_on_a_many_candidate_round(lib):
     """Model selection on data whose final round rejects every candidate (K candidates, the cached path from the third
     on), every round's K and F against the oracle."""

@@ -38,3 +38,7 @@ its = sum(len(t) for _, t in rounds)
 print(f"{fam} N={N} D={D} Ktrue={Kt}: found K={K} F={F:.6f} in {dt:.2f} s; {len(rounds)} rounds, {its} main VBEM iterations")
 print(f"  E-step launches {kt['estep_calls']} ({kt['estep_ms']:.1f} ms), suff-stat launches {kt['suffstat_calls']} ({kt['suffstat_ms']:.1f} ms)")
 print("  cluster sizes", Ns)
+if os.environ.get("LC_LB_TRACE"):  # every round's K and free-energy trace, one JSON line (tests/test_gpu_splitsearch.py)
+    import json
+
+    print("TRACE " + json.dumps([[int(k), [float(f) for f in t]] for k, t in rounds]))
