@@ -11,6 +11,8 @@ import numpy as np
 
 PKG = Path(__file__).resolve().parent
 LIB_PATH = PKG / "lib" / "libcluster_hip.so"
+if __import__("os").environ.get("LC_LIB_PATH"):  # kernel experiments (tools/variants.py): another build of the library
+    LIB_PATH = Path(__import__("os").environ["LC_LIB_PATH"])
 HEADER = PKG.parent / "include" / "libcluster_hip.h"
 
 LC_OK, LC_EINVAL, LC_ERUNTIME, LC_EHIP, LC_EDOMAIN = range(5)

@@ -25,7 +25,63 @@
 #define LC_ES_LQW_DEFAULT 0
 #endif
 
+// Scheduling knobs of the cluster loop (tools/variants.py builds and times alternatives; the defaults are the measured
+// best at every width: -4...5 % against all of them off, N = 10M, D = 64, K = 32: 22.2 -> 21.2 ms):
+//   LC_ES_SB     1: a scheduling fence after every step of the LDS parameter stream -- hipcc otherwise sinks the ring's
+//                reads to just before their use (s_waitcnt lgkmcnt(0) after every second read: the LDS latency is exposed)
+//   LC_ES_PF     reads in flight ahead of their use
+//   LC_ES_DEFER  1: the squares of a tile row are taken under the next row's first MFMAs (two accumulator sets), not
+//                straight behind the row's last MFMA (a matrix-pipe result is not readable for several issue slots)
+//   LC_ES_CPRE   1: c_jk of the cluster is fetched before the tile stream, not behind it (three exposed loads per cluster)
+#ifndef LC_ES_SB
+#define LC_ES_SB 1
+#endif
+#ifndef LC_ES_PF
+#define LC_ES_PF 4
+#endif
+#ifndef LC_ES_DEFER
+#define LC_ES_DEFER 1
+#endif
+#ifndef LC_ES_CPRE
+#define LC_ES_CPRE 1
+#endif
+//   LC_ES_DLDS   1: the next cluster's record goes from global memory straight into the other LDS buffer
+//                (global_load_lds_dwordx4: no staging registers, no ds_write)
+#ifndef LC_ES_DLDS
+#define LC_ES_DLDS 1
+#endif
+//   LC_ES_STDEF  1 (k-sliced scheme): a cluster's log q~ is stored at the top of the NEXT cluster's pass, so the stores
+//                have a whole pass to drain before the s_waitcnt vmcnt(0) in front of the barrier (vmcnt counts stores too)
+#ifndef LC_ES_STDEF
+#define LC_ES_STDEF 1
+#endif
+//   LC_ES_STAGGER n > 0: the waves that share a SIMD start their cluster loops n * 64 * (wave slot) clocks apart, so that
+//                their per-cluster tails (squares, lane sum, barrier, first LDS reads) do not fall together
+#ifndef LC_ES_STAGGER
+#define LC_ES_STAGGER 0
+#endif
+//   LC_ES_LQC    1: log q~ = c - d^2 / 2 comes straight out of the lane-sum MFMA (A = -1/2, C = c_jk): no v_fma behind it
+#ifndef LC_ES_LQC
+#define LC_ES_LQC 0
+#endif
+//   LC_ES_ONEEXP 1 (k-sliced scheme, K <= 64, no LL_k wanted): one exponential per entry -- e = exp(log q~ - max) stays in
+//                the registers the X fragments have vacated and q = e / sum(e); same sum, same logZ, q within 2 ulp of
+//                exp(log q~ - logZ)
+#ifndef LC_ES_ONEEXP
+#define LC_ES_ONEEXP 0
+#endif
+
 namespace lck {
+
+// max without the canonicalising self-max hipcc puts in front of fmax (three v_max_f64 per call where one does)
+__device__ __forceinline__ double max_raw(double a, double b) {
+#if LC_ES_CPRE
+  asm("v_max_f64 %0, %1, %2" : "=v"(a) : "v"(a), "v"(b));
+  return a;
+#else
+  return fmax(a, b);
+#endif
+}
 
 // ===========================================================================
 // E-step
@@ -47,8 +103,11 @@ namespace lck {
 // exp(x - logZ).
 // blocks per CU the register budget is set for.  D = 64: three row groups per wave (96 VGPRs of X fragments) at
 // three waves per SIMD measured 22.2 ms against 22.6 for four row groups at two waves per SIMD (N=10M, K=32).
+#ifndef LC_ES_R64
+#define LC_ES_R64 3
+#endif
 template <int DP>
-struct EstepOcc { static constexpr int BLOCKS = DP == 64 ? 3 : 2; };
+struct EstepOcc { static constexpr int BLOCKS = DP == 64 && LC_ES_R64 == 3 ? 3 : 2; };
 // waves per block of the standard variant (EstepCfg below): what estep_grid and the partial slots are sized for
 template <int DP>
 struct EstepWavesStd { static constexpr int W = DP >= 112 ? 8 : 4; };
@@ -62,7 +121,7 @@ __global__ void __launch_bounds__(WAVES * 64, LQW ? 2 : EstepOcc<DP>::BLOCKS) es
   constexpr int NT = DP / 4;
   constexpr int NTILES = NT * (NT + 1) / 2;
   constexpr int NREAD = NTILES + NT;  // LDS reads per cluster
-  constexpr int PF = 6;               // reads in flight ahead of their use
+  constexpr int PF = LC_ES_PF;        // reads in flight ahead of their use
   constexpr int PS = NTILES * 16 + DP;
   constexpr int NTHR = WAVES * 64;
   constexpr int NV2 = PS / 2;
@@ -115,6 +174,22 @@ __global__ void __launch_bounds__(WAVES * 64, LQW ? 2 : EstepOcc<DP>::BLOCKS) es
   for (int r = 0; r < R; ++r)
     if (hi == r) myok = rgok[r];
 
+#if LC_ES_DLDS
+  // 16 bytes per lane and instruction land at LDS address M0 + 16 * lane; a round of the block moves NTHR * 16 bytes
+  const unsigned dvoff = (unsigned)(wave * 1024 + lane * 16);
+  const unsigned dlds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)pbuf + (unsigned)(wave * 1024));
+#define LC_DMA(kk, bb)                                                                        \
+  {                                                                                           \
+    const char* src_ = reinterpret_cast<const char*>(a.params + (int64_t)__builtin_amdgcn_readfirstlane(kk) * PS); \
+    _Pragma("unroll") for (int i_ = 0; i_ < (PS * 8 + NTHR * 16 - 1) / (NTHR * 16); ++i_) { \
+      if (dvoff + i_ * (NTHR * 16) < (unsigned)(PS * 8))                                      \
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1"                     \
+                     ::"v"(dvoff), "s"(src_ + i_ * (NTHR * 16)), "s"(dlds0 + (bb) * (PS * 8) + i_ * (NTHR * 16)) : "memory");  \
+    }                                                                                         \
+  }
+#define LC_GLOAD(kk)
+#define LC_LSTORE(bb)
+#else
   // register double-buffer for the next cluster's parameter record
   double pre[NPRE][2];
 #define LC_GLOAD(kk)                                                                          \
@@ -135,6 +210,7 @@ __global__ void __launch_bounds__(WAVES * 64, LQW ? 2 : EstepOcc<DP>::BLOCKS) es
       if (idx_ < NV2) dst_[idx_] = make_double2(pre[i_][0], pre[i_][1]);                      \
     }                                                                                         \
   }
+#endif
 
   // Sparse mode (cluster.cpp:109-112, 134-135): the block walks only the clusters that are active (c_jk > -inf)
   // for at least one of its row groups -- no parameter staging, barrier or MFMA for the others; their columns
@@ -180,19 +256,55 @@ __global__ void __launch_bounds__(WAVES * 64, LQW ? 2 : EstepOcc<DP>::BLOCKS) es
   }
 
   if (nact > 0) {
+#if LC_ES_DLDS
+    LC_DMA(SPARSE ? klist[0] : 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
     LC_GLOAD(SPARSE ? klist[0] : 0);
     LC_LSTORE(0);
+#endif
   }
   __syncthreads();
 
   double mx[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) mx[r] = -INFINITY;
+#if LC_ES_STAGGER
+  if (blockIdx.x < 1024) {  // the first resident blocks only: later ones inherit the offsets of the blocks they replace
+    // HW_ID (register 4): wave slot of the SIMD in bits 3:0
+    if (tid == 0) reinterpret_cast<unsigned*>(fzw)[0] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) & 15u;
+    __syncthreads();  // (the block's waves move together: all take the offset of wave 0's slot)
+    const unsigned slot = reinterpret_cast<const unsigned*>(fzw)[0];
+    for (unsigned s = 0; s < (slot % 3u) * LC_ES_STAGGER; ++s) __builtin_amdgcn_s_sleep(1);
+  }
+#endif
 
+#if LC_ES_STDEF
+  double lqprev[R];
+  int kprev = -1;
+  auto flush_lq = [&]() {
+    if constexpr (ROWLANES) {
+      if (kprev >= 0 && !lqm && myok) a.qZ[(int64_t)kprev * a.ldq + (rg0 + hi) * RG + lo4] = lqprev[0];
+    } else if constexpr (!LQW) {
+      if (kprev >= 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          if (rgok[r] && hi == (kprev & 3)) a.qZ[(int64_t)kprev * a.ldq + (rg0 + r) * RG + lo4] = lqprev[r];
+      }
+    }
+  };
+#endif
   for (int ii = 0; ii < nact; ++ii) {
     const int k = SPARSE ? klist[ii] : ii;
     const int buf = ii & 1;
+#if LC_ES_STDEF
+    flush_lq();
+#endif
+#if LC_ES_DLDS
+    if (ii + 1 < nact) LC_DMA(SPARSE ? klist[ii + 1] : ii + 1, buf ^ 1);
+#else
     if (ii + 1 < nact) LC_GLOAD(SPARSE ? klist[ii + 1] : ii + 1);
+#endif
     const double* P = pbuf + buf * PS;
     const double* Pt = P + (lane & 3) + 4 * hi;  // this lane's element of every 4x4 tile
     const double* Pb = P + NTILES * 16 + hi;     // this lane's element of every 4-vector of -b
@@ -204,7 +316,7 @@ __global__ void __launch_bounds__(WAVES * 64, LQW ? 2 : EstepOcc<DP>::BLOCKS) es
       constexpr RdInfo ri = rd_info(ic);
       ring[ic] = ri.jt < 0 ? Pb[ri.off] : Pt[ri.off];
     });
-    double d2[R], acc[R];
+    double d2[R], acc[2][R];
 #pragma unroll
     for (int r = 0; r < R; ++r) d2[r] = 0.0;
     // sparse mode (cluster.cpp:109-112): a cluster that is inactive (c_jk = -inf) for the groups of ALL of this
@@ -216,10 +328,25 @@ __global__ void __launch_bounds__(WAVES * 64, LQW ? 2 : EstepOcc<DP>::BLOCKS) es
       for (int r = 0; r < R; ++r)
         wave_active = wave_active || (rgok[r] && a.ctab[(int64_t)grp[r] * K + k] != -INFINITY);
     }
-    if (wave_active)
+#if LC_ES_CPRE
+    double cv[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) cv[r] = a.ctab[(int64_t)grp[r] * K + k];
+#endif
+    auto square = [&](int set) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        d2[r] = fma(acc[set][r], acc[set][r], d2[r]);
+        // pin the running sum here: otherwise LLVM sinks the whole fma chain below the
+        // MFMA stream and keeps every row's accumulator alive (96 extra VGPRs, spills)
+        asm volatile("" : "+v"(d2[r]));
+      }
+    };
+    if (wave_active) {
     static_for<NREAD>([&](auto nc) {
       constexpr int n = nc;
       constexpr RdInfo ri = rd_info(n);
+      constexpr int set = LC_ES_DEFER ? (ri.it & 1) : 0;
       const double v = ring[n % PF];
       if constexpr (n + PF < NREAD) {
         constexpr RdInfo rn = rd_info(n + PF);
@@ -227,49 +354,76 @@ __global__ void __launch_bounds__(WAVES * 64, LQW ? 2 : EstepOcc<DP>::BLOCKS) es
       }
       if constexpr (ri.jt < 0) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = v;
+        for (int r = 0; r < R; ++r) acc[set][r] = v;
       } else {
 #pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = mfma4(v, xf[r][ri.jt], acc[r]);
-        if constexpr (ri.jt == ri.it) {
-#pragma unroll
-          for (int r = 0; r < R; ++r) {
-            d2[r] = fma(acc[r], acc[r], d2[r]);
-            // pin the running sum here: otherwise LLVM sinks the whole fma chain below the
-            // MFMA stream and keeps every row's accumulator alive (96 extra VGPRs, spills)
-            asm volatile("" : "+v"(d2[r]));
-          }
+        for (int r = 0; r < R; ++r) acc[set][r] = mfma4(v, xf[r][ri.jt], acc[set][r]);
+        if constexpr (LC_ES_DEFER) {
+          if constexpr (ri.it > 0 && ri.jt == 1) square(set ^ 1);  // the row above, six MFMAs after its last one
+        } else {
+          if constexpr (ri.jt == ri.it) square(set);
         }
       }
+#if LC_ES_SB
+      __builtin_amdgcn_sched_barrier(0);
+#endif
     });
+    if constexpr (LC_ES_DEFER) square((NT - 1) & 1);
+    }
     double lqsel = 0.0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       // sum over the four hi lanes on the matrix pipe: D[i][j] = sum_k 1 * B[k][j] leaves the
       // total in every lane (B[k=hi][j=row] is exactly where the partial sums live)
+#if LC_ES_LQC && LC_ES_CPRE
+      const double lq = mfma4(-0.5, d2[r], cv[r]);
+#elif LC_ES_CPRE
+      const double dd = mfma4(1.0, d2[r], 0.0);
+      const double lq = cv[r] - 0.5 * dd;
+#else
       const double dd = mfma4(1.0, d2[r], 0.0);
       const double lq = a.ctab[(int64_t)grp[r] * K + k] - 0.5 * dd;
-      mx[r] = fmax(mx[r], lq);
+#endif
+      mx[r] = max_raw(mx[r], lq);
       if constexpr (ROWLANES) {
         if (hi == r) lqsel = lq;
       } else if constexpr (LQW) {
         if (hi == (k & 3)) lqw[((k >> 2) * R + r) * 64] = lq;
       } else {
+#if LC_ES_STDEF
+        lqprev[r] = lq;
+#else
         if (rgok[r] && hi == (k & 3)) a.qZ[(int64_t)k * a.ldq + (rg0 + r) * RG + lo4] = lq;
+#endif
       }
     }
+#if LC_ES_STDEF
+    kprev = k;
+#endif
     // R == 4: lane (lo4, hi) keeps row group hi -- ONE 512-byte store per cluster column instead of four
     // 128-byte ones, and the normalisation below needs no cross-lane sums
     if constexpr (ROWLANES) {
       if (lqm) lql[k * NTHR + tid] = lqsel;
+#if LC_ES_STDEF
+      else lqprev[0] = lqsel;
+#else
       else if (myok) a.qZ[(int64_t)k * a.ldq + (rg0 + hi) * RG + lo4] = lqsel;
+#endif
     }
+#if LC_ES_DLDS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the record has landed (this wave's part; the barrier covers the rest)
+#else
     if (ii + 1 < nact) LC_LSTORE(buf ^ 1);
+#endif
     __syncthreads();
   }
 
 #undef LC_GLOAD
 #undef LC_LSTORE
+#undef LC_DMA
+#if LC_ES_STDEF
+  flush_lq();
+#endif
 
   if (a.raw) return;  // GaussWish::Eloglike: leave c_k - 0.5 d^2 in qZ, no normalisation
 
@@ -307,6 +461,38 @@ __global__ void __launch_bounds__(WAVES * 64, LQW ? 2 : EstepOcc<DP>::BLOCKS) es
     fz = (myok && myrow) ? logZ : 0.0;
   } else {
   double logZ[R];
+#if LC_ES_ONEEXP
+  constexpr int KQM = 16;  // K <= 64
+  if (!LQW && !a.ll_part && K <= 4 * KQM) {
+    double ev[R][KQM], inv[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      double s = 0.0;
+      const double* qp = a.qZ + (rg0 + r) * RG + lo4;
+#pragma unroll
+      for (int kq = 0; kq < KQM; ++kq) {
+        const int k = 4 * kq + hi;
+        ev[r][kq] = 0.0;
+        if (rgok[r] && k < K) {
+          ev[r][kq] = exp(qp[(int64_t)k * a.ldq] - mx[r]);
+          s += ev[r][kq];
+        }
+      }
+      s = sum_over_hi(s);
+      logZ[r] = log(s) + mx[r];
+      inv[r] = rowok[r] ? 1.0 / s : 0.0;
+    }
+#pragma unroll
+    for (int kq = 0; kq < KQM; ++kq) {
+      const int k = 4 * kq + hi;
+      if (k < K) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          if (rgok[r]) a.qZ[(int64_t)k * a.ldq + (rg0 + r) * RG + lo4] = ev[r][kq] * inv[r];
+      }
+    }
+  } else {
+#endif
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     double s = 0.0;
@@ -339,6 +525,9 @@ __global__ void __launch_bounds__(WAVES * 64, LQW ? 2 : EstepOcc<DP>::BLOCKS) es
       if (k < K && lo4 == 0) llw[wave * K + k] = ll;
     }
   }
+#if LC_ES_ONEEXP
+  }
+#endif
 #pragma unroll
   for (int r = 0; r < R; ++r)
     if (rgok[r] && rowok[r] && hi == 0) fz += logZ[r];
@@ -601,7 +790,7 @@ struct EstepCfg<32> { static constexpr int R = 4, WAVES = 4; };
 template <>
 struct EstepCfg<48> { static constexpr int R = 4, WAVES = 4; };
 template <>
-struct EstepCfg<64> { static constexpr int R = 3, WAVES = 4; };
+struct EstepCfg<64> { static constexpr int R = LC_ES_R64, WAVES = 4; };
 template <>
 struct EstepCfg<80> { static constexpr int R = 3, WAVES = 4; };
 template <>
