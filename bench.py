@@ -61,8 +61,11 @@ CONFIGS = {
                  label="DGMM (diagonal Gaussians, NormGamma) N=10M/GPU D=64 K=32"),
     "bemm": dict(N=10_000_000, D=64, K=32, w="Dirichlet", c="ExpGamma", seed=1007,
                  label="BEMM (exponential clusters, ExpGamma) N=10M/GPU D=64 K=32"),
+    # full covariances wider than 128 columns: estep_wide_kernel + panel launches of suffstat_kernel
+    "wide256": dict(N=1_000_000, D=256, K=16, w="Dirichlet", seed=1008,
+                    label="BGMM, wide observations: N=1M D=256 K=16 (chunk-streamed whitener, panel statistics)"),
 }
-OTHER_CONFIGS = ["2", "3", "5", "dgmm", "bemm"]  # short runs reported under "other_configs" of the default line
+OTHER_CONFIGS = ["2", "3", "5", "dgmm", "bemm", "wide256"]  # short runs reported under "other_configs" of the default line
 
 
 def mixture(D, K, seed, family="GaussWish", overlap=False):
@@ -141,7 +144,10 @@ def cpu_baseline(ctx, model, cfg, sample_rows, reps=5):
     peak, peak_desc = oc.host_fp64_peak_gflops(cores)
     gf = all_pts * w_dense / 1e9
     return {
-        "value": all_pts, "unit": "points/s", "cores": cores, "kind": "port",
+        "value": all_pts, "unit": "points/s", "cores": cores, "kind": "port", "per_core_value": all_pts / cores,
+        "cores_visible_note": (f"{cores} physical cores are visible to this process (os.sched_getaffinity: "
+                               f"{len(os.sched_getaffinity(0))} logical CPUs); the gpurun / driver leases expose two, "
+                               "so `value` is a two-thread figure there -- `per_core_value` is the comparable number"),
         "sample": f"first {n} rows of the same synthetic stream, E-step + suff-stats (oracle/lc_oracle_c.c, gcc -O3 "
                   f"-march=native -fopenmp, rows chunked over {cores} threads pinned with OMP_PROC_BIND=close "
                   f"OMP_PLACES=cores, X read once per 128-row tile for all K), median of {reps} after 1 warm-up",

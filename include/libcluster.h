@@ -38,8 +38,21 @@ struct ModelGuard {
   ModelGuard() : m(0) {}
   ~ModelGuard() { if (m) lc_model_free(m); }
 };
-template <class W, class C>
-inline double run(int algo, const vMatrixXd& X, vMatrixXd& qZ, std::vector<W>& weights,
+/* learnVDP / learnBGMM / learnDGMM / learnBEMM take ONE matrix: views of it as a one-group data set, so that neither X
+ * (5 GB at N = 10M, D = 64) nor qZ is copied on the host -- the reference does copy both (src/cluster.cpp:651, 661,
+ * 682, 692) */
+struct OneX {
+  const lcmat::MatrixXd* p;
+  size_t size() const { return 1; }
+  const lcmat::MatrixXd& operator[](size_t) const { return *p; }
+};
+struct OneQ {
+  lcmat::MatrixXd* p;
+  void resize(size_t) {}
+  lcmat::MatrixXd& operator[](size_t) { return *p; }
+};
+template <class W, class C, class XV, class QV>
+inline double run(int algo, const XV& X, QV& qZ, std::vector<W>& weights,
                   std::vector<C>& clusters, double wprior, double clusterprior, int maxclusters,
                   bool sparse, bool verbose, unsigned nthreads) {
   using distributions::detail::check;
@@ -125,11 +138,11 @@ inline double learnVDP(const lcmat::MatrixXd& X, lcmat::MatrixXd& qZ, distributi
                        std::vector<distributions::GaussWish>& clusters, const double clusterprior = PRIORVAL,
                        const int maxclusters = -1, const bool verbose = false,
                        const unsigned int nthreads = detail::default_threads()) {
-  vMatrixXd vX(1, X), vq;
+  const detail::OneX vX = {&X};
+  detail::OneQ vq = {&qZ};
   std::vector<distributions::StickBreak> vw(1, weights);
   const double F = detail::run(LC_ALGO_VDP, vX, vq, vw, clusters, weights.prior(), clusterprior, maxclusters, false,
                                verbose, nthreads);
-  qZ = vq[0];
   weights = vw[0];
   return F;
 }
@@ -139,11 +152,11 @@ inline double learnBGMM(const lcmat::MatrixXd& X, lcmat::MatrixXd& qZ, distribut
                         std::vector<distributions::GaussWish>& clusters, const double clusterprior = PRIORVAL,
                         const int maxclusters = -1, const bool verbose = false,
                         const unsigned int nthreads = detail::default_threads()) {
-  vMatrixXd vX(1, X), vq;
+  const detail::OneX vX = {&X};
+  detail::OneQ vq = {&qZ};
   std::vector<distributions::Dirichlet> vw(1, weights);
   const double F = detail::run(LC_ALGO_BGMM, vX, vq, vw, clusters, weights.prior(), clusterprior, maxclusters, false,
                                verbose, nthreads);
-  qZ = vq[0];
   weights = vw[0];
   return F;
 }
@@ -171,11 +184,11 @@ inline double learnDGMM(const lcmat::MatrixXd& X, lcmat::MatrixXd& qZ, distribut
                         std::vector<distributions::NormGamma>& clusters, const double clusterprior = PRIORVAL,
                         const int maxclusters = -1, const bool verbose = false,
                         const unsigned int nthreads = detail::default_threads()) {
-  vMatrixXd vX(1, X), vq;
+  const detail::OneX vX = {&X};
+  detail::OneQ vq = {&qZ};
   std::vector<distributions::Dirichlet> vw(1, weights);
   const double F = detail::run(LC_ALGO_DGMM, vX, vq, vw, clusters, weights.prior(), clusterprior, maxclusters, false,
                                verbose, nthreads);
-  qZ = vq[0];
   weights = vw[0];
   return F;
 }
@@ -185,11 +198,11 @@ inline double learnBEMM(const lcmat::MatrixXd& X, lcmat::MatrixXd& qZ, distribut
                         std::vector<distributions::ExpGamma>& clusters, const double clusterprior = PRIORVAL,
                         const int maxclusters = -1, const bool verbose = false,
                         const unsigned int nthreads = detail::default_threads()) {
-  vMatrixXd vX(1, X), vq;
+  const detail::OneX vX = {&X};
+  detail::OneQ vq = {&qZ};
   std::vector<distributions::Dirichlet> vw(1, weights);
   const double F = detail::run(LC_ALGO_BEMM, vX, vq, vw, clusters, weights.prior(), clusterprior, maxclusters, false,
                                verbose, nthreads);
-  qZ = vq[0];
   weights = vw[0];
   return F;
 }

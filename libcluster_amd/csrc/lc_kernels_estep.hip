@@ -71,6 +71,14 @@
 #define LC_ES_ONEEXP 0
 #endif
 
+#ifdef LC_ES_TRACE
+// experiments only: per block (XCC, CU/SIMD word, wall start, wall end, shader clocks) -- read with lc_debug_estep_trace
+__device__ long long lc_es_trace[5 * 65536];
+extern "C" int lc_debug_estep_trace(long long* out, int nblocks) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lc_es_trace), sizeof(long long) * 5 * (size_t)(nblocks < 65536 ? nblocks : 65536));
+}
+#endif
+
 namespace lck {
 
 // max without the canonicalising self-max hipcc puts in front of fmax (three v_max_f64 per call where one does)
@@ -145,6 +153,9 @@ __global__ void __launch_bounds__(WAVES * 64, LQW ? 2 : EstepOcc<DP>::BLOCKS) es
   const int lo4 = lane & 15, hi = lane >> 4;
   const int K = a.K;
   const int64_t rg0 = ((int64_t)blockIdx.x * WAVES + wave) * R;
+#ifdef LC_ES_TRACE
+  const long long tr_w0 = wall_clock64(), tr_c0 = clock64();
+#endif
   constexpr bool ROWLANES = R == 4;  // four row groups per wave: lane (lo4, hi) can own row group hi outright
 
   double xf[R][NT];
@@ -552,6 +563,16 @@ __global__ void __launch_bounds__(WAVES * 64, LQW ? 2 : EstepOcc<DP>::BLOCKS) es
     a.fz_part[slot0] = -s;  // cluster.cpp:137 returns -sum(logZ)
     for (int e = 1; e < SLOTS; ++e)
       if (slot0 + e < a.nslots) a.fz_part[slot0 + e] = 0.0;
+#ifdef LC_ES_TRACE
+    if (blockIdx.x < 65536) {
+      long long* t = lc_es_trace + 5 * (size_t)blockIdx.x;
+      t[0] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20);   // XCC_ID
+      t[1] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4);   // HW_ID
+      t[2] = tr_w0;
+      t[3] = wall_clock64();
+      t[4] = clock64() - tr_c0;
+    }
+#endif
   }
 }
 
