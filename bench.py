@@ -344,23 +344,40 @@ def measure(capi, cfg, steps, warmup, rank, world, local_rank, stream, nthreads,
         dist.barrier()
     if torch is not None:
         torch.cuda.synchronize()
-    else:
-        ctx.synchronize()
+    ctx.synchronize()
     t0 = time.perf_counter()
     F, tr, model = ctx.vbem(wkind, fixed_iters=steps, nthreads=nthreads, model=model, ckind=ckind)
     if torch is not None:
         torch.cuda.synchronize()
-    else:
-        ctx.synchronize()
+    ctx.synchronize()
     if dist is not None:
         dist.barrier()
-    dt = time.perf_counter() - t0
+    dt = own_dt = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     kt = ctx.timing_get()
+    ka = ctx.timing_get_all()
     ctx.timing_enable(False)
+    # what THIS rank spent where, per step (ms): its two kernels, the exchange step (the sum + the wait for the slowest
+    # rank), the host M-step, and the host's remaining wall time in the two data-pass phases (launches, copies,
+    # synchronisation) -- enough to tell a slow collective from a slow M-step from a straggler on a first 8-GPU run
+    it = max(1, ka["host_iters"])
+    dev_ms = (ka["estep_ms"] + ka["suffstat_ms"] + ka["fused_ms"] + ka["allreduce_ms"]) / it
+    rank_report = {
+        "rank": rank, "device": local_rank, "step_ms": own_dt / steps * 1e3,
+        "estep_ms": ka["estep_ms"] / max(1, ka["estep_calls"]), "suffstat_ms": ka["suffstat_ms"] / max(1, ka["suffstat_calls"]),
+        **({"fused_ms": ka["fused_ms"] / ka["fused_calls"]} if ka["fused_calls"] else {}),
+        "allreduce_ms": ka["allreduce_ms"] / it, "allreduce_calls_per_step": ka["allreduce_calls"] / it,
+        "mstep_ms": (ka["host_mstep_ms"] + ka["host_fenergy_ms"]) / it,
+        "wait_ms": max(0.0, (ka["host_stats_ms"] + ka["host_estep_ms"]) / it - dev_ms),
+        "mstep_threads": nthreads, "cpus": len(os.sched_getaffinity(0)),
+    }
+    per_rank = [rank_report]
+    if dist is not None:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, rank_report)
 
     fl = alg_flops(N, D, K)
     est = kt["estep_ms"] / max(1, kt["estep_calls"])
@@ -405,7 +422,130 @@ def measure(capi, cfg, steps, warmup, rank, world, local_rank, stream, nthreads,
         res["config"]["collective"] = comm_kind
         if comm_note:
             res["config"]["collective_note"] = comm_note
+    if world > 1 or comm_kind:
+        res["config"]["per_rank"] = per_rank
     return res, ctx, model, (wkind, ckind, mu, L, family)
+
+
+def main_inproc(args):
+    """`bench.py --gpus N --inproc`: the N ranks are host threads of THIS process, one context (own stream, own M-step
+    pool) per GPU and the library's own collective between them -- what LIBCLUSTER_GPUS=N does inside learnBGMM /
+    learnVDP / learnGMC (lc_capi.cpp learn_sharded).  RCCL (ncclCommInitRank from every thread) when the box has N
+    GPUs, the host-staged transport with all shards on GPU 0 otherwise (RCCL refuses two ranks on one device).  Same
+    timing contract: W untimed + K timed steps between thread barriers, the MAX over ranks, one JSON line."""
+    import threading
+
+    import torch  # noqa: F401  (one HIP runtime per process: capi binds to the copy torch loads)
+
+    from libcluster_amd import build, capi
+
+    if not capi.LIB_PATH.exists():
+        build.build()
+    world = args.gpus
+    cfg = dict(CONFIGS[args.config])
+    if args.rows:
+        cfg["N"] = args.rows
+    ndev = torch.cuda.device_count()
+    rccl = ndev >= world and world > 1 and args.comm == "native" and not os.environ.get("LC_ALL_RANKS_ON_GPU0")
+    uid = capi.comm_unique_id() if rccl else None
+    name = f"bench_inproc_{os.getpid()}"
+    cpus = sorted(os.sched_getaffinity(0))
+    per = max(1, len(cpus) // world)
+    nthreads = int(os.environ.get("LC_BENCH_THREADS", max(1, min(32, per))))
+    bar = threading.Barrier(world)
+    out, errs = [None] * world, [None] * world
+
+    class ThreadDist:  # the two things measure() asks of torch.distributed, between threads
+        def __init__(self, r):
+            self.r = r
+
+        def barrier(self):
+            bar.wait()
+
+        def get_backend(self):
+            return "threads"
+
+        def all_reduce(self, t, op=None):
+            out[self.r] = float(t[0])
+            bar.wait()
+            t[0] = max(out)
+            bar.wait()
+
+        def all_gather_object(self, lst, obj):
+            out[self.r] = obj
+            bar.wait()
+            lst[:] = list(out)
+            bar.wait()
+
+        class ReduceOp:
+            MAX = "max"
+
+    def worker(r):
+        try:
+            if per * world <= len(cpus):
+                os.sched_setaffinity(0, cpus[r * per:(r + 1) * per])  # (tid 0 = the calling thread)
+            dev = r if rccl else 0
+
+            def comm(ctx):
+                if world == 1:
+                    return None, None
+                if rccl:
+                    ctx.comm_init_rccl(uid, r, world)
+                else:
+                    ctx.comm_init_host(name, r, world)
+                got = ctx.allreduce([r + 1.0, 1.0, -0.25 * (r + 1)])
+                tot = 0.5 * world * (world + 1)
+                if not np.array_equal(got, [tot, float(world), -0.25 * tot]):
+                    raise RuntimeError(f"all-reduce self-check returned {got.tolist()}")
+                return ctx.comm_info()["kind"], None
+
+            class T:  # measure() only needs .tensor / .float64 for the max-over-ranks of one number
+                float64 = "f64"
+
+                @staticmethod
+                def tensor(v, dtype=None, device=None):
+                    class V(list):
+                        def item(self):
+                            return self[0]
+                    return V(v)
+
+                class cuda:
+                    @staticmethod
+                    def synchronize():
+                        pass
+
+            d = ThreadDist(r)
+            res, ctx, model, _ = measure(capi, cfg, args.steps, args.warmup, r, world, dev, None, nthreads, comm, d, T)
+            errs[r] = (res, ctx, model)
+        except BaseException as e:  # noqa: BLE001
+            errs[r] = e
+            bar.abort()
+
+    ths = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    bad = [e for e in errs if isinstance(e, BaseException)]
+    if bad:
+        first = [e for e in bad if not isinstance(e, threading.BrokenBarrierError)] or bad
+        print(f"bench --inproc failed: {first[0]!r}", file=sys.stderr)
+        return 1
+    res = errs[0][0]
+    res["config"]["parallelism"] += f"; ONE process, {world} host threads (one context per GPU)"
+    line = {
+        "metric": "E-step data-points/sec (full VBEM iteration: suff-stats + M-step + E-step)",
+        "value": res["value"], "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic", "config": res["config"], "free_energy": res["free_energy"],
+        "kernels": res["kernels"], "roofline": res["roofline"],
+    }
+    print(json.dumps(line), flush=True)
+    for _, ctx, model in errs:
+        if model is not None:
+            model.close()
+        ctx.close()
+    return 0
 
 
 def main():
@@ -422,8 +562,14 @@ def main():
     ap.add_argument("--parity-rows", type=int, default=1_000_000, help="N_par of SURVEY 8(d)")
     ap.add_argument("--comm", default="native", choices=["native", "torch"],
                     help="multi-GPU all-reduce: the library's own RCCL collective, or the torch.distributed hook")
+    ap.add_argument("--inproc", action="store_true",
+                    help="one process drives the N GPUs from N host threads (the LIBCLUSTER_GPUS mode of the learners: "
+                         "one context, stream and M-step pool per GPU, ncclCommInitRank per thread) instead of one "
+                         "process per GPU")
     args = ap.parse_args()
 
+    if args.inproc:
+        raise SystemExit(main_inproc(args))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
@@ -431,6 +577,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s)")
+    if world > 1:
+        # this rank's slice of the CPUs the job may use: its Python thread and the M-step pool the library starts (threads
+        # inherit the mask) stay off the other ranks' cores
+        cpus = sorted(os.sched_getaffinity(0))
+        per = len(cpus) // world
+        if per >= 1:
+            os.sched_setaffinity(0, cpus[rank * per:(rank + 1) * per])
     import torch
 
     if os.environ.get("LC_ALL_RANKS_ON_GPU0"):  # multi-rank smoke test on a 1-GPU box

@@ -199,6 +199,15 @@ int lc_ctx_timing_get(lc_ctx* ctx, double* estep_ms, int64_t* estep_calls, doubl
                       int64_t* suffstat_calls);
 /* launches of the fused pass (small observations, D <= 16: vbexpectation + the next iteration's updateSS in one kernel) */
 int lc_ctx_timing_get_fused(lc_ctx* ctx, double* fused_ms, int64_t* fused_calls);
+/* Everything the context timed since the last reset, for the per-rank report of a multi-GPU run (the loop over groups
+ * of src/cluster.cpp:207-223, one rank per GPU): out[0..LC_TIMING_FIELDS-1] =
+ *   0 estep_ms  1 estep_calls  2 suffstat_ms  3 suffstat_calls  4 fused_ms  5 fused_calls
+ *   6 allreduce_ms  7 allreduce_calls   (events around the exchange step: the sum + the wait for the slowest rank)
+ *   8 host_stats_ms  9 host_mstep_ms  10 host_estep_ms  11 host_fenergy_ms  12 host_iters
+ *     (host wall time per phase of the VBEM iterations: statistics pass + weights update, cluster M-step + parameter
+ *      packing, E-step, free energy) */
+#define LC_TIMING_FIELDS 13
+int lc_ctx_timing_get_all(lc_ctx* ctx, double* out, int n);
 
 /* ======================================================================== *
  * Variational Bayes EM on a context (vbem, cluster.cpp:177-239).

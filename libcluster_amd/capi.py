@@ -502,6 +502,18 @@ class Context:
         return {"estep_ms": a.value, "estep_calls": na.value, "suffstat_ms": b.value, "suffstat_calls": nb.value,
                 "fused_ms": f.value, "fused_calls": nf.value}
 
+    TIMING_FIELDS = ("estep_ms", "estep_calls", "suffstat_ms", "suffstat_calls", "fused_ms", "fused_calls",
+                     "allreduce_ms", "allreduce_calls", "host_stats_ms", "host_mstep_ms", "host_estep_ms",
+                     "host_fenergy_ms", "host_iters")
+
+    def timing_get_all(self):
+        """Kernel, collective and host-phase times since the last reset (lc_ctx_timing_get_all)."""
+        out = (C.c_double * len(self.TIMING_FIELDS))()
+        fn = lib().lc_ctx_timing_get_all
+        fn.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
+        check(fn(self._h, out, len(self.TIMING_FIELDS)))
+        return {k: (int(v) if k.endswith(("_calls", "_iters")) else float(v)) for k, v in zip(self.TIMING_FIELDS, out)}
+
     def synchronize(self):
         check(lib().lc_ctx_synchronize(self._h))
 

@@ -674,6 +674,19 @@ int lc_ctx_timing_get_fused(lc_ctx* ctx, double* fused_ms, int64_t* fused_calls)
   });
 }
 
+int lc_ctx_timing_get_all(lc_ctx* ctx, double* out, int n) {
+  return guarded([&] {
+    need(ctx, "ctx");
+    need(out, "out");
+    const lcc::KernelTimes t = ctx->impl.timing_get();
+    const double v[LC_TIMING_FIELDS] = {t.estep_ms, (double)t.estep_calls, t.suffstat_ms, (double)t.suffstat_calls,
+                                        t.fused_ms, (double)t.fused_calls, t.allreduce_ms, (double)t.allreduce_calls,
+                                        t.host_stats_ms, t.host_mstep_ms, t.host_estep_ms, t.host_fenergy_ms,
+                                        (double)t.host_iters};
+    for (int i = 0; i < n && i < LC_TIMING_FIELDS; ++i) out[i] = v[i];
+  });
+}
+
 // ---------------------------------------------------------------------------
 int lc_vbem(lc_ctx* ctx, lc_model** model, int wkind, int ckind, double wprior, double clusterprior, int maxit,
             int sparse, int fixed_iters, int verbose, unsigned nthreads, double* F, int* niter, double* Ftrace,

@@ -16,6 +16,8 @@
 #include <mutex>
 #include <stdexcept>
 #include <thread>
+#include <vector>
+#include <string>
 
 namespace lcm {
 
@@ -48,10 +50,28 @@ RcclApi& rccl() {
   std::call_once(once, [] {
     // multi-process GPU work on hosts whose driver only supports dmabuf IPC (hipIpcGetMemHandle fails otherwise)
     setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
-    const char* names[] = {std::getenv("LC_RCCL_LIBRARY"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* n : names) {
-      if (!n || !*n) continue;
-      api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    // Where to look: an explicit path, the loader's search path, and then NEXT TO THE HIP RUNTIME THIS PROCESS
+    // ALREADY USES (a pure C++ caller linked against /opt/rocm/lib/libamdhip64.so, a Python caller on the copy a
+    // PyTorch wheel bundles: RCCL must come from the same ROCm tree as the runtime it is going to drive)
+    std::vector<std::string> names;
+    if (const char* e = std::getenv("LC_RCCL_LIBRARY"); e && *e) names.push_back(e);
+    names.push_back("librccl.so.1");
+    names.push_back("librccl.so");
+    {
+      Dl_info info{};
+      if (dladdr(reinterpret_cast<const void*>(&hipGetDeviceCount), &info) && info.dli_fname) {
+        std::string dir(info.dli_fname);
+        const size_t slash = dir.rfind('/');
+        if (slash != std::string::npos) {
+          dir.resize(slash + 1);
+          names.push_back(dir + "librccl.so.1");
+          names.push_back(dir + "librccl.so");
+        }
+      }
+    }
+    names.push_back("/opt/rocm/lib/librccl.so.1");
+    for (const std::string& n : names) {
+      api.handle = dlopen(n.c_str(), RTLD_NOW | RTLD_GLOBAL);
       if (api.handle) break;
       api.error = dlerror();
     }

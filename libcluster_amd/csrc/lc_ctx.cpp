@@ -760,13 +760,24 @@ void Context::qz_split_from(const Context& sub, const RowSelection& sel, int k) 
 // hot path
 // ---------------------------------------------------------------------------
 void Context::allreduce(double* dbuf, int64_t count) {
+  if (!comm_ && !ar_fn_) return;
+  EvPair ev{};
+  if (timing_) {  // events around the exchange step: the sum plus the wait for the slowest rank
+    LC_HIP(hipEventCreate(&ev.a));
+    LC_HIP(hipEventCreate(&ev.b));
+    ev.kind = 3;
+    LC_HIP(hipEventRecord(ev.a, stream_));
+  }
   if (comm_) {  // RCCL / host-staged sum on this context's stream
     comm_->allreduce_sum(dbuf, count, stream_);
-    return;
+  } else {
+    const int rc = ar_fn_(ar_user_, dbuf, count, (void*)stream_);
+    if (rc != 0) throw std::runtime_error("all-reduce hook failed with status " + std::to_string(rc));
   }
-  if (!ar_fn_) return;
-  const int rc = ar_fn_(ar_user_, dbuf, count, (void*)stream_);
-  if (rc != 0) throw std::runtime_error("all-reduce hook failed with status " + std::to_string(rc));
+  if (timing_) {
+    LC_HIP(hipEventRecord(ev.b, stream_));
+    pending_.push_back(ev);
+  }
 }
 
 double Context::allreduce_value(double v) {
@@ -1322,8 +1333,16 @@ int Context::estep_cache(int K, const double* A, const double* m, const double* 
     dc_tagA_.resize((size_t)K);
     dc_tagm_.resize((size_t)K);
   }
-  // journal: what is about to be overwritten (a column is saved once per journal)
-  if (dc_journal_)
+  // journal: what is about to be overwritten (a column is saved once per journal).  Two steps, because the outcome must
+  // be the same on every rank: reserve the columns (which ones is a function of the replicated M-step, hence the same
+  // list everywhere; under group sharding ranks hold different numbers of rows, so ONE of them may run out of memory),
+  // agree on success with one all-reduced flag, and only then copy.  A failure anywhere is CacheNoRoom everywhere, before
+  // anything has been overwritten: vbem falls back to the ordinary E-step on all ranks together.
+  if (dc_journal_) {
+    std::vector<std::unique_ptr<SavedColumn>> fresh;
+    bool ok = true;
+    std::string why;
+    static const char* fail_rank = std::getenv("LC_TEST_JOURNAL_FAIL_RANK");  // tests: this rank cannot reserve
     for (int k : changed) {
       if (k >= dc_K_ || k >= dc_jK0_) continue;  // nothing valid there / not part of the state to return to
       bool done = false;
@@ -1331,18 +1350,34 @@ int Context::estep_cache(int K, const double* A, const double* m, const double* 
       if (done) continue;
       auto sv = std::make_unique<SavedColumn>();
       sv->col = k;
-      try {
-        sv->buf.reserve(NPs);
-      } catch (const HipFailure& e) {  // (nothing has been overwritten yet)
-        throw CacheNoRoom(std::string("no room for the distance cache's journal: ") + e.what());
+      if (ok) {
+        try {
+          if (fail_rank) {
+            const char* er = std::getenv("RANK");  // (hook-based runs have no communicator to ask)
+            if (std::atoi(fail_rank) == (comm_ ? comm_->rank() : er ? std::atoi(er) : 0)) throw HipFailure("LC_TEST_JOURNAL_FAIL_RANK");
+          }
+          sv->buf.reserve(NPs);
+        } catch (const HipFailure& e) {
+          ok = false;
+          why = e.what();
+        }
       }
-      if (NP_ > 0)
-        LC_HIP(hipMemcpyAsync(sv->buf.p, dc_slab_.p + (size_t)k * NP_, (size_t)NP_ * sizeof(double), hipMemcpyDeviceToDevice,
-                              stream_));
-      sv->A = dc_tagA_[(size_t)k];
-      sv->m = dc_tagm_[(size_t)k];
-      dc_saved_.push_back(std::move(sv));
+      fresh.push_back(std::move(sv));
     }
+    if (!fresh.empty()) {
+      if (allreduce_value(ok ? 0.0 : 1.0) > 0.0)
+        throw CacheNoRoom("no room for the distance cache's journal" + (why.empty() ? std::string(" on another rank") : ": " + why));
+      for (auto& sv : fresh) {
+        const int k = sv->col;
+        if (NP_ > 0)
+          LC_HIP(hipMemcpyAsync(sv->buf.p, dc_slab_.p + (size_t)k * NP_, (size_t)NP_ * sizeof(double), hipMemcpyDeviceToDevice,
+                                stream_));
+        sv->A = dc_tagA_[(size_t)k];
+        sv->m = dc_tagm_[(size_t)k];
+        dc_saved_.push_back(std::move(sv));
+      }
+    }
+  }
   // recompute: raw E-step (c = 0: the columns are -0.5 d^2), straight into the slab when the columns are adjacent
   if (nch > 0) {
     const bool adjacent = changed.back() - changed.front() + 1 == nch;
@@ -1738,7 +1773,10 @@ KernelTimes Context::timing_get() {
   for (auto& p : pending_) {
     float ms = 0.f;
     LC_HIP(hipEventElapsedTime(&ms, p.a, p.b));
-    if (p.kind == 2) {
+    if (p.kind == 3) {
+      times_.allreduce_ms += ms;
+      times_.allreduce_calls += 1;
+    } else if (p.kind == 2) {
       times_.fused_ms += ms;
       times_.fused_calls += 1;
     } else if (p.kind == 0) {

@@ -87,6 +87,13 @@ void cache_release_thread();
 struct KernelTimes {
   double estep_ms = 0, suffstat_ms = 0, fused_ms = 0;  // fused: E-step + statistics in one launch (small observations)
   int64_t estep_calls = 0, suffstat_calls = 0, fused_calls = 0;
+  // the exchange step (events around the collective on the context's stream: the sum itself plus the wait for the
+  // slowest rank to arrive) and the host's wall time per phase of a VBEM iteration (vbem): what a multi-GPU run
+  // needs to tell a slow collective from a slow M-step from a straggling rank
+  double allreduce_ms = 0;
+  int64_t allreduce_calls = 0;
+  double host_stats_ms = 0, host_mstep_ms = 0, host_estep_ms = 0, host_fenergy_ms = 0;
+  int64_t host_iters = 0;
 };
 
 class Context {
@@ -233,6 +240,14 @@ class Context {
 
   // ---- timing ---------------------------------------------------------------
   void timing_enable(bool on) { timing_ = on; }
+  bool timing_enabled() const { return timing_; }
+  void timing_host_phases(double stats_ms, double mstep_ms, double estep_ms, double fenergy_ms) {  // one VBEM iteration
+    times_.host_stats_ms += stats_ms;
+    times_.host_mstep_ms += mstep_ms;
+    times_.host_estep_ms += estep_ms;
+    times_.host_fenergy_ms += fenergy_ms;
+    times_.host_iters += 1;
+  }
   KernelTimes timing_get();  // resolves pending events (synchronises the stream)
   void timing_reset();
 

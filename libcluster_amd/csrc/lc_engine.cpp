@@ -343,7 +343,7 @@ double vbem(lcc::Context& ctx, Model& model, const VbemOptions& opt) {
         nre = ctx.estep_cache(K, A.data(), m.data(), c.data(), &Fz, opt.want_ll ? model.LLk.data() : nullptr, opt.inc->tol,
                               &stale);
       } catch (const lcc::CacheNoRoom&) {
-        // (every rank holds the same number of rows within one, so every rank gets here at the same K)
+        // (the room check and the journal reservation are agreed on by all ranks: every rank gets here together)
         ctx.dcache_release();
         opt.inc->on = false;
         opt.inc->no_room = true;
@@ -380,6 +380,7 @@ double vbem(lcc::Context& ctx, Model& model, const VbemOptions& opt) {
     if (trace_phases)
       std::cerr << "[vbem] suffstat+weights " << ms(t0, t1) << " ms, M-step+pack " << ms(t1, t2) << " ms, E-step "
                 << ms(t2, t3) << " ms, fenergy " << ms(t3, now()) << " ms" << std::endl;
+    if (ctx.timing_enabled()) ctx.timing_host_phases(ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, now()));
     ++done;
 
     if (opt.fixed_iters >= 0) {

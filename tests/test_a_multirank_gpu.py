@@ -50,6 +50,28 @@ def test_two_rank_cluster_equals_single_rank(lib, mode, family, D):
     np.testing.assert_allclose(one["N"], two["N"], rtol=1e-9)
 
 
+@pytest.mark.parametrize("mode", ["rows", "groups"])
+def test_one_rank_failing_to_journal_a_cache_column_is_a_joint_fallback(lib, mode):
+    """The distance cache's journal columns are reserved by every rank and the outcome is agreed on with one all-reduced
+    flag: when ONE rank cannot reserve (LC_TEST_JOURNAL_FAIL_RANK: rank 1 pretends to be out of memory -- under group
+    sharding ranks hold different numbers of rows), BOTH ranks leave the cache together and finish on the ordinary
+    kernels; the collectives stay matched and the rounds, K and F are those of a single rank."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = str(ROOT / "tools" / "dist_cluster_check.py")
+    args = ["30000", "24", "5", mode, "GaussWish"]
+    one = _run([sys.executable, script, *args])
+    two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                "--master-addr", "127.0.0.1", "--master-port", str(port), script, *args],
+               {"LC_DIST_BACKEND": "gloo", "LC_ALL_RANKS_ON_GPU0": "1", "LC_TEST_JOURNAL_FAIL_RANK": "1"})
+    assert two["world"] == 2 and one["K"] == two["K"] >= 5
+    assert [k for k, _ in one["rounds"]] == [k for k, _ in two["rounds"]]
+    for (_, a), (_, b) in zip(one["rounds"], two["rounds"]):
+        np.testing.assert_allclose(a, b, rtol=1e-10)
+    assert abs(one["F"] - two["F"]) <= 1e-10 * abs(one["F"])
+
+
 @pytest.mark.parametrize("model", ["scm", "mcm"])
 def test_two_rank_topic_model_equals_single_rank(lib, model):
     """learnSCM / learnMCM with whole groups (and their documents) per rank: all-reduced cluster statistics, N_tk,

@@ -295,6 +295,45 @@ def test_bench_starts_its_own_ranks(lib):
     line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["collective"] == "host-shm"
     assert line["config"]["rows_per_gpu"] == 200_000 and line["value"] > 0
+    _check_per_rank(line, 2)
+
+
+def _check_per_rank(line, world):
+    """The per-rank report a first real multi-GPU run is diagnosed with: every rank's kernel times, its exchange step
+    (events around the collective), host M-step and residual wait, consistent with the step time."""
+    pr = line["config"]["per_rank"]
+    assert [r["rank"] for r in pr] == list(range(world))
+    for r in pr:
+        for key in ("step_ms", "estep_ms", "suffstat_ms", "allreduce_ms", "mstep_ms", "wait_ms", "mstep_threads", "cpus"):
+            assert key in r and np.isfinite(r[key]) and r[key] >= 0, (key, r)
+        assert r["allreduce_calls_per_step"] >= 1          # statistics (+ F_z) are summed over ranks every iteration
+        assert r["allreduce_ms"] > 0 and r["mstep_ms"] > 0
+        assert r["step_ms"] <= line["ms_per_step"] * 1.001 + 1e-6  # the line carries the MAX over ranks
+        busy = r.get("fused_ms", 0.0) + r["estep_ms"] + r["suffstat_ms"]
+        assert busy + r["mstep_ms"] <= 1.5 * r["step_ms"] + 1.0
+
+
+@pytest.mark.gpu
+def test_bench_inproc_threads_drive_the_shards(lib):
+    """`bench.py --gpus 2 --inproc`: ONE process, one host thread + context per shard (the LIBCLUSTER_GPUS mode), the
+    library's collective between them (host-staged here: both shards on GPU 0); the same free energy as the
+    process-per-GPU mode on the same rows."""
+    import json
+    import sys
+
+    e = dict(os.environ)
+    e.update({"LC_DIST_BACKEND": "gloo", "LC_ALL_RANKS_ON_GPU0": "1"})
+    e.pop("WORLD_SIZE", None)
+    lines = []
+    for extra in (["--inproc"], []):
+        r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--config", "tiny", "--steps", "3",
+                            "--warmup", "1", *extra], capture_output=True, text=True, timeout=900, env=e, cwd=str(ROOT))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        lines.append(json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1]))
+    a, b = lines
+    assert a["n_gpus"] == 2 and a["config"]["collective"] == "host-shm" and "ONE process" in a["config"]["parallelism"]
+    _check_per_rank(a, 2)
+    assert abs(a["free_energy"] - b["free_energy"]) <= 1e-12 * abs(b["free_energy"])
 
 
 @pytest.mark.gpu
