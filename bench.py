@@ -325,7 +325,21 @@ def measure(capi, cfg, steps, warmup, rank, world, local_rank, stream, nthreads,
     ckind = {"GaussWish": capi.C_GAUSSWISH, "NormGamma": capi.C_NORMGAMMA, "ExpGamma": capi.C_EXPGAMMA}[family]
     mu, L = mixture(D, K, cfg["seed"], family)
     ctx = capi.Context(local_rank, stream)
-    if J == 1:
+    if J == 1 and D > 128:
+        # (the on-device generator stops at D = 128) the same mixture drawn on the host and uploaded once, outside the
+        # timed region; initial responsibilities = smoothed labels, as lc_ctx_synth leaves them
+        rng = np.random.default_rng([cfg["seed"], rank])
+        z = rng.integers(0, K, N)
+        X = np.empty((N, D))
+        for k in range(K):
+            idx = np.flatnonzero(z == k)
+            X[idx] = mu[k] + rng.standard_normal((idx.size, D)) @ L[k].T
+        q0 = np.full((N, K), 0.1 / (K - 1))
+        q0[np.arange(N), z] = 0.9
+        ctx.set_data(X)
+        ctx.set_qz(q0)
+        del X, q0
+    elif J == 1:
         ctx.synth(N, D, K, mu, L, cfg["seed"], rank * N, 0.9)  # this rank's row block of the one stream
     else:
         gids = list(range(rank * J, (rank + 1) * J))  # whole groups per rank
