@@ -512,6 +512,235 @@ __global__ void __launch_bounds__(256, (DP <= 64 ? (HALF != 0 ? 3 : 2) : (HALF !
   }
 }
 
+// ===========================================================================
+// Sufficient statistics as a feature GEMM (D = 64, 17 ... 32 clusters, dense)
+// ===========================================================================
+// suffstat_kernel forms q_k x per cluster: 9 fp64 VALU instructions per 36 MFMAs, and fp64 VALU shares the pipe with
+// the fp64 MFMAs (every such instruction costs about 8 matrix-pipe cycles) -- its ceiling is ~84 % of the
+// pipe.  Here the cluster index moves into the MFMA:  T = Q^T Phi(x), Phi(x) = [x_i x_j (i <= j) | x_i | 1], so that
+//   A operand = q[row 4 st + hi][cluster 4 c + lo2]          (one LDS read per cluster quad and step, all tiles share it)
+//   B operand = x[row][4 ia + lo2] * x[row][4 ja + blk]      (ONE multiply per 16 features, shared by ALL cluster quads)
+//   D[i = hi][j = lo2] of block blk = S_{4c + hi}[4 ia + lo2][4 ja + blk]
+// i.e. one v_mul_f64 per NQ = K / 4 MFMAs (1 : 8 at K = 32, against 1 : 4) and nothing else on the VALU: s_k and N_k
+// are the features x_i * 1 and 1 * 1 (a column of ones rides in the staged X rows).  A "tile" is 16 features: the 136
+// 4 x 4 patches (ia <= ja) of the symmetric 64 x 64 matrix, 4 tiles of s_k, 1 of N_k = 141; a wave owns 9 tiles x NQ
+// quads (<= 72 accumulators), 16 waves = 4 blocks cover a row chunk (as the 4 cluster slices of suffstat_kernel do).
+// Every tile reads its two operand fragments itself (LDS broadcast reads are cheap; no operand sharing to schedule).
+// Same partial records, same reduction, deterministic; the patch on the diagonal computes both halves of its 4 x 4
+// block from commuted products, so S_k comes out exactly symmetric.
+constexpr int FT_TPW = 9, FT_WAVES = 16, FT_TILES = 136 + 4 + 1;
+inline bool ss_feat_eligible(int DP, int K) {
+  static const bool off = getenv("LC_SS_FEAT") && atoi(getenv("LC_SS_FEAT")) == 0;
+  return !off && DP == 64 && K > 16 && K <= 32;
+}
+template <int NQ>
+__global__ void __launch_bounds__(256, 2) suffstat_feat_kernel(SuffstatLaunch a) {
+  constexpr int DP = 64, BR = SS_BR, LD = lds_row_stride(DP), QLD = 36, XBUF = BR * LD, QBUF = BR * QLD;  // (QLD: the two rows of a half-wave 8 banks apart)
+  constexpr int ONE = DP;  // column of the staged rows that holds 1.0
+  static_assert(LD > DP, "the staged rows need a spare column");
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* xbuf = lds;              // [2][BR][LD]
+  double* qbuf = lds + 2 * XBUF;   // [2][BR][QLD]   q[row][cluster], clusters >= K are zero
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hi = lane >> 4, blk = (lane >> 2) & 3, lo2 = lane & 3;
+  const int K = a.K;
+  int chunk, slice;
+  {  // (chunk, slice) placement as in suffstat_kernel: the four slices of a chunk back-to-back on one XCD
+    const int nslice = FT_WAVES / 4, nchunks = a.nchunks, b = blockIdx.x, full = (nchunks / 8) * 8;
+    if (b < full * nslice) {
+      const int xcd = b & 7, seq = b >> 3;
+      chunk = (seq / nslice) * 8 + xcd;
+      slice = seq % nslice;
+    } else {
+      const int t = b - full * nslice;
+      chunk = full + t / nslice;
+      slice = t % nslice;
+    }
+  }
+  const int64_t r0 = (int64_t)chunk * a.chunk_rows;
+  const int64_t r1 = (r0 + a.chunk_rows) < a.NP ? (r0 + a.chunk_rows) : a.NP;
+  // this wave's tiles and, per lane, where their two operand fragments sit in a staged batch (in doubles, step 0)
+  const int T0 = (slice * 4 + wave) * FT_TPW;
+  const int nt = FT_TILES - T0 < FT_TPW ? (FT_TILES - T0 > 0 ? FT_TILES - T0 : 0) : FT_TPW;
+  int offU[FT_TPW], offW[FT_TPW];
+#pragma unroll
+  for (int t = 0; t < FT_TPW; ++t) {
+    const int T = T0 + t;
+    int cu = ONE, cw = ONE;  // N_k tile (and the idle ones): 1 * 1
+    if (T < 136) {
+      int ja = 0;
+      while ((ja + 1) * (ja + 2) / 2 <= T) ++ja;
+      const int ia = T - ja * (ja + 1) / 2;
+      cu = 4 * ia + lo2;
+      cw = 4 * ja + blk;
+    } else if (T < 140) {
+      cu = 16 * (T - 136) + 4 * blk + lo2;
+    }
+    offU[t] = hi * LD + cu;
+    offW[t] = hi * LD + cw;
+  }
+  double acc[FT_TPW][NQ];
+#pragma unroll
+  for (int t = 0; t < FT_TPW; ++t)
+#pragma unroll
+    for (int c = 0; c < NQ; ++c) acc[t][c] = 0.0;
+
+  // ---- staging: registers hold the next batch while the current one is consumed
+  constexpr int NV2 = BR * DP / 2, NPRE = NV2 / 256;  // double2 per thread
+  static_assert(NPRE * 256 == NV2, "batch size");
+  double pre[NPRE][2], qpre[4];
+  // this thread's cluster column and row quad of the q batch (32 x 8 = 256): clusters fastest, so that the 16-lane
+  // groups of a ds_write_b64 fill one LDS row (rows fastest put all eight row quads of a group on one bank: 8-way)
+  const int qcl = tid & 31, qrq = tid >> 5;
+  // X batch: thread -> 16 bytes of NPRE consecutive rows (row quad tid / 32, column pair tid % 32): one address register
+  // on either side, the rows are immediate offsets (512 bytes apart in memory, LD * 8 in LDS)
+  static_assert(NPRE == 4, "one row quad per 32 threads");
+  const int xrq = tid >> 5, xc2 = tid & 31;
+  double* const xdst = xbuf + (4 * xrq) * LD + 2 * xc2;
+  double* const qdst = qbuf + (4 * qrq) * QLD + qcl;
+  auto gload = [&](int64_t b0) {
+    const int64_t xrow = b0 + 4 * xrq;
+    const double* src = a.X + xrow * DP + 2 * xc2;
+    const bool xok = xrow < r1;  // (a row quad lies inside the chunk or outside it: chunk_rows is a multiple of 4)
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) {
+      double2 v = make_double2(0.0, 0.0);
+      if (xok) v = *reinterpret_cast<const double2*>(src + i * DP);
+      pre[i][0] = v.x;
+      pre[i][1] = v.y;
+    }
+    const int64_t qrow = b0 + 4 * qrq;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) qpre[i] = 0.0;
+    if (qcl < K && qrow < r1) {
+      const double2* qp = reinterpret_cast<const double2*>(a.qZ + (int64_t)qcl * a.ldq + qrow);
+      const double2 v0 = qp[0], v1 = qp[1];
+      qpre[0] = v0.x, qpre[1] = v0.y, qpre[2] = v1.x, qpre[3] = v1.y;
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i)
+      *reinterpret_cast<double2*>(xdst + buf * XBUF + i * LD) = make_double2(pre[i][0], pre[i][1]);
+    if (qcl < 4 * NQ) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) qdst[buf * QBUF + i * QLD] = qpre[i];
+    }
+  };
+  if (tid < 2 * BR) xbuf[(tid / BR) * XBUF + (tid % BR) * LD + ONE] = 1.0;
+  if (r0 < r1) {
+    gload(r0);
+    lstore(0);
+  }
+  __syncthreads();
+  // per-lane LDS addresses of the fragments in buffer 0, step 0: buffer and step are compile-time offsets of the reads
+  const double* pu[FT_TPW];
+  const double* pw[FT_TPW];
+#pragma unroll
+  for (int t = 0; t < FT_TPW; ++t) {
+    pu[t] = xbuf + offU[t];
+    pw[t] = xbuf + offW[t];
+  }
+  const double* pq = qbuf + hi * QLD + lo2;
+  // One batch from buffer B.  All BR / 4 steps and all FT_TPW tiles run (rows past the chunk end were staged as zeros
+  // with q = 0; the three idle tiles of the last wave accumulate 1 * 1 products nobody reads): nothing in the loop
+  // depends on run-time counts.  The next tile's fragments -- behind the last tile the next step's first tile and its
+  // q quads -- are issued BEFORE this tile's MFMAs and arrive under them (two register sets that swap roles; the fences
+  // keep hipcc from sinking the reads to their uses).
+  auto batch = [&](auto bsel) {
+    constexpr int B = decltype(bsel)::value, XO = B * XBUF, QO = B * QBUF;
+    double qa[2][NQ], u[2], w[2];
+    u[0] = pu[0][XO];
+    w[0] = pw[0][XO];
+#pragma unroll
+    for (int c = 0; c < NQ; ++c) qa[0][c] = pq[QO + 4 * c];
+#pragma unroll
+    for (int st = 0; st < BR / 4; ++st) {
+#pragma unroll
+      for (int t = 0; t < FT_TPW; ++t) {
+        const int cur = (st * FT_TPW + t) & 1, nxt = cur ^ 1;
+        const double p = u[cur] * w[cur];
+        if (t + 1 < FT_TPW) {
+          u[nxt] = pu[t + 1][XO + st * 4 * LD];
+          w[nxt] = pw[t + 1][XO + st * 4 * LD];
+        } else if (st + 1 < BR / 4) {
+          u[nxt] = pu[0][XO + (st + 1) * 4 * LD];
+          w[nxt] = pw[0][XO + (st + 1) * 4 * LD];
+#pragma unroll
+          for (int c = 0; c < NQ; ++c) qa[(st + 1) & 1][c] = pq[QO + (st + 1) * 4 * QLD + 4 * c];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < NQ; ++c) acc[t][c] = mfma4(qa[st & 1][c], p, acc[t][c]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+  for (int64_t b0 = r0; b0 < r1; b0 += 2 * BR) {  // two batches per trip: the buffer index is a compile-time constant
+    const bool more1 = b0 + BR < r1, more2 = b0 + 2 * BR < r1;
+    if (more1) gload(b0 + BR);
+    batch(std::integral_constant<int, 0>{});
+    if (more1) lstore(1);
+    __syncthreads();
+    if (!more1) break;
+    if (more2) gload(b0 + 2 * BR);
+    batch(std::integral_constant<int, 1>{});
+    if (more2) lstore(0);
+    __syncthreads();
+  }
+  if (nt == 0) return;
+
+  // ---- partial records: [N_k, s_k[DP], S_k[DP x DP]] per (chunk, cluster), as suffstat_kernel writes them
+  const int64_t SS = 1 + (int64_t)DP + (int64_t)DP * DP;
+#pragma unroll
+  for (int t = 0; t < FT_TPW; ++t) {
+    if (t >= nt) continue;
+    const int T = T0 + t;
+    int ia = 0, ja = 0;
+    if (T < 136) {
+      while ((ja + 1) * (ja + 2) / 2 <= T) ++ja;
+      ia = T - ja * (ja + 1) / 2;
+    }
+#pragma unroll
+    for (int c = 0; c < NQ; ++c) {
+      const int k = 4 * c + hi;
+      if (k >= K) continue;
+      double* out = a.partial + ((int64_t)chunk * a.KR + k) * SS;
+      const double v = acc[t][c];
+      if (T < 136) {
+        const int gi = 4 * ia + lo2, gj = 4 * ja + blk;
+        double* S = out + 1 + DP;
+        S[(int64_t)gi * DP + gj] = v;
+        S[(int64_t)gj * DP + gi] = v;
+      } else if (T < 140) {
+        out[1 + 16 * (T - 136) + 4 * blk + lo2] = v;
+      } else if (blk == 0 && lo2 == 0) {
+        out[0] = v;
+      }
+    }
+  }
+}
+
+template <int NQ>
+static hipError_t launch_ss_feat_q(const SuffstatLaunch& a, hipStream_t stream) {
+  constexpr int BR = SS_BR, LD = lds_row_stride(64), QLD = 36;
+  const size_t shmem = (size_t)(2 * BR * LD + 2 * BR * QLD) * sizeof(double);
+  SuffstatLaunch b = a;
+  b.nslice = FT_WAVES / 4;
+  if (b.KR < a.K) b.KR = a.K;
+  hipLaunchKernelGGL(suffstat_feat_kernel<NQ>, dim3((unsigned)(a.nchunks * (FT_WAVES / 4))), dim3(256), shmem, stream, b);
+  return hipGetLastError();
+}
+static hipError_t launch_ss_feat(const SuffstatLaunch& a, hipStream_t stream) {
+  switch ((a.K + 3) / 4) {
+    case 5: return launch_ss_feat_q<5>(a, stream);
+    case 6: return launch_ss_feat_q<6>(a, stream);
+    case 7: return launch_ss_feat_q<7>(a, stream);
+    case 8: return launch_ss_feat_q<8>(a, stream);
+  }
+  return hipErrorInvalidValue;
+}
+
 template <int DP>
 struct SSCfg;
 template <>
@@ -547,6 +776,7 @@ static int ss_row_classes(int active) { return active == 1 ? 4 : active == 2 ? 2
 int suffstat_extra_records(int DP, int K, bool skip_or_items, int* klast0) {
   if (klast0) *klast0 = K;
   if (DP > 128 || skip_or_items || K < 1) return 0;
+  if (ss_feat_eligible(DP, K)) return 0;  // (the feature-GEMM kernel covers any K of its range with the same 16 waves)
   if (DP > 80 && getenv("LC_SS_WHOLE")) return 0;  // (the one-launch tuning variant has no row-split instance)
   const int cpw = ss_cpw(DP, K), kwaves = (K + cpw - 1) / cpw, nslice = (kwaves + 3) / 4;
   const int rs = ss_row_classes(kwaves - (nslice - 1) * 4);
@@ -691,6 +921,8 @@ hipError_t launch_suffstat(const SuffstatLaunch& a, hipStream_t stream) {
     const bool skip = a.skip_zero > 0 || (a.skip_zero == 0 && a.smask);
     return skip ? launch_ss_wide<true>(a, stream) : launch_ss_wide<false>(a, stream);
   }
+  if (ss_feat_eligible(a.DP, a.K) && !a.smask && !a.items && a.skip_zero <= 0 && a.KR <= a.K)
+    return launch_ss_feat(a, stream);
   const int cpw = ss_cpw(a.DP, a.K);
   switch (a.DP) {
     case 16:

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""The feature-GEMM statistics kernel (suffstat_feat_kernel, D = 64, 17..32 clusters) against the per-cluster kernel
+(LC_SS_FEAT=0) and numpy: N_k, s_k, S_k on ragged row counts and every cluster count of its range; then timing at the
+north-star shape.  Usage: tools/ssfeat_check.py [child]"""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+CASES = [(1000, 64, 17), (4099, 64, 20), (777, 50, 24), (30001, 64, 29), (65536, 64, 32), (123457, 61, 32), (31, 64, 18)]
+
+if len(sys.argv) > 1 and sys.argv[1] == "child":
+    import torch  # noqa: F401
+    from libcluster_amd import capi
+
+    out = []
+    for N, D, K in CASES:
+        rng = np.random.default_rng(N + K)
+        X = rng.normal(size=(N, D)) * 2.0 + rng.normal(size=(1, D))
+        q = rng.dirichlet(np.ones(K) * 0.3, N)
+        with capi.Context(0) as ctx:
+            ctx.set_data(X)
+            ctx.set_qz(q)
+            Nk, xs, xxs, Njk = ctx.suffstat()
+        rN = q.sum(0)
+        rs = q.T @ X
+        rS = np.einsum("nk,ni,nj->kij", q, X, X)
+        out.append(dict(case=[N, D, K], sym=bool(np.array_equal(xxs, np.transpose(xxs, (0, 2, 1)))),
+                        eN=float(np.max(np.abs(Nk - rN) / rN)), es=float(np.max(np.abs(xs - rs)) / np.max(np.abs(rs))),
+                        eS=float(np.max(np.abs(xxs - rS)) / np.max(np.abs(rS))),
+                        h=[float(Nk.sum()), float(xs.sum()), float(xxs.sum())]))
+    print("RESULT " + json.dumps(out))
+    sys.exit(0)
+
+res = {}
+for name, env in (("feat", {}), ("percluster", {"LC_SS_FEAT": "0"})):
+    e = dict(os.environ, **env)
+    p = subprocess.run([sys.executable, __file__, "child"], capture_output=True, text=True, env=e, timeout=900)
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")]
+    if p.returncode or not line:
+        print(name, "FAILED", p.stderr[-2000:])
+        sys.exit(1)
+    res[name] = json.loads(line[-1][7:])
+ok = True
+for a, b in zip(res["feat"], res["percluster"]):
+    good = a["sym"] and a["eN"] < 1e-12 and a["es"] < 1e-12 and a["eS"] < 1e-12
+    ok = ok and good
+    print(a["case"], "feat: sym", a["sym"], f"eN {a['eN']:.1e} es {a['es']:.1e} eS {a['eS']:.1e}", "| per-cluster:",
+          f"eN {b['eN']:.1e} es {b['es']:.1e} eS {b['eS']:.1e}", "OK" if good else "BAD")
+print("ALL OK" if ok else "FAILURES")
+for name, env in (("feat", {}), ("percluster", {"LC_SS_FEAT": "0"})):
+    e = dict(os.environ, **env)
+    p = subprocess.run([sys.executable, str(ROOT / "tools" / "variants.py"), "run", "--iters", "8", "default"], capture_output=True,
+                       text=True, env=e, timeout=900)
+    print(name, [ln for ln in p.stdout.splitlines() if ln.startswith("default")])
+sys.exit(0 if ok else 1)
