@@ -19,7 +19,9 @@ inline int padded_dim(int D) {
 // LDS row stride (doubles) of a staged X batch in the statistics kernels: DP + 16 puts the two rows a ds_read_b64
 // half-wave touches on disjoint banks when the stride is 16 mod 32; 48, 80 and 112 need 32 more for that (16 keeps
 // the stride it was tuned with)
-__host__ __device__ constexpr int lds_row_stride(int DP) { return DP > 16 && (DP + 16) % 32 != 16 ? DP + 32 : DP + 16; }
+// (DP = 16: no padding at all -- 32 dwords per row put the two rows of a half-wave on the two halves of the 64 banks;
+// the DP + 16 = 32 doubles of round 2 put them on the SAME banks: the bank conflicts of suffstat_kernel<16> in its profile)
+__host__ __device__ constexpr int lds_row_stride(int DP) { return DP == 16 ? 16 : (DP + 16) % 32 != 16 ? DP + 32 : DP + 16; }
 // wider observations are padded to a multiple of 64 columns: the separable (diagonal / exponential) families process
 // them in 128-column blocks with a possible half block at the end (any D), the Gauss-Wishart kernels in 64-column
 // panels / 64 x 64 whitener blocks

@@ -34,7 +34,12 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a) {
   constexpr int NREAD = NTILES + NT;
   constexpr int PF = 6;
   constexpr int PS = NTILES * 16 + DP;
-  constexpr int LD = DP + 2;  // row stride of the staged tile: conflict-free for both halves' fragment reads
+  // row stride of the staged tile (36 dwords).  E-step half: a half-wave reads rows lo4 = 0..15 at two columns -- 36 lo4
+  // mod 64 are sixteen different multiples of 4: conflict-free.  Statistics half: a half-wave reads all 16 columns of TWO
+  // rows, which must lie 32 banks apart: rows r and r + 8 do (8 x 36 = 4 x 64 + 32), consecutive rows do not (the bank
+  // conflicts of the round-2 profile) -- so a four-row step takes rows {t, t + 8, t + 4, t + 12} of a 16-row block (any
+  // four rows serve as the reduction index of the MFMA, as long as q is read for the same rows)
+  constexpr int LD = DP + 2;
   constexpr int R = 4;
   static_assert(4 * CPW <= FUSED_KMAX, "statistics accumulators");
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -162,13 +167,21 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a) {
     }
     // logsumexp and normalisation in the reference's order: max, sum exp(x - max), log + max, exp(x - logZ)
     {
+      // (without LL_k: ONE exponential per entry -- e = exp(log q~ - max) goes back into the lane's slot and q = e / sum(e);
+      //  the same sum and logZ, q within 2 ulp of exp(log q~ - logZ))
       double s = 0.0;
-      for (int k = 0; k < K; ++k) s += exp(qt[k * 256 + tid] - mymx);
+      const bool onexp = !a.want_ll;
+      for (int k = 0; k < K; ++k) {
+        const double e = exp(qt[k * 256 + tid] - mymx);
+        s += e;
+        if (onexp) qt[k * 256 + tid] = e;
+      }
       const double logZ = log(s) + mymx;
+      const double inv = 1.0 / s;
       double* qp = a.qZ + row0 + tid;
       for (int k = 0; k < K; ++k) {
         const double lq = qt[k * 256 + tid];
-        double q = exp(lq - logZ);
+        double q = onexp ? lq * inv : exp(lq - logZ);
         if (!myok || !myrow) q = 0.0;
         if (myok) qp[(int64_t)k * a.ldq] = q;
         qt[k * 256 + tid] = q;
@@ -183,18 +196,20 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a) {
 
     // ---- statistics half: 64 four-row steps over the tile, this wave's clusters
     {
-      const double* xb = xt + hi * LD + lo2;
-      const double* qb = qt + hi;
+      const int rsub = 8 * (hi & 1) + 4 * (hi >> 1);  // this lane's row of a step inside its 16-row block (see LD)
+      const double* xb = xt + rsub * LD + lo2;
+      const double* qb = qt + rsub;
 #pragma unroll 4
       for (int st = 0; st < FUSED_ROWS / 4; ++st) {
+        const int rbase = (st >> 2) * 16 + (st & 3);
         double xr[3];
 #pragma unroll
-        for (int s = 0; s < 3; ++s) xr[s] = xb[st * 4 * LD + 4 * ((blk + s) & 3)];
+        for (int s = 0; s < 3; ++s) xr[s] = xb[rbase * LD + 4 * ((blk + s) & 3)];
 #pragma unroll
         for (int c = 0; c < CPW; ++c) {
           const int k = wave + 4 * c;
           if (k < K) {  // wave-uniform
-            const double q = qb[k * 256 + st * 4];
+            const double q = qb[k * 256 + rbase];
             const double qx = q * xr[0];
             sacc[c] += qx;
             nacc[c] += q;
