@@ -829,8 +829,16 @@ void Context::pack_estep_params(int K, const double* A, const double* m, const d
       double* C = P;
       for (int I = 0; I < DP / 64; ++I)
         for (int Jb = 0; Jb <= I; ++Jb, C += lck::WIDE_CHUNK) {
+          // tile column jt = 4 q + jr holds the columns {16 q + jr + 4 h}: estep_wide_kernel's column groups (wide_col)
           for (int it = 0; it < 16; ++it)
-            for (int jt = 0; jt < 16; ++jt) fill_tile(C + (size_t)(it * 16 + jt) * 16, 64 * I + 4 * it, 64 * Jb + 4 * jt);
+            for (int jt = 0; jt < 16; ++jt) {
+              double* T = C + (size_t)(it * 16 + jt) * 16;
+              for (int h = 0; h < 4; ++h)
+                for (int lo = 0; lo < 4; ++lo) {
+                  const int i = 64 * I + 4 * it + lo, j = 64 * Jb + 16 * (jt / 4) + 4 * h + (jt % 4);
+                  T[lo + 4 * h] = (i < D && j <= i) ? Ak[(size_t)i * D + j] : 0.0;
+                }
+            }
           std::copy(bneg.begin() + 64 * I, bneg.begin() + 64 * (I + 1), C + 4096);
         }
     }

@@ -582,27 +582,42 @@ __global__ void __launch_bounds__(WAVES * 64, LQW ? 2 : EstepOcc<DP>::BLOCKS) es
 // Same arithmetic, same operand layout; what changes is what stays resident.  A cluster's whitener no longer fits in
 // LDS (268 KB at D = 256) and a row group's X fragments no longer fit in registers, so the lower-triangular A_k is cut
 // into 64 x 64 blocks (I, J <= I) that stream through a two-deep LDS ring in row-major order -- one chunk = the 256
-// 4x4 tiles of a block (a diagonal block reads only the 136 on or below its diagonal) followed by -b_I -- and a wave keeps
+// 4x4 tiles of a block (a diagonal block reads only the WIDE_NLOW tiles that reach its diagonal) followed by -b_I -- and a wave keeps
 //   * the 16 tile-row accumulators of block row I for its R row groups (y_I = sum_J A_IJ x_J - b_I), and
 //   * the X fragments of column panel J only, re-read from L2 for every chunk (the loads return in order, so the
 //     first MFMAs start as soon as the first fragments are back).
 // After the diagonal chunk (J = I) the 16 accumulators are squared into the running distance.  Normalisation as in
 // estep_kernel (k-sliced scheme).  lc_ctx.cpp packs the chunks (wide_chunk_stride doubles each, K * NCH of them).
+// Column groups: tile column jt = 4 q + jr of a 64-column panel stands for the columns {16 q + jr + 4 h : h = 0..3},
+// so that lane hi holds columns 16 q + 4 hi + (0..3) for jr = 0..3 -- FOUR CONTIGUOUS doubles per (row, q), fetched with
+// two 16-byte loads, a row's 128-byte line consumed by its four hi lanes at once.  (With contiguous groups 4 jt + hi a
+// lane's sixteen values lie 32 bytes apart: 32 eight-byte loads per chunk, every line of the wave's 16 KB working set
+// fetched from L2 four times over -- the kernel sat at 0.52 of the peak waiting on those loads.)  lc_ctx.cpp packs the
+// whitener's tiles with the same column map (wide_col).  A diagonal block keeps 160 of its 256 tiles instead of 136.
+__host__ __device__ constexpr int wide_col(int jt, int h) { return 16 * (jt / 4) + 4 * h + (jt % 4); }
+__host__ __device__ constexpr bool wide_low(int it, int jt) { return wide_col(jt, 0) <= 4 * it + 3; }  // any entry on / below the diagonal
 // n-th tile read of a chunk -> 16 * it + jt.  Tile rows go in pairs (it = 2 (m / 32) + (m & 1), jt = (m % 32) / 2 over
-// m = 0..255) so that 2R independent accumulator chains alternate; the 136 tiles on or below the diagonal come first,
-// the 120 above it after them: a diagonal block stops after the first part.
+// m = 0..255) so that 2R independent accumulator chains alternate; the tiles a diagonal block needs come first, the
+// others after them: a diagonal block stops after the first part.
 __host__ __device__ constexpr int wide_read(int n) {
   int c = 0;
   for (int part = 0; part < 2; ++part)
     for (int m = 0; m < 256; ++m) {
       const int it = 2 * (m / 32) + (m & 1), jt = (m % 32) / 2;
-      if ((jt <= it) == (part == 0)) {
+      if (wide_low(it, jt) == (part == 0)) {
         if (c == n) return it * 16 + jt;
         ++c;
       }
     }
   return -1;
 }
+__host__ __device__ constexpr int wide_nlow() {
+  int c = 0;
+  for (int it = 0; it < 16; ++it)
+    for (int jt = 0; jt < 16; ++jt) c += wide_low(it, jt) ? 1 : 0;
+  return c;
+}
+constexpr int WIDE_NLOW = wide_nlow();
 template <int R, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64, 2) estep_wide_kernel(EstepLaunch a) {
   constexpr int CHS = WIDE_CHUNK;  // 256 tiles x 16 + 64
@@ -637,7 +652,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) estep_wide_kernel(EstepLaunch a
     }
     grp[r] = info >> 5;
     rowok[r] = lo4 < (info & 31);
-    xbase[r] = a.X + ((rgok[r] ? rg : 0) * RG + lo4) * (int64_t)DPW + hi;
+    xbase[r] = a.X + ((rgok[r] ? rg : 0) * RG + lo4) * (int64_t)DPW + 4 * hi;
   }
 
   double pre[NPRE][2];
@@ -672,11 +687,15 @@ __global__ void __launch_bounds__(WAVES * 64, 2) estep_wide_kernel(EstepLaunch a
   for (int64_t g = 0; g < total; ++g) {
     const int buf = (int)(g & 1);
     if (g + 1 < total) gload(g + 1);
-    double xf[R][16];
+    double xf[R][16];  // xf[r][4 q + jr] = x[row][64 J + 16 q + 4 hi + jr]
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
-      for (int jt = 0; jt < 16; ++jt) xf[r][jt] = xbase[r][64 * J + 4 * jt];
+      for (int q = 0; q < 4; ++q) {
+        const double2* p2 = reinterpret_cast<const double2*>(xbase[r] + 64 * J + 16 * q);
+        const double2 v0 = p2[0], v1 = p2[1];
+        xf[r][4 * q] = v0.x, xf[r][4 * q + 1] = v0.y, xf[r][4 * q + 2] = v1.x, xf[r][4 * q + 3] = v1.y;
+      }
     const double* P = pbuf + buf * CHS;
     const double* Pt = P + (lane & 3) + 4 * hi;  // this lane's element of every 4x4 tile
     if (J == 0) {
@@ -706,8 +725,8 @@ __global__ void __launch_bounds__(WAVES * 64, 2) estep_wide_kernel(EstepLaunch a
         for (int r = 0; r < R; ++r) acc[it][r] = mfma4(v, xf[r][jt], acc[it][r]);
       });
     };
-    reads(std::integral_constant<int, 0>{}, std::integral_constant<int, 136>{});
-    if (J != I) reads(std::integral_constant<int, 136>{}, std::integral_constant<int, 120>{});
+    reads(std::integral_constant<int, 0>{}, std::integral_constant<int, WIDE_NLOW>{});
+    if (J != I) reads(std::integral_constant<int, WIDE_NLOW>{}, std::integral_constant<int, 256 - WIDE_NLOW>{});
     if (J == I) {  // block row complete
 #pragma unroll
       for (int it = 0; it < 16; ++it)
