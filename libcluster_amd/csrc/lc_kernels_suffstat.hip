@@ -2,6 +2,12 @@
 // (one translation unit per kernel family; the file header of lc_kernels_estep.hip maps kernels to the reference)
 #include "lc_device.hpp"
 
+// widths at which the feature-GEMM form of the statistics pass is the default for more than 16 clusters (measured:
+// tools/ssfeat_check.py; LC_SS_FEAT=2 selects it wherever it exists, 0 nowhere)
+#ifndef LC_SS_FEAT_WIDTHS
+#define LC_SS_FEAT_WIDTHS(DP) ((DP) == 32 || (DP) == 48 || (DP) == 64 || (DP) == 128)  // (80, 96, 112: the 8-quad instances spill)
+#endif
+
 namespace lck {
 
 // ===========================================================================
@@ -513,40 +519,54 @@ __global__ void __launch_bounds__(256, (DP <= 64 ? (HALF != 0 ? 3 : 2) : (HALF !
 }
 
 // ===========================================================================
-// Sufficient statistics as a feature GEMM (D = 64, 17 ... 32 clusters, dense)
+// Sufficient statistics as a feature GEMM (32 <= D <= 128, more than 16 clusters, dense)
 // ===========================================================================
-// suffstat_kernel forms q_k x per cluster: 9 fp64 VALU instructions per 36 MFMAs, and fp64 VALU shares the pipe with
-// the fp64 MFMAs (every such instruction costs about 8 matrix-pipe cycles) -- its ceiling is ~84 % of the
-// pipe.  Here the cluster index moves into the MFMA:  T = Q^T Phi(x), Phi(x) = [x_i x_j (i <= j) | x_i | 1], so that
-//   A operand = q[row 4 st + hi][cluster 4 c + lo2]          (one LDS read per cluster quad and step, all tiles share it)
+// suffstat_kernel forms q_k x per cluster: 9 fp64 VALU instructions per 36 MFMAs, and an fp64 VALU instruction inside a
+// stream of fp64 MFMAs costs the matrix pipe about 11 clocks (tools/mfma_mix_probe.hip) -- its ceiling is ~81 % of the
+// pipe, and it sits there.  Here the cluster index moves into the MFMA:  T = Q^T Phi(x), Phi(x) = [x_i x_j (i <= j) | x_i | 1]:
+//   A operand = q[row 4 st + hi][cluster k0 + 4 c + lo2]     (one LDS read per cluster quad and step, all tiles share it)
 //   B operand = x[row][4 ia + lo2] * x[row][4 ja + blk]      (ONE multiply per 16 features, shared by ALL cluster quads)
-//   D[i = hi][j = lo2] of block blk = S_{4c + hi}[4 ia + lo2][4 ja + blk]
-// i.e. one v_mul_f64 per NQ = K / 4 MFMAs (1 : 8 at K = 32, against 1 : 4) and nothing else on the VALU: s_k and N_k
-// are the features x_i * 1 and 1 * 1 (a column of ones rides in the staged X rows).  A "tile" is 16 features: the 136
-// 4 x 4 patches (ia <= ja) of the symmetric 64 x 64 matrix, 4 tiles of s_k, 1 of N_k = 141; a wave owns 9 tiles x NQ
-// quads (<= 72 accumulators), 16 waves = 4 blocks cover a row chunk (as the 4 cluster slices of suffstat_kernel do).
-// Every tile reads its two operand fragments itself (LDS broadcast reads are cheap; no operand sharing to schedule).
+//   D[i = hi][j = lo2] of block blk = S_{k0 + 4c + hi}[4 ia + lo2][4 ja + blk]
+// i.e. one v_mul_f64 per NQ MFMAs (NQ = cluster quads per launch, up to 8: 1 : 8 against 1 : 4) and nothing else on the
+// VALU: s_k and N_k are the features x_i * 1 and 1 * 1 (a column of ones rides in the staged X rows).  A "tile" is 16
+// features: the 4 x 4 patches (ia <= ja) of the symmetric matrix, DP / 16 tiles of s_k, one of N_k (141 at D = 64); a
+// wave owns up to 9 tiles x NQ quads (<= 72 accumulators), nslice blocks of four waves cover a row chunk (as the cluster
+// slices of suffstat_kernel do).  Every tile reads its two operand fragments itself (LDS broadcast reads cost the
+// matrix pipe nothing; no operand sharing to schedule).  More than 32 clusters: one launch per range of <= 32.
 // Same partial records, same reduction, deterministic; the patch on the diagonal computes both halves of its 4 x 4
 // block from commuted products, so S_k comes out exactly symmetric.
-constexpr int FT_TPW = 9, FT_WAVES = 16, FT_TILES = 136 + 4 + 1;
+__host__ __device__ constexpr int ft_tiles(int DP) { return (DP / 4) * (DP / 4 + 1) / 2 + DP / 16 + 1; }
+__host__ __device__ constexpr int ft_nslice(int DP) { return (ft_tiles(DP) + 35) / 36; }                     // blocks per row chunk
+__host__ __device__ constexpr int ft_tpw(int DP) { return (ft_tiles(DP) + 4 * ft_nslice(DP) - 1) / (4 * ft_nslice(DP)); }  // tiles per wave (<= 9)
+__host__ __device__ constexpr int ft_batch_rows(int DP) { return DP > 96 ? 24 : 32; }  // (two blocks per CU: 160 KB of LDS)
+constexpr int FT_QLD = 36;  // row stride of the staged q quads: the two rows of a half-wave 8 banks apart
 inline bool ss_feat_eligible(int DP, int K) {
-  static const bool off = getenv("LC_SS_FEAT") && atoi(getenv("LC_SS_FEAT")) == 0;
-  return !off && DP == 64 && K > 16 && K <= 32;
+  static const int mode = getenv("LC_SS_FEAT") ? atoi(getenv("LC_SS_FEAT")) : 1;  // 0 off, 1 where it wins, 2 everywhere it exists
+  if (mode == 0 || K <= 16 || DP < 32 || DP > 128) return false;
+  if (mode == 2) return true;
+  // measured (tools/ssfeat_check.py, MI355X): it wins where a launch carries 7 or 8 cluster quads (one multiply per 7-8
+  // MFMAs); with 5-6 quads the per-cluster kernel's 72 MFMAs per step are worth more than the saved multiplies
+  const int nr = (K + 31) / 32, per = ((K + nr - 1) / nr + 3) / 4 * 4;
+  const int last = K - (nr - 1) * per;
+  return LC_SS_FEAT_WIDTHS(DP) && per >= 28 && last >= 25;
 }
-template <int NQ>
+template <int DP, int NQ>
 __global__ void __launch_bounds__(256, 2) suffstat_feat_kernel(SuffstatLaunch a) {
-  constexpr int DP = 64, BR = SS_BR, LD = lds_row_stride(DP), QLD = 36, XBUF = BR * LD, QBUF = BR * QLD;  // (QLD: the two rows of a half-wave 8 banks apart)
+  constexpr int BR = ft_batch_rows(DP), LD = lds_row_stride(DP), QLD = FT_QLD, XBUF = BR * LD, QBUF = BR * QLD;
+  constexpr int TPW = ft_tpw(DP), TILES = ft_tiles(DP), NPATCH = (DP / 4) * (DP / 4 + 1) / 2, NSL = ft_nslice(DP);
   constexpr int ONE = DP;  // column of the staged rows that holds 1.0
   static_assert(LD > DP, "the staged rows need a spare column");
+  static_assert(TPW * NQ <= 72, "accumulators");
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* xbuf = lds;              // [2][BR][LD]
-  double* qbuf = lds + 2 * XBUF;   // [2][BR][QLD]   q[row][cluster], clusters >= K are zero
+  double* qbuf = lds + 2 * XBUF;   // [2][BR][QLD]   q[row][cluster - k0], clusters past the range are zero
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hi = lane >> 4, blk = (lane >> 2) & 3, lo2 = lane & 3;
-  const int K = a.K;
+  const int k0 = a.klast0;                                  // first cluster of this launch's range
+  const int KC = a.K - k0 < 4 * NQ ? a.K - k0 : 4 * NQ;     // clusters in the range
   int chunk, slice;
-  {  // (chunk, slice) placement as in suffstat_kernel: the four slices of a chunk back-to-back on one XCD
-    const int nslice = FT_WAVES / 4, nchunks = a.nchunks, b = blockIdx.x, full = (nchunks / 8) * 8;
+  {  // (chunk, slice) placement as in suffstat_kernel: the slices of a chunk back-to-back on one XCD
+    const int nslice = NSL, nchunks = a.nchunks, b = blockIdx.x, full = (nchunks / 8) * 8;
     if (b < full * nslice) {
       const int xcd = b & 7, seq = b >> 3;
       chunk = (seq / nslice) * 8 + xcd;
@@ -560,69 +580,82 @@ __global__ void __launch_bounds__(256, 2) suffstat_feat_kernel(SuffstatLaunch a)
   const int64_t r0 = (int64_t)chunk * a.chunk_rows;
   const int64_t r1 = (r0 + a.chunk_rows) < a.NP ? (r0 + a.chunk_rows) : a.NP;
   // this wave's tiles and, per lane, where their two operand fragments sit in a staged batch (in doubles, step 0)
-  const int T0 = (slice * 4 + wave) * FT_TPW;
-  const int nt = FT_TILES - T0 < FT_TPW ? (FT_TILES - T0 > 0 ? FT_TILES - T0 : 0) : FT_TPW;
-  int offU[FT_TPW], offW[FT_TPW];
+  const int T0 = (slice * 4 + wave) * TPW;
+  const int nt = TILES - T0 < TPW ? (TILES - T0 > 0 ? TILES - T0 : 0) : TPW;
+  const double* pu[TPW];
+  const double* pw[TPW];
 #pragma unroll
-  for (int t = 0; t < FT_TPW; ++t) {
+  for (int t = 0; t < TPW; ++t) {
     const int T = T0 + t;
     int cu = ONE, cw = ONE;  // N_k tile (and the idle ones): 1 * 1
-    if (T < 136) {
+    if (T < NPATCH) {
       int ja = 0;
       while ((ja + 1) * (ja + 2) / 2 <= T) ++ja;
       const int ia = T - ja * (ja + 1) / 2;
       cu = 4 * ia + lo2;
       cw = 4 * ja + blk;
-    } else if (T < 140) {
-      cu = 16 * (T - 136) + 4 * blk + lo2;
+    } else if (T < NPATCH + DP / 16) {
+      cu = 16 * (T - NPATCH) + 4 * blk + lo2;
     }
-    offU[t] = hi * LD + cu;
-    offW[t] = hi * LD + cw;
+    pu[t] = xbuf + hi * LD + cu;
+    pw[t] = xbuf + hi * LD + cw;
   }
-  double acc[FT_TPW][NQ];
+  double acc[TPW][NQ];
 #pragma unroll
-  for (int t = 0; t < FT_TPW; ++t)
+  for (int t = 0; t < TPW; ++t)
 #pragma unroll
     for (int c = 0; c < NQ; ++c) acc[t][c] = 0.0;
 
-  // ---- staging: registers hold the next batch while the current one is consumed
-  constexpr int NV2 = BR * DP / 2, NPRE = NV2 / 256;  // double2 per thread
-  static_assert(NPRE * 256 == NV2, "batch size");
+  // ---- staging: registers hold the next batch while the current one is consumed.
+  // X batch: thread -> 16 bytes of NPRE consecutive rows (row group tid / TPR, column pair tid % TPR): one address
+  // register on either side, the rows are immediate offsets.  q batch: thread -> (cluster tid % 32, row quad tid / 32):
+  // clusters fastest, so that the 16-lane groups of a ds_write_b64 fill one LDS row (rows fastest would put all the row
+  // quads of a group on one bank)
+  constexpr int TPR = DP / 2, NV2 = BR * TPR, NPRE = (NV2 + 255) / 256;  // double2 per row / per batch / per thread
+  constexpr int RPP = 256 / TPR;                                          // rows covered by one pass of the block
+  static_assert(256 % TPR == 0 || NPRE * 256 >= NV2, "staging");
   double pre[NPRE][2], qpre[4];
-  // this thread's cluster column and row quad of the q batch (32 x 8 = 256): clusters fastest, so that the 16-lane
-  // groups of a ds_write_b64 fill one LDS row (rows fastest put all eight row quads of a group on one bank: 8-way)
   const int qcl = tid & 31, qrq = tid >> 5;
-  // X batch: thread -> 16 bytes of NPRE consecutive rows (row quad tid / 32, column pair tid % 32): one address register
-  // on either side, the rows are immediate offsets (512 bytes apart in memory, LD * 8 in LDS)
-  static_assert(NPRE == 4, "one row quad per 32 threads");
-  const int xrq = tid >> 5, xc2 = tid & 31;
-  double* const xdst = xbuf + (4 * xrq) * LD + 2 * xc2;
+  const bool qthr = qrq < BR / 4;
+  const int xr0 = tid / TPR, xc2 = tid % TPR;  // (DP = 80, 112: 256 is not a multiple of TPR -- the generic index below)
   double* const qdst = qbuf + (4 * qrq) * QLD + qcl;
   auto gload = [&](int64_t b0) {
-    const int64_t xrow = b0 + 4 * xrq;
-    const double* src = a.X + xrow * DP + 2 * xc2;
-    const bool xok = xrow < r1;  // (a row quad lies inside the chunk or outside it: chunk_rows is a multiple of 4)
 #pragma unroll
     for (int i = 0; i < NPRE; ++i) {
+      int row, c2;
+      if constexpr (256 % TPR == 0) {
+        row = xr0 + i * RPP, c2 = xc2;
+      } else {
+        const int idx = tid + i * 256;
+        row = idx / TPR, c2 = idx % TPR;
+      }
       double2 v = make_double2(0.0, 0.0);
-      if (xok) v = *reinterpret_cast<const double2*>(src + i * DP);
+      if (row < BR && b0 + row < r1) v = *reinterpret_cast<const double2*>(a.X + (b0 + row) * DP + 2 * c2);
       pre[i][0] = v.x;
       pre[i][1] = v.y;
     }
     const int64_t qrow = b0 + 4 * qrq;
 #pragma unroll
     for (int i = 0; i < 4; ++i) qpre[i] = 0.0;
-    if (qcl < K && qrow < r1) {
-      const double2* qp = reinterpret_cast<const double2*>(a.qZ + (int64_t)qcl * a.ldq + qrow);
+    if (qthr && qcl < KC && qrow < r1) {  // (a row quad lies inside the chunk or outside it: chunk_rows is a multiple of 4)
+      const double2* qp = reinterpret_cast<const double2*>(a.qZ + (int64_t)(k0 + qcl) * a.ldq + qrow);
       const double2 v0 = qp[0], v1 = qp[1];
       qpre[0] = v0.x, qpre[1] = v0.y, qpre[2] = v1.x, qpre[3] = v1.y;
     }
   };
   auto lstore = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < NPRE; ++i)
-      *reinterpret_cast<double2*>(xdst + buf * XBUF + i * LD) = make_double2(pre[i][0], pre[i][1]);
-    if (qcl < 4 * NQ) {
+    for (int i = 0; i < NPRE; ++i) {
+      int row, c2;
+      if constexpr (256 % TPR == 0) {
+        row = xr0 + i * RPP, c2 = xc2;
+      } else {
+        const int idx = tid + i * 256;
+        row = idx / TPR, c2 = idx % TPR;
+      }
+      if (row < BR) *reinterpret_cast<double2*>(xbuf + buf * XBUF + row * LD + 2 * c2) = make_double2(pre[i][0], pre[i][1]);
+    }
+    if (qthr && qcl < 4 * NQ) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) qdst[buf * QBUF + i * QLD] = qpre[i];
     }
@@ -633,17 +666,9 @@ __global__ void __launch_bounds__(256, 2) suffstat_feat_kernel(SuffstatLaunch a)
     lstore(0);
   }
   __syncthreads();
-  // per-lane LDS addresses of the fragments in buffer 0, step 0: buffer and step are compile-time offsets of the reads
-  const double* pu[FT_TPW];
-  const double* pw[FT_TPW];
-#pragma unroll
-  for (int t = 0; t < FT_TPW; ++t) {
-    pu[t] = xbuf + offU[t];
-    pw[t] = xbuf + offW[t];
-  }
   const double* pq = qbuf + hi * QLD + lo2;
-  // One batch from buffer B.  All BR / 4 steps and all FT_TPW tiles run (rows past the chunk end were staged as zeros
-  // with q = 0; the three idle tiles of the last wave accumulate 1 * 1 products nobody reads): nothing in the loop
+  // One batch from buffer B.  All BR / 4 steps and all TPW tiles run (rows past the chunk end were staged as zeros
+  // with q = 0; the idle tiles of the last waves accumulate 1 * 1 products nobody reads): nothing in the loop
   // depends on run-time counts.  The next tile's fragments -- behind the last tile the next step's first tile and its
   // q quads -- are issued BEFORE this tile's MFMAs and arrive under them (two register sets that swap roles; the fences
   // keep hipcc from sinking the reads to their uses).
@@ -657,10 +682,10 @@ __global__ void __launch_bounds__(256, 2) suffstat_feat_kernel(SuffstatLaunch a)
 #pragma unroll
     for (int st = 0; st < BR / 4; ++st) {
 #pragma unroll
-      for (int t = 0; t < FT_TPW; ++t) {
-        const int cur = (st * FT_TPW + t) & 1, nxt = cur ^ 1;
+      for (int t = 0; t < TPW; ++t) {
+        const int cur = (st * TPW + t) & 1, nxt = cur ^ 1;
         const double p = u[cur] * w[cur];
-        if (t + 1 < FT_TPW) {
+        if (t + 1 < TPW) {
           u[nxt] = pu[t + 1][XO + st * 4 * LD];
           w[nxt] = pw[t + 1][XO + st * 4 * LD];
         } else if (st + 1 < BR / 4) {
@@ -693,27 +718,27 @@ __global__ void __launch_bounds__(256, 2) suffstat_feat_kernel(SuffstatLaunch a)
   // ---- partial records: [N_k, s_k[DP], S_k[DP x DP]] per (chunk, cluster), as suffstat_kernel writes them
   const int64_t SS = 1 + (int64_t)DP + (int64_t)DP * DP;
 #pragma unroll
-  for (int t = 0; t < FT_TPW; ++t) {
+  for (int t = 0; t < TPW; ++t) {
     if (t >= nt) continue;
     const int T = T0 + t;
     int ia = 0, ja = 0;
-    if (T < 136) {
+    if (T < NPATCH) {
       while ((ja + 1) * (ja + 2) / 2 <= T) ++ja;
       ia = T - ja * (ja + 1) / 2;
     }
 #pragma unroll
     for (int c = 0; c < NQ; ++c) {
-      const int k = 4 * c + hi;
-      if (k >= K) continue;
-      double* out = a.partial + ((int64_t)chunk * a.KR + k) * SS;
+      const int kk = 4 * c + hi;
+      if (kk >= KC) continue;
+      double* out = a.partial + ((int64_t)chunk * a.KR + k0 + kk) * SS;
       const double v = acc[t][c];
-      if (T < 136) {
+      if (T < NPATCH) {
         const int gi = 4 * ia + lo2, gj = 4 * ja + blk;
         double* S = out + 1 + DP;
         S[(int64_t)gi * DP + gj] = v;
         S[(int64_t)gj * DP + gi] = v;
-      } else if (T < 140) {
-        out[1 + 16 * (T - 136) + 4 * blk + lo2] = v;
+      } else if (T < NPATCH + DP / 16) {
+        out[1 + 16 * (T - NPATCH) + 4 * blk + lo2] = v;
       } else if (blk == 0 && lo2 == 0) {
         out[0] = v;
       }
@@ -721,22 +746,47 @@ __global__ void __launch_bounds__(256, 2) suffstat_feat_kernel(SuffstatLaunch a)
   }
 }
 
-template <int NQ>
-static hipError_t launch_ss_feat_q(const SuffstatLaunch& a, hipStream_t stream) {
-  constexpr int BR = SS_BR, LD = lds_row_stride(64), QLD = 36;
-  const size_t shmem = (size_t)(2 * BR * LD + 2 * BR * QLD) * sizeof(double);
-  SuffstatLaunch b = a;
-  b.nslice = FT_WAVES / 4;
-  if (b.KR < a.K) b.KR = a.K;
-  hipLaunchKernelGGL(suffstat_feat_kernel<NQ>, dim3((unsigned)(a.nchunks * (FT_WAVES / 4))), dim3(256), shmem, stream, b);
+template <int DP, int NQ>
+static hipError_t launch_ss_feat_q(const SuffstatLaunch& b, hipStream_t stream) {
+  constexpr int BR = ft_batch_rows(DP), LD = lds_row_stride(DP);
+  const size_t shmem = (size_t)(2 * BR * LD + 2 * BR * FT_QLD) * sizeof(double);
+  auto kern = suffstat_feat_kernel<DP, NQ>;
+  static LdsGrant grant;
+  if (hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(kern), shmem, grant); e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(b.nchunks * ft_nslice(DP))), dim3(256), shmem, stream, b);
   return hipGetLastError();
 }
+template <int DP>
+static hipError_t launch_ss_feat_d(const SuffstatLaunch& a, hipStream_t stream) {
+  // cluster ranges of at most 32 (8 quads), near-equal sizes: every range re-reads X, which an MFMA-bound pass affords
+  const int nr = (a.K + 31) / 32, per = ((a.K + nr - 1) / nr + 3) / 4 * 4;
+  SuffstatLaunch b = a;
+  b.nslice = ft_nslice(DP);
+  if (b.KR < a.K) b.KR = a.K;
+  for (int k0 = 0; k0 < a.K; k0 += per) {
+    b.klast0 = k0;
+    const int nq = ((a.K - k0 < per ? a.K - k0 : per) + 3) / 4;
+    hipError_t e = hipErrorInvalidValue;
+    switch (nq) {
+      case 1: case 2: case 3: case 4: e = launch_ss_feat_q<DP, 4>(b, stream); break;
+      case 5: e = launch_ss_feat_q<DP, 5>(b, stream); break;
+      case 6: e = launch_ss_feat_q<DP, 6>(b, stream); break;
+      case 7: e = launch_ss_feat_q<DP, 7>(b, stream); break;
+      case 8: e = launch_ss_feat_q<DP, 8>(b, stream); break;
+    }
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
 static hipError_t launch_ss_feat(const SuffstatLaunch& a, hipStream_t stream) {
-  switch ((a.K + 3) / 4) {
-    case 5: return launch_ss_feat_q<5>(a, stream);
-    case 6: return launch_ss_feat_q<6>(a, stream);
-    case 7: return launch_ss_feat_q<7>(a, stream);
-    case 8: return launch_ss_feat_q<8>(a, stream);
+  switch (a.DP) {
+    case 32: return launch_ss_feat_d<32>(a, stream);
+    case 48: return launch_ss_feat_d<48>(a, stream);
+    case 64: return launch_ss_feat_d<64>(a, stream);
+    case 80: return launch_ss_feat_d<80>(a, stream);
+    case 96: return launch_ss_feat_d<96>(a, stream);
+    case 112: return launch_ss_feat_d<112>(a, stream);
+    case 128: return launch_ss_feat_d<128>(a, stream);
   }
   return hipErrorInvalidValue;
 }

@@ -12,7 +12,11 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
-CASES = [(1000, 64, 17), (4099, 64, 20), (777, 50, 24), (30001, 64, 29), (65536, 64, 32), (123457, 61, 32), (31, 64, 18)]
+CASES = [(1000, 64, 17), (4099, 64, 20), (777, 50, 24), (30001, 64, 29), (65536, 64, 32), (123457, 61, 32), (31, 64, 18),
+         (5000, 32, 17), (9001, 20, 33), (7000, 48, 32), (6007, 40, 70), (5003, 80, 24), (4001, 70, 64), (4999, 96, 32),
+         (3001, 112, 40), (6000, 128, 32), (5001, 128, 64), (2000, 100, 65), (3000, 64, 64), (2500, 64, 45)]
+TIMING = [(4000000, 32, 32), (2000000, 48, 32), (2000000, 64, 32), (1500000, 80, 32), (1000000, 96, 32), (1000000, 112, 32),
+          (1000000, 128, 32), (1000000, 128, 64), (2000000, 64, 64), (2000000, 64, 24)]
 
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     import torch  # noqa: F401
@@ -34,18 +38,37 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
                         eN=float(np.max(np.abs(Nk - rN) / rN)), es=float(np.max(np.abs(xs - rs)) / np.max(np.abs(rs))),
                         eS=float(np.max(np.abs(xxs - rS)) / np.max(np.abs(rS))),
                         h=[float(Nk.sum()), float(xs.sum()), float(xxs.sum())]))
-    print("RESULT " + json.dumps(out))
+    times = []
+    for N, D, K in TIMING:
+        rng = np.random.default_rng(1)
+        X = rng.normal(size=(N, D))
+        with capi.Context(0) as ctx:
+            ctx.set_data(X)
+            del X
+            q = rng.dirichlet(np.ones(K) * 0.3, N)
+            ctx.set_qz(q)
+            del q
+            ctx.timing_enable(True)
+            for rep in range(3):
+                ctx.timing_reset()
+                ctx.suffstat()
+                t = ctx.timing_get()
+            DP = max(16, (D + 15) // 16 * 16)
+            ms = t["suffstat_ms"] / t["suffstat_calls"]
+            times.append([N, D, K, ms, N * K * (DP * DP + 3 * DP + 1) / ms / 1e9 / 78.6])
+    print("RESULT " + json.dumps([out, times]))
     sys.exit(0)
 
 res = {}
-for name, env in (("feat", {}), ("percluster", {"LC_SS_FEAT": "0"})):
+tim = {}
+for name, env in (("feat", {"LC_SS_FEAT": "2"}), ("percluster", {"LC_SS_FEAT": "0"})):
     e = dict(os.environ, **env)
     p = subprocess.run([sys.executable, __file__, "child"], capture_output=True, text=True, env=e, timeout=900)
     line = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")]
     if p.returncode or not line:
         print(name, "FAILED", p.stderr[-2000:])
         sys.exit(1)
-    res[name] = json.loads(line[-1][7:])
+    res[name], tim[name] = json.loads(line[-1][7:])
 ok = True
 for a, b in zip(res["feat"], res["percluster"]):
     good = a["sym"] and a["eN"] < 1e-12 and a["es"] < 1e-12 and a["eS"] < 1e-12
@@ -53,9 +76,6 @@ for a, b in zip(res["feat"], res["percluster"]):
     print(a["case"], "feat: sym", a["sym"], f"eN {a['eN']:.1e} es {a['es']:.1e} eS {a['eS']:.1e}", "| per-cluster:",
           f"eN {b['eN']:.1e} es {b['es']:.1e} eS {b['eS']:.1e}", "OK" if good else "BAD")
 print("ALL OK" if ok else "FAILURES")
-for name, env in (("feat", {}), ("percluster", {"LC_SS_FEAT": "0"})):
-    e = dict(os.environ, **env)
-    p = subprocess.run([sys.executable, str(ROOT / "tools" / "variants.py"), "run", "--iters", "8", "default"], capture_output=True,
-                       text=True, env=e, timeout=900)
-    print(name, [ln for ln in p.stdout.splitlines() if ln.startswith("default")])
+for a, b in zip(tim["feat"], tim["percluster"]):
+    print(f"N={a[0]} D={a[1]} K={a[2]}: feature GEMM {a[3]:8.3f} ms ({a[4]:.3f} of the fp64 peak)   per-cluster {b[3]:8.3f} ms ({b[4]:.3f})   {'FEAT' if a[3] < b[3] else 'per-cluster'} wins")
 sys.exit(0 if ok else 1)
