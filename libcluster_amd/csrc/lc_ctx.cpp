@@ -1605,9 +1605,11 @@ void Context::estep_diag(int K, const double* av, const double* w2, const double
       std::fill(ck, ck + K + 1, 0.0);
       std::fill(wt, wt + nw, 0.0);
       // W[k][f]: f < NT*4 quadratic weights (w2), then linear weights (w1 - 2 w2 a'); tile (it, jt) element
-      // (lo, hi) = W[4 it + lo][4 jt + hi]
+      // (lo, hh) = W[4 it + lo][column 16 q + jr + 4 hh of its half], jt = 4 q + jr: the kernel's column groups (a lane
+      // holds four contiguous columns per sixteen)
       auto put = [&](int k, int f, double v) {
-        const int it = k >> 2, lo = k & 3, jt = f >> 2, hh = f & 3;
+        const int it = k >> 2, lo = k & 3, half = f / DP, d = f % DP;
+        const int jt = half * NT + 4 * (d / 16) + (d % 4), hh = (d % 16) / 4;
         wt[((size_t)it * NTF + jt) * 16 + lo + 4 * hh] = v;
       };
       (void)KT;

@@ -486,11 +486,20 @@ __global__ void __launch_bounds__(256, 2)
         }
       }
       infon[r] = info;
-      const double* xr = X + ((ok ? rg : 0) * RG + lo4) * DP + hi;
+      // feature tile jt = 4 q + jr stands for the columns {16 q + jr + 4 h}: lane hi holds columns 16 q + 4 hi + (0..3) --
+      // four contiguous doubles per (row, q), two 16-byte loads, a row's 128-byte line consumed by its four hi lanes at
+      // once (contiguous groups 4 jt + hi take 8-byte loads 32 bytes apart: four times the cache-line requests).  The
+      // weight tiles are packed with the same column map (lc_ctx.cpp, estep_diag).
+      const double* xr = X + ((ok ? rg : 0) * RG + lo4) * DP + 4 * hi;
 #pragma unroll
-      for (int jt = 0; jt < NT; ++jt) xn[r][jt] = xr[4 * jt];
+      for (int q = 0; q < NT / 4; ++q) {
+        const double2* p2 = reinterpret_cast<const double2*>(xr + 16 * q);
+        const double2 v0 = p2[0], v1 = p2[1];
+        xn[r][4 * q] = v0.x, xn[r][4 * q + 1] = v0.y, xn[r][4 * q + 2] = v1.x, xn[r][4 * q + 3] = v1.y;
+      }
     }
   };
+  static_assert(NT % 4 == 0, "column groups of sixteen");
   fetch(blockIdx.x);
   for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
     const int64_t rg0 = (tile * 4 + wave) * R;
@@ -509,7 +518,7 @@ __global__ void __launch_bounds__(256, 2)
     if constexpr (QUAD) {
 #pragma unroll
       for (int jt = 0; jt < NT; ++jt) {
-        const double m = mul[4 * jt + hi];
+        const double m = mul[16 * (jt / 4) + 4 * hi + (jt % 4)];
 #pragma unroll
         for (int r = 0; r < R; ++r) f[r][jt] -= m;
       }
