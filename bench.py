@@ -634,9 +634,9 @@ def main():
     res, ctx, model, (wkind, ckind, mu, L, family) = measure(capi, cfg, args.steps, args.warmup, rank, world,
                                                               local_rank, stream, nthreads, comm, dist, torch)
     if rank == 0:
-        tf = ROOT / "profiles" / "r02_pmc_traffic.json"  # HBM bytes per launch from the committed PMC passes (not live)
+        tf = ROOT / "profiles" / "r03_pmc_traffic.json"  # HBM bytes per launch from the committed PMC passes (not live)
         if not tf.exists():
-            tf = ROOT / "profiles" / "r01_pmc_traffic.json"
+            tf = ROOT / "profiles" / "r02_pmc_traffic.json"
         traffic = json.loads(tf.read_text()) if tf.exists() else {}
         if not args.rows:
             res["roofline"]["traffic"] = traffic.get(args.config, {}).get(res["roofline"]["kernel"])

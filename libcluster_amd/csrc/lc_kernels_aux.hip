@@ -618,17 +618,27 @@ __global__ void __launch_bounds__(256) softmax_cached_kernel(CachedNormLaunch a)
       v[j] += crow[j];
       mx = fmax(mx, v[j]);
     }
+  // (a.dq, a.ll_part: launch-uniform)
+  // Without LL_k: ONE exponential per entry -- e = exp(x - max) replaces x in its register and q = e / sum(e) (the same
+  // sum and logZ; q within 2 ulp of exp(x - logZ), far inside the tolerance of the moved-row test below, and the same
+  // bits for the same inputs, which is what "unchanged rows are not written" relies on).  With LL_k the log value is
+  // still needed behind the sum, so the second exponential stays.
+  const bool onexp = a.ll_part == nullptr;
   double s = 0.0;
 #pragma unroll
   for (int j = 0; j < KT; ++j)
-    if (j < K) s += exp(v[j] - mx);
+    if (j < K) {
+      const double e = exp(v[j] - mx);
+      s += e;
+      if (onexp) v[j] = e;
+    }
   const double logZ = log(s) + mx;
-  // (a.dq, a.ll_part: launch-uniform)
+  const double inv = 1.0 / s;
 #pragma unroll
   for (int j = 0; j < KT; ++j)
     if (j < K) {
       const double lq = v[j];
-      double q = exp(lq - logZ);
+      double q = onexp ? lq * inv : exp(lq - logZ);
       if (!ok) q = 0.0;
       v[j] = q;
       if (a.ll_part) {  // the data term of the split ordering (cluster.cpp:407-410), as estep_kernel's sweep forms it
@@ -697,6 +707,7 @@ hipError_t launch_softmax_cached(const CachedNormLaunch& a, hipStream_t stream) 
   if (a.K <= 16) return go(softmax_cached_kernel<16>);
   if (a.K <= 24) return go(softmax_cached_kernel<24>);
   if (a.K <= 32) return go(softmax_cached_kernel<32>);
+  if (a.K <= 36) return go(softmax_cached_kernel<36>);  // (a round's candidates run at K + 1: 33 columns, not 40)
   if (a.K <= 40) return go(softmax_cached_kernel<40>);
   if (a.K <= 56) return go(softmax_cached_kernel<56>);
   return go(softmax_cached_kernel<72>);
