@@ -432,13 +432,18 @@ __global__ void __launch_bounds__(256)
 // lanes with two shuffles.  Reference operation order of logsumexp and of the normalisation (probutils.cpp:141-150,
 // cluster.cpp:130-131).
 // KTM > 0: K <= 4 KTM and log q~ stays in registers (KTM x R values per lane); KTM == 0: any K, per-lane LDS slots.
-template <int NT, bool QUAD, int R, int KTM>
+// PLAIN: the instance the VBEM iterations use -- normalised responsibilities, no split-ordering term: `raw` and
+// `ll_part` are compile-time constants there (they are tested per cluster tile and row group otherwise: several hundred
+// scalar and exec-mask branches per tile of the generic instance)
+template <int NT, bool QUAD, int R, int KTM, bool PLAIN = false>
 __global__ void __launch_bounds__(256, 2)
     estep_diag_mfma_kernel(const double* __restrict__ X, const double* __restrict__ Wt, const double* __restrict__ mu,
                            const double* __restrict__ constk, const double* __restrict__ ctab,
                            const int* __restrict__ rginfo, double* __restrict__ qZ, double* __restrict__ fz_part,
-                           double* __restrict__ ll_part, int K, int64_t nrg, int64_t nrows, int64_t ldq, int raw,
+                           double* __restrict__ ll_part_, int K, int64_t nrg, int64_t nrows, int64_t ldq, int raw_,
                            int64_t nslots) {
+  const int raw = PLAIN ? 0 : raw_;
+  double* const ll_part = PLAIN ? nullptr : ll_part_;
   constexpr int DP = NT * 4;
   constexpr int NTF = QUAD ? 2 * NT : NT;  // feature tiles per cluster tile
   constexpr int PF = NTF < 8 ? NTF : 8;    // weight-tile reads in flight ahead of their MFMAs
@@ -695,9 +700,13 @@ template <int NT, bool QUAD, int R, int KTM>
 static hipError_t launch_edm_k(const DiagEstepLaunch& a, hipStream_t stream) {
   const int KT = (a.K + 3) / 4, NTF = QUAD ? 2 * NT : NT;
   const size_t shmem = edm_lds_bytes(NT, NTF, KT, R, KTM == 0);
-  auto kern = estep_diag_mfma_kernel<NT, QUAD, R, KTM>;
-  static LdsGrant grant;
-  if (hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(kern), shmem, grant); e != hipSuccess) return e;
+#ifndef LC_EDM_PLAIN_QUAD
+#define LC_EDM_PLAIN_QUAD 0  // (measured: the plain instance gains 10 % for the linear features, loses 4 % with the quadratic half)
+#endif
+  const bool plain = KTM > 0 && !a.raw && !a.ll_part && (!QUAD || LC_EDM_PLAIN_QUAD);
+  auto kern = plain ? estep_diag_mfma_kernel<NT, QUAD, R, KTM, (KTM > 0)> : estep_diag_mfma_kernel<NT, QUAD, R, KTM>;
+  static LdsGrant grants[2];
+  if (hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(kern), shmem, grants[plain ? 1 : 0]); e != hipSuccess) return e;
   const int64_t ntile = (a.nrg + 4 * R - 1) / (4 * R);
   const int64_t nslots = estep_diag_grid(a.nrg);
   static int cus = 0;
