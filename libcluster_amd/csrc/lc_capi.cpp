@@ -7,6 +7,8 @@
 #include <new>
 #include <algorithm>
 #include <string>
+#include <sched.h>
+#include <atomic>
 #include <thread>
 
 #include "../../include/libcluster_hip.h"
@@ -222,8 +224,28 @@ double learn_sharded(int algo, int J, const double* const* Xj, const int64_t* Nj
   m->shards.clear();
   for (int r = 0; r < W; ++r) m->shards.emplace_back(new lc_model::Shard());
   const int64_t N0 = single ? Nj[0] : 0;
+  std::atomic<int> first_fail{-1};  // the shard whose failure made the others fail (they only see aborted collectives)
+  // every shard thread -- and the M-step pool its context starts, which inherits the mask -- keeps to its slice of the
+  // CPUs this process may use; the caller's own thread (shard 0) gets its mask back afterwards
+  cpu_set_t all_cpus;
+  CPU_ZERO(&all_cpus);
+  const bool have_mask = sched_getaffinity(0, sizeof(all_cpus), &all_cpus) == 0 && CPU_COUNT(&all_cpus) >= 2 * W;
+  auto pin = [&](int r) {
+    if (!have_mask) return;
+    const int per = CPU_COUNT(&all_cpus) / W;
+    cpu_set_t mine;
+    CPU_ZERO(&mine);
+    int seen = 0;
+    for (int c = 0; c < CPU_SETSIZE; ++c)
+      if (CPU_ISSET(c, &all_cpus)) {
+        if (seen >= r * per && seen < (r + 1) * per) CPU_SET(c, &mine);
+        ++seen;
+      }
+    (void)sched_setaffinity(0, sizeof(mine), &mine);  // (0 = the calling thread)
+  };
   auto work = [&](int r) {
     try {
+      pin(r);
       lc_model::Shard& sh = *m->shards[(size_t)r];
       sh.device = devices[(size_t)r];
       if (hipSetDevice(sh.device) != hipSuccess) throw lcc::HipFailure("hipSetDevice failed for a shard");
@@ -265,18 +287,21 @@ double learn_sharded(int algo, int J, const double* const* Xj, const int64_t* Nj
       lcc::cache_release_thread();  // this thread ends here: its cached blocks may serve other threads from now on
     } catch (...) {
       errs[(size_t)r] = std::current_exception();
+      int none = -1;
+      first_fail.compare_exchange_strong(none, r);  // (the shards that fail AFTER this one report the abort below)
       for (auto& c : comms) c->abort();  // the other shards fail in their next collective instead of waiting
+      lcc::cache_release_thread();
     }
   };
   std::vector<std::thread> th;
   for (int r = 1; r < W; ++r) th.emplace_back(work, r);
   work(0);
   for (auto& t : th) t.join();
-  for (auto& e : errs)
-    if (e) {
-      m->shards.clear();
-      std::rethrow_exception(e);
-    }
+  if (have_mask) (void)sched_setaffinity(0, sizeof(all_cpus), &all_cpus);
+  if (const int f = first_fail.load(); f >= 0) {  // the root cause, not a secondary "communicator was aborted"
+    m->shards.clear();
+    std::rethrow_exception(errs[(size_t)f]);
+  }
   // every shard ran the same M-steps on the same reduced statistics: clusters, F and the rounds are identical; the
   // group weights live with the shard that holds the group
   lce::Model out = std::move(models[0]);

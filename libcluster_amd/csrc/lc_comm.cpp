@@ -299,50 +299,85 @@ std::shared_ptr<Comm> host_init_shm(const std::string& name, int rank, int world
   const double limit = timeout_seconds();
   const auto t0 = std::chrono::steady_clock::now();
   auto expired = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit; };
-  int fd = -1;
-  if (rank == 0) {
-    shm_unlink(reg->shm_name.c_str());  // a stale object of a crashed run
-    fd = shm_open(reg->shm_name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
-    if (fd < 0) fail("shm_open(" + reg->shm_name + ") failed: " + std::strerror(errno));
-    if (ftruncate(fd, (off_t)reg->bytes) != 0) {
-      close(fd);
-      shm_unlink(reg->shm_name.c_str());
-      fail("ftruncate of the shared region failed: " + std::string(std::strerror(errno)));
-    }
-  } else {
-    for (;;) {  // wait for rank 0 to create and size the object
-      fd = shm_open(reg->shm_name.c_str(), O_RDWR, 0600);
-      if (fd >= 0) {
-        struct stat st;
-        if (fstat(fd, &st) == 0 && (size_t)st.st_size >= reg->bytes) break;
+  // Which object does the name refer to right now?  (0: none.)  A run that crashed during its rendezvous leaves an
+  // object behind that already carries the magic word: a rank > 0 may open THAT one before rank 0 has replaced it, and
+  // would wait there for ranks that never come.  So a waiting rank keeps checking that the name still leads to the
+  // object it is attached to, and starts over on the new one otherwise.
+  auto current_inode = [&]() -> ino_t {
+    const int f = shm_open(reg->shm_name.c_str(), O_RDONLY, 0600);
+    if (f < 0) return 0;
+    struct stat st;
+    const ino_t ino = fstat(f, &st) == 0 ? st.st_ino : 0;
+    close(f);
+    return ino;
+  };
+  for (;;) {
+    int fd = -1;
+    ino_t mine = 0;
+    if (rank == 0) {
+      shm_unlink(reg->shm_name.c_str());  // a stale object of a crashed run
+      fd = shm_open(reg->shm_name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+      if (fd < 0) fail("shm_open(" + reg->shm_name + ") failed: " + std::strerror(errno));
+      if (ftruncate(fd, (off_t)reg->bytes) != 0) {
         close(fd);
-        fd = -1;
+        shm_unlink(reg->shm_name.c_str());
+        fail("ftruncate of the shared region failed: " + std::string(std::strerror(errno)));
       }
-      if (expired()) fail("timed out waiting for rank 0 to create " + reg->shm_name);
-      std::this_thread::sleep_for(std::chrono::milliseconds(2));
+    } else {
+      for (;;) {  // wait for rank 0 to create and size the object
+        fd = shm_open(reg->shm_name.c_str(), O_RDWR, 0600);
+        if (fd >= 0) {
+          struct stat st;
+          if (fstat(fd, &st) == 0 && (size_t)st.st_size >= reg->bytes) {
+            mine = st.st_ino;
+            break;
+          }
+          close(fd);
+          fd = -1;
+        }
+        if (expired()) fail("timed out waiting for rank 0 to create " + reg->shm_name);
+        std::this_thread::sleep_for(std::chrono::milliseconds(2));
+      }
     }
-  }
-  reg->base = mmap(nullptr, reg->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-  close(fd);
-  if (reg->base == MAP_FAILED) {
+    reg->base = mmap(nullptr, reg->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (reg->base == MAP_FAILED) {
+      reg->base = nullptr;
+      fail("mmap of the shared region failed: " + std::string(std::strerror(errno)));
+    }
+    Ctrl* c = reg->ctrl();
+    bool stale = false;
+    auto replaced = [&] {  // (ranks > 0) the name leads elsewhere AND this object is still waiting for ranks: a left-over
+      const ino_t now = current_inode();
+      return now != 0 && now != mine;
+    };
+    if (rank == 0) {
+      init_ctrl(c, world);
+    } else {
+      int tick = 0;
+      while (c->magic.load(std::memory_order_acquire) != HOST_MAGIC) {
+        if (expired()) fail("timed out waiting for rank 0 to initialise " + reg->shm_name);
+        if (++tick % 100 == 0 && replaced()) { stale = true; break; }
+        std::this_thread::sleep_for(std::chrono::milliseconds(1));
+      }
+      if (!stale && (c->world != (uint32_t)world || c->slot_doubles != SLOT_DOUBLES)) {
+        if (replaced()) stale = true;
+        else fail("ranks disagree about the communicator size");
+      }
+    }
+    if (!stale) {
+      // the name is only needed for the rendezvous: once everybody is attached rank 0 removes it
+      c->attached.fetch_add(1, std::memory_order_acq_rel);
+      int tick = 0;
+      while (c->attached.load(std::memory_order_acquire) < (uint32_t)world) {
+        if (expired()) fail("timed out waiting for all ranks to attach to " + reg->shm_name);
+        if (rank != 0 && ++tick % 100 == 0 && replaced()) { stale = true; break; }
+        std::this_thread::sleep_for(std::chrono::milliseconds(1));
+      }
+    }
+    if (!stale) break;
+    munmap(reg->base, reg->bytes);  // a left-over of a crashed run: attach to the object rank 0 has created since
     reg->base = nullptr;
-    fail("mmap of the shared region failed: " + std::string(std::strerror(errno)));
-  }
-  Ctrl* c = reg->ctrl();
-  if (rank == 0) {
-    init_ctrl(c, world);
-  } else {
-    while (c->magic.load(std::memory_order_acquire) != HOST_MAGIC) {
-      if (expired()) fail("timed out waiting for rank 0 to initialise " + reg->shm_name);
-      std::this_thread::sleep_for(std::chrono::milliseconds(1));
-    }
-    if (c->world != (uint32_t)world || c->slot_doubles != SLOT_DOUBLES) fail("ranks disagree about the communicator size");
-  }
-  // the name is only needed for the rendezvous: once everybody is attached rank 0 removes it
-  c->attached.fetch_add(1, std::memory_order_acq_rel);
-  while (c->attached.load(std::memory_order_acquire) < (uint32_t)world) {
-    if (expired()) fail("timed out waiting for all ranks to attach to " + reg->shm_name);
-    std::this_thread::sleep_for(std::chrono::milliseconds(1));
   }
   if (rank == 0) shm_unlink(reg->shm_name.c_str());
   return std::make_shared<HostComm>(reg, rank, world);

@@ -2,6 +2,7 @@
 #include "lc_engine.hpp"  // the host worker pool (parallel_chunks)
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <iostream>
@@ -38,9 +39,20 @@ struct BlockCache {
   std::mutex m;
   std::vector<Block> dev, pinned;
   size_t dev_bytes = 0;
+  // A tag per host thread: a counter, never re-used (the OS recycles thread ids, and a hash of one could hand a block
+  // with work in flight to an unrelated thread).  The thread's last act is to let go of its blocks: a short-lived API
+  // thread, or a shard thread that threw, does not leave blocks behind that nobody else may take.
+  struct ThreadTag {
+    size_t id;
+    ThreadTag() {
+      static std::atomic<size_t> next{1};
+      id = next.fetch_add(1);
+    }
+    ~ThreadTag();  // cache_release_thread() for this tag
+  };
   static size_t thread_tag() {
-    const size_t h = std::hash<std::thread::id>()(std::this_thread::get_id());
-    return h ? h : 1;
+    static thread_local ThreadTag t;
+    return t.id;
   }
   static BlockCache& get() {
     static BlockCache* c = new BlockCache();  // intentionally leaked
@@ -94,15 +106,18 @@ int current_device() {
 RelaxedFit::RelaxedFit() { ++BlockCache::relaxed_fit(); }
 RelaxedFit::~RelaxedFit() { --BlockCache::relaxed_fit(); }
 
-void cache_release_thread() {
+static void cache_release_tag(size_t me) {
   BlockCache& c = BlockCache::get();
-  const size_t me = BlockCache::thread_tag();
   std::lock_guard<std::mutex> g(c.m);
   for (auto& b : c.dev)
     if (b.owner == me) b.owner = 0;
   for (auto& b : c.pinned)
     if (b.owner == me) b.owner = 0;
 }
+void cache_release_thread() { cache_release_tag(BlockCache::thread_tag()); }
+namespace {
+BlockCache::ThreadTag::~ThreadTag() { cache_release_tag(id); }
+}  // namespace
 
 void trim_cache() {
   BlockCache& c = BlockCache::get();

@@ -265,18 +265,27 @@ static size_t fused_lds_bytes(int DP, int K) {
 // branch whatever its share of the rows, an empty share included)
 bool fused_eligible(int DP, int K) {
   static const bool off = getenv("LC_FUSED_SMALL") && atoi(getenv("LC_FUSED_SMALL")) == 0;
-  return !off && DP == 16 && K >= 1 && K <= FUSED_KMAX;
+  if (off || DP != 16 || K < 1 || K > FUSED_KMAX) return false;
+  // the pass keeps a 256-row tile, all K parameter records and a K x 256 table in LDS (93 KB at K = 16): the answer must
+  // also hold on the device at hand -- and be the same on every rank, so it is asked of the architecture the library is
+  // built for (gfx950: 160 KB per workgroup), never of "whichever device is current"
+  constexpr size_t GFX950_LDS_PER_BLOCK = 160 * 1024;
+  return fused_lds_bytes(DP, K) <= GFX950_LDS_PER_BLOCK;
 }
 
 // number of persistent blocks (= partial records per cluster, fz / ll partial slots)
 int fused_plan(int DP, int64_t nrg, int K) {
   if (!fused_eligible(DP, K) || nrg <= 0) return 0;
-  static int cus = 0;
+  // compute units of the CURRENT device (a process may hold contexts on several)
+  static int cus_of[16] = {};
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;
+  if (dev >= 0) cus = cus_of[dev];
   if (!cus) {
-    int dev = 0;
     hipDeviceProp_t p;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
+    if (dev >= 0 && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
     if (cus <= 0) cus = 256;
+    if (dev >= 0) cus_of[dev] = cus;
   }
   const int64_t ntile = (nrg * RG + FUSED_ROWS - 1) / FUSED_ROWS;
   const size_t lds = fused_lds_bytes(DP, K);
