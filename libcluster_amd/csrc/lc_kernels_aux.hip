@@ -365,46 +365,67 @@ hipError_t launch_gather_rows(const double* X, int DP, const int64_t* idx, int64
 // distributions.cpp:373-385, NormGamma :495-505): q0 = (sum_d (x_d - m_d) v_d >= 0); mode 1 (first pass of
 // ExpGamma :575-581): q0 = sum_d x_d v_d (the projection itself, for the per-group mean); mode 2 (second
 // pass): q0 = (q0 > thr[group]).  q1 = 1 - q0 in modes 0 and 2; pad rows 0.  mv = [m(DP), v(DP)].
+// Eight lanes per row: lane t of a row takes the column pairs 2 t + 16 j (a row's eight 16-byte loads are 128 contiguous
+// bytes), the partial sums meet through three shuffles.  (One lane per row walked its 512-byte row 8 bytes at a time,
+// every load instruction touching 64 cache lines: 0.82 ms for 300k rows, 0.2 TB/s -- 5 % of a model-selection run.)
 __global__ void __launch_bounds__(256) split_init_kernel(const double* X, int DP, int D, int64_t NP, const int* rginfo,
                                                          int64_t nrows, const double* mv, double* q, int64_t ldq,
                                                          int mode, const double* thr) {
-  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= NP) return;
+  const int t = threadIdx.x & 7;
+  const int64_t row = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+  const bool inb = row < NP;
   int grp = 0;
-  bool ok;
-  if (rginfo) {
-    const int info = rginfo[row >> 4];
-    grp = info >> 5;
-    ok = (int)(row & 15) < (info & 31);
-  } else {
-    ok = row < nrows;
+  bool ok = false;
+  if (inb) {
+    if (rginfo) {
+      const int info = rginfo[row >> 4];
+      grp = info >> 5;
+      ok = (int)(row & 15) < (info & 31);
+    } else {
+      ok = row < nrows;
+    }
   }
   double q0 = 0.0, q1 = 0.0;
-  if (ok) {
-    if (mode == 2) {
+  if (mode == 2) {
+    if (ok) {
       q0 = q[row] > thr[grp] ? 1.0 : 0.0;
       q1 = 1.0 - q0;
-    } else {
-      double s = 0.0;
+    }
+  } else {
+    double s = 0.0;
+    if (ok) {  // (DP is a multiple of 16 and the pad columns of X are zero: whole column pairs, no tail)
+      const double* xr = X + row * DP;
+      for (int d = 2 * t; d < DP; d += 16) {
+        const double2 x = *reinterpret_cast<const double2*>(xr + d);
+        const double m0 = mode == 0 ? mv[d] : 0.0, m1 = mode == 0 ? mv[d + 1] : 0.0;
+        const double v0 = d < D ? mv[DP + d] : 0.0, v1 = d + 1 < D ? mv[DP + d + 1] : 0.0;
+        s += (x.x - m0) * v0;
+        s += (x.y - m1) * v1;
+      }
+    }
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 4);
+    if (ok) {
       if (mode == 0) {
-        for (int d = 0; d < D; ++d) s += (X[row * DP + d] - mv[d]) * mv[DP + d];
         q0 = s >= 0.0 ? 1.0 : 0.0;
         q1 = 1.0 - q0;
       } else {
-        for (int d = 0; d < D; ++d) s += X[row * DP + d] * mv[DP + d];
         q0 = s;
       }
     }
   }
-  q[row] = q0;
-  q[ldq + row] = q1;
+  if (inb && t == 0) {
+    q[row] = q0;
+    q[ldq + row] = q1;
+  }
 }
 
 hipError_t launch_split_init(const double* X, int DP, int D, int64_t NP, const int* rginfo, int64_t nrows,
                              const double* mv, double* q, int64_t ldq, int mode, const double* thr,
                              hipStream_t stream) {
   if (NP <= 0) return hipSuccess;
-  hipLaunchKernelGGL(split_init_kernel, dim3((unsigned)((NP + 255) / 256)), dim3(256), 0, stream, X, DP, D, NP, rginfo,
+  hipLaunchKernelGGL(split_init_kernel, dim3((unsigned)((NP + 31) / 32)), dim3(256), 0, stream, X, DP, D, NP, rginfo,
                      nrows, mv, q, ldq, mode, thr);
   return hipGetLastError();
 }

@@ -875,7 +875,9 @@ int suffstat_plan(int DP, int64_t NP, int K, int64_t* chunk_rows) {
   if (want * rounds <= cap) want *= rounds;
   else if (want < cap) want = cap;
   else if (want > cap && DP > 128) want = cap > 1 ? cap : 1;
-  int64_t maxchunks = (NP + 255) / 256;
+  // at least 1024 rows per chunk where that still leaves two chunks per CU (a chunk's K records are written and read
+  // back by the reduction: at 256 rows they are half of a two-cluster sub-problem's traffic), 256 rows otherwise
+  int64_t maxchunks = std::max<int64_t>((NP + 1023) / 1024, std::min<int64_t>((NP + 255) / 256, 512));
   if (want > maxchunks) want = maxchunks;
   if (want < 1) want = 1;
   int64_t rows = (NP + want - 1) / want;
