@@ -396,7 +396,13 @@ def measure(capi, cfg, steps, warmup, rank, world, local_rank, stream, nthreads,
     fl = alg_flops(N, D, K)
     est = kt["estep_ms"] / max(1, kt["estep_calls"])
     sst = kt["suffstat_ms"] / max(1, kt["suffstat_calls"])
-    dom = "estep_kernel" if est >= sst else "suffstat_kernel"
+    ssname = "suffstat_kernel"
+    if family == "GaussWish":
+        fn = capi.lib().lc_statistics_kernel_name  # per-cluster form or the feature GEMM: what rocprofv3 will list
+        fn.restype = __import__("ctypes").c_char_p
+        fn.argtypes = [__import__("ctypes").c_int, __import__("ctypes").c_int]
+        ssname = fn(D, K).decode()
+    dom = "estep_kernel" if est >= sst else ssname
     if family != "GaussWish":
         dom = dom.replace("_kernel", "_diag_kernel")
     dom_ms = max(est, sst)

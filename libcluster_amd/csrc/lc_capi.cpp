@@ -325,7 +325,11 @@ double learn_sharded(int algo, int J, const double* const* Xj, const int64_t* Nj
 extern "C" {
 
 const char* lc_last_error(void) { return g_err.c_str(); }
-int lc_version(void) { return 200; }
+int lc_version(void) { return 300; }
+const char* lc_statistics_kernel_name(int D, int K) {
+  const int DP = D <= 128 ? lck::padded_dim(D) : 0;
+  return DP > 0 ? lck::suffstat_kernel_name(DP, K) : "suffstat_kernel";
+}
 #ifndef LC_SOURCE_HASH
 #define LC_SOURCE_HASH "unknown"
 #endif

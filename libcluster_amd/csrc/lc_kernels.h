@@ -134,6 +134,7 @@ struct SuffstatLaunch {
 int suffstat_plan(int DP, int64_t NP, int K, int64_t* chunk_rows);
 hipError_t launch_suffstat(const SuffstatLaunch& a, hipStream_t stream);
 int suffstat_clusters_per_block(int DP, int K);  // 4 waves x clusters per wave
+const char* suffstat_kernel_name(int DP, int K);  // "suffstat_kernel" or "suffstat_feat_kernel" (dense pass of this shape)
 // When the last cluster slice of the dense pass fills only one or two of its four waves, the idle waves take over part
 // of the active waves' rows (2 or 4 row classes) and write partial records of their own: `extra` more records per
 // chunk, laid out after the K regular ones ([row class - 1][cluster of the last slice]).  Returns extra (0: no split);

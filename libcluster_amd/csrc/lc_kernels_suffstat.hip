@@ -854,6 +854,11 @@ hipError_t launch_fold_extra(double* rec, int64_t SS, int K, int klast0, int ext
   return hipGetLastError();
 }
 
+// which kernel a dense Gauss-Wishart statistics pass of this shape runs (bench.py names the kernel it prices)
+const char* suffstat_kernel_name(int DP, int K) {
+  return DP <= 128 && ss_feat_eligible(DP, K) ? "suffstat_feat_kernel" : "suffstat_kernel";
+}
+
 int suffstat_clusters_per_block(int DP, int K) { return DP > 128 ? 4 : 4 * ss_cpw(DP, K); }
 
 int suffstat_plan(int DP, int64_t NP, int K, int64_t* chunk_rows) {

@@ -103,18 +103,19 @@ def run(argv):
     libs += sorted((p.stem, p) for p in VDIR.glob("*.so") if not names or p.stem in names)
     rep = int(os.environ.get("LC_VARIANT_REPEAT", "1"))
     for shape in shapes:
-      print(f"shape N,D,K = {shape} family {fam}, {iters} timed iterations")
-      for r in range(rep):
-        for name, path in libs:
-              e = dict(os.environ, LC_LIB_PATH=str(path), LC_ALLOW_STALE_LIB="1")
-              p = subprocess.run([sys.executable, "-c", CHILD.format(root=str(ROOT), N=shape[0], D=shape[1], K=shape[2], fam=fam, iters=iters)],
-                                 capture_output=True, text=True, env=e, timeout=600)
-              line = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")]
-              if p.returncode != 0 or not line:
-                  print(f"{name:28s} FAILED rc={p.returncode} {p.stderr[-400:]}")
-                  continue
-              d = json.loads(line[-1][7:])
-              print(f"{name:28s} estep {d['estep_ms']:7.3f} ms  suffstat {d['suffstat_ms']:7.3f} ms  fused {d['fused_ms']:6.3f}  iter {d['iter_ms']:7.3f} ms  F {d['F']} {d['F2']}", flush=True)
+        print(f"shape N,D,K = {shape} family {fam}, {iters} timed iterations")
+        for r in range(rep):
+            for name, path in libs:
+                e = dict(os.environ, LC_LIB_PATH=str(path), LC_ALLOW_STALE_LIB="1")
+                code = CHILD.format(root=str(ROOT), N=shape[0], D=shape[1], K=shape[2], fam=fam, iters=iters)
+                p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=e, timeout=600)
+                line = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")]
+                if p.returncode != 0 or not line:
+                    print(f"{name:28s} FAILED rc={p.returncode} {p.stderr[-400:]}")
+                    continue
+                d = json.loads(line[-1][7:])
+                print(f"{name:28s} estep {d['estep_ms']:7.3f} ms  suffstat {d['suffstat_ms']:7.3f} ms  fused {d['fused_ms']:6.3f}  "
+                      f"iter {d['iter_ms']:7.3f} ms  F {d['F']} {d['F2']}", flush=True)
 
 
 if __name__ == "__main__":
