@@ -14,8 +14,12 @@
 //     an LDS table the statistics half reads back (the statistics never re-read q or X from memory);
 //   * the statistics accumulators live in registers across all the tiles of the block: one partial record per
 //     (block, cluster) at the very end, folded by reduce_partials_kernel in fixed order.
-// Layouts are those of estep_kernel (row-owning scheme: lane (lo4, hi) owns row 16 hi + lo4 of its wave's 64 rows)
-// and of suffstat_kernel (MFMA block blk computes tile ((blk + s) & 3, blk) of the one 16 x 16 block, s = 0..2).
+// Layouts: the E-step half is estep_kernel's row-owning scheme (lane (lo4, hi) owns row 16 hi + lo4 of its wave's 64
+// rows); the statistics half is the feature GEMM of suffstat_feat_kernel (round 3: the cluster index inside the MFMA --
+// A = q[row][cluster quad], B = x_i x_j for one 4 x 4 patch of the 16 x 16 matrix, one multiply per patch for ALL
+// cluster quads; s_k and N_k are the features x_i * 1 and 1 * 1 with a column of ones in the staged tile).  Twelve tiles
+// (10 patches + s_k + N_k) x NQ cluster quads per wave; the four waves split the tile's 64 four-row steps and meet once,
+// at the very end, through LDS in wave order.
 #include "lc_device.hpp"
 
 #include <algorithm>
@@ -24,8 +28,9 @@ namespace lck {
 
 constexpr int FUSED_KMAX = 16;  // clusters per block-resident parameter set (four per wave in the statistics half)
 constexpr int FUSED_ROWS = 256; // rows per tile
+constexpr int FUSED_QS = FUSED_ROWS + 4;  // q table: 260 doubles per cluster = 8 banks between consecutive clusters
 
-// CPW: clusters per wave in the statistics half (K <= 4 CPW)
+// CPW: cluster quads of the statistics half (K <= 4 CPW)
 template <int DP, int CPW>
 __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a) {
   static_assert(DP == 16, "one 16 x 16 block of S_k (the general blocking lives in suffstat_kernel)");
@@ -35,32 +40,33 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a) {
   constexpr int PF = 6;
   constexpr int PS = NTILES * 16 + DP;
   // row stride of the staged tile (36 dwords).  E-step half: a half-wave reads rows lo4 = 0..15 at two columns -- 36 lo4
-  // mod 64 are sixteen different multiples of 4: conflict-free.  Statistics half: a half-wave reads all 16 columns of TWO
-  // rows, which must lie 32 banks apart: rows r and r + 8 do (8 x 36 = 4 x 64 + 32), consecutive rows do not (the bank
-  // conflicts of the round-2 profile) -- so a four-row step takes rows {t, t + 8, t + 4, t + 12} of a 16-row block (any
-  // four rows serve as the reduction index of the MFMA, as long as q is read for the same rows)
+  // mod 64 are sixteen different multiples of 4: conflict-free.  Statistics half (feature form): a half-wave reads four
+  // columns of two CONSECUTIVE rows (36 dwords apart: 8 banks each, disjoint), and q[row][cluster] with consecutive
+  // clusters 8 banks apart (FUSED_QS): conflict-free as well.  Column DP of every row holds 1.0 (s_k, N_k features).
   constexpr int LD = DP + 2;
   constexpr int R = 4;
   static_assert(4 * CPW <= FUSED_KMAX, "statistics accumulators");
+  constexpr int NQ = CPW, NTL = 12;    // cluster quads; feature tiles: 10 patches (ia <= ja), s_k, N_k
+  constexpr int QS = FUSED_QS;         // row stride of the q table: consecutive clusters 8 banks apart
+  constexpr int ONE = DP;              // column of the staged tile that holds 1.0
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int K = a.K;
   double* xt = lds;                    // [256][LD]
   double* par = xt + FUSED_ROWS * LD;  // [K][PS]
-  double* qt = par + (size_t)K * PS;   // [K][256]: log q~, then q, of the tile's rows
-  double* llw = qt + (size_t)K * 256;  // [4][K]
+  double* qt = par + (size_t)K * PS;   // [4 NQ][QS]: log q~, then q, of the tile's rows (clusters >= K: zeros)
+  double* llw = qt + (size_t)4 * NQ * QS;  // [4][K]
   double* fzw = llw + 4 * K;           // [4]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lo4 = lane & 15, hi = lane >> 4, blk = (lane >> 2) & 3, lo2 = lane & 3;
   for (int i = tid; i < K * PS; i += 256) par[i] = a.params[i];
   for (int i = tid; i < 4 * K; i += 256) llw[i] = 0.0;
-  // statistics half: wave w owns clusters w, w + 4, w + 8, w + 12
-  double acc[CPW][3], sacc[CPW], nacc[CPW];
+  for (int i = tid; i < 4 * NQ * QS; i += 256) qt[i] = 0.0;
+  xt[tid * LD + ONE] = 1.0;  // (the staging below writes columns 0 .. DP - 1 only)
+  double acc[NTL][NQ];
 #pragma unroll
-  for (int c = 0; c < CPW; ++c) {
-    sacc[c] = nacc[c] = 0.0;
+  for (int t = 0; t < NTL; ++t)
 #pragma unroll
-    for (int s = 0; s < 3; ++s) acc[c][s] = 0.0;
-  }
+    for (int c = 0; c < NQ; ++c) acc[t][c] = 0.0;
   double fz = 0.0;
   const int64_t NP = a.nrg * RG;
   const int64_t ntile = (NP + FUSED_ROWS - 1) / FUSED_ROWS;
@@ -163,7 +169,7 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a) {
         if (hi == r) lqsel = lq;
       }
       mymx = fmax(mymx, lqsel);
-      qt[k * 256 + tid] = lqsel;  // (this lane's own slot: no barrier needed before it reads it back)
+      qt[k * QS + tid] = lqsel;  // (this lane's own slot: no barrier needed before it reads it back)
     }
     // logsumexp and normalisation in the reference's order: max, sum exp(x - max), log + max, exp(x - logZ)
     {
@@ -172,19 +178,19 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a) {
       double s = 0.0;
       const bool onexp = !a.want_ll;
       for (int k = 0; k < K; ++k) {
-        const double e = exp(qt[k * 256 + tid] - mymx);
+        const double e = exp(qt[k * QS + tid] - mymx);
         s += e;
-        if (onexp) qt[k * 256 + tid] = e;
+        if (onexp) qt[k * QS + tid] = e;
       }
       const double logZ = log(s) + mymx;
       const double inv = 1.0 / s;
       double* qp = a.qZ + row0 + tid;
       for (int k = 0; k < K; ++k) {
-        const double lq = qt[k * 256 + tid];
+        const double lq = qt[k * QS + tid];
         double q = onexp ? lq * inv : exp(lq - logZ);
         if (!myok || !myrow) q = 0.0;
         if (myok) qp[(int64_t)k * a.ldq] = q;
-        qt[k * 256 + tid] = q;
+        qt[k * QS + tid] = q;
         if (a.want_ll) {  // wave-uniform
           const double ll = wave_sum(q > 0.0 ? q * (lq - a.ctab[(int64_t)mygrp * K + k]) : 0.0);
           if (lane == 0) llw[wave * K + k] += ll;
@@ -194,57 +200,76 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a) {
     }
     __syncthreads();
 
-    // ---- statistics half: 64 four-row steps over the tile, this wave's clusters
+    // ---- statistics half: this wave's 16 of the tile's 64 four-row steps, all feature tiles, all cluster quads.
+    // Tile t < 10 is the patch (ia, ja): x[row][4 ia + lo2] * x[row][4 ja + blk] -- two lane-dependent base pointers and
+    // compile-time column offsets; t = 10: x[row][4 blk + lo2] * 1 (s_k); t = 11: 1 * 1 (N_k).
     {
-      const int rsub = 8 * (hi & 1) + 4 * (hi >> 1);  // this lane's row of a step inside its 16-row block (see LD)
-      const double* xb = xt + rsub * LD + lo2;
-      const double* qb = qt + rsub;
-#pragma unroll 4
-      for (int st = 0; st < FUSED_ROWS / 4; ++st) {
-        const int rbase = (st >> 2) * 16 + (st & 3);
-        double xr[3];
+      const double* xu = xt + hi * LD + lo2;        // + 4 ia
+      const double* xw = xt + hi * LD + blk;        // + 4 ja
+      const double* xs = xt + hi * LD + 4 * blk + lo2;
+      const double* x1 = xt + hi * LD + ONE;
+      const double* qb = qt + lo2 * QS + hi;
+#pragma unroll 2
+      for (int s4 = 0; s4 < FUSED_ROWS / 16; ++s4) {
+        const int st = 4 * s4 + wave, ro = 4 * st * LD;
+        double qa[NQ];
 #pragma unroll
-        for (int s = 0; s < 3; ++s) xr[s] = xb[rbase * LD + 4 * ((blk + s) & 3)];
-#pragma unroll
-        for (int c = 0; c < CPW; ++c) {
-          const int k = wave + 4 * c;
-          if (k < K) {  // wave-uniform
-            const double q = qb[k * 256 + rbase];
-            const double qx = q * xr[0];
-            sacc[c] += qx;
-            nacc[c] += q;
-#pragma unroll
-            for (int s = 0; s < 3; ++s) acc[c][s] = mfma4(xr[s], qx, acc[c][s]);
+        for (int c = 0; c < NQ; ++c) qa[c] = qb[4 * c * QS + 4 * st];
+        const double one = x1[ro];
+        static_for<NTL>([&](auto tc) {
+          constexpr int t = tc;
+          double p;
+          if constexpr (t < 10) {
+            constexpr int ja = t < 1 ? 0 : t < 3 ? 1 : t < 6 ? 2 : 3, ia = t - ja * (ja + 1) / 2;
+            p = xu[ro + 4 * ia] * xw[ro + 4 * ja];
+          } else if constexpr (t == 10) {
+            p = xs[ro];
+          } else {
+            p = one;
           }
-        }
+#pragma unroll
+          for (int c = 0; c < NQ; ++c) acc[t][c] = mfma4(qa[c], p, acc[t][c]);
+        });
       }
     }
     __syncthreads();  // the next tile overwrites xt and qt
   }
 
-  // ---- one partial record per (block, cluster): [N_k, s_k(DP), S_k(DP x DP)]
+  // ---- one partial record per (block, cluster): [N_k, s_k(DP), S_k(DP x DP)].  The four waves' accumulators meet in
+  // LDS in wave order (fixed: deterministic); then every thread writes its share of the 12 x NQ x 64 entries.
   const int64_t SS = 1 + DP + DP * DP;
   double* rec = a.partial + (int64_t)blockIdx.x * (K * SS + 1 + K);
+  {
+    double* red = xt;  // (the tile is not needed any more: 12 x NQ x 64 doubles <= 24.6 KB)
+    __syncthreads();
+    for (int w = 0; w < 4; ++w) {
+      if (wave == w) {
 #pragma unroll
-  for (int c = 0; c < CPW; ++c) {
-    const int k = wave + 4 * c;
-    if (k < K) {
+        for (int t = 0; t < NTL; ++t)
+#pragma unroll
+          for (int c = 0; c < NQ; ++c) {
+            double* r = red + (t * NQ + c) * 64 + lane;
+            *r = w == 0 ? acc[t][c] : *r + acc[t][c];
+          }
+      }
+      __syncthreads();
+    }
+    for (int e = tid; e < NTL * NQ * 64; e += 256) {
+      const int l = e & 63, tc = e >> 6, t = tc / NQ, c = tc % NQ;
+      const int h = l >> 4, b = (l >> 2) & 3, lo = l & 3, k = 4 * c + h;
+      if (k >= K) continue;
       double* out = rec + (int64_t)k * SS;
-      const double nsum = sum_over_hi(nacc[c]);
-      if (lane == 0) out[0] = nsum;
-      const double ssum = sum_over_hi(sacc[c]);
-      if (hi == 0) out[1 + lo4] = ssum;
-      double* S = out + 1 + DP;
-#pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        // s = 0: the diagonal tiles; s = 1: every pair {t, t + 1 mod 4} once; s = 2: the pairs {0,2}, {1,3} twice
-        // (the lower copy is kept)
-        const int ti = (blk + s) & 3, tj = blk;
-        const int gi = 4 * ti + hi, gj = 4 * tj + lo2;
-        if (ti == tj || s == 1 || ti > tj) {
-          S[gi * DP + gj] = acc[c][s];
-          if (ti != tj) S[gj * DP + gi] = acc[c][s];
-        }
+      const double v = red[e];
+      if (t < 10) {
+        int ja = 0;
+        while ((ja + 1) * (ja + 2) / 2 <= t) ++ja;
+        const int ia = t - ja * (ja + 1) / 2, gi = 4 * ia + lo, gj = 4 * ja + b;
+        out[1 + DP + gi * DP + gj] = v;
+        out[1 + DP + gj * DP + gi] = v;
+      } else if (t == 10) {
+        out[1 + 4 * b + lo] = v;
+      } else if (b == 0 && lo == 0) {
+        out[0] = v;
       }
     }
   }
@@ -258,7 +283,8 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a) {
 
 static size_t fused_lds_bytes(int DP, int K) {
   const int NT = DP / 4, PS = NT * (NT + 1) / 2 * 16 + DP;
-  return ((size_t)FUSED_ROWS * (DP + 2) + (size_t)K * PS + (size_t)K * 256 + 4 * K + 4) * sizeof(double);
+  const int NQ = K <= 4 ? 1 : K <= 8 ? 2 : 4;  // the instance launch_fused picks
+  return ((size_t)FUSED_ROWS * (DP + 2) + (size_t)K * PS + (size_t)4 * NQ * FUSED_QS + 4 * K + 4) * sizeof(double);
 }
 
 // does this shape have a fused path?  (a property of (DP, K) alone: every rank of a distributed run must take the same
