@@ -536,8 +536,12 @@ __global__ void __launch_bounds__(256, (DP <= 64 ? (HALF != 0 ? 3 : 2) : (HALF !
 // Same partial records, same reduction, deterministic; the patch on the diagonal computes both halves of its 4 x 4
 // block from commuted products, so S_k comes out exactly symmetric.
 __host__ __device__ constexpr int ft_tiles(int DP) { return (DP / 4) * (DP / 4 + 1) / 2 + DP / 16 + 1; }
-__host__ __device__ constexpr int ft_nslice(int DP) { return (ft_tiles(DP) + 35) / 36; }                     // blocks per row chunk
-__host__ __device__ constexpr int ft_tpw(int DP) { return (ft_tiles(DP) + 4 * ft_nslice(DP) - 1) / (4 * ft_nslice(DP)); }  // tiles per wave (<= 9)
+// tiles per wave: as many as the accumulators allow (72 doubles; 64 for 8 quads at D = 80, 96, 112, where 72 spill) -- 9 tiles
+// with 8 cluster quads, 12 with 6, 14 with 5: a launch with fewer quads keeps its MFMAs per step (and has fewer blocks
+// re-staging the same rows)
+__host__ __device__ constexpr int ft_tpw_max(int DP, int NQ) { return (NQ >= 8 && DP > 64 && DP < 128 ? 64 : 72) / NQ; }
+__host__ __device__ constexpr int ft_nslice(int DP, int NQ) { return (ft_tiles(DP) + 4 * ft_tpw_max(DP, NQ) - 1) / (4 * ft_tpw_max(DP, NQ)); }  // blocks per row chunk
+__host__ __device__ constexpr int ft_tpw(int DP, int NQ) { return (ft_tiles(DP) + 4 * ft_nslice(DP, NQ) - 1) / (4 * ft_nslice(DP, NQ)); }
 __host__ __device__ constexpr int ft_batch_rows(int DP) { return DP > 96 ? 24 : 32; }  // (two blocks per CU: 160 KB of LDS)
 constexpr int FT_QLD = 36;  // row stride of the staged q quads: the two rows of a half-wave 8 banks apart
 inline bool ss_feat_eligible(int DP, int K) {
@@ -553,7 +557,7 @@ inline bool ss_feat_eligible(int DP, int K) {
 template <int DP, int NQ>
 __global__ void __launch_bounds__(256, 2) suffstat_feat_kernel(SuffstatLaunch a) {
   constexpr int BR = ft_batch_rows(DP), LD = lds_row_stride(DP), QLD = FT_QLD, XBUF = BR * LD, QBUF = BR * QLD;
-  constexpr int TPW = ft_tpw(DP), TILES = ft_tiles(DP), NPATCH = (DP / 4) * (DP / 4 + 1) / 2, NSL = ft_nslice(DP);
+  constexpr int TPW = ft_tpw(DP, NQ), TILES = ft_tiles(DP), NPATCH = (DP / 4) * (DP / 4 + 1) / 2, NSL = ft_nslice(DP, NQ);
   constexpr int ONE = DP;  // column of the staged rows that holds 1.0
   static_assert(LD > DP, "the staged rows need a spare column");
   static_assert(TPW * NQ <= 72, "accumulators");
@@ -753,7 +757,7 @@ static hipError_t launch_ss_feat_q(const SuffstatLaunch& b, hipStream_t stream) 
   auto kern = suffstat_feat_kernel<DP, NQ>;
   static LdsGrant grant;
   if (hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(kern), shmem, grant); e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(b.nchunks * ft_nslice(DP))), dim3(256), shmem, stream, b);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(b.nchunks * ft_nslice(DP, NQ))), dim3(256), shmem, stream, b);
   return hipGetLastError();
 }
 template <int DP>
@@ -761,7 +765,6 @@ static hipError_t launch_ss_feat_d(const SuffstatLaunch& a, hipStream_t stream) 
   // cluster ranges of at most 32 (8 quads), near-equal sizes: every range re-reads X, which an MFMA-bound pass affords
   const int nr = (a.K + 31) / 32, per = ((a.K + nr - 1) / nr + 3) / 4 * 4;
   SuffstatLaunch b = a;
-  b.nslice = ft_nslice(DP);
   if (b.KR < a.K) b.KR = a.K;
   for (int k0 = 0; k0 < a.K; k0 += per) {
     b.klast0 = k0;
