@@ -904,11 +904,6 @@ void Context::estep(int K, const double* A, const double* m, const double* c, do
   a.fz_part = fzpart_.p;
   a.ll_part = LLk ? llpart_.p : nullptr;
   a.raw = raw ? 1 : 0;
-  if (!tilectr_.p) {
-    tilectr_.reserve(2);
-    LC_HIP(hipMemsetAsync(tilectr_.p, 0, 2 * sizeof(int), stream_));
-  }
-  a.tile_ctr = tilectr_.p;
   for (size_t t = 0; t < (size_t)J_ * K && !a.sparse; ++t)
     if (c[t] == -std::numeric_limits<double>::infinity()) a.sparse = 1;
   EvPair ev{};

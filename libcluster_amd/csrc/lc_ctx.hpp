@@ -309,7 +309,6 @@ class Context {
   DevBuf<int> selcnt_;
   DevBuf<int64_t> seloff_;
   DevBuf<double> mv_;
-  DevBuf<int> tilectr_;  // two zeroed ints: the tile counter of the persistent E-step (estep_persist_kernel leaves it zeroed)
   PinnedBuf hpack_, hred_, hss_;
 
   bool timing_ = false;

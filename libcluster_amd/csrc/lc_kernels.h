@@ -72,8 +72,6 @@ struct EstepLaunch {
   int sparse = 0;        // 1: ctab holds -inf entries; waves skip clusters inactive for all their rows
   int lq_lds = 0;        // filled in by launch_estep: log q~ waits in LDS (D <= 48, small K) instead of in qZ
   int64_t nslots = 0;    // filled in by launch_estep: partial slots (= estep_grid) the kernel has to fill
-  int* tile_ctr = nullptr;  // two zeroed ints owned by the caller: given, the dense pass runs as persistent workgroups that
-                            // pull tiles from tile_ctr[0] (it is left zeroed again)
 };
 int estep_rows_per_block(int DP);
 int64_t estep_grid(int DP, int64_t nrg);

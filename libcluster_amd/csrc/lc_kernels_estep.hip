@@ -124,10 +124,8 @@ struct EstepWavesStd { static constexpr int W = DP >= 112 ? 8 : 4; };
 // (the lane that wrote a value is the lane that reads it back: no barrier), instead of making a round trip through the
 // qZ buffer -- the kernel then reads X once and writes q once.  12 KB per wave at K = 32, R = 3: one block of eight
 // waves per CU next to the 36 KB parameter ring (two waves per SIMD instead of three).
-// One tile of the E-step: the 16 * R * WAVES rows of "block" bid (the kernel below runs one tile per workgroup; the
-// persistent kernel pulls tiles from a counter).
 template <int DP, int R, int WAVES, bool SPARSE, bool LQW = false>
-__device__ __forceinline__ void estep_tile(const EstepLaunch& a, const int64_t bid) {
+__global__ void __launch_bounds__(WAVES * 64, LQW ? 2 : EstepOcc<DP>::BLOCKS) estep_kernel(EstepLaunch a) {
   constexpr int NT = DP / 4;
   constexpr int NTILES = NT * (NT + 1) / 2;
   constexpr int NREAD = NTILES + NT;  // LDS reads per cluster
@@ -154,7 +152,7 @@ __device__ __forceinline__ void estep_tile(const EstepLaunch& a, const int64_t b
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lo4 = lane & 15, hi = lane >> 4;
   const int K = a.K;
-  const int64_t rg0 = ((int64_t)bid * WAVES + wave) * R;
+  const int64_t rg0 = ((int64_t)blockIdx.x * WAVES + wave) * R;
 #ifdef LC_ES_TRACE
   const long long tr_w0 = wall_clock64(), tr_c0 = clock64();
 #endif
@@ -283,7 +281,7 @@ __device__ __forceinline__ void estep_tile(const EstepLaunch& a, const int64_t b
 #pragma unroll
   for (int r = 0; r < R; ++r) mx[r] = -INFINITY;
 #if LC_ES_STAGGER
-  if (bid < 1024) {  // the first resident blocks only: later ones inherit the offsets of the blocks they replace
+  if (blockIdx.x < 1024) {  // the first resident blocks only: later ones inherit the offsets of the blocks they replace
     // HW_ID (register 4): wave slot of the SIMD in bits 3:0
     if (tid == 0) reinterpret_cast<unsigned*>(fzw)[0] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) & 15u;
     __syncthreads();  // (the block's waves move together: all take the offset of wave 0's slot)
@@ -550,7 +548,7 @@ __device__ __forceinline__ void estep_tile(const EstepLaunch& a, const int64_t b
   __syncthreads();
   // partial slots are sized for the 4-wave blocks of the standard variant (estep_grid): a block of 2 x 4 waves fills two
   constexpr int SLOTS = LQW ? WAVES / EstepWavesStd<DP>::W : 1;
-  const int64_t slot0 = (int64_t)bid * SLOTS;
+  const int64_t slot0 = (int64_t)blockIdx.x * SLOTS;
   if (a.ll_part)
     for (int k = tid; k < K; k += NTHR) {
       double s = 0.0;
@@ -566,8 +564,8 @@ __device__ __forceinline__ void estep_tile(const EstepLaunch& a, const int64_t b
     for (int e = 1; e < SLOTS; ++e)
       if (slot0 + e < a.nslots) a.fz_part[slot0 + e] = 0.0;
 #ifdef LC_ES_TRACE
-    if (bid < 65536) {
-      long long* t = lc_es_trace + 5 * (size_t)bid;
+    if (blockIdx.x < 65536) {
+      long long* t = lc_es_trace + 5 * (size_t)blockIdx.x;
       t[0] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20);   // XCC_ID
       t[1] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4);   // HW_ID
       t[2] = tr_w0;
@@ -575,38 +573,6 @@ __device__ __forceinline__ void estep_tile(const EstepLaunch& a, const int64_t b
       t[4] = clock64() - tr_c0;
     }
 #endif
-  }
-}
-
-template <int DP, int R, int WAVES, bool SPARSE, bool LQW = false>
-__global__ void __launch_bounds__(WAVES * 64, LQW ? 2 : EstepOcc<DP>::BLOCKS) estep_kernel(EstepLaunch a) {
-  estep_tile<DP, R, WAVES, SPARSE, LQW>(a, (int64_t)blockIdx.x);
-}
-
-// Persistent form of the dense standard variant: as many workgroups as are resident pull tiles from one counter
-// (a.tile_ctr[0]; the last workgroup to leave resets it for the next launch).  A slot never waits for the dispatcher
-// between two tiles, and a fast XCD simply takes more tiles than a slow one (with one tile per workgroup the placement
-// is static round-robin and the launch ends with the slowest XCD: 1.5 % apart in tools/estep_trace_probe.py).
-// (a real call per tile: inlined into the tile loop, hipcc hoists the tile's lane-constant address arithmetic out of
-// the loop and keeps it in 45-60 more VGPRs for the whole kernel -- spills at D = 64, an occupancy step down elsewhere)
-template <int DP, int R, int WAVES>
-__device__ __attribute__((noinline)) void estep_tile_call(const EstepLaunch& a, const int64_t bid) {
-  estep_tile<DP, R, WAVES, false, false>(a, bid);
-}
-template <int DP, int R, int WAVES>
-__global__ void __launch_bounds__(WAVES * 64, EstepOcc<DP>::BLOCKS) estep_persist_kernel(EstepLaunch a) {
-  __shared__ int next_tile;
-  for (;;) {
-    __syncthreads();  // (the previous tile's readers of the LDS buffers are done)
-    if (threadIdx.x == 0) next_tile = atomicAdd(a.tile_ctr, 1);
-    __syncthreads();
-    const int64_t bid = next_tile;
-    if (bid >= a.nslots) break;
-    estep_tile_call<DP, R, WAVES>(a, bid);
-  }
-  if (threadIdx.x == 0 && atomicAdd(a.tile_ctr + 1, 1) == (int)gridDim.x - 1) {
-    a.tile_ctr[0] = 0;  // every workgroup has drawn its last (out-of-range) tile: ready for the next launch
-    a.tile_ctr[1] = 0;
   }
 }
 
@@ -874,18 +840,6 @@ struct EstepCfg<112> { static constexpr int R = 2, WAVES = 8; };  // (three row 
 template <>
 struct EstepCfg<128> { static constexpr int R = 2, WAVES = 8; };
 
-// compute units of the current device (a process may hold contexts on several)
-static int device_cus() {
-  static int cus_of[16] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
-  if (!cus_of[dev]) {
-    hipDeviceProp_t p;
-    cus_of[dev] = hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
-  }
-  return cus_of[dev];
-}
-
 template <int DP>
 static int rows_per_block_t() { return EstepCfg<DP>::R * EstepCfg<DP>::WAVES * RG; }
 
@@ -952,22 +906,11 @@ static hipError_t launch_estep_s(const EstepLaunch& a, hipStream_t stream) {
     b.lq_lds = 1;  // log q~ stays in LDS until the normalisation
     shmem += (size_t)a.K * WAVES * 64 * sizeof(double);
   }
-  const int64_t grid = estep_grid(DP, a.nrg);
-  if (grid <= 0) return hipSuccess;
-  if constexpr (!SPARSE) {
-    static const int persist = getenv("LC_ES_PERSIST") ? atoi(getenv("LC_ES_PERSIST")) : 1;
-    const int64_t resident = (int64_t)device_cus() * EstepOcc<DP>::BLOCKS;
-    if (persist && a.tile_ctr && grid > 2 * resident && grid < (int64_t)1 << 31) {  // (few tiles: nothing to balance)
-      auto pk = estep_persist_kernel<DP, R, WAVES>;
-      static LdsGrant pgrant;
-      if (hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(pk), shmem, pgrant); e != hipSuccess) return e;
-      hipLaunchKernelGGL(pk, dim3((unsigned)resident), dim3(WAVES * 64), shmem, stream, b);
-      return hipGetLastError();
-    }
-  }
   auto kern = estep_kernel<DP, R, WAVES, SPARSE>;
   static LdsGrant grant;  // largest dynamic-LDS size already granted, per device
   if (hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(kern), shmem, grant); e != hipSuccess) return e;
+  const int64_t grid = estep_grid(DP, a.nrg);
+  if (grid <= 0) return hipSuccess;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVES * 64), shmem, stream, b);
   return hipGetLastError();
 }
