@@ -601,3 +601,28 @@ def test_mstep_failure_on_a_pool_thread_reaches_the_caller(lib):
         F, tr, m = ctx.vbem(capi.W_DIRICHLET, fixed_iters=2, nthreads=8)
         m.close()
         assert np.isfinite(F)
+
+
+def test_feature_gemm_statistics_at_every_width_and_cluster_range(lib):
+    """suffstat_feat_kernel (the statistics as ONE feature GEMM, cluster index inside the MFMA) forced on wherever it
+    exists (LC_SS_FEAT=2: D = 17 ... 128, more than 16 clusters, cluster ranges of <= 32 per launch) and the per-cluster
+    suffstat_kernel (LC_SS_FEAT=0) on the same ragged inputs: N_k, s_k, S_k of updateSS / GaussWish::addobs
+    (src/cluster.cpp:53-82, src/distributions.cpp:301-313) against numpy to 1e-12 of the largest entry, S_k exactly
+    symmetric."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    for mode in ("2", "0"):
+        e = dict(os.environ, LC_SS_FEAT=mode, LC_SSFEAT_NOTIME="1")
+        r = subprocess.run([sys.executable, str(root / "tools" / "ssfeat_check.py"), "child"], capture_output=True, text=True,
+                           env=e, timeout=900, cwd=str(root))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        cases, _ = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+        assert len(cases) >= 20
+        for c in cases:
+            assert c["sym"], (mode, c)
+            assert c["eN"] < 1e-12 and c["es"] < 1e-12 and c["eS"] < 1e-12, (mode, c)

@@ -41,7 +41,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
                         eS=float(np.max(np.abs(xxs - rS)) / np.max(np.abs(rS))),
                         h=[float(Nk.sum()), float(xs.sum()), float(xxs.sum())]))
     times = []
-    for N, D, K in TIMING:
+    for N, D, K in ([] if os.environ.get("LC_SSFEAT_NOTIME") else TIMING):
         rng = np.random.default_rng(1)
         X = rng.normal(size=(N, D))
         with capi.Context(0) as ctx:
