@@ -539,7 +539,10 @@ __host__ __device__ constexpr int ft_tiles(int DP) { return (DP / 4) * (DP / 4 +
 // tiles per wave: as many as the accumulators allow (72 doubles; 64 for 8 quads at D = 80, 96, 112, where 72 spill) -- 9 tiles
 // with 8 cluster quads, 12 with 6, 14 with 5: a launch with fewer quads keeps its MFMAs per step (and has fewer blocks
 // re-staging the same rows)
-__host__ __device__ constexpr int ft_tpw_max(int DP, int NQ) { return (NQ >= 8 && DP > 64 && DP < 128 ? 64 : 72) / NQ; }
+__host__ __device__ constexpr int ft_tpw_max(int DP, int NQ) {
+  const int t = (NQ >= 8 && DP > 64 && DP < 128 ? 64 : 72) / NQ;
+  return t < 14 ? t : 14;  // (two address registers per tile)
+}
 __host__ __device__ constexpr int ft_nslice(int DP, int NQ) { return (ft_tiles(DP) + 4 * ft_tpw_max(DP, NQ) - 1) / (4 * ft_tpw_max(DP, NQ)); }  // blocks per row chunk
 __host__ __device__ constexpr int ft_tpw(int DP, int NQ) { return (ft_tiles(DP) + 4 * ft_nslice(DP, NQ) - 1) / (4 * ft_nslice(DP, NQ)); }
 __host__ __device__ constexpr int ft_batch_rows(int DP) { return DP > 96 ? 24 : 32; }  // (two blocks per CU: 160 KB of LDS)
@@ -548,11 +551,11 @@ inline bool ss_feat_eligible(int DP, int K) {
   static const int mode = getenv("LC_SS_FEAT") ? atoi(getenv("LC_SS_FEAT")) : 1;  // 0 off, 1 where it wins, 2 everywhere it exists
   if (mode == 0 || K <= 16 || DP < 32 || DP > 128) return false;
   if (mode == 2) return true;
-  // measured (tools/ssfeat_check.py, MI355X): it wins where a launch carries 7 or 8 cluster quads (one multiply per 7-8
-  // MFMAs); with 5-6 quads the per-cluster kernel's 72 MFMAs per step are worth more than the saved multiplies
-  const int nr = (K + 31) / 32, per = ((K + nr - 1) / nr + 3) / 4 * 4;
-  const int last = K - (nr - 1) * per;
-  return LC_SS_FEAT_WIDTHS(DP) && per >= 28 && last >= 25;
+  // measured (tools/ssfeat_check.py, MI355X): it wins where EVERY launch carries 7 or 8 cluster quads (one multiply per
+  // 7-8 MFMAs): K = 28..32, 60..64, ...; a remainder launch with few quads costs a whole pass over X at a poor ratio
+  // (K = 33: 6.8 against 5.8 ms at N = 2M), and with 5-6 quads the two kernels are level
+  const int rem = K % 32;
+  return LC_SS_FEAT_WIDTHS(DP) && (rem == 0 || rem >= 28);
 }
 template <int DP, int NQ>
 __global__ void __launch_bounds__(256, 2) suffstat_feat_kernel(SuffstatLaunch a) {
@@ -762,16 +765,18 @@ static hipError_t launch_ss_feat_q(const SuffstatLaunch& b, hipStream_t stream) 
 }
 template <int DP>
 static hipError_t launch_ss_feat_d(const SuffstatLaunch& a, hipStream_t stream) {
-  // cluster ranges of at most 32 (8 quads), near-equal sizes: every range re-reads X, which an MFMA-bound pass affords
-  const int nr = (a.K + 31) / 32, per = ((a.K + nr - 1) / nr + 3) / 4 * 4;
+  // cluster ranges: as many full ranges of 32 (8 quads: one multiply per 8 MFMAs) as there are, the remainder in a last
+  // range of its own -- near-equal ranges (K = 48 as 24 + 24) put BOTH launches at the poor 5-6 quad ratio.  Every range
+  // re-reads X, which an MFMA-bound pass affords.
   SuffstatLaunch b = a;
   if (b.KR < a.K) b.KR = a.K;
-  for (int k0 = 0; k0 < a.K; k0 += per) {
+  for (int k0 = 0; k0 < a.K; k0 += 32) {
     b.klast0 = k0;
-    const int nq = ((a.K - k0 < per ? a.K - k0 : per) + 3) / 4;
+    const int nq = ((a.K - k0 < 32 ? a.K - k0 : 32) + 3) / 4;
     hipError_t e = hipErrorInvalidValue;
     switch (nq) {
-      case 1: case 2: case 3: case 4: e = launch_ss_feat_q<DP, 4>(b, stream); break;
+      case 1: case 2: e = launch_ss_feat_q<DP, 2>(b, stream); break;
+      case 3: case 4: e = launch_ss_feat_q<DP, 4>(b, stream); break;
       case 5: e = launch_ss_feat_q<DP, 5>(b, stream); break;
       case 6: e = launch_ss_feat_q<DP, 6>(b, stream); break;
       case 7: e = launch_ss_feat_q<DP, 7>(b, stream); break;
