@@ -60,6 +60,11 @@
 #ifndef LC_ES_STAGGER
 #define LC_ES_STAGGER 0
 #endif
+//   LC_ES_SADDR  1 (dense k-sliced scheme): c_jk loads and log q~ stores in the scalar-base form (global_load / store
+//                ... voffset, saddr): the cluster index lives in SGPRs, no 64-bit VALU address arithmetic in the loop
+#ifndef LC_ES_SADDR
+#define LC_ES_SADDR 1
+#endif
 //   LC_ES_LQC    1: log q~ = c - d^2 / 2 comes straight out of the lane-sum MFMA (A = -1/2, C = c_jk): no v_fma behind it
 #ifndef LC_ES_LQC
 #define LC_ES_LQC 0
@@ -290,11 +295,34 @@ __global__ void __launch_bounds__(WAVES * 64, LQW ? 2 : EstepOcc<DP>::BLOCKS) es
   }
 #endif
 
+  constexpr bool SADDR = LC_ES_SADDR && LC_ES_STDEF && LC_ES_CPRE && LC_ES_DLDS && !SPARSE && !ROWLANES && !LQW;
+  unsigned coff[R];              // SADDR: byte offset of the c_jk row of row group r's group (J K 8 < 4 GB)
+  const unsigned qoff = lo4 * 8u;  // SADDR: this lane's byte offset inside a 16-row piece of a qZ column
+  // SADDR: byte address of the wave's first row in column 0 of qZ (wave-uniform)
+  const char* qwave = reinterpret_cast<const char*>(a.qZ) +
+                      (((int64_t)blockIdx.x * WAVES + __builtin_amdgcn_readfirstlane(wave)) * R * RG) * 8;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    coff[r] = (unsigned)grp[r] * (unsigned)K * 8u;
+    if constexpr (SADDR) asm volatile("" : "+v"(coff[r]));  // (kept: hipcc would redo the multiply in every pass of the loop)
+  }
 #if LC_ES_STDEF
   double lqprev[R];
   int kprev = -1;
   auto flush_lq = [&]() {
-    if constexpr (ROWLANES) {
+    if constexpr (SADDR) {
+      if (kprev >= 0) {
+        const char* qk = qwave + (int64_t)kprev * a.ldq * 8;
+        const bool mine = hi == (kprev & 3);
+        if (rgok[0] && mine) asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(qoff), "v"(lqprev[0]), "s"(qk) : "memory");
+        if constexpr (R > 1) {
+          if (rgok[1] && mine) asm volatile("global_store_dwordx2 %0, %1, %2 offset:128" ::"v"(qoff), "v"(lqprev[1]), "s"(qk) : "memory");
+        }
+        if constexpr (R > 2) {
+          if (rgok[2] && mine) asm volatile("global_store_dwordx2 %0, %1, %2 offset:256" ::"v"(qoff), "v"(lqprev[R > 2 ? 2 : 0]), "s"(qk) : "memory");
+        }
+      }
+    } else if constexpr (ROWLANES) {
       if (kprev >= 0 && !lqm && myok) a.qZ[(int64_t)kprev * a.ldq + (rg0 + hi) * RG + lo4] = lqprev[0];
     } else if constexpr (!LQW) {
       if (kprev >= 0) {
@@ -341,8 +369,14 @@ __global__ void __launch_bounds__(WAVES * 64, LQW ? 2 : EstepOcc<DP>::BLOCKS) es
     }
 #if LC_ES_CPRE
     double cv[R];
+    if constexpr (SADDR) {
+      const double* ck = a.ctab + k;  // (scalar)
 #pragma unroll
-    for (int r = 0; r < R; ++r) cv[r] = a.ctab[(int64_t)grp[r] * K + k];
+      for (int r = 0; r < R; ++r) asm volatile("global_load_dwordx2 %0, %1, %2" : "=&v"(cv[r]) : "v"(coff[r]), "s"(ck) : "memory");
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; ++r) cv[r] = a.ctab[(int64_t)grp[r] * K + k];
+    }
 #endif
     auto square = [&](int set) {
 #pragma unroll
@@ -382,6 +416,12 @@ __global__ void __launch_bounds__(WAVES * 64, LQW ? 2 : EstepOcc<DP>::BLOCKS) es
     if constexpr (LC_ES_DEFER) square((NT - 1) & 1);
     }
     double lqsel = 0.0;
+#if LC_ES_CPRE
+    if constexpr (SADDR) {  // the asm loads of c_jk are invisible to hipcc's waitcnt pass (the LDS-direct record with them)
+      if constexpr (R == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(cv[0]), "+v"(cv[1]), "+v"(cv[2])::"memory");
+      else asm volatile("s_waitcnt vmcnt(0)" : "+v"(cv[0]), "+v"(cv[R > 1 ? 1 : 0])::"memory");
+    }
+#endif
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       // sum over the four hi lanes on the matrix pipe: D[i][j] = sum_k 1 * B[k][j] leaves the
@@ -434,6 +474,7 @@ __global__ void __launch_bounds__(WAVES * 64, LQW ? 2 : EstepOcc<DP>::BLOCKS) es
 #undef LC_DMA
 #if LC_ES_STDEF
   flush_lq();
+  if constexpr (SADDR) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (asm stores: re-read below by the same lanes)
 #endif
 
   if (a.raw) return;  // GaussWish::Eloglike: leave c_k - 0.5 d^2 in qZ, no normalisation
