@@ -28,7 +28,7 @@ namespace lck {
 
 constexpr int FUSED_KMAX = 16;  // clusters per block-resident parameter set (four per wave in the statistics half)
 constexpr int FUSED_ROWS = 256; // rows per tile
-constexpr int FUSED_QS = FUSED_ROWS + 4;  // q table: 260 doubles per cluster = 8 banks between consecutive clusters
+constexpr int FUSED_QS = FUSED_ROWS + 2;  // q table: 258 doubles per cluster = 4 banks between consecutive clusters
 
 // CPW: cluster quads of the statistics half (K <= 4 CPW)
 template <int DP, int CPW>
@@ -40,9 +40,9 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a) {
   constexpr int PF = 6;
   constexpr int PS = NTILES * 16 + DP;
   // row stride of the staged tile (36 dwords).  E-step half: a half-wave reads rows lo4 = 0..15 at two columns -- 36 lo4
-  // mod 64 are sixteen different multiples of 4: conflict-free.  Statistics half (feature form): a half-wave reads four
-  // columns of two CONSECUTIVE rows (36 dwords apart: 8 banks each, disjoint), and q[row][cluster] with consecutive
-  // clusters 8 banks apart (FUSED_QS): conflict-free as well.  Column DP of every row holds 1.0 (s_k, N_k features).
+  // mod 64 are sixteen different multiples of 4: conflict-free.  Statistics half (feature form): a half-wave reads up to
+  // sixteen columns of two rows that lie 8 rows apart (288 dwords = 32 banks: disjoint), and q[row][cluster] with
+  // consecutive clusters 4 banks apart (FUSED_QS): conflict-free as well.  Column DP of every row holds 1.0 (s_k, N_k).
   constexpr int LD = DP + 2;
   constexpr int R = 4;
   static_assert(4 * CPW <= FUSED_KMAX, "statistics accumulators");
@@ -93,8 +93,9 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a) {
     for (int i = 0; i < NPRE; ++i) {
       const int idx = tid + i * 256;
       const int row = idx / C2, c2 = idx % C2;
-      xt[row * LD + 2 * c2] = pre[i].x;
-      xt[row * LD + 2 * c2 + 1] = pre[i].y;
+      // (one 16-byte store: its 8-lane groups fill one row's 128 bytes; two 8-byte stores put two rows, 36 dwords apart,
+      //  into a 16-lane group: a 2-way conflict on the 32 write banks)
+      *reinterpret_cast<double2*>(xt + row * LD + 2 * c2) = pre[i];
     }
     __syncthreads();
     fetch(tile + gridDim.x);  // in flight during both halves of this tile
@@ -204,17 +205,21 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a) {
     // Tile t < 10 is the patch (ia, ja): x[row][4 ia + lo2] * x[row][4 ja + blk] -- two lane-dependent base pointers and
     // compile-time column offsets; t = 10: x[row][4 blk + lo2] * 1 (s_k); t = 11: 1 * 1 (N_k).
     {
-      const double* xu = xt + hi * LD + lo2;        // + 4 ia
-      const double* xw = xt + hi * LD + blk;        // + 4 ja
-      const double* xs = xt + hi * LD + 4 * blk + lo2;
-      const double* x1 = xt + hi * LD + ONE;
-      const double* qb = qt + lo2 * QS + hi;
+      // a step's four rows are {t, t + 8, t + 4, t + 12} of a 16-row block: the two rows of a half-wave then lie 32 banks
+      // apart (8 x 36 dwords), which every fragment of the step needs -- the 8-bank patch operands and the 32-bank s_k
+      // tile alike -- and in the q table 16 dwords apart, between the 4-dword steps of consecutive clusters (FUSED_QS)
+      const int rsub = 8 * (hi & 1) + 4 * (hi >> 1);
+      const double* xu = xt + rsub * LD + lo2;        // + 4 ia
+      const double* xw = xt + rsub * LD + blk;        // + 4 ja
+      const double* xs = xt + rsub * LD + 4 * blk + lo2;
+      const double* x1 = xt + rsub * LD + ONE;
+      const double* qb = qt + lo2 * QS + rsub;
 #pragma unroll 2
       for (int s4 = 0; s4 < FUSED_ROWS / 16; ++s4) {
-        const int st = 4 * s4 + wave, ro = 4 * st * LD;
+        const int st = 4 * s4 + wave, rbase = (st >> 2) * 16 + (st & 3), ro = rbase * LD;
         double qa[NQ];
 #pragma unroll
-        for (int c = 0; c < NQ; ++c) qa[c] = qb[4 * c * QS + 4 * st];
+        for (int c = 0; c < NQ; ++c) qa[c] = qb[4 * c * QS + rbase];
         const double one = x1[ro];
         static_for<NTL>([&](auto tc) {
           constexpr int t = tc;
