@@ -545,7 +545,10 @@ __host__ __device__ constexpr int ft_tpw_max(int DP, int NQ) {
 }
 __host__ __device__ constexpr int ft_nslice(int DP, int NQ) { return (ft_tiles(DP) + 4 * ft_tpw_max(DP, NQ) - 1) / (4 * ft_tpw_max(DP, NQ)); }  // blocks per row chunk
 __host__ __device__ constexpr int ft_tpw(int DP, int NQ) { return (ft_tiles(DP) + 4 * ft_nslice(DP, NQ) - 1) / (4 * ft_nslice(DP, NQ)); }
-__host__ __device__ constexpr int ft_batch_rows(int DP) { return DP > 96 ? 24 : 32; }  // (two blocks per CU: 160 KB of LDS)
+#ifndef LC_FT_BR
+#define LC_FT_BR 32
+#endif
+__host__ __device__ constexpr int ft_batch_rows(int DP) { return DP > 96 ? 24 : LC_FT_BR; }  // (two blocks per CU: 160 KB of LDS)
 constexpr int FT_QLD = 36;  // row stride of the staged q quads: the two rows of a half-wave 8 banks apart
 inline bool ss_feat_eligible(int DP, int K) {
   static const int mode = getenv("LC_SS_FEAT") ? atoi(getenv("LC_SS_FEAT")) : 1;  // 0 off, 1 where it wins, 2 everywhere it exists
