@@ -922,6 +922,18 @@ void Context::estep(int K, const double* A, const double* m, const double* c, do
     LC_HIP(hipStreamSynchronize(stream_));
     return;
   }
+  hred_.resize((size_t)1 + K);
+  static const bool direct_env = [] { const char* e = std::getenv("LC_DIRECT_HOST"); return !e || std::atoi(e) != 0; }();
+  if (direct_env && !distributed() && grid > 0) {
+    // nothing to sum over ranks: the folds write F_z (and LL_k) straight into the page-locked host buffer
+    redtmp_.reserve((size_t)lck::REDUCE_TMP_ELEMS * 64);
+    LC_HIP(lck::launch_reduce_partials(fzpart_.p, (int)grid, 1, hred_.data(), stream_, redtmp_.p));
+    if (LLk) LC_HIP(lck::launch_reduce_partials(llpart_.p, (int)grid, K, hred_.data() + 1, stream_, redtmp_.p));
+    LC_HIP(hipStreamSynchronize(stream_));
+    if (Fz) *Fz = hred_[0];
+    if (LLk) std::copy(hred_.begin() + 1, hred_.end(), LLk);
+    return;
+  }
   if (grid > 0) {
     redtmp_.reserve((size_t)lck::REDUCE_TMP_ELEMS * 64);
     LC_HIP(lck::launch_reduce_partials(fzpart_.p, (int)grid, 1, red_.p, stream_, redtmp_.p));
@@ -931,7 +943,6 @@ void Context::estep(int K, const double* A, const double* m, const double* c, do
     LC_HIP(hipMemsetAsync(red_.p, 0, (size_t)(1 + K) * sizeof(double), stream_));
   }
   allreduce(red_.p, 1 + K);
-  hred_.resize((size_t)1 + K);
   LC_HIP(hipMemcpyAsync(hred_.data(), red_.p, (size_t)(1 + K) * sizeof(double), hipMemcpyDeviceToHost, stream_));
   LC_HIP(hipStreamSynchronize(stream_));
   if (Fz) *Fz = hred_[0];
@@ -1117,6 +1128,12 @@ void Context::suffstat(const unsigned char* smask, double* Nk, double* xs, doubl
   ssout_.reserve(nout);
   double* njk_d = ssout_.p + (size_t)K * SS;
   const bool own_counts = J_ > 1 || group_sharded() || smask != nullptr;  // N_jk from a column-sum pass of their own
+  // Nothing to sum over ranks, one group, no mask: the fold of the per-chunk records writes straight into the page-locked
+  // host buffer (device-visible; complete when the stream synchronises) -- no fill and no copy-back command, which
+  // count where a pass lasts 0.1 ms (the sub-problems of the split search run thousands of them)
+  static const bool direct_env = [] { const char* e = std::getenv("LC_DIRECT_HOST"); return !e || std::atoi(e) != 0; }();
+  const bool direct = direct_env && !distributed() && !own_counts && NP_ > 0;
+  hss_.resize(nout);
   if (NP_ > 0) {
     int64_t chunk_rows = 0;
     const int nchunks = lck::suffstat_plan(DP, NP_, K, &chunk_rows);
@@ -1187,16 +1204,17 @@ void Context::suffstat(const unsigned char* smask, double* Nk, double* xs, doubl
     else if (extra > 0) {
       LC_HIP(lck::launch_reduce_partials(sspart_.p, nchunks, (int64_t)KR * SS, ssext_.p, stream_));
       LC_HIP(lck::launch_fold_extra(ssext_.p, SS, K, klast0, extra, stream_));
-      LC_HIP(hipMemcpyAsync(ssout_.p, ssext_.p, (size_t)K * SS * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+      LC_HIP(hipMemcpyAsync(direct ? hss_.data() : ssout_.p, ssext_.p, (size_t)K * SS * sizeof(double),
+                            direct ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, stream_));
     } else
-      LC_HIP(lck::launch_reduce_partials(sspart_.p, nchunks, (int64_t)K * SS, ssout_.p, stream_));
+      LC_HIP(lck::launch_reduce_partials(sspart_.p, nchunks, (int64_t)K * SS, direct ? hss_.data() : ssout_.p, stream_));
     // per-group counts N_jk: with one group they are the N_k just reduced (filled in on the host below) -- unless the
     // records are about to be summed over ranks that hold OTHER groups, or a mask removes clusters from them
     if (own_counts) {
       redtmp_.reserve((size_t)lck::REDUCE_TMP_ELEMS * 64);
       LC_HIP(lck::launch_group_colsum(qz_[cur_].buf.p, NP_, K, goff_d_.p, J_, njk_d, stream_, redtmp_.p, NP_));
     }
-    else LC_HIP(hipMemsetAsync(njk_d, 0, (size_t)K * sizeof(double), stream_));
+    else if (!direct) LC_HIP(hipMemsetAsync(njk_d, 0, (size_t)K * sizeof(double), stream_));
     if (smask && J_ == 1)  // single group: a masked cluster receives nothing from it (cluster.cpp:67-70)
       for (int k = 0; k < K; ++k)
         if (!smask[k]) LC_HIP(hipMemsetAsync(ssout_.p + (size_t)k * SS, 0, (size_t)SS * sizeof(double), stream_));
@@ -1205,9 +1223,10 @@ void Context::suffstat(const unsigned char* smask, double* Nk, double* xs, doubl
   }
   // rows of the same groups on every rank: everything is summed.  Whole groups per rank: the K
   // cluster records are summed, the per-group counts are local by construction.
-  allreduce(ssout_.p, group_sharded_ ? (int64_t)K * SS : (int64_t)nout);
-  hss_.resize(nout);
-  LC_HIP(hipMemcpyAsync(hss_.data(), ssout_.p, nout * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  if (!direct) {
+    allreduce(ssout_.p, group_sharded_ ? (int64_t)K * SS : (int64_t)nout);
+    LC_HIP(hipMemcpyAsync(hss_.data(), ssout_.p, nout * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  }
   LC_HIP(hipStreamSynchronize(stream_));
   for (int k = 0; k < K; ++k) {
     const double* rec = hss_.data() + (size_t)k * SS;
@@ -1442,6 +1461,10 @@ int Context::estep_cache(int K, const double* A, const double* m, const double* 
   if (LLk) llpart_.reserve((size_t)std::max<int64_t>(grid, 1) * K);
   red_.reserve((size_t)1 + K);
   const bool delta = delta_tol >= 0.0 && have_old;
+  const int nred = LLk ? 1 + K : 1;
+  hred_.resize((size_t)nred);
+  static const bool direct_env = [] { const char* e = std::getenv("LC_DIRECT_HOST"); return !e || std::atoi(e) != 0; }();
+  const bool direct = direct_env && !distributed() && NP_ > 0;
   if (NP_ > 0) {
     hpack_.assign((size_t)J_ * K, 0.0);
     std::memcpy(hpack_.data(), c, (size_t)J_ * K * sizeof(double));
@@ -1484,15 +1507,16 @@ int Context::estep_cache(int K, const double* A, const double* m, const double* 
       pending_.push_back(ev);
     }
     redtmp_.reserve((size_t)lck::REDUCE_TMP_ELEMS * 64);
-    LC_HIP(lck::launch_reduce_partials(fzpart_.p, (int)grid, 1, red_.p, stream_, redtmp_.p));
-    if (LLk) LC_HIP(lck::launch_reduce_partials(llpart_.p, (int)grid, K, red_.p + 1, stream_, redtmp_.p));
+    double* dst = direct ? hred_.data() : red_.p;  // (single rank: the folds write into the page-locked host buffer)
+    LC_HIP(lck::launch_reduce_partials(fzpart_.p, (int)grid, 1, dst, stream_, redtmp_.p));
+    if (LLk) LC_HIP(lck::launch_reduce_partials(llpart_.p, (int)grid, K, dst + 1, stream_, redtmp_.p));
   } else {
     LC_HIP(hipMemsetAsync(red_.p, 0, (size_t)(1 + K) * sizeof(double), stream_));
   }
-  const int nred = LLk ? 1 + K : 1;
-  allreduce(red_.p, nred);
-  hred_.resize((size_t)nred);
-  LC_HIP(hipMemcpyAsync(hred_.data(), red_.p, (size_t)nred * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  if (!direct) {
+    allreduce(red_.p, nred);
+    LC_HIP(hipMemcpyAsync(hred_.data(), red_.p, (size_t)nred * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  }
   LC_HIP(hipStreamSynchronize(stream_));  // (also covers the host vectors the asynchronous copies read)
   if (Fz) *Fz = hred_[0];
   if (LLk) std::copy(hred_.begin() + 1, hred_.begin() + 1 + K, LLk);
