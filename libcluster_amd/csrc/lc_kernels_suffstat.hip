@@ -543,12 +543,28 @@ __host__ __device__ constexpr int ft_tpw_max(int DP, int NQ) {
   const int t = (NQ >= 8 && DP > 64 && DP < 128 ? 64 : 72) / NQ;
   return t < 14 ? t : 14;  // (two address registers per tile)
 }
-__host__ __device__ constexpr int ft_nslice(int DP, int NQ) { return (ft_tiles(DP) + 4 * ft_tpw_max(DP, NQ) - 1) / (4 * ft_tpw_max(DP, NQ)); }  // blocks per row chunk
-__host__ __device__ constexpr int ft_tpw(int DP, int NQ) { return (ft_tiles(DP) + 4 * ft_nslice(DP, NQ) - 1) / (4 * ft_nslice(DP, NQ)); }
+// Waves per block.  The waves of a block share one staged batch, so 8 waves (one block per CU, longer batches) halve
+// the staging instructions and barriers per MFMA against 4 waves (two blocks per CU) -- where the tiles still divide
+// evenly over the waves: D = 64 (141 tiles = 2 blocks x 8 waves x 9 less 3) 22.03 -> 21.70 ms at N = 10M, K = 32;
+// D = 128 (537 tiles: 15 x 4 x 9 less 3, but 8 x 8 x 9 less 39) 73.0 -> 77.2 ms, so it keeps 4.
+#ifndef LC_FT_WAVES64
+#define LC_FT_WAVES64 8
+#endif
 #ifndef LC_FT_BR
 #define LC_FT_BR 32
 #endif
-__host__ __device__ constexpr int ft_batch_rows(int DP) { return DP > 96 ? 24 : LC_FT_BR; }  // (two blocks per CU: 160 KB of LDS)
+#ifndef LC_FT_BR64
+#define LC_FT_BR64 48
+#endif
+__host__ __device__ constexpr int ft_waves(int DP) { return DP == 64 ? LC_FT_WAVES64 : 4; }
+__host__ __device__ constexpr int ft_nslice(int DP, int NQ) {  // blocks per row chunk
+  return (ft_tiles(DP) + ft_waves(DP) * ft_tpw_max(DP, NQ) - 1) / (ft_waves(DP) * ft_tpw_max(DP, NQ));
+}
+__host__ __device__ constexpr int ft_tpw(int DP, int NQ) {
+  return (ft_tiles(DP) + ft_waves(DP) * ft_nslice(DP, NQ) - 1) / (ft_waves(DP) * ft_nslice(DP, NQ));
+}
+// (160 KB of LDS per CU: two blocks of 4 waves or one of 8)
+__host__ __device__ constexpr int ft_batch_rows(int DP) { return DP > 96 ? 24 : DP == 64 && ft_waves(DP) == 8 ? LC_FT_BR64 : LC_FT_BR; }
 constexpr int FT_QLD = 36;  // row stride of the staged q quads: the two rows of a half-wave 8 banks apart
 inline bool ss_feat_eligible(int DP, int K) {
   static const int mode = getenv("LC_SS_FEAT") ? atoi(getenv("LC_SS_FEAT")) : 1;  // 0 off, 1 where it wins, 2 everywhere it exists
@@ -561,7 +577,8 @@ inline bool ss_feat_eligible(int DP, int K) {
   return LC_SS_FEAT_WIDTHS(DP) && (rem == 0 || rem >= 28);
 }
 template <int DP, int NQ>
-__global__ void __launch_bounds__(256, 2) suffstat_feat_kernel(SuffstatLaunch a) {
+__global__ void __launch_bounds__(64 * ft_waves(DP), 2) suffstat_feat_kernel(SuffstatLaunch a) {
+  constexpr int FTW = ft_waves(DP);
   constexpr int BR = ft_batch_rows(DP), LD = lds_row_stride(DP), QLD = FT_QLD, XBUF = BR * LD, QBUF = BR * QLD;
   constexpr int TPW = ft_tpw(DP, NQ), TILES = ft_tiles(DP), NPATCH = (DP / 4) * (DP / 4 + 1) / 2, NSL = ft_nslice(DP, NQ);
   constexpr int ONE = DP;  // column of the staged rows that holds 1.0
@@ -590,7 +607,7 @@ __global__ void __launch_bounds__(256, 2) suffstat_feat_kernel(SuffstatLaunch a)
   const int64_t r0 = (int64_t)chunk * a.chunk_rows;
   const int64_t r1 = (r0 + a.chunk_rows) < a.NP ? (r0 + a.chunk_rows) : a.NP;
   // this wave's tiles and, per lane, where their two operand fragments sit in a staged batch (in doubles, step 0)
-  const int T0 = (slice * 4 + wave) * TPW;
+  const int T0 = (slice * FTW + wave) * TPW;
   const int nt = TILES - T0 < TPW ? (TILES - T0 > 0 ? TILES - T0 : 0) : TPW;
   const double* pu[TPW];
   const double* pw[TPW];
@@ -621,9 +638,11 @@ __global__ void __launch_bounds__(256, 2) suffstat_feat_kernel(SuffstatLaunch a)
   // register on either side, the rows are immediate offsets.  q batch: thread -> (cluster tid % 32, row quad tid / 32):
   // clusters fastest, so that the 16-lane groups of a ds_write_b64 fill one LDS row (rows fastest would put all the row
   // quads of a group on one bank)
-  constexpr int TPR = DP / 2, NV2 = BR * TPR, NPRE = (NV2 + 255) / 256;  // double2 per row / per batch / per thread
-  constexpr int RPP = 256 / TPR;                                          // rows covered by one pass of the block
-  static_assert(256 % TPR == 0 || NPRE * 256 >= NV2, "staging");
+  constexpr int NTHR = 64 * FTW;
+  constexpr int TPR = DP / 2, NV2 = BR * TPR, NPRE = (NV2 + NTHR - 1) / NTHR;  // double2 per row / per batch / per thread
+  constexpr int RPP = NTHR / TPR;                                               // rows covered by one pass of the block
+  static_assert(NTHR % TPR == 0 || NPRE * NTHR >= NV2, "staging");
+  static_assert(BR / 4 <= NTHR / 32 && 2 * BR <= NTHR, "q staging / ones column");
   double pre[NPRE][2], qpre[4];
   const int qcl = tid & 31, qrq = tid >> 5;
   const bool qthr = qrq < BR / 4;
@@ -633,10 +652,10 @@ __global__ void __launch_bounds__(256, 2) suffstat_feat_kernel(SuffstatLaunch a)
 #pragma unroll
     for (int i = 0; i < NPRE; ++i) {
       int row, c2;
-      if constexpr (256 % TPR == 0) {
+      if constexpr (NTHR % TPR == 0) {
         row = xr0 + i * RPP, c2 = xc2;
       } else {
-        const int idx = tid + i * 256;
+        const int idx = tid + i * NTHR;
         row = idx / TPR, c2 = idx % TPR;
       }
       double2 v = make_double2(0.0, 0.0);
@@ -657,10 +676,10 @@ __global__ void __launch_bounds__(256, 2) suffstat_feat_kernel(SuffstatLaunch a)
 #pragma unroll
     for (int i = 0; i < NPRE; ++i) {
       int row, c2;
-      if constexpr (256 % TPR == 0) {
+      if constexpr (NTHR % TPR == 0) {
         row = xr0 + i * RPP, c2 = xc2;
       } else {
-        const int idx = tid + i * 256;
+        const int idx = tid + i * NTHR;
         row = idx / TPR, c2 = idx % TPR;
       }
       if (row < BR) *reinterpret_cast<double2*>(xbuf + buf * XBUF + row * LD + 2 * c2) = make_double2(pre[i][0], pre[i][1]);
@@ -763,7 +782,7 @@ static hipError_t launch_ss_feat_q(const SuffstatLaunch& b, hipStream_t stream) 
   auto kern = suffstat_feat_kernel<DP, NQ>;
   static LdsGrant grant;
   if (hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(kern), shmem, grant); e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(b.nchunks * ft_nslice(DP, NQ))), dim3(256), shmem, stream, b);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(b.nchunks * ft_nslice(DP, NQ))), dim3(64 * ft_waves(DP)), shmem, stream, b);
   return hipGetLastError();
 }
 template <int DP>
