@@ -544,11 +544,15 @@ __host__ __device__ constexpr int ft_tpw_max(int DP, int NQ) {
   return t < 14 ? t : 14;  // (two address registers per tile)
 }
 // Waves per block.  The waves of a block share one staged batch, so 8 waves (one block per CU, longer batches) halve
-// the staging instructions and barriers per MFMA against 4 waves (two blocks per CU) -- where the tiles still divide
-// evenly over the waves: D = 64 (141 tiles = 2 blocks x 8 waves x 9 less 3) 22.03 -> 21.70 ms at N = 10M, K = 32;
-// D = 128 (537 tiles: 15 x 4 x 9 less 3, but 8 x 8 x 9 less 39) 73.0 -> 77.2 ms, so it keeps 4.
+// the staging instructions and barriers per MFMA against 4 waves (two blocks per CU): D = 64, N = 10M, K = 32:
+// 22.03 -> 21.70 ms.  With 8 waves the tiles are dealt out unevenly -- the first TILES % NW of a chunk's NW = waves x
+// nslice waves take one tile more than the others (ft_tpw is the larger count) -- so no wave carries idle tiles (D = 128:
+// 537 tiles = 25 waves x 9 + 39 x 8; with 9 everywhere 64 waves would carry 39 idle ones: 73.0 -> 77.2 ms).
 #ifndef LC_FT_WAVES64
 #define LC_FT_WAVES64 8
+#endif
+#ifndef LC_FT_WAVES128
+#define LC_FT_WAVES128 8
 #endif
 #ifndef LC_FT_BR
 #define LC_FT_BR 32
@@ -556,15 +560,20 @@ __host__ __device__ constexpr int ft_tpw_max(int DP, int NQ) {
 #ifndef LC_FT_BR64
 #define LC_FT_BR64 48
 #endif
-__host__ __device__ constexpr int ft_waves(int DP) { return DP == 64 ? LC_FT_WAVES64 : 4; }
+#ifndef LC_FT_BR128
+#define LC_FT_BR128 32
+#endif
+__host__ __device__ constexpr int ft_waves(int DP) { return DP == 64 ? LC_FT_WAVES64 : DP == 128 ? LC_FT_WAVES128 : 4; }
 __host__ __device__ constexpr int ft_nslice(int DP, int NQ) {  // blocks per row chunk
   return (ft_tiles(DP) + ft_waves(DP) * ft_tpw_max(DP, NQ) - 1) / (ft_waves(DP) * ft_tpw_max(DP, NQ));
 }
-__host__ __device__ constexpr int ft_tpw(int DP, int NQ) {
+__host__ __device__ constexpr int ft_tpw(int DP, int NQ) {  // tiles of the fuller waves
   return (ft_tiles(DP) + ft_waves(DP) * ft_nslice(DP, NQ) - 1) / (ft_waves(DP) * ft_nslice(DP, NQ));
 }
 // (160 KB of LDS per CU: two blocks of 4 waves or one of 8)
-__host__ __device__ constexpr int ft_batch_rows(int DP) { return DP > 96 ? 24 : DP == 64 && ft_waves(DP) == 8 ? LC_FT_BR64 : LC_FT_BR; }
+__host__ __device__ constexpr int ft_batch_rows(int DP) {
+  return DP == 128 && ft_waves(DP) == 8 ? LC_FT_BR128 : DP > 96 ? 24 : DP == 64 && ft_waves(DP) == 8 ? LC_FT_BR64 : LC_FT_BR;
+}
 constexpr int FT_QLD = 36;  // row stride of the staged q quads: the two rows of a half-wave 8 banks apart
 inline bool ss_feat_eligible(int DP, int K) {
   static const int mode = getenv("LC_SS_FEAT") ? atoi(getenv("LC_SS_FEAT")) : 1;  // 0 off, 1 where it wins, 2 everywhere it exists
@@ -607,8 +616,15 @@ __global__ void __launch_bounds__(64 * ft_waves(DP), 2) suffstat_feat_kernel(Suf
   const int64_t r0 = (int64_t)chunk * a.chunk_rows;
   const int64_t r1 = (r0 + a.chunk_rows) < a.NP ? (r0 + a.chunk_rows) : a.NP;
   // this wave's tiles and, per lane, where their two operand fragments sit in a staged batch (in doubles, step 0)
-  const int T0 = (slice * FTW + wave) * TPW;
-  const int nt = TILES - T0 < TPW ? (TILES - T0 > 0 ? TILES - T0 : 0) : TPW;
+  // 8 waves: NFULL waves of TPW tiles, then TPW - 1 (two instances of the batch body).  4 waves: TPW everywhere, the
+  // last waves of a chunk carry idle tiles -- the second instance costs more there than the idle tiles do (D = 128,
+  // 4 waves: 72.9 -> 77.2 ms with the uneven deal; both bodies compete for the instruction cache)
+  constexpr bool UNEVEN = FTW == 8;
+  constexpr int NW = FTW * NSL, TPWL = UNEVEN ? TILES / NW : TPW, NFULL = UNEVEN ? TILES - TPWL * NW : 0;
+  static_assert(TPWL >= 1 && (NFULL == 0 ? TPWL : TPWL + 1) == TPW, "tile deal");
+  const int gw = slice * FTW + wave;
+  const int T0 = UNEVEN ? gw * TPWL + (gw < NFULL ? gw : NFULL) : gw * TPW;
+  const int nt = UNEVEN ? TPWL + (gw < NFULL ? 1 : 0) : (TILES - T0 < TPW ? (TILES - T0 > 0 ? TILES - T0 : 0) : TPW);
   const double* pu[TPW];
   const double* pw[TPW];
 #pragma unroll
@@ -696,13 +712,12 @@ __global__ void __launch_bounds__(64 * ft_waves(DP), 2) suffstat_feat_kernel(Suf
   }
   __syncthreads();
   const double* pq = qbuf + hi * QLD + lo2;
-  // One batch from buffer B.  All BR / 4 steps and all TPW tiles run (rows past the chunk end were staged as zeros
-  // with q = 0; the idle tiles of the last waves accumulate 1 * 1 products nobody reads): nothing in the loop
-  // depends on run-time counts.  The next tile's fragments -- behind the last tile the next step's first tile and its
+  // One batch from buffer B, for a wave of NT tiles (two instances: the fuller waves and the others).  All BR / 4 steps
+  // run (rows past the chunk end were staged as zeros with q = 0): nothing in the loop depends on run-time counts.  The next tile's fragments -- behind the last tile the next step's first tile and its
   // q quads -- are issued BEFORE this tile's MFMAs and arrive under them (two register sets that swap roles; the fences
   // keep hipcc from sinking the reads to their uses).
-  auto batch = [&](auto bsel) {
-    constexpr int B = decltype(bsel)::value, XO = B * XBUF, QO = B * QBUF;
+  auto batch = [&](auto bsel, auto ntsel) {
+    constexpr int B = decltype(bsel)::value, XO = B * XBUF, QO = B * QBUF, NT = decltype(ntsel)::value;
     double qa[2][NQ], u[2], w[2];
     u[0] = pu[0][XO];
     w[0] = pw[0][XO];
@@ -711,10 +726,10 @@ __global__ void __launch_bounds__(64 * ft_waves(DP), 2) suffstat_feat_kernel(Suf
 #pragma unroll
     for (int st = 0; st < BR / 4; ++st) {
 #pragma unroll
-      for (int t = 0; t < TPW; ++t) {
-        const int cur = (st * TPW + t) & 1, nxt = cur ^ 1;
+      for (int t = 0; t < NT; ++t) {
+        const int cur = (st * NT + t) & 1, nxt = cur ^ 1;
         const double p = u[cur] * w[cur];
-        if (t + 1 < TPW) {
+        if (t + 1 < NT) {
           u[nxt] = pu[t + 1][XO + st * 4 * LD];
           w[nxt] = pw[t + 1][XO + st * 4 * LD];
         } else if (st + 1 < BR / 4) {
@@ -733,16 +748,17 @@ __global__ void __launch_bounds__(64 * ft_waves(DP), 2) suffstat_feat_kernel(Suf
   for (int64_t b0 = r0; b0 < r1; b0 += 2 * BR) {  // two batches per trip: the buffer index is a compile-time constant
     const bool more1 = b0 + BR < r1, more2 = b0 + 2 * BR < r1;
     if (more1) gload(b0 + BR);
-    batch(std::integral_constant<int, 0>{});
+    if (NFULL == 0 || nt == TPW) batch(std::integral_constant<int, 0>{}, std::integral_constant<int, TPW>{});
+    else batch(std::integral_constant<int, 0>{}, std::integral_constant<int, TPWL>{});
     if (more1) lstore(1);
     __syncthreads();
     if (!more1) break;
     if (more2) gload(b0 + 2 * BR);
-    batch(std::integral_constant<int, 1>{});
+    if (NFULL == 0 || nt == TPW) batch(std::integral_constant<int, 1>{}, std::integral_constant<int, TPW>{});
+    else batch(std::integral_constant<int, 1>{}, std::integral_constant<int, TPWL>{});
     if (more2) lstore(0);
     __syncthreads();
   }
-  if (nt == 0) return;
 
   // ---- partial records: [N_k, s_k[DP], S_k[DP x DP]] per (chunk, cluster), as suffstat_kernel writes them
   const int64_t SS = 1 + (int64_t)DP + (int64_t)DP * DP;
