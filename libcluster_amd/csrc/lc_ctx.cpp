@@ -929,6 +929,7 @@ void Context::estep(int K, const double* A, const double* m, const double* c, do
     redtmp_.reserve((size_t)lck::REDUCE_TMP_ELEMS * 64);
     LC_HIP(lck::launch_reduce_partials(fzpart_.p, (int)grid, 1, hred_.data(), stream_, redtmp_.p));
     if (LLk) LC_HIP(lck::launch_reduce_partials(llpart_.p, (int)grid, K, hred_.data() + 1, stream_, redtmp_.p));
+    run_overlap();
     LC_HIP(hipStreamSynchronize(stream_));
     if (Fz) *Fz = hred_[0];
     if (LLk) std::copy(hred_.begin() + 1, hred_.end(), LLk);
@@ -944,6 +945,7 @@ void Context::estep(int K, const double* A, const double* m, const double* c, do
   }
   allreduce(red_.p, 1 + K);
   LC_HIP(hipMemcpyAsync(hred_.data(), red_.p, (size_t)(1 + K) * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  run_overlap();
   LC_HIP(hipStreamSynchronize(stream_));
   if (Fz) *Fz = hred_[0];
   if (LLk) std::copy(hred_.begin() + 1, hred_.end(), LLk);
@@ -1020,6 +1022,7 @@ bool Context::estep_suffstat_fused(int K, const double* A, const double* m, cons
     allreduce(ssout_.p, (int64_t)(group_sharded_ ? nrec : nout));
     LC_HIP(hipMemcpyAsync(hss_.data(), ssout_.p, nout * sizeof(double), hipMemcpyDeviceToHost, stream_));
   }
+  run_overlap();
   LC_HIP(hipStreamSynchronize(stream_));
   for (int k = 0; k < K; ++k) {
     const double* rec = hss_.data() + (size_t)k * SS;
@@ -1517,6 +1520,7 @@ int Context::estep_cache(int K, const double* A, const double* m, const double* 
     allreduce(red_.p, nred);
     LC_HIP(hipMemcpyAsync(hred_.data(), red_.p, (size_t)nred * sizeof(double), hipMemcpyDeviceToHost, stream_));
   }
+  run_overlap();
   LC_HIP(hipStreamSynchronize(stream_));  // (also covers the host vectors the asynchronous copies read)
   if (Fz) *Fz = hred_[0];
   if (LLk) std::copy(hred_.begin() + 1, hred_.begin() + 1 + K, LLk);
@@ -1725,6 +1729,7 @@ void Context::estep_diag(int K, const double* av, const double* w2, const double
   allreduce(red_.p, 1 + K);
   hred_.resize((size_t)1 + K);
   LC_HIP(hipMemcpyAsync(hred_.data(), red_.p, (size_t)(1 + K) * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  run_overlap();
   LC_HIP(hipStreamSynchronize(stream_));
   if (Fz) *Fz = hred_[0];
   if (LLk) std::copy(hred_.begin() + 1, hred_.end(), LLk);

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <functional>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -238,6 +239,18 @@ class Context {
   // N_k, x_s = sum q x [K*D], xx_s = sum q x^2 [K*D] (elementwise), Njk[J*K]
   void suffstat_diag(const unsigned char* smask, double* Nk, double* xs, double* xxs, double* Njk);
 
+  // Host work to run while the NEXT normalising E-step is on the device: the E-step calls it once, after its last
+  // launch and before it waits for the stream (vbem hands over the free-energy terms that depend on the posteriors
+  // only).  A hook that is still pending when the E-step returns was not called; the owner runs it itself.
+  void set_overlap(std::function<void()> f) { overlap_ = std::move(f); }
+  bool overlap_pending() const { return (bool)overlap_; }
+  void run_overlap() {
+    if (!overlap_) return;
+    std::function<void()> f = std::move(overlap_);
+    overlap_ = nullptr;
+    f();
+  }
+
   // ---- timing ---------------------------------------------------------------
   void timing_enable(bool on) { timing_ = on; }
   bool timing_enabled() const { return timing_; }
@@ -310,6 +323,7 @@ class Context {
   DevBuf<int64_t> seloff_;
   DevBuf<double> mv_;
   PinnedBuf hpack_, hred_, hss_;
+  std::function<void()> overlap_;
 
   bool timing_ = false;
   struct EvPair {

@@ -326,6 +326,22 @@ double vbem(lcc::Context& ctx, Model& model, const VbemOptions& opt) {
     }
     double Fz = 0.0;
     const auto t2 = now();
+    // fenergy (:145-165), the terms that depend on the posteriors only: computed on this thread while the E-step runs on
+    // the device (the context calls the hook between its last launch and its wait; the M-step's pool is idle then)
+    double Fw = 0.0, Fc = 0.0, fe_ms = 0.0;
+    std::vector<double> fck(K);
+    auto posterior_terms = [&]() {
+      const auto ta = now();
+      for (const auto& w : model.weights) Fw += w.fenergy();
+      parallel_for(K, opt.nthreads, full ? 1.0 * D * D : 8.0 * D, [&](int k) { fck[k] = model.clusters[k].fenergy(); });
+      for (int k = 0; k < K; ++k) Fc += fck[k];
+      fe_ms = ms(ta, now());
+    };
+    ctx.set_overlap(posterior_terms);
+    struct ClearHook {  // (the hook refers to this frame: it must not outlive it, whatever the E-step throws)
+      lcc::Context& c;
+      ~ClearHook() { c.set_overlap(nullptr); }
+    } clear_hook{ctx};
     // small observations: the E-step and the statistics the NEXT iteration starts from in one pass (updateSS runs at
     // the top of the next iteration on exactly these responsibilities, cluster.cpp:198-212)
     if (full && !opt.sparse) {
@@ -368,18 +384,14 @@ double vbem(lcc::Context& ctx, Model& model, const VbemOptions& opt) {
     }
     const auto t3 = now();
 
-    // fenergy (:145-165)
-    double Fw = 0.0, Fc = 0.0;
-    for (const auto& w : model.weights) Fw += w.fenergy();
+    if (ctx.overlap_pending()) ctx.run_overlap();  // (an E-step path without the hook, or one that threw CacheNoRoom first)
     if (ctx.group_sharded()) Fw = ctx.allreduce_value(Fw);  // other ranks hold the other groups' weights
-    std::vector<double> fck(K);
-    parallel_for(K, opt.nthreads, full ? 1.0 * D * D : 8.0 * D, [&](int k) { fck[k] = model.clusters[k].fenergy(); });
-    for (int k = 0; k < K; ++k) Fc += fck[k];
     F = Fc + Fw + Fz;
     if (opt.trace) opt.trace->push_back(F);
     if (trace_phases)
       std::cerr << "[vbem] suffstat+weights " << ms(t0, t1) << " ms, M-step+pack " << ms(t1, t2) << " ms, E-step "
-                << ms(t2, t3) << " ms, fenergy " << ms(t3, now()) << " ms" << std::endl;
+                << ms(t2, t3) << " ms (free energy terms " << fe_ms << " ms under it), fenergy " << ms(t3, now()) << " ms"
+                << std::endl;
     if (ctx.timing_enabled()) ctx.timing_host_phases(ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, now()));
     ++done;
 
