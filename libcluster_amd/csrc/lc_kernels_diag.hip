@@ -463,7 +463,11 @@ __global__ void __launch_bounds__(256, 2)
     const double2* src = reinterpret_cast<const double2*>(Wt);
     double2* dst = reinterpret_cast<double2*>(wl);
     for (int i = tid; i < KT * NTF * 8; i += 256) dst[i] = src[i];
-    for (int i = tid; i < 4 * KT; i += 256) cst[i] = i < K ? constk[i] : 0.0;
+    // One group (no row-group table): c_jk is one row of K values -- folded into the staged constants.  The table read
+    // in tile_const is a vector load at the head of every cluster tile, and the vector-memory counter retires in order:
+    // waiting for it is waiting for the next tile's rows issued just before it (an HBM round trip per cluster tile --
+    // the kernel's "half of the wave time waiting").  With several groups the table is still read there.
+    for (int i = tid; i < 4 * KT; i += 256) cst[i] = i < K ? constk[i] + (rginfo ? 0.0 : ctab[i]) : 0.0;
     for (int i = tid; i < DP; i += 256) mul[i] = QUAD ? mu[i] : 0.0;
     for (int it = 0; it < KT; ++it) lls[it * 256 + tid] = 0.0;
   }
@@ -557,7 +561,7 @@ __global__ void __launch_bounds__(256, 2)
       const int k = 4 * it + hi;
       const double ck = cst[k];
 #pragma unroll
-      for (int r = 0; r < R; ++r) out[r] = k < K ? ctab[(int64_t)grp[r] * K + k] + ck : -INFINITY;
+      for (int r = 0; r < R; ++r) out[r] = k < K ? (rginfo ? ctab[(int64_t)grp[r] * K + k] + ck : ck) : -INFINITY;
     };
     auto tile_done = [&](int it, double (&v)[R]) {
       const int k = 4 * it + hi;
