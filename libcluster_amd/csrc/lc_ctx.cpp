@@ -1701,6 +1701,8 @@ void Context::estep_diag(int K, const double* av, const double* w2, const double
     a.wt = params_.p + wt_off;
     a.mu = params_.p + mu_off;
     a.constk = params_.p + ck_off;
+    sink_.reserve(256);
+    a.sink = sink_.p;
   }
   EvPair ev{};
   if (timing_) {

@@ -311,6 +311,7 @@ class Context {
   std::vector<std::unique_ptr<SavedColumn>> dc_saved_;
   bool dc_journal_ = false;
   int dc_jK0_ = 0;
+  DevBuf<double> sink_;  // estep_diag_mfma_kernel's store sink
   DevBuf<double> dq_, amax_;  // estep_cache(delta_tol): q_new - q_old [K x NP] (moved rows), per-row max |.|
   double dq_tol_ = 0.0;
   int dq_K_ = 0;

@@ -176,6 +176,7 @@ struct DiagEstepLaunch {
   const double* wt = nullptr;      // packed weight tiles [ceil(K/4)][NTF][16]; nullptr: the difference-form VALU kernel
   const double* mu = nullptr;      // [DP] centre (unused in mode 2)
   const double* constk = nullptr;  // [K] sum_d (w2 a'^2 + w1 mu)
+  double* sink = nullptr;          // [256] scratch: where the lanes of padding clusters / missing row groups store (see the kernel)
 };
 inline int64_t estep_diag_grid(int64_t nrg) { return (nrg * RG + 63) / 64; }
 int64_t estep_diag_mfma_weights(int DP, int K, int mode);

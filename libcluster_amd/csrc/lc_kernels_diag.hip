@@ -441,7 +441,7 @@ __global__ void __launch_bounds__(256, 2)
                            const double* __restrict__ constk, const double* __restrict__ ctab,
                            const int* __restrict__ rginfo, double* __restrict__ qZ, double* __restrict__ fz_part,
                            double* __restrict__ ll_part_, int K, int64_t nrg, int64_t nrows, int64_t ldq, int raw_,
-                           int64_t nslots) {
+                           int64_t nslots, double* __restrict__ sink) {
   const int raw = PLAIN ? 0 : raw_;
   double* const ll_part = PLAIN ? nullptr : ll_part_;
   constexpr int DP = NT * 4;
@@ -652,19 +652,23 @@ __global__ void __launch_bounds__(256, 2)
       se = sum_over_hi(se);
       const double logZ = log(se) + m;
       const double inv = 1.0 / se;
+      // The store is UNCONDITIONAL: lanes of padding clusters (k >= K, cluster tiles past the last one included) and of
+      // row groups past the end write a zero to their slot of `sink`.  A store under a branch is one the compiler cannot
+      // count on, and the vector-memory counter retires in order: the wait for the prefetched rows at the head of the
+      // next tile then became "until at most the 8 newest operations are outstanding" -- i.e. until all 16 stores of
+      // this tile had reached memory.  Counted, they stay in flight under the next tile's MFMAs.
       auto finish = [&](int it, double v) {
         const int k = 4 * it + hi;
-        if (k < K) {
-          double q = ll_part ? exp(v - logZ) : v * inv;
-          if (!rowok[r]) q = 0.0;
-          if (rgok[r]) qZ[(int64_t)k * ldq + (rg0 + r) * RG + lo4] = q;
-          if (ll_part && q > 0.0) lls[it * 256 + tid] += q * (v - ctab[(int64_t)grp[r] * K + k]);
-        }
+        const bool kin = k < K;
+        double q = ll_part ? exp(v - logZ) : v * inv;
+        if (!rowok[r] || !kin) q = 0.0;
+        double* dst = kin && rgok[r] ? qZ + ((int64_t)k * ldq + (rg0 + r) * RG + lo4) : sink + tid;
+        *dst = q;
+        if (ll_part && kin && q > 0.0) lls[it * 256 + tid] += q * (v - ctab[(int64_t)grp[r] * K + k]);
       };
       if constexpr (REGS) {
 #pragma unroll
-        for (int it = 0; it < KTM; ++it)
-          if (it < KT) finish(it, lq[it][r]);
+        for (int it = 0; it < KTM; ++it) finish(it, lq[it][r]);
       } else {
         for (int it = 0; it < KT; ++it) finish(it, lqme[(it * R + r) * 256]);
       }
@@ -705,9 +709,10 @@ static hipError_t launch_edm_k(const DiagEstepLaunch& a, hipStream_t stream) {
   const int KT = (a.K + 3) / 4, NTF = QUAD ? 2 * NT : NT;
   const size_t shmem = edm_lds_bytes(NT, NTF, KT, R, KTM == 0);
 #ifndef LC_EDM_PLAIN_QUAD
-#define LC_EDM_PLAIN_QUAD 0  // (measured: the plain instance gains 10 % for the linear features, loses 4 % with the quadratic half)
+#define LC_EDM_PLAIN_QUAD 1  // (with unconditional stores the plain instance wins for both: linear features 10 %, with the quadratic half 6.5 %; it lost 4 % there before)
 #endif
   const bool plain = KTM > 0 && !a.raw && !a.ll_part && (!QUAD || LC_EDM_PLAIN_QUAD);
+  if (!a.sink) return hipErrorInvalidValue;
   auto kern = plain ? estep_diag_mfma_kernel<NT, QUAD, R, KTM, (KTM > 0)> : estep_diag_mfma_kernel<NT, QUAD, R, KTM>;
   static LdsGrant grants[2];
   if (hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(kern), shmem, grants[plain ? 1 : 0]); e != hipSuccess) return e;
@@ -725,7 +730,7 @@ static hipError_t launch_edm_k(const DiagEstepLaunch& a, hipStream_t stream) {
   int64_t grid = std::min<int64_t>(std::min<int64_t>(ntile, nslots), (int64_t)cus * per_cu);
   if (grid <= 0) return hipSuccess;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), shmem, stream, a.X, a.wt, a.mu, a.constk, a.ctab, a.rginfo,
-                     a.qZ, a.fz_part, a.ll_part, a.K, a.nrg, a.nrows, a.ldq, a.raw, nslots);
+                     a.qZ, a.fz_part, a.ll_part, a.K, a.nrg, a.nrows, a.ldq, a.raw, nslots, a.sink);
   return hipGetLastError();
 }
 
