@@ -56,10 +56,16 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a) {
   double* qt = par + (size_t)K * PS;   // [4 NQ][QS]: log q~, then q, of the tile's rows (clusters >= K: zeros)
   double* llw = qt + (size_t)4 * NQ * QS;  // [4][K]
   double* fzw = llw + 4 * K;           // [4]
+  // One group: the K constants c_k wait in LDS.  Read from global memory inside the cluster loop they are vector loads
+  // issued AFTER the next tile's prefetch, and the vector-memory counter retires in order: every wait for a constant was
+  // a wait for the prefetch (an HBM round trip per tile, exposed).  With several groups the table is still read there.
+  double* ctl = fzw + 4;               // [K]
+  const bool onegroup = a.rginfo == nullptr;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lo4 = lane & 15, hi = lane >> 4, blk = (lane >> 2) & 3, lo2 = lane & 3;
   for (int i = tid; i < K * PS; i += 256) par[i] = a.params[i];
   for (int i = tid; i < 4 * K; i += 256) llw[i] = 0.0;
+  for (int i = tid; i < K; i += 256) ctl[i] = onegroup ? a.ctab[i] : 0.0;
   for (int i = tid; i < 4 * NQ * QS; i += 256) qt[i] = 0.0;
   xt[tid * LD + ONE] = 1.0;  // (the staging below writes columns 0 .. DP - 1 only)
   double acc[NTL][NQ];
@@ -166,7 +172,7 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a) {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const double dd = mfma4(1.0, d2[r], 0.0);  // sum over the four hi lanes, total in every lane
-        const double lq = a.ctab[(int64_t)grp[r] * K + k] - 0.5 * dd;
+        const double lq = (onegroup ? ctl[k] : a.ctab[(int64_t)grp[r] * K + k]) - 0.5 * dd;
         if (hi == r) lqsel = lq;
       }
       mymx = fmax(mymx, lqsel);
@@ -193,7 +199,7 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a) {
         if (myok) qp[(int64_t)k * a.ldq] = q;
         qt[k * QS + tid] = q;
         if (a.want_ll) {  // wave-uniform
-          const double ll = wave_sum(q > 0.0 ? q * (lq - a.ctab[(int64_t)mygrp * K + k]) : 0.0);
+          const double ll = wave_sum(q > 0.0 ? q * (lq - (onegroup ? ctl[k] : a.ctab[(int64_t)mygrp * K + k])) : 0.0);
           if (lane == 0) llw[wave * K + k] += ll;
         }
       }
@@ -289,7 +295,7 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a) {
 static size_t fused_lds_bytes(int DP, int K) {
   const int NT = DP / 4, PS = NT * (NT + 1) / 2 * 16 + DP;
   const int NQ = K <= 4 ? 1 : K <= 8 ? 2 : 4;  // the instance launch_fused picks
-  return ((size_t)FUSED_ROWS * (DP + 2) + (size_t)K * PS + (size_t)4 * NQ * FUSED_QS + 4 * K + 4) * sizeof(double);
+  return ((size_t)FUSED_ROWS * (DP + 2) + (size_t)K * PS + (size_t)4 * NQ * FUSED_QS + 4 * K + 4 + K) * sizeof(double);
 }
 
 // does this shape have a fused path?  (a property of (DP, K) alone: every rank of a distributed run must take the same
