@@ -435,13 +435,19 @@ __global__ void __launch_bounds__(256)
 // PLAIN: the instance the VBEM iterations use -- normalised responsibilities, no split-ordering term: `raw` and
 // `ll_part` are compile-time constants there (they are tested per cluster tile and row group otherwise: several hundred
 // scalar and exec-mask branches per tile of the generic instance)
-template <int NT, bool QUAD, int R, int KTM, bool PLAIN = false>
+// ONEGRP (with PLAIN): one group, known at compile time -- no row-group table.  With the table as a run-time choice the
+// two ways of forming a row group's `info` end in the same register, and the compiler protects that register with a
+// `s_waitcnt vmcnt(0)` in the table-less path too: a full drain (the previous tile's stores, the prefetch just issued) at
+// the head of every tile.
+template <int NT, bool QUAD, int R, int KTM, bool PLAIN = false, bool ONEGRP = false>
 __global__ void __launch_bounds__(256, 2)
     estep_diag_mfma_kernel(const double* __restrict__ X, const double* __restrict__ Wt, const double* __restrict__ mu,
                            const double* __restrict__ constk, const double* __restrict__ ctab,
-                           const int* __restrict__ rginfo, double* __restrict__ qZ, double* __restrict__ fz_part,
+                           const int* __restrict__ rginfo_, double* __restrict__ qZ, double* __restrict__ fz_part,
                            double* __restrict__ ll_part_, int K, int64_t nrg, int64_t nrows, int64_t ldq, int raw_,
                            int64_t nslots, double* __restrict__ sink) {
+  static_assert(!ONEGRP || PLAIN, "the one-group instance is a plain one");
+  const int* const rginfo = ONEGRP ? nullptr : rginfo_;
   const int raw = PLAIN ? 0 : raw_;
   double* const ll_part = PLAIN ? nullptr : ll_part_;
   constexpr int DP = NT * 4;
@@ -712,10 +718,13 @@ static hipError_t launch_edm_k(const DiagEstepLaunch& a, hipStream_t stream) {
 #define LC_EDM_PLAIN_QUAD 1  // (with unconditional stores the plain instance wins for both: linear features 10 %, with the quadratic half 6.5 %; it lost 4 % there before)
 #endif
   const bool plain = KTM > 0 && !a.raw && !a.ll_part && (!QUAD || LC_EDM_PLAIN_QUAD);
+  const bool onegrp = plain && !a.rginfo;
   if (!a.sink) return hipErrorInvalidValue;
-  auto kern = plain ? estep_diag_mfma_kernel<NT, QUAD, R, KTM, (KTM > 0)> : estep_diag_mfma_kernel<NT, QUAD, R, KTM>;
-  static LdsGrant grants[2];
-  if (hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(kern), shmem, grants[plain ? 1 : 0]); e != hipSuccess) return e;
+  auto kern = onegrp ? estep_diag_mfma_kernel<NT, QUAD, R, KTM, (KTM > 0), (KTM > 0)>
+              : plain ? estep_diag_mfma_kernel<NT, QUAD, R, KTM, (KTM > 0)> : estep_diag_mfma_kernel<NT, QUAD, R, KTM>;
+  static LdsGrant grants[3];
+  if (hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(kern), shmem, grants[onegrp ? 2 : plain ? 1 : 0]); e != hipSuccess)
+    return e;
   const int64_t ntile = (a.nrg + 4 * R - 1) / (4 * R);
   const int64_t nslots = estep_diag_grid(a.nrg);
   static int cus = 0;
