@@ -31,8 +31,13 @@ constexpr int FUSED_ROWS = 256; // rows per tile
 constexpr int FUSED_QS = FUSED_ROWS + 2;  // q table: 258 doubles per cluster = 4 banks between consecutive clusters
 
 // CPW: cluster quads of the statistics half (K <= 4 CPW)
-template <int DP, int CPW>
-__global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a) {
+// ONEGRP: one group, known at compile time (no row-group table).  As a run-time choice the table read and the computed
+// `info` end in one register, which the compiler guards with `s_waitcnt vmcnt(0)` in BOTH paths -- four full drains of
+// the just-issued prefetch at the head of every tile.
+template <int DP, int CPW, bool ONEGRP = false>
+__global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
+  FusedLaunch a = a_;
+  if constexpr (ONEGRP) a.rginfo = nullptr;
   static_assert(DP == 16, "one 16 x 16 block of S_k (the general blocking lives in suffstat_kernel)");
   constexpr int NT = DP / 4;
   constexpr int NTILES = NT * (NT + 1) / 2;
@@ -60,7 +65,7 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a) {
   // issued AFTER the next tile's prefetch, and the vector-memory counter retires in order: every wait for a constant was
   // a wait for the prefetch (an HBM round trip per tile, exposed).  With several groups the table is still read there.
   double* ctl = fzw + 4;               // [K]
-  const bool onegroup = a.rginfo == nullptr;
+  const bool onegroup = ONEGRP || a.rginfo == nullptr;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lo4 = lane & 15, hi = lane >> 4, blk = (lane >> 2) & 3, lo2 = lane & 3;
   for (int i = tid; i < K * PS; i += 256) par[i] = a.params[i];
@@ -116,7 +121,10 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a) {
       const int64_t rg = rg0 + r;
       rgok[r] = rg < a.nrg;
       int info = 0;
-      if (rgok[r]) {
+      if constexpr (ONEGRP) {
+        const int64_t rem = a.nrows - rg * RG;
+        info = !rgok[r] ? 0 : rem >= RG ? RG : (rem > 0 ? (int)rem : 0);
+      } else if (rgok[r]) {
         if (a.rginfo) {
           info = a.rginfo[rg];
         } else {
@@ -333,12 +341,17 @@ int fused_plan(int DP, int64_t nrg, int K) {
 hipError_t launch_fused(const FusedLaunch& a, hipStream_t stream) {
   if (a.DP != 16 || a.grid <= 0) return hipErrorInvalidValue;
   const size_t shmem = fused_lds_bytes(a.DP, a.K);
-  static LdsGrant grants[3];
+  static LdsGrant grants[6];
   auto go = [&](auto kern, LdsGrant& g) {
     if (hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(kern), shmem, g); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)a.grid), dim3(256), shmem, stream, a);
     return hipGetLastError();
   };
+  if (!a.rginfo) {
+    if (a.K <= 4) return go(fused_small_kernel<16, 1, true>, grants[3]);
+    if (a.K <= 8) return go(fused_small_kernel<16, 2, true>, grants[4]);
+    return go(fused_small_kernel<16, 4, true>, grants[5]);
+  }
   if (a.K <= 4) return go(fused_small_kernel<16, 1>, grants[0]);
   if (a.K <= 8) return go(fused_small_kernel<16, 2>, grants[1]);
   return go(fused_small_kernel<16, 4>, grants[2]);
