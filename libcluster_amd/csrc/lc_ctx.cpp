@@ -989,6 +989,7 @@ bool Context::estep_suffstat_fused(int K, const double* A, const double* m, cons
   a.partial = sspart_.p;
   a.want_ll = LLk != nullptr;
   a.grid = grid;
+  a.ngroups = J_;
   EvPair ev{};
   if (timing_) {
     LC_HIP(hipEventCreate(&ev.a));

@@ -94,7 +94,9 @@ struct FusedLaunch {
   double* partial;       // [grid x fused_record(DP, K)]
   bool want_ll;          // also the split-ordering data term
   int grid;              // fused_plan(...)
+  int ngroups = 1;       // J: rows of ctab (the table waits in LDS when J x K <= FUSED_CT_CAP)
 };
+constexpr int FUSED_CT_CAP = 1024;
 inline int64_t fused_record(int DP, int K) { return (int64_t)K * (1 + DP + (int64_t)DP * DP) + 1 + K; }
 bool fused_eligible(int DP, int K);          // a property of the shape alone (identical on every rank)
 int fused_plan(int DP, int64_t nrg, int K);  // persistent blocks for nrg row groups (0 when there are none)

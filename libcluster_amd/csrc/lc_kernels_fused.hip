@@ -34,8 +34,12 @@ constexpr int FUSED_QS = FUSED_ROWS + 2;  // q table: 258 doubles per cluster = 
 // ONEGRP: one group, known at compile time (no row-group table).  As a run-time choice the table read and the computed
 // `info` end in one register, which the compiler guards with `s_waitcnt vmcnt(0)` in BOTH paths -- four full drains of
 // the just-issued prefetch at the head of every tile.
-template <int DP, int CPW, bool ONEGRP = false>
+// GRP 0 = that instance; 1: several groups, the J x K table c_jk waits in LDS (J x K <= FUSED_CT_CAP); 2: several groups, the
+// table is read from global memory inside the cluster loop (each read then waits for the prefetch as well).  Compile-time
+// because a run-time choice between an LDS read and a global read ends in a combined `vmcnt(0) lgkmcnt(0)` at the merge.
+template <int DP, int CPW, int GRP = 2>
 __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
+  constexpr bool ONEGRP = GRP == 0, CTLDS = GRP != 2;
   FusedLaunch a = a_;
   if constexpr (ONEGRP) a.rginfo = nullptr;
   static_assert(DP == 16, "one 16 x 16 block of S_k (the general blocking lives in suffstat_kernel)");
@@ -64,13 +68,14 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
   // One group: the K constants c_k wait in LDS.  Read from global memory inside the cluster loop they are vector loads
   // issued AFTER the next tile's prefetch, and the vector-memory counter retires in order: every wait for a constant was
   // a wait for the prefetch (an HBM round trip per tile, exposed).  With several groups the table is still read there.
-  double* ctl = fzw + 4;               // [K]
-  const bool onegroup = ONEGRP || a.rginfo == nullptr;
+  double* ctl = fzw + 4;               // [FUSED_CT_CAP]: the table c_jk when it fits (J x K entries), else unused
+  const int ctrows = ONEGRP ? 1 : a.ngroups;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lo4 = lane & 15, hi = lane >> 4, blk = (lane >> 2) & 3, lo2 = lane & 3;
   for (int i = tid; i < K * PS; i += 256) par[i] = a.params[i];
   for (int i = tid; i < 4 * K; i += 256) llw[i] = 0.0;
-  for (int i = tid; i < K; i += 256) ctl[i] = onegroup ? a.ctab[i] : 0.0;
+  if constexpr (CTLDS)
+    for (int i = tid; i < ctrows * K; i += 256) ctl[i] = a.ctab[i];
   for (int i = tid; i < 4 * NQ * QS; i += 256) qt[i] = 0.0;
   xt[tid * LD + ONE] = 1.0;  // (the staging below writes columns 0 .. DP - 1 only)
   double acc[NTL][NQ];
@@ -109,9 +114,10 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
       *reinterpret_cast<double2*>(xt + row * LD + 2 * c2) = pre[i];
     }
     __syncthreads();
-    fetch(tile + gridDim.x);  // in flight during both halves of this tile
 
     // ---- E-step half: this wave's 64 rows as four row groups
+    // (the row groups' table entries are read BEFORE the next tile's prefetch goes out: they are waited for at once, and
+    //  the vector-memory counter retires in order)
     const int64_t rg0 = tile * (FUSED_ROWS / RG) + wave * R;
     double xf[R][NT];
     int grp[R];
@@ -132,8 +138,14 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
           info = rem >= RG ? RG : (rem > 0 ? (int)rem : 0);
         }
       }
+      if constexpr (!ONEGRP) asm volatile("" : "+v"(info));  // (the table entry has to be HERE: its wait stands in front of the prefetch)
       grp[r] = info >> 5;
       rowok[r] = lo4 < (info & 31);
+    }
+    if constexpr (!ONEGRP) __builtin_amdgcn_sched_barrier(0);
+    fetch(tile + gridDim.x);  // in flight during both halves of this tile
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
       const double* xr = xt + (wave * 64 + r * 16 + lo4) * LD + hi;
 #pragma unroll
       for (int jt = 0; jt < NT; ++jt) xf[r][jt] = xr[4 * jt];
@@ -180,7 +192,11 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const double dd = mfma4(1.0, d2[r], 0.0);  // sum over the four hi lanes, total in every lane
-        const double lq = (onegroup ? ctl[k] : a.ctab[(int64_t)grp[r] * K + k]) - 0.5 * dd;
+        double cjk;
+        if constexpr (ONEGRP) cjk = ctl[k];
+        else if constexpr (CTLDS) cjk = ctl[grp[r] * K + k];
+        else cjk = a.ctab[(int64_t)grp[r] * K + k];
+        const double lq = cjk - 0.5 * dd;
         if (hi == r) lqsel = lq;
       }
       mymx = fmax(mymx, lqsel);
@@ -207,7 +223,11 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
         if (myok) qp[(int64_t)k * a.ldq] = q;
         qt[k * QS + tid] = q;
         if (a.want_ll) {  // wave-uniform
-          const double ll = wave_sum(q > 0.0 ? q * (lq - (onegroup ? ctl[k] : a.ctab[(int64_t)mygrp * K + k])) : 0.0);
+          double cjk;
+          if constexpr (ONEGRP) cjk = ctl[k];
+          else if constexpr (CTLDS) cjk = ctl[mygrp * K + k];
+          else cjk = a.ctab[(int64_t)mygrp * K + k];
+          const double ll = wave_sum(q > 0.0 ? q * (lq - cjk) : 0.0);
           if (lane == 0) llw[wave * K + k] += ll;
         }
       }
@@ -303,7 +323,7 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
 static size_t fused_lds_bytes(int DP, int K) {
   const int NT = DP / 4, PS = NT * (NT + 1) / 2 * 16 + DP;
   const int NQ = K <= 4 ? 1 : K <= 8 ? 2 : 4;  // the instance launch_fused picks
-  return ((size_t)FUSED_ROWS * (DP + 2) + (size_t)K * PS + (size_t)4 * NQ * FUSED_QS + 4 * K + 4 + K) * sizeof(double);
+  return ((size_t)FUSED_ROWS * (DP + 2) + (size_t)K * PS + (size_t)4 * NQ * FUSED_QS + 4 * K + 4 + FUSED_CT_CAP) * sizeof(double);
 }
 
 // does this shape have a fused path?  (a property of (DP, K) alone: every rank of a distributed run must take the same
@@ -341,20 +361,25 @@ int fused_plan(int DP, int64_t nrg, int K) {
 hipError_t launch_fused(const FusedLaunch& a, hipStream_t stream) {
   if (a.DP != 16 || a.grid <= 0) return hipErrorInvalidValue;
   const size_t shmem = fused_lds_bytes(a.DP, a.K);
-  static LdsGrant grants[6];
+  static LdsGrant grants[9];
   auto go = [&](auto kern, LdsGrant& g) {
     if (hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(kern), shmem, g); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)a.grid), dim3(256), shmem, stream, a);
     return hipGetLastError();
   };
   if (!a.rginfo) {
-    if (a.K <= 4) return go(fused_small_kernel<16, 1, true>, grants[3]);
-    if (a.K <= 8) return go(fused_small_kernel<16, 2, true>, grants[4]);
-    return go(fused_small_kernel<16, 4, true>, grants[5]);
+    if (a.K <= 4) return go(fused_small_kernel<16, 1, 0>, grants[3]);
+    if (a.K <= 8) return go(fused_small_kernel<16, 2, 0>, grants[4]);
+    return go(fused_small_kernel<16, 4, 0>, grants[5]);
   }
-  if (a.K <= 4) return go(fused_small_kernel<16, 1>, grants[0]);
-  if (a.K <= 8) return go(fused_small_kernel<16, 2>, grants[1]);
-  return go(fused_small_kernel<16, 4>, grants[2]);
+  if ((int64_t)a.ngroups * a.K <= FUSED_CT_CAP) {
+    if (a.K <= 4) return go(fused_small_kernel<16, 1, 1>, grants[6]);
+    if (a.K <= 8) return go(fused_small_kernel<16, 2, 1>, grants[7]);
+    return go(fused_small_kernel<16, 4, 1>, grants[8]);
+  }
+  if (a.K <= 4) return go(fused_small_kernel<16, 1, 2>, grants[0]);
+  if (a.K <= 8) return go(fused_small_kernel<16, 2, 2>, grants[1]);
+  return go(fused_small_kernel<16, 4, 2>, grants[2]);
 }
 
 }  // namespace lck
