@@ -1704,6 +1704,7 @@ void Context::estep_diag(int K, const double* av, const double* w2, const double
     a.constk = params_.p + ck_off;
     sink_.reserve(256);
     a.sink = sink_.p;
+    a.ngroups = J_;
   }
   EvPair ev{};
   if (timing_) {

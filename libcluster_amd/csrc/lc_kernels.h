@@ -178,8 +178,10 @@ struct DiagEstepLaunch {
   const double* wt = nullptr;      // packed weight tiles [ceil(K/4)][NTF][16]; nullptr: the difference-form VALU kernel
   const double* mu = nullptr;      // [DP] centre (unused in mode 2)
   const double* constk = nullptr;  // [K] sum_d (w2 a'^2 + w1 mu)
+  int ngroups = 1;                 // J: rows of ctab (with several groups the plain instance keeps the table in LDS when J x K <= EDM_CT_CAP)
   double* sink = nullptr;          // [256] scratch: where the lanes of padding clusters / missing row groups store (see the kernel)
 };
+constexpr int EDM_CT_CAP = 1024;
 inline int64_t estep_diag_grid(int64_t nrg) { return (nrg * RG + 63) / 64; }
 int64_t estep_diag_mfma_weights(int DP, int K, int mode);
 hipError_t launch_estep_diag(const DiagEstepLaunch& a, hipStream_t stream);

@@ -439,14 +439,17 @@ __global__ void __launch_bounds__(256)
 // two ways of forming a row group's `info` end in the same register, and the compiler protects that register with a
 // `s_waitcnt vmcnt(0)` in the table-less path too: a full drain (the previous tile's stores, the prefetch just issued) at
 // the head of every tile.
-template <int NT, bool QUAD, int R, int KTM, bool PLAIN = false, bool ONEGRP = false>
+// GRP: 0 = that instance; 1 (PLAIN too): several groups, the J x K table c_jk waits in LDS (J x K <= EDM_CT_CAP); 2: the table
+// (if any) is read from global memory at the head of every cluster tile.
+template <int NT, bool QUAD, int R, int KTM, bool PLAIN = false, int GRP = 2>
 __global__ void __launch_bounds__(256, 2)
     estep_diag_mfma_kernel(const double* __restrict__ X, const double* __restrict__ Wt, const double* __restrict__ mu,
                            const double* __restrict__ constk, const double* __restrict__ ctab,
                            const int* __restrict__ rginfo_, double* __restrict__ qZ, double* __restrict__ fz_part,
                            double* __restrict__ ll_part_, int K, int64_t nrg, int64_t nrows, int64_t ldq, int raw_,
-                           int64_t nslots, double* __restrict__ sink) {
-  static_assert(!ONEGRP || PLAIN, "the one-group instance is a plain one");
+                           int64_t nslots, double* __restrict__ sink, int ngroups) {
+  constexpr bool ONEGRP = GRP == 0, CTLDS = GRP == 1;
+  static_assert(GRP == 2 || PLAIN, "the one-group and LDS-table instances are plain ones");
   const int* const rginfo = ONEGRP ? nullptr : rginfo_;
   const int raw = PLAIN ? 0 : raw_;
   double* const ll_part = PLAIN ? nullptr : ll_part_;
@@ -463,6 +466,7 @@ __global__ void __launch_bounds__(256, 2)
   double* fzw = mul + DP;                     // [4]
   double* lls = fzw + 4;                      // [KT][256]: running q * data term per lane (split-ordering term)
   double* lqs = lls + (size_t)KT * 256;       // [KT][R][256] (KTM == 0): every lane's own log q~ slots
+  double* ctl = lqs + (KTM == 0 ? (size_t)KT * R * 256 : 0);  // [EDM_CT_CAP] (GRP == 1): the table c_jk
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lo4 = lane & 15, hi = lane >> 4;
   {
@@ -475,6 +479,8 @@ __global__ void __launch_bounds__(256, 2)
     // the kernel's "half of the wave time waiting").  With several groups the table is still read there.
     for (int i = tid; i < 4 * KT; i += 256) cst[i] = i < K ? constk[i] + (rginfo ? 0.0 : ctab[i]) : 0.0;
     for (int i = tid; i < DP; i += 256) mul[i] = QUAD ? mu[i] : 0.0;
+    if constexpr (CTLDS)
+      for (int i = tid; i < ngroups * K; i += 256) ctl[i] = ctab[i];
     for (int it = 0; it < KT; ++it) lls[it * 256 + tid] = 0.0;
   }
   __syncthreads();
@@ -567,7 +573,10 @@ __global__ void __launch_bounds__(256, 2)
       const int k = 4 * it + hi;
       const double ck = cst[k];
 #pragma unroll
-      for (int r = 0; r < R; ++r) out[r] = k < K ? (rginfo ? ctab[(int64_t)grp[r] * K + k] + ck : ck) : -INFINITY;
+      for (int r = 0; r < R; ++r) {
+        if constexpr (CTLDS) out[r] = k < K ? ctl[grp[r] * K + k] + ck : -INFINITY;
+        else out[r] = k < K ? (rginfo ? ctab[(int64_t)grp[r] * K + k] + ck : ck) : -INFINITY;
+      }
     };
     auto tile_done = [&](int it, double (&v)[R]) {
       const int k = 4 * it + hi;
@@ -706,24 +715,31 @@ __global__ void __launch_bounds__(256, 2)
   }
 }
 
-static size_t edm_lds_bytes(int NT, int NTF, int KT, int R, bool slots) {
-  return ((size_t)KT * NTF * 16 + 4 * KT + 4 * NT + 4 + (size_t)KT * 256 + (slots ? (size_t)KT * R * 256 : 0)) * sizeof(double);
+static size_t edm_lds_bytes(int NT, int NTF, int KT, int R, bool slots, bool table = false) {
+  return ((size_t)KT * NTF * 16 + 4 * KT + 4 * NT + 4 + (size_t)KT * 256 + (slots ? (size_t)KT * R * 256 : 0) +
+          (table ? EDM_CT_CAP : 0)) * sizeof(double);
 }
 
 template <int NT, bool QUAD, int R, int KTM>
 static hipError_t launch_edm_k(const DiagEstepLaunch& a, hipStream_t stream) {
   const int KT = (a.K + 3) / 4, NTF = QUAD ? 2 * NT : NT;
-  const size_t shmem = edm_lds_bytes(NT, NTF, KT, R, KTM == 0);
+  size_t shmem = edm_lds_bytes(NT, NTF, KT, R, KTM == 0);
 #ifndef LC_EDM_PLAIN_QUAD
 #define LC_EDM_PLAIN_QUAD 1  // (with unconditional stores the plain instance wins for both: linear features 10 %, with the quadratic half 6.5 %; it lost 4 % there before)
 #endif
   const bool plain = KTM > 0 && !a.raw && !a.ll_part && (!QUAD || LC_EDM_PLAIN_QUAD);
   const bool onegrp = plain && !a.rginfo;
+  const bool tabled = plain && a.rginfo && (int64_t)a.ngroups * a.K <= EDM_CT_CAP &&
+                      edm_lds_bytes(NT, NTF, KT, R, KTM == 0, true) <= 150 * 1024;
+  if (tabled) shmem = edm_lds_bytes(NT, NTF, KT, R, KTM == 0, true);
   if (!a.sink) return hipErrorInvalidValue;
-  auto kern = onegrp ? estep_diag_mfma_kernel<NT, QUAD, R, KTM, (KTM > 0), (KTM > 0)>
-              : plain ? estep_diag_mfma_kernel<NT, QUAD, R, KTM, (KTM > 0)> : estep_diag_mfma_kernel<NT, QUAD, R, KTM>;
-  static LdsGrant grants[3];
-  if (hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(kern), shmem, grants[onegrp ? 2 : plain ? 1 : 0]); e != hipSuccess)
+  auto kern = onegrp   ? estep_diag_mfma_kernel<NT, QUAD, R, KTM, (KTM > 0), (KTM > 0 ? 0 : 2)>
+              : tabled ? estep_diag_mfma_kernel<NT, QUAD, R, KTM, (KTM > 0), (KTM > 0 ? 1 : 2)>
+              : plain  ? estep_diag_mfma_kernel<NT, QUAD, R, KTM, (KTM > 0)>
+                       : estep_diag_mfma_kernel<NT, QUAD, R, KTM>;
+  static LdsGrant grants[4];
+  if (hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(kern), shmem, grants[onegrp ? 3 : tabled ? 2 : plain ? 1 : 0]);
+      e != hipSuccess)
     return e;
   const int64_t ntile = (a.nrg + 4 * R - 1) / (4 * R);
   const int64_t nslots = estep_diag_grid(a.nrg);
@@ -739,7 +755,7 @@ static hipError_t launch_edm_k(const DiagEstepLaunch& a, hipStream_t stream) {
   int64_t grid = std::min<int64_t>(std::min<int64_t>(ntile, nslots), (int64_t)cus * per_cu);
   if (grid <= 0) return hipSuccess;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), shmem, stream, a.X, a.wt, a.mu, a.constk, a.ctab, a.rginfo,
-                     a.qZ, a.fz_part, a.ll_part, a.K, a.nrg, a.nrows, a.ldq, a.raw, nslots, a.sink);
+                     a.qZ, a.fz_part, a.ll_part, a.K, a.nrg, a.nrows, a.ldq, a.raw, nslots, a.sink, a.ngroups);
   return hipGetLastError();
 }
 
