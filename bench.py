@@ -442,6 +442,12 @@ def measure(capi, cfg, steps, warmup, rank, world, local_rank, stream, nthreads,
         res["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": gbs / HBM_PEAK_GBS, "traffic": None,
                            "alg_bytes_per_launch": 8.0 * N * (D + K), "avg_launch_ms": dom_ms}
+    if model is not None and rank == 0 and family == "GaussWish":
+        # what the M-step made of the REDUCED statistics (N_k, the posterior means' and scatter matrices' sums, log|W_k|):
+        # a sharded run and the one-rank run over the same rows must agree on these (tests/test_gpu_comm.py, 8 ranks)
+        cl = [model.cluster(k) for k in range(K)]
+        res["check"] = {"Nk": [c["N"] for c in cl], "mean_sum": [float(np.sum(c["mean"])) for c in cl],
+                        "iW_trace": [float(np.trace(c["iW"])) for c in cl], "logdW": [c["logdW"] for c in cl]}
     if comm_kind:
         res["config"]["collective"] = comm_kind
         if comm_note:
@@ -469,6 +475,8 @@ def main_inproc(args):
     cfg = dict(CONFIGS[args.config])
     if args.rows:
         cfg["N"] = args.rows
+    if args.groups:
+        cfg["J"] = args.groups
     ndev = torch.cuda.device_count()
     rccl = ndev >= world and world > 1 and args.comm == "native" and not os.environ.get("LC_ALL_RANKS_ON_GPU0")
     uid = capi.comm_unique_id() if rccl else None
@@ -563,6 +571,7 @@ def main_inproc(args):
         "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic", "config": res["config"], "free_energy": res["free_energy"],
         "kernels": res["kernels"], "roofline": res["roofline"],
+        **({"check": res["check"]} if "check" in res else {}),
     }
     print(json.dumps(line), flush=True)
     for _, ctx, model in errs:
@@ -579,6 +588,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="northstar", choices=sorted(CONFIGS))
     ap.add_argument("--rows", type=int, default=0, help="override rows per GPU")
+    ap.add_argument("--groups", type=int, default=0, help="override groups per GPU (grouped configurations)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
@@ -601,6 +611,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s)")
+    narrowed = False
     if world > 1:
         # this rank's slice of the CPUs the job may use: its Python thread and the M-step pool the library starts (threads
         # inherit the mask) stay off the other ranks' cores
@@ -608,6 +619,7 @@ def main():
         per = len(cpus) // world
         if per >= 1:
             os.sched_setaffinity(0, cpus[rank * per:(rank + 1) * per])
+            narrowed = True
     import torch
 
     if os.environ.get("LC_ALL_RANKS_ON_GPU0"):  # multi-rank smoke test on a 1-GPU box
@@ -634,7 +646,13 @@ def main():
     cfg = dict(CONFIGS[args.config])
     if args.rows:
         cfg["N"] = args.rows
-    nthreads = max(1, min(32, len(os.sched_getaffinity(0)) // max(1, world)))  # host M-step threads of this rank
+    if args.groups:
+        cfg["J"] = args.groups
+    # host M-step threads of this rank = the size of ITS mask: the mask above is already the rank's 1 / world slice (dividing
+    # it by the world size again left one thread per rank on a 64-core node with 8 ranks); only when the ranks could not
+    # be given disjoint slices (fewer CPUs than ranks) do they share the whole mask
+    mine = len(os.sched_getaffinity(0))
+    nthreads = max(1, min(32, mine if (narrowed or world == 1) else mine // world))
     nthreads = int(os.environ.get("LC_BENCH_THREADS", nthreads))
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -656,6 +674,7 @@ def main():
             "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic", "config": res["config"], "free_energy": res["free_energy"],
             "kernels": res["kernels"], "roofline": res["roofline"],
+            **({"check": res["check"]} if "check" in res else {}),
         }
         N, D, K = cfg["N"], cfg["D"], cfg["K"]
         if world == 1 and not args.no_cpu_baseline:

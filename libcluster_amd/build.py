@@ -17,6 +17,10 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 OBJ = PKG / "lib" / "obj"
 LIB = PKG / "lib" / "libcluster_hip.so"
+# the same library with the fault-injection hooks of the tests compiled in (-DLC_TEST_HOOKS: LC_TEST_CACHE_NO_ROOM,
+# LC_TEST_JOURNAL_FAIL_RANK in lc_ctx.cpp); tests load it through LC_LIB_PATH, the shipped library has no such switches
+LIB_TESTHOOKS = PKG / "lib" / "libcluster_hip_testhooks.so"
+HOOKED_SOURCES = ["lc_ctx.cpp"]
 ARCH = "gfx950"
 
 # Device-side scheduling: the AMDGPU register-pressure trackers (and no "unclustered high-RP" re-scheduling stage)
@@ -83,6 +87,14 @@ def build(force: bool = False, verbose: bool = False) -> Path:
             if src.endswith(".hip"):
                 cmd[2:2] = DEVICE_FLAGS
             jobs.append(cmd)
+    hooked_objs = list(objs)
+    for src in HOOKED_SOURCES:
+        s = CSRC / src
+        o = OBJ / (Path(src).stem + "_testhooks.o")
+        hooked_objs[SOURCES.index(src)] = o
+        if force or _newer(o, [s, *hdrs]):
+            jobs.append([hipcc, f"--offload-arch={ARCH}", *common, "-DLC_TEST_HOOKS", "-c", str(s), "-o", str(o)])
+            LAST_BUILD["compiled"].append(src + " (test hooks)")
     if jobs:  # the translation units are independent: compile them side by side
         from concurrent.futures import ThreadPoolExecutor
 
@@ -101,6 +113,9 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
+        LAST_BUILD["linked"] = True
+    if force or _newer(LIB_TESTHOOKS, hooked_objs):
+        subprocess.run([hipcc, "-shared", "-o", str(LIB_TESTHOOKS), *map(str, hooked_objs), "-lpthread", "-ldl", "-lrt"], check=True)
         LAST_BUILD["linked"] = True
     return LIB
 

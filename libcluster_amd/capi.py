@@ -61,7 +61,8 @@ def declared_symbols() -> list[str]:
 def _load_checked() -> C.CDLL:
     """dlopen the library and compare the source hash compiled into it (lc_source_hash) with the tree it sits in: a
     stale binary (sources edited after the last build; the .so is git-ignored and travels prebuilt) is rebuilt when
-    hipcc is there and refused otherwise.  LC_ALLOW_STALE_LIB=1 skips the check."""
+    hipcc is there and refused otherwise.  LC_ALLOW_STALE_LIB=1 skips the check, and so does LC_LIB_PATH (a user-supplied
+    library is loaded as it is)."""
     import os
 
     from . import build as _build
@@ -75,7 +76,9 @@ def _load_checked() -> C.CDLL:
             return L, "missing"
 
     L, have = load()
-    if os.environ.get("LC_ALLOW_STALE_LIB"):
+    # LC_LIB_PATH names another build of the library (kernel experiments): it is the caller's, never compared with this
+    # tree and never rebuilt into or over
+    if os.environ.get("LC_ALLOW_STALE_LIB") or os.environ.get("LC_LIB_PATH"):
         return L
     want = _build.source_hash()
     if have == want:

@@ -225,8 +225,10 @@ double learn_sharded(int algo, int J, const double* const* Xj, const int64_t* Nj
   for (int r = 0; r < W; ++r) m->shards.emplace_back(new lc_model::Shard());
   const int64_t N0 = single ? Nj[0] : 0;
   std::atomic<int> first_fail{-1};  // the shard whose failure made the others fail (they only see aborted collectives)
-  // every shard thread -- and the M-step pool its context starts, which inherits the mask -- keeps to its slice of the
-  // CPUs this process may use; the caller's own thread (shard 0) gets its mask back afterwards
+  // every shard thread -- and the M-step pool it starts (thread_local per calling thread, lc_engine.cpp; its workers
+  // inherit the mask) -- keeps to its slice of the CPUs this process may use.  ALL shards run on short-lived threads and
+  // the caller only joins: its own mask, and the masks of the persistent pool workers it may already own, are never
+  // narrowed (a shard on the caller's thread left that thread's pool on 1 / W of the cores for later calls).
   cpu_set_t all_cpus;
   CPU_ZERO(&all_cpus);
   const bool have_mask = sched_getaffinity(0, sizeof(all_cpus), &all_cpus) == 0 && CPU_COUNT(&all_cpus) >= 2 * W;
@@ -290,14 +292,16 @@ double learn_sharded(int algo, int J, const double* const* Xj, const int64_t* Nj
       int none = -1;
       first_fail.compare_exchange_strong(none, r);  // (the shards that fail AFTER this one report the abort below)
       for (auto& c : comms) c->abort();  // the other shards fail in their next collective instead of waiting
+      // the owner tag's contract is "let go after a sync": copies or kernels of this shard may still target its blocks
+      // (page-locked blocks are shared across devices); errors of the sync itself are of no interest here
+      (void)hipSetDevice(devices[(size_t)r]);
+      (void)hipDeviceSynchronize();
       lcc::cache_release_thread();
     }
   };
   std::vector<std::thread> th;
-  for (int r = 1; r < W; ++r) th.emplace_back(work, r);
-  work(0);
+  for (int r = 0; r < W; ++r) th.emplace_back(work, r);
   for (auto& t : th) t.join();
-  if (have_mask) (void)sched_setaffinity(0, sizeof(all_cpus), &all_cpus);
   if (const int f = first_fail.load(); f >= 0) {  // the root cause, not a secondary "communicator was aborted"
     m->shards.clear();
     std::rethrow_exception(errs[(size_t)f]);

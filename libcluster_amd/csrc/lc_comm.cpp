@@ -150,9 +150,11 @@ struct Ctrl {
   std::atomic<uint32_t> count;
   std::atomic<uint32_t> gen;
   std::atomic<uint32_t> aborted;
+  std::atomic<uint32_t> ready;  // set by rank 0 once every rank of ITS run is attached (just before the name is removed)
   uint32_t world;
+  uint32_t pad0;
   uint64_t slot_doubles;
-  char pad[64 - 5 * 4 - 4 - 8];
+  char pad[64 - 6 * 4 - 4 - 4 - 8];
 };
 static_assert(sizeof(Ctrl) == 64, "control block is one cache line");
 static_assert(std::atomic<uint32_t>::is_always_lock_free, "process-shared atomics must be lock-free");
@@ -247,6 +249,7 @@ void init_ctrl(Ctrl* c, int world) {
   c->count.store(0);
   c->gen.store(0);
   c->aborted.store(0);
+  c->ready.store(0);
   c->world = (uint32_t)world;
   c->slot_doubles = SLOT_DOUBLES;
   c->magic.store(HOST_MAGIC, std::memory_order_release);
@@ -315,7 +318,27 @@ std::shared_ptr<Comm> host_init_shm(const std::string& name, int rank, int world
     int fd = -1;
     ino_t mine = 0;
     if (rank == 0) {
-      shm_unlink(reg->shm_name.c_str());  // a stale object of a crashed run
+      // a stale object of a crashed run: POISON it before the name goes (magic cleared, abort flag set), so that a rank
+      // of this run that attached to it in the meantime -- it may even complete the dead run's attach count -- is sent
+      // back to the name by its magic / inode re-check, or at the latest fails in its first barrier instead of waiting
+      // out the timeout
+      {
+        const int old = shm_open(reg->shm_name.c_str(), O_RDWR, 0600);
+        if (old >= 0) {
+          struct stat st;
+          if (fstat(old, &st) == 0 && (size_t)st.st_size >= sizeof(Ctrl)) {
+            void* p = mmap(nullptr, sizeof(Ctrl), PROT_READ | PROT_WRITE, MAP_SHARED, old, 0);
+            if (p != MAP_FAILED) {
+              Ctrl* dead = static_cast<Ctrl*>(p);
+              dead->aborted.store(1, std::memory_order_release);
+              dead->magic.store(0, std::memory_order_release);
+              munmap(p, sizeof(Ctrl));
+            }
+          }
+          close(old);
+        }
+      }
+      shm_unlink(reg->shm_name.c_str());
       fd = shm_open(reg->shm_name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
       if (fd < 0) fail("shm_open(" + reg->shm_name + ") failed: " + std::strerror(errno));
       if (ftruncate(fd, (off_t)reg->bytes) != 0) {
@@ -373,6 +396,24 @@ std::shared_ptr<Comm> host_init_shm(const std::string& name, int rank, int world
         if (expired()) fail("timed out waiting for all ranks to attach to " + reg->shm_name);
         if (rank != 0 && ++tick % 100 == 0 && replaced()) { stale = true; break; }
         std::this_thread::sleep_for(std::chrono::milliseconds(1));
+      }
+    }
+    // The attach count alone does not say WHOSE run this is: a left-over object of a run that died during its
+    // rendezvous with attached == world - 1 lets a rank > 0 through the loop above without a single look at the name.
+    // So rank 0 confirms: `ready` is set only by the rank 0 that created the object, once all ranks of its run are
+    // there -- a dead run's object never gets it (its rank 0 would have removed the name right afterwards), and the
+    // ranks waiting here move on to the new object as soon as the name leads to it (or its magic word is cleared).
+    if (!stale) {
+      if (rank == 0) {
+        c->ready.store(1, std::memory_order_release);
+      } else {
+        int tick = 0;
+        while (c->ready.load(std::memory_order_acquire) == 0) {
+          if (c->magic.load(std::memory_order_acquire) != HOST_MAGIC) { stale = true; break; }
+          if (expired()) fail("timed out waiting for rank 0 to confirm the rendezvous on " + reg->shm_name);
+          if (++tick % 100 == 0 && replaced()) { stale = true; break; }
+          std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        }
       }
     }
     if (!stale) break;

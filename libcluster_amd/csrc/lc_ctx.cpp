@@ -1353,8 +1353,10 @@ int Context::estep_cache(int K, const double* A, const double* m, const double* 
       }
       ok = need <= free_b;
     }
+#ifdef LC_TEST_HOOKS  // (libcluster_hip_testhooks.so only: the shipped library has no fault hooks)
     static const char* fake = std::getenv("LC_TEST_CACHE_NO_ROOM");  // tests: pretend the device is full from this K on
     if (fake && K >= std::atoi(fake)) ok = false;
+#endif
     if (allreduce_value(ok ? 0.0 : 1.0) > 0.0)
       throw CacheNoRoom("no room for the distance cache at K = " + std::to_string(K) + ": " + std::to_string(need) +
                         " bytes needed, " + std::to_string(free_b) + " free on this rank");
@@ -1388,7 +1390,9 @@ int Context::estep_cache(int K, const double* A, const double* m, const double* 
     std::vector<std::unique_ptr<SavedColumn>> fresh;
     bool ok = true;
     std::string why;
+#ifdef LC_TEST_HOOKS
     static const char* fail_rank = std::getenv("LC_TEST_JOURNAL_FAIL_RANK");  // tests: this rank cannot reserve
+#endif
     for (int k : changed) {
       if (k >= dc_K_ || k >= dc_jK0_) continue;  // nothing valid there / not part of the state to return to
       bool done = false;
@@ -1398,10 +1402,12 @@ int Context::estep_cache(int K, const double* A, const double* m, const double* 
       sv->col = k;
       if (ok) {
         try {
+#ifdef LC_TEST_HOOKS
           if (fail_rank) {
             const char* er = std::getenv("RANK");  // (hook-based runs have no communicator to ask)
             if (std::atoi(fail_rank) == (comm_ ? comm_->rank() : er ? std::atoi(er) : 0)) throw HipFailure("LC_TEST_JOURNAL_FAIL_RANK");
           }
+#endif
           sv->buf.reserve(NPs);
         } catch (const HipFailure& e) {
           ok = false;

@@ -358,8 +358,9 @@ double vbem(lcc::Context& ctx, Model& model, const VbemOptions& opt) {
       try {
         nre = ctx.estep_cache(K, A.data(), m.data(), c.data(), &Fz, opt.want_ll ? model.LLk.data() : nullptr, opt.inc->tol,
                               &stale);
-      } catch (const lcc::CacheNoRoom&) {
+      } catch (const lcc::CacheNoRoom& e) {
         // (the room check and the journal reservation are agreed on by all ranks: every rank gets here together)
+        if (trace_phases) std::cerr << "[vbem] distance cache given up, ordinary E-step from here: " << e.what() << std::endl;
         ctx.dcache_release();
         opt.inc->on = false;
         opt.inc->no_room = true;

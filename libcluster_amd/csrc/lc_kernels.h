@@ -71,7 +71,6 @@ struct EstepLaunch {
   int raw = 0;           // 1: stop after writing log q~ (no log-sum-exp, fz/ll untouched)
   int sparse = 0;        // 1: ctab holds -inf entries; waves skip clusters inactive for all their rows
   int lq_lds = 0;        // filled in by launch_estep: log q~ waits in LDS (D <= 48, small K) instead of in qZ
-  int64_t nslots = 0;    // filled in by launch_estep: partial slots (= estep_grid) the kernel has to fill
 };
 int estep_rows_per_block(int DP);
 int64_t estep_grid(int DP, int64_t nrg);

@@ -18,82 +18,22 @@
 //   D[i][j] of block blk : j = lo2, i = hi
 #include "lc_device.hpp"
 
-// log q~ on chip for the k-sliced scheme (LQW below): measured at the north-star shape 23.8 ms against 22.9 ms for the
-// round trip through the qZ buffer (two waves per SIMD instead of three cost more than the 5 GB of traffic they save:
-// the kernel is bound by the matrix pipe, not by HBM) -- off by default, LC_ES_LQW=1 selects it
-#ifndef LC_ES_LQW_DEFAULT
-#define LC_ES_LQW_DEFAULT 0
-#endif
-
-// Scheduling knobs of the cluster loop (tools/variants.py builds and times alternatives; the defaults are the measured
-// best at every width: -4...5 % against all of them off, N = 10M, D = 64, K = 32: 22.2 -> 21.2 ms):
-//   LC_ES_SB     1: a scheduling fence after every step of the LDS parameter stream -- hipcc otherwise sinks the ring's
-//                reads to just before their use (s_waitcnt lgkmcnt(0) after every second read: the LDS latency is exposed)
-//   LC_ES_PF     reads in flight ahead of their use
-//   LC_ES_DEFER  1: the squares of a tile row are taken under the next row's first MFMAs (two accumulator sets), not
-//                straight behind the row's last MFMA (a matrix-pipe result is not readable for several issue slots)
-//   LC_ES_CPRE   1: c_jk of the cluster is fetched before the tile stream, not behind it (three exposed loads per cluster)
-#ifndef LC_ES_SB
-#define LC_ES_SB 1
-#endif
-#ifndef LC_ES_PF
-#define LC_ES_PF 4
-#endif
-#ifndef LC_ES_DEFER
-#define LC_ES_DEFER 1
-#endif
-#ifndef LC_ES_CPRE
-#define LC_ES_CPRE 1
-#endif
-//   LC_ES_DLDS   1: the next cluster's record goes from global memory straight into the other LDS buffer
-//                (global_load_lds_dwordx4: no staging registers, no ds_write)
-#ifndef LC_ES_DLDS
-#define LC_ES_DLDS 1
-#endif
-//   LC_ES_STDEF  1 (k-sliced scheme): a cluster's log q~ is stored at the top of the NEXT cluster's pass, so the stores
-//                have a whole pass to drain before the s_waitcnt vmcnt(0) in front of the barrier (vmcnt counts stores too)
-#ifndef LC_ES_STDEF
-#define LC_ES_STDEF 1
-#endif
-//   LC_ES_STAGGER n > 0: the waves that share a SIMD start their cluster loops n * 64 * (wave slot) clocks apart, so that
-//                their per-cluster tails (squares, lane sum, barrier, first LDS reads) do not fall together
-#ifndef LC_ES_STAGGER
-#define LC_ES_STAGGER 0
-#endif
-//   LC_ES_SADDR  1 (dense k-sliced scheme): c_jk loads and log q~ stores in the scalar-base form (global_load / store
-//                ... voffset, saddr): the cluster index lives in SGPRs, no 64-bit VALU address arithmetic in the loop
-#ifndef LC_ES_SADDR
-#define LC_ES_SADDR 1
-#endif
-//   LC_ES_LQC    1: log q~ = c - d^2 / 2 comes straight out of the lane-sum MFMA (A = -1/2, C = c_jk): no v_fma behind it
-#ifndef LC_ES_LQC
-#define LC_ES_LQC 0
-#endif
-//   LC_ES_ONEEXP 1 (k-sliced scheme, K <= 64, no LL_k wanted): one exponential per entry -- e = exp(log q~ - max) stays in
-//                the registers the X fragments have vacated and q = e / sum(e); same sum, same logZ, q within 2 ulp of
-//                exp(log q~ - logZ)
-#ifndef LC_ES_ONEEXP
-#define LC_ES_ONEEXP 0
-#endif
-
-#ifdef LC_ES_TRACE
-// experiments only: per block (XCC, CU/SIMD word, wall start, wall end, shader clocks) -- read with lc_debug_estep_trace
-__device__ long long lc_es_trace[5 * 65536];
-extern "C" int lc_debug_estep_trace(long long* out, int nblocks) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lc_es_trace), sizeof(long long) * 5 * (size_t)(nblocks < 65536 ? nblocks : 65536));
-}
-#endif
+// The cluster loop's schedule is fixed by hand (DESIGN 4.1 has the measurements of every alternative; git keeps their
+// code): a scheduling fence after every step of the LDS parameter stream (hipcc otherwise sinks the ring's reads to
+// just before their use), ES_PF reads in flight ahead of their use, the squares of a tile row taken under the next
+// row's first MFMAs (two accumulator sets), c_jk fetched before the tile stream, the next cluster's record brought
+// from global memory straight into the other LDS buffer (global_load_lds_dwordx4: no staging registers, no ds_write),
+// a cluster's log q~ stored at the top of the NEXT cluster's pass (the s_waitcnt vmcnt(0) in front of the barrier then
+// finds the stores long retired), and -- dense k-sliced scheme -- c_jk loads / log q~ stores in the scalar-base form.
 
 namespace lck {
 
+constexpr int ES_PF = 4;  // LDS reads in flight ahead of their use (2...10 are within 1 %)
+
 // max without the canonicalising self-max hipcc puts in front of fmax (three v_max_f64 per call where one does)
 __device__ __forceinline__ double max_raw(double a, double b) {
-#if LC_ES_CPRE
   asm("v_max_f64 %0, %1, %2" : "=v"(a) : "v"(a), "v"(b));
   return a;
-#else
-  return fmax(a, b);
-#endif
 }
 
 // ===========================================================================
@@ -106,39 +46,27 @@ __device__ __forceinline__ double max_raw(double a, double b) {
 //     log q~[n,k] = c_jk - 0.5 * || A_k x_n - b_k ||^2
 // which equals E_logZ(k) + Eloglike_k(x_n) of cluster.cpp:120-121.
 // A_k arrives as 4x4 tiles in consumption order (only tiles on or below the
-// diagonal), staged through LDS with register double-buffering; one tile read
-// feeds R MFMAs.  MFMA block b <-> rows 4b..4b+3 of the row-group, so
+// diagonal), double-buffered in LDS; one tile read feeds R MFMAs.  MFMA block
+// b <-> rows 4b..4b+3 of the row-group, so
 //   A operand = tile A_k[4it+lo2][4jt+hi]   (same for all 4 blocks)
 //   B operand = x[row = lane&15][4jt + hi]
 //   D         = y[4it+hi][row = lane&15]
-// log q~ is written to the qZ buffer as scratch, then normalised in place in
-// the same arithmetic order as the reference: max, sum exp(x-max), log+max,
-// exp(x - logZ).
+// log q~ is written to the qZ buffer as scratch (or waits in LDS, lq_lds), then
+// normalised in place in the same arithmetic order as the reference: max,
+// sum exp(x-max), log+max, exp(x - logZ).
 // blocks per CU the register budget is set for.  D = 64: three row groups per wave (96 VGPRs of X fragments) at
 // three waves per SIMD measured 22.2 ms against 22.6 for four row groups at two waves per SIMD (N=10M, K=32).
-#ifndef LC_ES_R64
-#define LC_ES_R64 3
-#endif
 template <int DP>
-struct EstepOcc { static constexpr int BLOCKS = DP == 64 && LC_ES_R64 == 3 ? 3 : 2; };
-// waves per block of the standard variant (EstepCfg below): what estep_grid and the partial slots are sized for
-template <int DP>
-struct EstepWavesStd { static constexpr int W = DP >= 112 ? 8 : 4; };
+struct EstepOcc { static constexpr int BLOCKS = DP == 64 ? 3 : 2; };
 
-// LQW (k-sliced scheme, R < 4): log q~ waits for the normalisation in LDS, in per-lane slots [K/4][R][64] of the wave
-// (the lane that wrote a value is the lane that reads it back: no barrier), instead of making a round trip through the
-// qZ buffer -- the kernel then reads X once and writes q once.  12 KB per wave at K = 32, R = 3: one block of eight
-// waves per CU next to the 36 KB parameter ring (two waves per SIMD instead of three).
-template <int DP, int R, int WAVES, bool SPARSE, bool LQW = false>
-__global__ void __launch_bounds__(WAVES * 64, LQW ? 2 : EstepOcc<DP>::BLOCKS) estep_kernel(EstepLaunch a) {
+template <int DP, int R, int WAVES, bool SPARSE>
+__global__ void __launch_bounds__(WAVES * 64, EstepOcc<DP>::BLOCKS) estep_kernel(EstepLaunch a) {
   constexpr int NT = DP / 4;
   constexpr int NTILES = NT * (NT + 1) / 2;
   constexpr int NREAD = NTILES + NT;  // LDS reads per cluster
-  constexpr int PF = LC_ES_PF;        // reads in flight ahead of their use
+  constexpr int PF = ES_PF;
   constexpr int PS = NTILES * 16 + DP;
   constexpr int NTHR = WAVES * 64;
-  constexpr int NV2 = PS / 2;
-  constexpr int NPRE = (NV2 + NTHR - 1) / NTHR;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* pbuf = lds;              // [2][PS]
   double* llw = lds + 2 * PS;      // [WAVES][K]
@@ -147,10 +75,7 @@ __global__ void __launch_bounds__(WAVES * 64, LQW ? 2 : EstepOcc<DP>::BLOCKS) es
   // LDS for the normalisation, [K][threads], instead of making a round trip through the qZ buffer
   double* lql = fzw + WAVES;
   const bool lqm = R == 4 && a.lq_lds != 0;
-  const int KQ = (a.K + 3) / 4;
-  // this lane's slots of the wave's log q~ table: slot (k / 4, r) holds cluster k of row group r for hi == (k & 3)
-  double* lqw = lql + ((size_t)(threadIdx.x >> 6) * KQ * R) * 64 + (threadIdx.x & 63);
-  int* klist = reinterpret_cast<int*>(lql + (lqm ? (size_t)a.K * NTHR : LQW ? (size_t)WAVES * KQ * R * 64 : 0));  // sparse mode: [K] active clusters of this block, [K] flags,
+  int* klist = reinterpret_cast<int*>(lql + (lqm ? (size_t)a.K * NTHR : 0));  // sparse mode: [K] active clusters of this block, [K] flags,
   int* kflag = klist + a.K;                          // [WAVES*R] groups of the block's row groups, [1] count
   int* bgrp = kflag + a.K;
 
@@ -158,9 +83,6 @@ __global__ void __launch_bounds__(WAVES * 64, LQW ? 2 : EstepOcc<DP>::BLOCKS) es
   const int lo4 = lane & 15, hi = lane >> 4;
   const int K = a.K;
   const int64_t rg0 = ((int64_t)blockIdx.x * WAVES + wave) * R;
-#ifdef LC_ES_TRACE
-  const long long tr_w0 = wall_clock64(), tr_c0 = clock64();
-#endif
   constexpr bool ROWLANES = R == 4;  // four row groups per wave: lane (lo4, hi) can own row group hi outright
 
   double xf[R][NT];
@@ -190,43 +112,21 @@ __global__ void __launch_bounds__(WAVES * 64, LQW ? 2 : EstepOcc<DP>::BLOCKS) es
   for (int r = 0; r < R; ++r)
     if (hi == r) myok = rgok[r];
 
-#if LC_ES_DLDS
-  // 16 bytes per lane and instruction land at LDS address M0 + 16 * lane; a round of the block moves NTHR * 16 bytes
+  // The next cluster's record, global -> LDS without staging registers: 16 bytes per lane and instruction land at LDS
+  // address M0 + 16 * lane; a round of the block moves NTHR * 16 bytes.  M0 is written here behind the compiler's back (it
+  // refuses M0 in a clobber list: "reserved register"); gfx950 code needs M0 for nothing else in this kernel, and
+  // tools/check_isa.py asserts exactly that on the generated ISA: every instruction that names m0 is one of these pairs.
   const unsigned dvoff = (unsigned)(wave * 1024 + lane * 16);
   const unsigned dlds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)pbuf + (unsigned)(wave * 1024));
-#define LC_DMA(kk, bb)                                                                        \
-  {                                                                                           \
-    const char* src_ = reinterpret_cast<const char*>(a.params + (int64_t)__builtin_amdgcn_readfirstlane(kk) * PS); \
-    _Pragma("unroll") for (int i_ = 0; i_ < (PS * 8 + NTHR * 16 - 1) / (NTHR * 16); ++i_) { \
-      if (dvoff + i_ * (NTHR * 16) < (unsigned)(PS * 8))                                      \
-        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1"                     \
-                     ::"v"(dvoff), "s"(src_ + i_ * (NTHR * 16)), "s"(dlds0 + (bb) * (PS * 8) + i_ * (NTHR * 16)) : "memory");  \
-    }                                                                                         \
-  }
-#define LC_GLOAD(kk)
-#define LC_LSTORE(bb)
-#else
-  // register double-buffer for the next cluster's parameter record
-  double pre[NPRE][2];
-#define LC_GLOAD(kk)                                                                          \
-  {                                                                                           \
-    const double2* src_ = reinterpret_cast<const double2*>(a.params + (int64_t)(kk) * PS);   \
-    _Pragma("unroll") for (int i_ = 0; i_ < NPRE; ++i_) {                                     \
-      const int idx_ = tid + i_ * NTHR;                                                       \
-      const double2 v_ = src_[idx_ < NV2 ? idx_ : NV2 - 1];                                   \
-      pre[i_][0] = v_.x;                                                                      \
-      pre[i_][1] = v_.y;                                                                      \
-    }                                                                                         \
-  }
-#define LC_LSTORE(bb)                                                                         \
-  {                                                                                           \
-    double2* dst_ = reinterpret_cast<double2*>(pbuf + (bb) * PS);                             \
-    _Pragma("unroll") for (int i_ = 0; i_ < NPRE; ++i_) {                                     \
-      const int idx_ = tid + i_ * NTHR;                                                       \
-      if (idx_ < NV2) dst_[idx_] = make_double2(pre[i_][0], pre[i_][1]);                      \
-    }                                                                                         \
-  }
-#endif
+  auto dma_record = [&](int kk, int bb) {
+    const char* src = reinterpret_cast<const char*>(a.params + (int64_t)__builtin_amdgcn_readfirstlane(kk) * PS);
+#pragma unroll
+    for (int i = 0; i < (PS * 8 + NTHR * 16 - 1) / (NTHR * 16); ++i) {
+      if (dvoff + i * (NTHR * 16) < (unsigned)(PS * 8))
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1"
+                     ::"v"(dvoff), "s"(src + i * (NTHR * 16)), "s"(dlds0 + bb * (PS * 8) + i * (NTHR * 16)) : "memory");
+    }
+  };
 
   // Sparse mode (cluster.cpp:109-112, 134-135): the block walks only the clusters that are active (c_jk > -inf)
   // for at least one of its row groups -- no parameter staging, barrier or MFMA for the others; their columns
@@ -260,42 +160,25 @@ __global__ void __launch_bounds__(WAVES * 64, LQW ? 2 : EstepOcc<DP>::BLOCKS) es
         else if (myok) a.qZ[(int64_t)k * a.ldq + (rg0 + hi) * RG + lo4] = -INFINITY;
       } else {
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-          if constexpr (LQW) {
-            if (hi == (k & 3)) lqw[((k >> 2) * R + r) * 64] = -INFINITY;
-          } else {
-            if (rgok[r] && hi == (k & 3)) a.qZ[(int64_t)k * a.ldq + (rg0 + r) * RG + lo4] = -INFINITY;
-          }
-        }
+        for (int r = 0; r < R; ++r)
+          if (rgok[r] && hi == (k & 3)) a.qZ[(int64_t)k * a.ldq + (rg0 + r) * RG + lo4] = -INFINITY;
       }
     }
   }
 
   if (nact > 0) {
-#if LC_ES_DLDS
-    LC_DMA(SPARSE ? klist[0] : 0, 0);
+    dma_record(SPARSE ? klist[0] : 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
-    LC_GLOAD(SPARSE ? klist[0] : 0);
-    LC_LSTORE(0);
-#endif
   }
   __syncthreads();
 
   double mx[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) mx[r] = -INFINITY;
-#if LC_ES_STAGGER
-  if (blockIdx.x < 1024) {  // the first resident blocks only: later ones inherit the offsets of the blocks they replace
-    // HW_ID (register 4): wave slot of the SIMD in bits 3:0
-    if (tid == 0) reinterpret_cast<unsigned*>(fzw)[0] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) & 15u;
-    __syncthreads();  // (the block's waves move together: all take the offset of wave 0's slot)
-    const unsigned slot = reinterpret_cast<const unsigned*>(fzw)[0];
-    for (unsigned s = 0; s < (slot % 3u) * LC_ES_STAGGER; ++s) __builtin_amdgcn_s_sleep(1);
-  }
-#endif
 
-  constexpr bool SADDR = LC_ES_SADDR && LC_ES_STDEF && LC_ES_CPRE && LC_ES_DLDS && !SPARSE && !ROWLANES && !LQW;
+  // SADDR (dense k-sliced scheme): c_jk loads and log q~ stores in the scalar-base form (global_load / store ...
+  // voffset, saddr): the cluster index lives in SGPRs, no 64-bit VALU address arithmetic in the loop
+  constexpr bool SADDR = !SPARSE && !ROWLANES;
   unsigned coff[R];              // SADDR: byte offset of the c_jk row of row group r's group (J K 8 < 4 GB)
   const unsigned qoff = lo4 * 8u;  // SADDR: this lane's byte offset inside a 16-row piece of a qZ column
   // SADDR: byte address of the wave's first row in column 0 of qZ (wave-uniform)
@@ -306,10 +189,9 @@ __global__ void __launch_bounds__(WAVES * 64, LQW ? 2 : EstepOcc<DP>::BLOCKS) es
     coff[r] = (unsigned)grp[r] * (unsigned)K * 8u;
     if constexpr (SADDR) asm volatile("" : "+v"(coff[r]));  // (kept: hipcc would redo the multiply in every pass of the loop)
   }
-#if LC_ES_STDEF
   double lqprev[R];
   int kprev = -1;
-  auto flush_lq = [&]() {
+  auto flush_lq = [&]() {  // the previous cluster's log q~: stored one pass late (see the top of the file)
     if constexpr (SADDR) {
       if (kprev >= 0) {
         const char* qk = qwave + (int64_t)kprev * a.ldq * 8;
@@ -324,7 +206,7 @@ __global__ void __launch_bounds__(WAVES * 64, LQW ? 2 : EstepOcc<DP>::BLOCKS) es
       }
     } else if constexpr (ROWLANES) {
       if (kprev >= 0 && !lqm && myok) a.qZ[(int64_t)kprev * a.ldq + (rg0 + hi) * RG + lo4] = lqprev[0];
-    } else if constexpr (!LQW) {
+    } else {
       if (kprev >= 0) {
 #pragma unroll
         for (int r = 0; r < R; ++r)
@@ -332,18 +214,11 @@ __global__ void __launch_bounds__(WAVES * 64, LQW ? 2 : EstepOcc<DP>::BLOCKS) es
       }
     }
   };
-#endif
   for (int ii = 0; ii < nact; ++ii) {
     const int k = SPARSE ? klist[ii] : ii;
     const int buf = ii & 1;
-#if LC_ES_STDEF
     flush_lq();
-#endif
-#if LC_ES_DLDS
-    if (ii + 1 < nact) LC_DMA(SPARSE ? klist[ii + 1] : ii + 1, buf ^ 1);
-#else
-    if (ii + 1 < nact) LC_GLOAD(SPARSE ? klist[ii + 1] : ii + 1);
-#endif
+    if (ii + 1 < nact) dma_record(SPARSE ? klist[ii + 1] : ii + 1, buf ^ 1);
     const double* P = pbuf + buf * PS;
     const double* Pt = P + (lane & 3) + 4 * hi;  // this lane's element of every 4x4 tile
     const double* Pb = P + NTILES * 16 + hi;     // this lane's element of every 4-vector of -b
@@ -367,8 +242,7 @@ __global__ void __launch_bounds__(WAVES * 64, LQW ? 2 : EstepOcc<DP>::BLOCKS) es
       for (int r = 0; r < R; ++r)
         wave_active = wave_active || (rgok[r] && a.ctab[(int64_t)grp[r] * K + k] != -INFINITY);
     }
-#if LC_ES_CPRE
-    double cv[R];
+    double cv[R];  // c_jk of this cluster, fetched before the tile stream
     if constexpr (SADDR) {
       const double* ck = a.ctab + k;  // (scalar)
 #pragma unroll
@@ -377,7 +251,6 @@ __global__ void __launch_bounds__(WAVES * 64, LQW ? 2 : EstepOcc<DP>::BLOCKS) es
 #pragma unroll
       for (int r = 0; r < R; ++r) cv[r] = a.ctab[(int64_t)grp[r] * K + k];
     }
-#endif
     auto square = [&](int set) {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -391,7 +264,7 @@ __global__ void __launch_bounds__(WAVES * 64, LQW ? 2 : EstepOcc<DP>::BLOCKS) es
     static_for<NREAD>([&](auto nc) {
       constexpr int n = nc;
       constexpr RdInfo ri = rd_info(n);
-      constexpr int set = LC_ES_DEFER ? (ri.it & 1) : 0;
+      constexpr int set = ri.it & 1;
       const double v = ring[n % PF];
       if constexpr (n + PF < NREAD) {
         constexpr RdInfo rn = rd_info(n + PF);
@@ -403,79 +276,47 @@ __global__ void __launch_bounds__(WAVES * 64, LQW ? 2 : EstepOcc<DP>::BLOCKS) es
       } else {
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[set][r] = mfma4(v, xf[r][ri.jt], acc[set][r]);
-        if constexpr (LC_ES_DEFER) {
-          if constexpr (ri.it > 0 && ri.jt == 1) square(set ^ 1);  // the row above, six MFMAs after its last one
-        } else {
-          if constexpr (ri.jt == ri.it) square(set);
-        }
+        if constexpr (ri.it > 0 && ri.jt == 1) square(set ^ 1);  // the row above, six MFMAs after its last one
       }
-#if LC_ES_SB
       __builtin_amdgcn_sched_barrier(0);
-#endif
     });
-    if constexpr (LC_ES_DEFER) square((NT - 1) & 1);
+    square((NT - 1) & 1);
     }
     double lqsel = 0.0;
-#if LC_ES_CPRE
-    if constexpr (SADDR) {  // the asm loads of c_jk are invisible to hipcc's waitcnt pass (the LDS-direct record with them)
+    // The asm loads of c_jk are invisible to hipcc's waitcnt pass (the LDS-direct record with them): waited for here, in
+    // one asm statement that also names cv[] as in-out operands, so that no copy of a not-yet-loaded register can be
+    // scheduled above it.  tools/check_isa.py asserts that the kernel has no scratch and that nothing reads these
+    // registers between the loads and this wait.
+    if constexpr (SADDR) {
       if constexpr (R == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(cv[0]), "+v"(cv[1]), "+v"(cv[2])::"memory");
       else asm volatile("s_waitcnt vmcnt(0)" : "+v"(cv[0]), "+v"(cv[R > 1 ? 1 : 0])::"memory");
     }
-#endif
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       // sum over the four hi lanes on the matrix pipe: D[i][j] = sum_k 1 * B[k][j] leaves the
       // total in every lane (B[k=hi][j=row] is exactly where the partial sums live)
-#if LC_ES_LQC && LC_ES_CPRE
-      const double lq = mfma4(-0.5, d2[r], cv[r]);
-#elif LC_ES_CPRE
       const double dd = mfma4(1.0, d2[r], 0.0);
       const double lq = cv[r] - 0.5 * dd;
-#else
-      const double dd = mfma4(1.0, d2[r], 0.0);
-      const double lq = a.ctab[(int64_t)grp[r] * K + k] - 0.5 * dd;
-#endif
       mx[r] = max_raw(mx[r], lq);
       if constexpr (ROWLANES) {
         if (hi == r) lqsel = lq;
-      } else if constexpr (LQW) {
-        if (hi == (k & 3)) lqw[((k >> 2) * R + r) * 64] = lq;
       } else {
-#if LC_ES_STDEF
         lqprev[r] = lq;
-#else
-        if (rgok[r] && hi == (k & 3)) a.qZ[(int64_t)k * a.ldq + (rg0 + r) * RG + lo4] = lq;
-#endif
       }
     }
-#if LC_ES_STDEF
     kprev = k;
-#endif
     // R == 4: lane (lo4, hi) keeps row group hi -- ONE 512-byte store per cluster column instead of four
     // 128-byte ones, and the normalisation below needs no cross-lane sums
     if constexpr (ROWLANES) {
       if (lqm) lql[k * NTHR + tid] = lqsel;
-#if LC_ES_STDEF
       else lqprev[0] = lqsel;
-#else
-      else if (myok) a.qZ[(int64_t)k * a.ldq + (rg0 + hi) * RG + lo4] = lqsel;
-#endif
     }
-#if LC_ES_DLDS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the record has landed (this wave's part; the barrier covers the rest)
-#else
-    if (ii + 1 < nact) LC_LSTORE(buf ^ 1);
-#endif
     __syncthreads();
   }
 
-#undef LC_GLOAD
-#undef LC_LSTORE
-#undef LC_DMA
-#if LC_ES_STDEF
   flush_lq();
   if constexpr (SADDR) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (asm stores: re-read below by the same lanes)
-#endif
 
   if (a.raw) return;  // GaussWish::Eloglike: leave c_k - 0.5 d^2 in qZ, no normalisation
 
@@ -513,45 +354,13 @@ __global__ void __launch_bounds__(WAVES * 64, LQW ? 2 : EstepOcc<DP>::BLOCKS) es
     fz = (myok && myrow) ? logZ : 0.0;
   } else {
   double logZ[R];
-#if LC_ES_ONEEXP
-  constexpr int KQM = 16;  // K <= 64
-  if (!LQW && !a.ll_part && K <= 4 * KQM) {
-    double ev[R][KQM], inv[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      double s = 0.0;
-      const double* qp = a.qZ + (rg0 + r) * RG + lo4;
-#pragma unroll
-      for (int kq = 0; kq < KQM; ++kq) {
-        const int k = 4 * kq + hi;
-        ev[r][kq] = 0.0;
-        if (rgok[r] && k < K) {
-          ev[r][kq] = exp(qp[(int64_t)k * a.ldq] - mx[r]);
-          s += ev[r][kq];
-        }
-      }
-      s = sum_over_hi(s);
-      logZ[r] = log(s) + mx[r];
-      inv[r] = rowok[r] ? 1.0 / s : 0.0;
-    }
-#pragma unroll
-    for (int kq = 0; kq < KQM; ++kq) {
-      const int k = 4 * kq + hi;
-      if (k < K) {
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-          if (rgok[r]) a.qZ[(int64_t)k * a.ldq + (rg0 + r) * RG + lo4] = ev[r][kq] * inv[r];
-      }
-    }
-  } else {
-#endif
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     double s = 0.0;
     if (rgok[r]) {
       const double* qp = a.qZ + (rg0 + r) * RG + lo4;
 #pragma unroll 8
-      for (int k = hi; k < K; k += 4) s += exp((LQW ? lqw[((k >> 2) * R + r) * 64] : qp[(int64_t)k * a.ldq]) - mx[r]);
+      for (int k = hi; k < K; k += 4) s += exp(qp[(int64_t)k * a.ldq] - mx[r]);
     }
     s = sum_over_hi(s);
     logZ[r] = log(s) + mx[r];
@@ -564,7 +373,7 @@ __global__ void __launch_bounds__(WAVES * 64, LQW ? 2 : EstepOcc<DP>::BLOCKS) es
       for (int r = 0; r < R; ++r) {
         if (rgok[r]) {
           double* qp = a.qZ + (int64_t)k * a.ldq + (rg0 + r) * RG + lo4;
-          const double lq = LQW ? lqw[((kb >> 2) * R + r) * 64] : *qp;
+          const double lq = *qp;
           double q = exp(lq - logZ[r]);
           if (!rowok[r]) q = 0.0;
           *qp = q;
@@ -577,9 +386,6 @@ __global__ void __launch_bounds__(WAVES * 64, LQW ? 2 : EstepOcc<DP>::BLOCKS) es
       if (k < K && lo4 == 0) llw[wave * K + k] = ll;
     }
   }
-#if LC_ES_ONEEXP
-  }
-#endif
 #pragma unroll
   for (int r = 0; r < R; ++r)
     if (rgok[r] && rowok[r] && hi == 0) fz += logZ[r];
@@ -587,33 +393,16 @@ __global__ void __launch_bounds__(WAVES * 64, LQW ? 2 : EstepOcc<DP>::BLOCKS) es
   fz = wave_sum(fz);
   if (lane == 0) fzw[wave] = fz;
   __syncthreads();
-  // partial slots are sized for the 4-wave blocks of the standard variant (estep_grid): a block of 2 x 4 waves fills two
-  constexpr int SLOTS = LQW ? WAVES / EstepWavesStd<DP>::W : 1;
-  const int64_t slot0 = (int64_t)blockIdx.x * SLOTS;
   if (a.ll_part)
     for (int k = tid; k < K; k += NTHR) {
       double s = 0.0;
       for (int w = 0; w < WAVES; ++w) s += llw[w * K + k];
-      a.ll_part[slot0 * K + k] = s;
-      for (int e = 1; e < SLOTS; ++e)
-        if (slot0 + e < a.nslots) a.ll_part[(slot0 + e) * K + k] = 0.0;
+      a.ll_part[(int64_t)blockIdx.x * K + k] = s;
     }
   if (tid == 0) {
     double s = 0.0;
     for (int w = 0; w < WAVES; ++w) s += fzw[w];
-    a.fz_part[slot0] = -s;  // cluster.cpp:137 returns -sum(logZ)
-    for (int e = 1; e < SLOTS; ++e)
-      if (slot0 + e < a.nslots) a.fz_part[slot0 + e] = 0.0;
-#ifdef LC_ES_TRACE
-    if (blockIdx.x < 65536) {
-      long long* t = lc_es_trace + 5 * (size_t)blockIdx.x;
-      t[0] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20);   // XCC_ID
-      t[1] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4);   // HW_ID
-      t[2] = tr_w0;
-      t[3] = wall_clock64();
-      t[4] = clock64() - tr_c0;
-    }
-#endif
+    a.fz_part[blockIdx.x] = -s;  // cluster.cpp:137 returns -sum(logZ)
   }
 }
 
@@ -871,7 +660,7 @@ struct EstepCfg<32> { static constexpr int R = 4, WAVES = 4; };
 template <>
 struct EstepCfg<48> { static constexpr int R = 4, WAVES = 4; };
 template <>
-struct EstepCfg<64> { static constexpr int R = LC_ES_R64, WAVES = 4; };
+struct EstepCfg<64> { static constexpr int R = 3, WAVES = 4; };
 template <>
 struct EstepCfg<80> { static constexpr int R = 3, WAVES = 4; };
 template <>
@@ -904,44 +693,12 @@ int64_t estep_grid(int DP, int64_t nrg) {
   return (nrg + rgpb - 1) / rgpb;
 }
 
-// log q~ in LDS for the k-sliced scheme (LQW): D = 64 with up to 32 clusters (8 waves x 12 KB next to the 36 KB ring)
-template <int DP, bool SPARSE>
-static hipError_t launch_estep_lqw(const EstepLaunch& a, hipStream_t stream, bool* done) {
-  *done = false;
-  if constexpr (DP == 64) {
-    constexpr int R = EstepCfg<DP>::R, WAVES = 8;
-    static_assert(EstepWavesStd<DP>::W == EstepCfg<DP>::WAVES, "slot bookkeeping");
-    static const int mode = getenv("LC_ES_LQW") ? atoi(getenv("LC_ES_LQW")) : LC_ES_LQW_DEFAULT;  // 0 off, 1 on
-    const size_t shmem = (size_t)(2 * pstride(DP) + WAVES * a.K + WAVES) * sizeof(double) +
-                         (size_t)WAVES * ((a.K + 3) / 4) * R * 64 * sizeof(double) +
-                         (size_t)(2 * a.K + WAVES * R + 2) * sizeof(int);
-    if (mode == 0 || a.raw || shmem > 160 * 1024) return hipSuccess;
-    auto kern = estep_kernel<DP, R, WAVES, SPARSE, true>;
-    static LdsGrant grant;
-    if (hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(kern), shmem, grant); e != hipSuccess) return e;
-    EstepLaunch b = a;
-    b.nslots = estep_grid(DP, a.nrg);
-    const int64_t grid = (b.nslots + 1) / 2;
-    *done = true;
-    if (grid <= 0) return hipSuccess;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVES * 64), shmem, stream, b);
-    return hipGetLastError();
-  }
-  return hipSuccess;
-}
-
 template <int DP, bool SPARSE>
 static hipError_t launch_estep_s(const EstepLaunch& a, hipStream_t stream) {
-  {
-    bool done = false;
-    const hipError_t e = launch_estep_lqw<DP, SPARSE>(a, stream, &done);
-    if (e != hipSuccess || done) return e;
-  }
   constexpr int R = EstepCfg<DP>::R, WAVES = EstepCfg<DP>::WAVES;
   size_t shmem = (size_t)(2 * pstride(DP) + WAVES * a.K + WAVES) * sizeof(double) +
                  (size_t)(2 * a.K + WAVES * R + 2) * sizeof(int);
   EstepLaunch b = a;
-  b.nslots = estep_grid(DP, a.nrg);
   static const bool no_lql = getenv("LC_ES_NOLQL") != nullptr;  // tuning knob: log q~ through the qZ buffer everywhere
   if (R == 4 && !a.raw && !no_lql && shmem + (size_t)a.K * WAVES * 64 * sizeof(double) <= 40 * 1024) {  // (four blocks per CU still fit; at 74 KB, K = 32, the lost occupancy costs 8 %)
     b.lq_lds = 1;  // log q~ stays in LDS until the normalisation

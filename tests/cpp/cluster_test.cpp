@@ -6,6 +6,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
+#include <string>
+#include <vector>
 
 #include "distributions.h"
 #include "libcluster.h"
@@ -255,6 +257,97 @@ int main() {
   threw = false;
   try { StickBreak bad(0.0); } catch (const invalid_argument&) { threw = true; }
   REQUIRE(threw);
+  // LIBCLUSTER_GPUS=8 (all shards on GPU 0, host-staged sums): the same calls, unsharded and over eight shards -- row
+  // blocks for the single-matrix learners, whole groups for the GMC family (16 unequal groups, two per shard) -- must
+  // agree in K, F, responsibilities, weights and cluster parameters.  The loop being distributed: cluster.cpp:207-223.
+  {
+    const char* keep_g = getenv("LIBCLUSTER_GPUS");
+    const char* keep_s = getenv("LIBCLUSTER_GPUS_SAME_DEVICE");
+    const string old_g = keep_g ? keep_g : "", old_s = keep_s ? keep_s : "";
+    const int J8 = 16, D8 = 3, K8 = 5;
+    unsigned long long st = 88172645463325252ULL;  // xorshift64: the same points on every platform
+    auto uni = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (double)(st >> 11) / 9007199254740992.0; };
+    auto gauss = [&]() { const double u = uni() + 1e-300, v = uni(); return sqrt(-2.0 * log(u)) * cos(6.283185307179586 * v); };
+    double mu8[K8][D8];
+    for (int k = 0; k < K8; ++k)
+      for (int d = 0; d < D8; ++d) mu8[k][d] = 7.0 * gauss();
+    vMatrixXd Xg(J8);
+    int ntot = 0;
+    for (int j = 0; j < J8; ++j) {
+      const int nj = 400 + 37 * j;
+      Xg[j].resize(nj, D8);
+      for (int r = 0; r < nj; ++r) {
+        const int k = (int)(uni() * K8) % K8;
+        for (int d = 0; d < D8; ++d) Xg[j](r, d) = mu8[k][d] + (0.6 + 0.1 * k) * gauss();
+      }
+      ntot += nj;
+    }
+    lcmat::MatrixXd Xall(ntot, D8);
+    for (int j = 0, o = 0; j < J8; o += Xg[j].rows(), ++j)
+      for (int r = 0; r < Xg[j].rows(); ++r)
+        for (int d = 0; d < D8; ++d) Xall(o + r, d) = Xg[j](r, d);
+    double Fb1 = 0, Fv1 = 0, Fg1 = 0;
+    lcmat::MatrixXd qb1, qv1;
+    vMatrixXd qg1;
+    vector<GaussWish> cb1, cv1, cg1;
+    vector<GDirichlet> wg1;
+    Dirichlet wb1;
+    StickBreak wv1;
+    for (int pass = 0; pass < 2; ++pass) {
+      if (pass == 0) {
+        unsetenv("LIBCLUSTER_GPUS");
+        unsetenv("LIBCLUSTER_GPUS_SAME_DEVICE");
+      } else {
+        setenv("LIBCLUSTER_GPUS", "8", 1);
+        setenv("LIBCLUSTER_GPUS_SAME_DEVICE", "1", 1);
+      }
+      lcmat::MatrixXd qb, qv;
+      vMatrixXd qg;
+      vector<GaussWish> cb2, cv2, cg2;
+      vector<GDirichlet> wg2;
+      Dirichlet wb2;
+      StickBreak wv2;
+      const double Fb2 = learnBGMM(Xall, qb, wb2, cb2, PRIORVAL, -1, pass == 1);  // (verbose: "Sharding over 8 GPU(s)")
+      const double Fv2 = learnVDP(Xall, qv, wv2, cv2);
+      const double Fg2 = learnGMC(Xg, qg, wg2, cg2);
+      if (pass == 0) {
+        Fb1 = Fb2; Fv1 = Fv2; Fg1 = Fg2;
+        qb1 = qb; qv1 = qv; qg1 = qg; cb1 = cb2; cv1 = cv2; cg1 = cg2; wg1 = wg2; wb1 = wb2; wv1 = wv2;
+        REQUIRE(cb1.size() >= 3 && cv1.size() >= 3 && cg1.size() >= 3);
+        continue;
+      }
+      REQUIRE(cb2.size() == cb1.size() && cv2.size() == cv1.size() && cg2.size() == cg1.size());
+      REQUIRE(fabs(Fb2 - Fb1) <= 1e-10 * fabs(Fb1) && fabs(Fv2 - Fv1) <= 1e-10 * fabs(Fv1) && fabs(Fg2 - Fg1) <= 1e-10 * fabs(Fg1));
+      REQUIRE(qb.rows() == ntot && qb.cols() == (int)cb1.size() && qv.rows() == ntot && qg.size() == (size_t)J8);
+      for (int r = 0; r < ntot; ++r) {
+        for (int k = 0; k < qb.cols(); ++k) REQUIRE(fabs(qb(r, k) - qb1(r, k)) < 1e-9);
+        for (int k = 0; k < qv.cols(); ++k) REQUIRE(fabs(qv(r, k) - qv1(r, k)) < 1e-9);
+      }
+      for (int j = 0; j < J8; ++j) {
+        REQUIRE(qg[j].rows() == Xg[j].rows() && qg[j].cols() == (int)cg1.size());
+        for (int r = 0; r < qg[j].rows(); ++r)
+          for (int k = 0; k < qg[j].cols(); ++k) REQUIRE(fabs(qg[j](r, k) - qg1[j](r, k)) < 1e-9);
+        for (int k = 0; k < (int)cg1.size(); ++k)
+          REQUIRE(fabs(wg2[j].Elogweight()(k) - wg1[j].Elogweight()(k)) < 1e-9 * (1.0 + fabs(wg1[j].Elogweight()(k))));
+      }
+      for (size_t k = 0; k < cb1.size(); ++k) {
+        REQUIRE(fabs(cb2[k].getN() - cb1[k].getN()) < 1e-8 * (1.0 + cb1[k].getN()));
+        REQUIRE(fabs(wb2.Elogweight()(k) - wb1.Elogweight()(k)) < 1e-9 * (1.0 + fabs(wb1.Elogweight()(k))));
+        for (int d = 0; d < D8; ++d) {
+          REQUIRE(fabs(cb2[k].getmean()(d) - cb1[k].getmean()(d)) < 1e-8);
+          for (int e = 0; e < D8; ++e) REQUIRE(fabs(cb2[k].getcov()(d, e) - cb1[k].getcov()(d, e)) < 1e-8);
+        }
+      }
+      for (size_t k = 0; k < cv1.size(); ++k) {
+        REQUIRE(fabs(cv2[k].getN() - cv1[k].getN()) < 1e-8 * (1.0 + cv1[k].getN()));
+        REQUIRE(fabs(wv2.Elogweight()(k) - wv1.Elogweight()(k)) < 1e-9 * (1.0 + fabs(wv1.Elogweight()(k))));
+      }
+      for (size_t k = 0; k < cg1.size(); ++k) REQUIRE(fabs(cg2[k].getN() - cg1[k].getN()) < 1e-8 * (1.0 + cg1[k].getN()));
+    }
+    if (keep_g) setenv("LIBCLUSTER_GPUS", old_g.c_str(), 1); else unsetenv("LIBCLUSTER_GPUS");
+    if (keep_s) setenv("LIBCLUSTER_GPUS_SAME_DEVICE", old_s.c_str(), 1); else unsetenv("LIBCLUSTER_GPUS_SAME_DEVICE");
+    cout << "eight shards OK" << endl;
+  }
   cout << "cluster_test OK" << endl;
   return 0;
 }

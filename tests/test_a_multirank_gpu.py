@@ -20,7 +20,9 @@ def _run(cmd, env=None):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=e, cwd=str(ROOT))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     line = [x for x in r.stdout.splitlines() if x.startswith("RESULT ")][-1]
-    return json.loads(line[len("RESULT "):])
+    out = json.loads(line[len("RESULT "):])
+    out["_log"] = r.stdout + r.stderr
+    return out
 
 
 @pytest.mark.parametrize("mode,family,D", [("rows", "GaussWish", 6), ("groups", "GaussWish", 6), ("rows", "NormGamma", 6),
@@ -64,7 +66,10 @@ def test_one_rank_failing_to_journal_a_cache_column_is_a_joint_fallback(lib, mod
     one = _run([sys.executable, script, *args])
     two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                 "--master-addr", "127.0.0.1", "--master-port", str(port), script, *args],
-               {"LC_DIST_BACKEND": "gloo", "LC_ALL_RANKS_ON_GPU0": "1", "LC_TEST_JOURNAL_FAIL_RANK": "1"})
+               {"LC_DIST_BACKEND": "gloo", "LC_ALL_RANKS_ON_GPU0": "1", "LC_TEST_JOURNAL_FAIL_RANK": "1", "LC_TRACE_PHASES": "1",
+                "LC_LIB_PATH": str(ROOT / "libcluster_amd" / "lib" / "libcluster_hip_testhooks.so")})
+    # both ranks gave the cache up together: rank 1 because its (test-hooked) reservation failed, rank 0 "on another rank"
+    assert "LC_TEST_JOURNAL_FAIL_RANK" in two["_log"] and "on another rank" in two["_log"]
     assert two["world"] == 2 and one["K"] == two["K"] >= 5
     assert [k for k, _ in one["rounds"]] == [k for k, _ in two["rounds"]]
     for (_, a), (_, b) in zip(one["rounds"], two["rounds"]):

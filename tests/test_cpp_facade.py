@@ -65,3 +65,6 @@ def test_reference_test_main_passes_on_gpu(lib, xcat, xcat_traces, gpus):
     assert "Learning GMC..." in r.stdout and "<" in r.stdout and ">" in r.stdout and "Finished!" in r.stdout
     assert "Learning SCM..." in r.stdout and "Learning MCM..." in r.stdout
     assert "Number of top level clusters = " in r.stdout and ", and bottom level clusters = " in r.stdout
+    # LIBCLUSTER_GPUS=8 inside the main (set with setenv between the calls): eight row blocks / sixteen groups on eight
+    # shards equal to the unsharded calls
+    assert "Sharding over 8 GPU(s), host-local all-reduce" in r.stdout and "eight shards OK" in r.stdout

@@ -296,6 +296,69 @@ def test_bench_starts_its_own_ranks(lib):
     assert line["n_gpus"] == 2 and line["config"]["collective"] == "host-shm"
     assert line["config"]["rows_per_gpu"] == 200_000 and line["value"] > 0
     _check_per_rank(line, 2)
+    ncpu = len(os.sched_getaffinity(0))
+    for r in line["config"]["per_rank"]:  # the M-step pool covers the rank's whole slice of the CPUs
+        assert r["cpus"] == (ncpu // 2 if ncpu >= 2 else ncpu) and r["mstep_threads"] == min(32, r["cpus"]), r
+
+
+def _bench_line(args, env, timeout=1500):
+    import json
+    import sys
+
+    e = dict(os.environ)
+    e.update(env)
+    e.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), *args, "--no-cpu-baseline", "--no-parity", "--no-other-configs"],
+                       capture_output=True, text=True, timeout=timeout, env=e, cwd=str(ROOT))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config,one,eight", [
+    # BASELINE config 4's shape (BGMM, D = 64, K = 32), 8 row blocks of 1.25M rows = ranks 0..7 of the one Philox stream
+    ("northstar", ["--rows", "10000000"], ["--rows", "1250000"]),
+    # BASELINE config 5's shape (GMC, D = 128, K = 64): 64 groups of 60k rows, eight whole groups per rank
+    ("5", ["--rows", "3840000", "--groups", "64"], ["--rows", "480000", "--groups", "8"]),
+])
+def test_bench_eight_ranks_on_one_gpu_equal_one_rank(lib, config, one, eight):
+    """The `--gpus 8` path the driver's scaling run takes, executed with a world of EIGHT before it ever meets eight GPUs:
+    eight processes (torch.distributed.run started by bench.py itself, gloo rendezvous, all on GPU 0), the library's
+    native host-staged collective in every iteration, the eight-entry per-rank report -- and the same model as ONE rank
+    over the same rows: free energy and what the M-step made of the reduced statistics (N_k, means, scatter traces,
+    log-determinants) to 1e-11.  Also: every rank's M-step runs on ALL the CPUs of its slice (the affinity mask used to
+    be divided by the world size twice).  The loop being distributed: src/cluster.cpp:207-223."""
+    base = ["--config", config, "--steps", "3", "--warmup", "1"]
+    a = _bench_line(["--gpus", "1", *base, *one], {})
+    b = _bench_line(["--gpus", "8", *base, *eight], {"LC_DIST_BACKEND": "gloo", "LC_ALL_RANKS_ON_GPU0": "1"})
+    assert a["n_gpus"] == 1 and b["n_gpus"] == 8
+    assert b["config"]["collective"] == "host-shm"  # the library's own transport, not the torch.distributed hook
+    assert len(b["config"]["per_rank"]) == 8
+    _check_per_rank(b, 8)
+    ncpu = len(os.sched_getaffinity(0))
+    for r in b["config"]["per_rank"]:
+        assert r["mstep_threads"] == min(32, r["cpus"]) or ncpu < 8, r
+        assert r["cpus"] == (ncpu // 8 if ncpu >= 8 else ncpu), r
+    assert abs(a["free_energy"] - b["free_energy"]) <= 1e-11 * abs(a["free_energy"])
+    for key, tol in (("Nk", 1e-11), ("mean_sum", 1e-9), ("iW_trace", 1e-11), ("logdW", 1e-11)):
+        x, y = np.array(a["check"][key]), np.array(b["check"][key])
+        assert x.shape == y.shape and x.size == a["config"]["K"]
+        np.testing.assert_allclose(y, x, rtol=tol, atol=tol * (1.0 + np.max(np.abs(x))), err_msg=key)
+
+
+@pytest.mark.gpu
+def test_bench_eight_inproc_shards_equal_eight_processes(lib):
+    """`--gpus 8 --inproc` (one process, eight host threads / contexts / streams / M-step pools: the LIBCLUSTER_GPUS=8
+    deployment) against eight processes on the same rows: same free energy, eight per-rank entries."""
+    base = ["--gpus", "8", "--config", "northstar", "--rows", "400000", "--steps", "3", "--warmup", "1"]
+    env = {"LC_DIST_BACKEND": "gloo", "LC_ALL_RANKS_ON_GPU0": "1"}
+    a = _bench_line([*base, "--inproc"], env)
+    b = _bench_line(base, env)
+    assert a["config"]["collective"] == "host-shm" == b["config"]["collective"] and "ONE process" in a["config"]["parallelism"]
+    assert len(a["config"]["per_rank"]) == 8
+    _check_per_rank(a, 8)
+    assert abs(a["free_energy"] - b["free_energy"]) <= 1e-12 * abs(b["free_energy"])
+    np.testing.assert_allclose(a["check"]["Nk"], b["check"]["Nk"], rtol=1e-12)
 
 
 def _check_per_rank(line, world):

@@ -119,7 +119,9 @@ def _run_snippet(env, **kw):
     r = subprocess.run([sys.executable, "-c", _SNIPPET.format(root=str(ROOT), **kw)], capture_output=True, text=True,
                        timeout=600, env=e, cwd=str(ROOT))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    return json.loads(r.stdout.strip().splitlines()[-1])
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    out["_stderr"] = r.stderr
+    return out
 
 
 @pytest.mark.parametrize("kw", [dict(seed=5, K=5, D=20, N=6000, J=1, scale=0.8),    # heavy overlap: the cache stops paying
@@ -162,7 +164,12 @@ def test_model_selection_carries_on_when_the_distance_cache_does_not_fit(lib):
     kernels with the same rounds, K and F."""
     kw = dict(seed=7, K=7, D=33, N=4000, J=1, scale=6.0)
     a = _run_snippet({}, **kw)
-    b = _run_snippet({"LC_TEST_CACHE_NO_ROOM": "4"}, **kw)
+    hooked = str(ROOT / "libcluster_amd" / "lib" / "libcluster_hip_testhooks.so")
+    b = _run_snippet({"LC_TEST_CACHE_NO_ROOM": "4", "LC_LIB_PATH": hooked, "LC_TRACE_PHASES": "1"}, **kw)
+    assert "distance cache given up" in b["_stderr"] and "no room for the distance cache at K = 4" in b["_stderr"]
+    # the shipped library has no fault hooks: the switch does nothing there
+    c = _run_snippet({"LC_TEST_CACHE_NO_ROOM": "4", "LC_TRACE_PHASES": "1"}, **kw)
+    assert "distance cache given up" not in c["_stderr"] and c["K"] == a["K"]
     assert a["K"] == b["K"] >= 6 and [k for k, _ in a["rounds"]] == [k for k, _ in b["rounds"]]
     for (_, x), (_, y) in zip(a["rounds"], b["rounds"]):
         np.testing.assert_allclose(x, y, rtol=1e-10)
