@@ -662,12 +662,22 @@ def main():
     res, ctx, model, (wkind, ckind, mu, L, family) = measure(capi, cfg, args.steps, args.warmup, rank, world,
                                                               local_rank, stream, nthreads, comm, dist, torch)
     if rank == 0:
-        tf = ROOT / "profiles" / "r03_pmc_traffic.json"  # HBM bytes per launch from the committed PMC passes (not live)
-        if not tf.exists():
-            tf = ROOT / "profiles" / "r02_pmc_traffic.json"
-        traffic = json.loads(tf.read_text()) if tf.exists() else {}
-        if not args.rows:
-            res["roofline"]["traffic"] = traffic.get(args.config, {}).get(res["roofline"]["kernel"])
+        # HBM bytes per launch from the committed PMC passes (not live): the newest profiles/rNN_pmc_traffic.json, which
+        # tools/pmc_traffic.py GENERATES from the rocprofv3 summaries next to it (tests/test_host.py checks that)
+        tfs = sorted((ROOT / "profiles").glob("r[0-9][0-9]_pmc_traffic.json"))
+        traffic = json.loads(tfs[-1].read_text()) if tfs else {}
+
+        def put_traffic(roof, cfgname):
+            e = traffic.get(cfgname, {})
+            roof["traffic"] = e.get(roof["kernel"])
+            lps = e.get("_launches_per_step", {}).get(roof["kernel"])
+            if lps is not None:
+                roof["traffic_launches_per_step"] = lps
+            if roof["traffic"] is not None:
+                roof["traffic_source"] = f"profiles/{tfs[-1].name} <- profiles/{e.get('_summary', '?')}"
+
+        if not args.rows and not args.groups:
+            put_traffic(res["roofline"], args.config)
         line = {
             "metric": "E-step data-points/sec (full VBEM iteration: suff-stats + M-step + E-step)",
             "value": res["value"], "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -704,7 +714,7 @@ def main():
                 # (the 0.25 ms iteration of the small configuration needs more steps for a steady number)
                 st, wu = (200, 20) if c2["N"] * c2["D"] * c2["K"] < 1e9 else (5, 1)
                 r2, x2, m2, _ = measure(capi, c2, st, wu, 0, 1, local_rank, stream, nthreads, None, None, torch)
-                r2["roofline"]["traffic"] = traffic.get(name, {}).get(r2["roofline"]["kernel"])
+                put_traffic(r2["roofline"], name)
                 others.append({"config": name, "workload": c2["label"], "steps": st, "warmup": wu,
                                "value": r2["value"], "ms_per_step": r2["ms_per_step"], "kernels": r2["kernels"],
                                "roofline": r2["roofline"]})

@@ -23,6 +23,13 @@ __device__ __forceinline__ double mfma4(double a, double b, double c) {
   return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
 }
 
+// max without the canonicalising self-max hipcc puts in front of fmax (three v_max_f64 per call where one does;
+// the operands here are never signalling NaNs)
+__device__ __forceinline__ double max_raw(double a, double b) {
+  asm("v_max_f64 %0, %1, %2" : "=v"(a) : "v"(a), "v"(b));
+  return a;
+}
+
 // n-th read of a cluster's parameter stream (for it: -b[it], tile(it,0), ..., tile(it,it)):
 // .jt < 0: element of the -b vector (offset in doubles from Pb), else of tile (it,jt) (from Pt)
 struct RdInfo {

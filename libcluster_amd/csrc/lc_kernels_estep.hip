@@ -30,12 +30,6 @@ namespace lck {
 
 constexpr int ES_PF = 4;  // LDS reads in flight ahead of their use (2...10 are within 1 %)
 
-// max without the canonicalising self-max hipcc puts in front of fmax (three v_max_f64 per call where one does)
-__device__ __forceinline__ double max_raw(double a, double b) {
-  asm("v_max_f64 %0, %1, %2" : "=v"(a) : "v"(a), "v"(b));
-  return a;
-}
-
 // ===========================================================================
 // E-step
 // ===========================================================================

@@ -31,13 +31,25 @@ constexpr int FUSED_ROWS = 256; // rows per tile
 constexpr int FUSED_QS = FUSED_ROWS + 2;  // q table: 258 doubles per cluster = 4 banks between consecutive clusters
 
 // CPW: cluster quads of the statistics half (K <= 4 CPW)
-// ONEGRP: one group, known at compile time (no row-group table).  As a run-time choice the table read and the computed
-// `info` end in one register, which the compiler guards with `s_waitcnt vmcnt(0)` in BOTH paths -- four full drains of
-// the just-issued prefetch at the head of every tile.
-// GRP 0 = that instance; 1: several groups, the J x K table c_jk waits in LDS (J x K <= FUSED_CT_CAP); 2: several groups, the
-// table is read from global memory inside the cluster loop (each read then waits for the prefetch as well).  Compile-time
-// because a run-time choice between an LDS read and a global read ends in a combined `vmcnt(0) lgkmcnt(0)` at the merge.
-template <int DP, int CPW, int GRP = 2>
+// GRP 0: one group, known at compile time (no row-group table; as a run-time choice the table read and the computed
+// `info` end in one register, which the compiler guards with `s_waitcnt vmcnt(0)` in BOTH paths -- full drains of the
+// just-issued prefetch at the head of every tile); 1: several groups, the J x K table c_jk waits in LDS (J x K <=
+// FUSED_CT_CAP); 2: several groups, the table is read from global memory inside the cluster loop (each read then waits
+// for the prefetch as well).  Compile-time because a run-time choice between an LDS read and a global read ends in a
+// combined `vmcnt(0) lgkmcnt(0)` at the merge.
+// WANT_LL: also the split-ordering data term LL_k (cluster()'s rounds; the VBEM iterations run the plain instance, whose
+// normalisation takes one exponential per entry and has no per-cluster wave reductions).
+//
+// Round 4: the E-step half is ONE instruction stream over all clusters.  The round-3 loop issued a cluster's seven LDS
+// reads at its head and waited for them (an exposed LDS round trip per cluster), and ended every cluster in four
+// exec-masked blocks `if (hi == r) { read c_k; wait; fma }` (four more): ~ 4 000 of a wave's 25 000 cycles per tile.
+// Now (i) the parameter ring runs SEVEN reads ahead ACROSS cluster boundaries (NREAD = 14 = 2 x 7: the ring slots line
+// up from cluster to cluster), fenced as in estep_kernel; (ii) a cluster's tail -- the squares of its last tile row, the
+// sum over the four `hi` lanes and the choice of the lane's own row group -- is done under the NEXT cluster's MFMAs:
+// four chained MFMAs  t = sum_r A_r d2_r + c  with selector operands A_r[i][.] = -1/2 [i == r]  leave
+// log q~ = c - d^2 / 2 of row group `hi` in lane (lo4, hi) directly: no select, no branch, no VALU; (iii) c_k is read at
+// the head of the cluster it belongs to and rides into the chain as its C operand.
+template <int DP, int CPW, int GRP, bool WANT_LL>
 __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
   constexpr bool ONEGRP = GRP == 0, CTLDS = GRP != 2;
   FusedLaunch a = a_;
@@ -46,7 +58,8 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
   constexpr int NT = DP / 4;
   constexpr int NTILES = NT * (NT + 1) / 2;
   constexpr int NREAD = NTILES + NT;
-  constexpr int PF = 6;
+  constexpr int PF = 7;
+  static_assert(NREAD % PF == 0, "the ring's slots must line up from one cluster to the next");
   constexpr int PS = NTILES * 16 + DP;
   // row stride of the staged tile (36 dwords).  E-step half: a half-wave reads rows lo4 = 0..15 at two columns -- 36 lo4
   // mod 64 are sixteen different multiples of 4: conflict-free.  Statistics half (feature form): a half-wave reads up to
@@ -70,7 +83,8 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
   // a wait for the prefetch (an HBM round trip per tile, exposed).  With several groups the table is still read there.
   double* ctl = fzw + 4;               // [FUSED_CT_CAP]: the table c_jk when it fits (J x K entries), else unused
   const int ctrows = ONEGRP ? 1 : a.ngroups;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave-uniform: its arithmetic belongs on the scalar unit)
   const int lo4 = lane & 15, hi = lane >> 4, blk = (lane >> 2) & 3, lo2 = lane & 3;
   for (int i = tid; i < K * PS; i += 256) par[i] = a.params[i];
   for (int i = tid; i < 4 * K; i += 256) llw[i] = 0.0;
@@ -83,6 +97,13 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
   for (int t = 0; t < NTL; ++t)
 #pragma unroll
     for (int c = 0; c < NQ; ++c) acc[t][c] = 0.0;
+  // selector operands of the lane-sum chain: A_r[i = lo2][k = hi] = -1/2 [lo2 == r]
+  double selA[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    selA[r] = lo2 == r ? -0.5 : 0.0;
+    asm volatile("" : "+v"(selA[r]));  // (four registers for the whole kernel, not a compare + select per use)
+  }
   double fz = 0.0;
   const int64_t NP = a.nrg * RG;
   const int64_t ntile = (NP + FUSED_ROWS - 1) / FUSED_ROWS;
@@ -92,45 +113,47 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
   auto fetch = [&](int64_t tile) {
     const int64_t r0 = tile * FUSED_ROWS;
     const int64_t left = tile < ntile ? NP - r0 : 0;
-    const int lim = (int)(left < FUSED_ROWS ? left : FUSED_ROWS) * C2;
     const double2* X2 = reinterpret_cast<const double2*>(a.X) + (tile < ntile ? r0 : 0) * C2;
+    if (left >= FUSED_ROWS) {  // (uniform) a whole tile: no per-load bounds
 #pragma unroll
-    for (int i = 0; i < NPRE; ++i) {
-      const int idx = tid + i * 256;
-      pre[i] = idx < lim ? X2[idx] : make_double2(0.0, 0.0);
+      for (int i = 0; i < NPRE; ++i) pre[i] = X2[tid + i * 256];
+    } else {
+      const int lim = (int)left * C2;
+#pragma unroll
+      for (int i = 0; i < NPRE; ++i) {
+        const int idx = tid + i * 256;
+        pre[i] = idx < lim ? X2[idx] : make_double2(0.0, 0.0);
+      }
     }
   };
   fetch(blockIdx.x);
   __syncthreads();
+  // n-th read of cluster `kk`'s parameter stream relative to the running pointers of the current cluster
+  const double* Pt = par + (lane & 3) + 4 * hi;  // this lane's element of every 4x4 tile (cluster 0)
+  const double* Pb = par + NTILES * 16 + hi;     // this lane's element of every 4-vector of -b (cluster 0)
+  double* const xstage = xt + (tid / C2) * LD + 2 * (tid % C2);
   for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
     const int64_t row0 = tile * FUSED_ROWS;
     // ---- the tile of X -> LDS (its loads were issued a whole tile ago)
+    // (one 16-byte store per piece: its 8-lane groups fill one row's 128 bytes; two 8-byte stores put two rows, 36 dwords
+    //  apart, into a 16-lane group: a 2-way conflict on the 32 write banks)
 #pragma unroll
-    for (int i = 0; i < NPRE; ++i) {
-      const int idx = tid + i * 256;
-      const int row = idx / C2, c2 = idx % C2;
-      // (one 16-byte store: its 8-lane groups fill one row's 128 bytes; two 8-byte stores put two rows, 36 dwords apart,
-      //  into a 16-lane group: a 2-way conflict on the 32 write banks)
-      *reinterpret_cast<double2*>(xt + row * LD + 2 * c2) = pre[i];
-    }
+    for (int i = 0; i < NPRE; ++i) *reinterpret_cast<double2*>(xstage + i * (256 / C2) * LD) = pre[i];
     __syncthreads();
 
-    // ---- E-step half: this wave's 64 rows as four row groups
-    // (the row groups' table entries are read BEFORE the next tile's prefetch goes out: they are waited for at once, and
-    //  the vector-memory counter retires in order)
-    const int64_t rg0 = tile * (FUSED_ROWS / RG) + wave * R;
-    double xf[R][NT];
-    int grp[R];
-    bool rowok[R], rgok[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int64_t rg = rg0 + r;
-      rgok[r] = rg < a.nrg;
+    // ---- E-step half: this wave's 64 rows as four row groups; lane (lo4, hi) owns row 16 hi + lo4 = row `tid` of the tile
+    // (a table entry is read BEFORE the next tile's prefetch goes out: it is waited for at once, and the vector-memory
+    //  counter retires in order)
+    const int64_t left = NP - row0;  // padded rows from here on (a multiple of 16)
+    const bool myok = tid < left;    // this lane's row group exists
+    bool myrow;
+    int mygrp = 0;
+    if constexpr (ONEGRP) {
+      myrow = row0 + tid < a.nrows;
+    } else {
       int info = 0;
-      if constexpr (ONEGRP) {
-        const int64_t rem = a.nrows - rg * RG;
-        info = !rgok[r] ? 0 : rem >= RG ? RG : (rem > 0 ? (int)rem : 0);
-      } else if (rgok[r]) {
+      if (myok) {
+        const int64_t rg = row0 / RG + (tid >> 4);
         if (a.rginfo) {
           info = a.rginfo[rg];
         } else {
@@ -138,100 +161,152 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
           info = rem >= RG ? RG : (rem > 0 ? (int)rem : 0);
         }
       }
-      if constexpr (!ONEGRP) asm volatile("" : "+v"(info));  // (the table entry has to be HERE: its wait stands in front of the prefetch)
-      grp[r] = info >> 5;
-      rowok[r] = lo4 < (info & 31);
+      asm volatile("" : "+v"(info));  // (the table entry has to be HERE: its wait stands in front of the prefetch)
+      mygrp = info >> 5;
+      myrow = lo4 < (info & 31);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if constexpr (!ONEGRP) __builtin_amdgcn_sched_barrier(0);
     fetch(tile + gridDim.x);  // in flight during both halves of this tile
+    double xf[R][NT];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const double* xr = xt + (wave * 64 + r * 16 + lo4) * LD + hi;
 #pragma unroll
       for (int jt = 0; jt < NT; ++jt) xf[r][jt] = xr[4 * jt];
     }
-    bool myok = false, myrow = false;
-    int mygrp = 0;
+    // the constant of cluster k for this lane's row group
+    auto cjk_of = [&](int k) -> double {
+      if constexpr (ONEGRP) return ctl[k];
+      else if constexpr (CTLDS) return ctl[mygrp * K + k];
+      else return a.ctab[(int64_t)mygrp * K + k];
+    };
+    double ring[PF];
+    static_for<PF>([&](auto ic) {
+      constexpr RdInfo ri = rd_info(ic);
+      ring[ic] = ri.jt < 0 ? Pb[ri.off] : Pt[ri.off];
+    });
+    // carried from cluster k - 1 into cluster k's pass: its last tile row (not yet squared), its partial squared norms
+    // and its constant (-inf before the first cluster: that pass's "log q~" is -inf and changes nothing)
+    double accP[R], d2P[R], cP = -INFINITY, mymx = -INFINITY;
 #pragma unroll
-    for (int r = 0; r < R; ++r)
-      if (hi == r) myok = rgok[r], myrow = rowok[r], mygrp = grp[r];
-    double mymx = -INFINITY;
+    for (int r = 0; r < R; ++r) accP[r] = 0.0, d2P[r] = 0.0;
     for (int k = 0; k < K; ++k) {
-      const double* P = par + (size_t)k * PS;
-      const double* Pt = P + (lane & 3) + 4 * hi;  // this lane's element of every 4x4 tile
-      const double* Pb = P + NTILES * 16 + hi;     // this lane's element of every 4-vector of -b
-      double ring[PF];
-      static_for<PF>([&](auto ic) {
-        constexpr RdInfo ri = rd_info(ic);
-        ring[ic] = ri.jt < 0 ? Pb[ri.off] : Pt[ri.off];
-      });
-      double d2[R], acc1[R];
-#pragma unroll
-      for (int r = 0; r < R; ++r) d2[r] = 0.0;
+      const double* Ptk = Pt + (size_t)k * PS;
+      const double* Pbk = Pb + (size_t)k * PS;
+      const double cK = cjk_of(k);
+      double* const qslot = qt + (size_t)(k > 0 ? k - 1 : 0) * QS + tid;  // (k = 0 writes -inf where cluster 0 lands next)
+      double d2[R], accs[2][R], t = 0.0;
       static_for<NREAD>([&](auto nc) {
         constexpr int n = nc;
         constexpr RdInfo ri = rd_info(n);
+        constexpr int set = ri.it & 1;
         const double v = ring[n % PF];
-        if constexpr (n + PF < NREAD) {
-          constexpr RdInfo rn = rd_info(n + PF);
-          ring[n % PF] = rn.jt < 0 ? Pb[rn.off] : Pt[rn.off];
+        {  // the read PF ahead: of this cluster, or already of the next one
+          constexpr int m = n + PF;
+          constexpr RdInfo rn = rd_info(m < NREAD ? m : m - NREAD);
+          constexpr int over = m < NREAD ? 0 : PS;
+          ring[n % PF] = rn.jt < 0 ? Pbk[rn.off + over] : Ptk[rn.off + over];
         }
         if constexpr (ri.jt < 0) {
 #pragma unroll
-          for (int r = 0; r < R; ++r) acc1[r] = v;  // y starts at -b: y = A x - b
+          for (int r = 0; r < R; ++r) accs[set][r] = v;  // y starts at -b: y = A x - b
         } else {
 #pragma unroll
-          for (int r = 0; r < R; ++r) acc1[r] = mfma4(v, xf[r][ri.jt], acc1[r]);
-          if constexpr (ri.jt == ri.it) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) d2[r] = fma(acc1[r], acc1[r], d2[r]);
-          }
+          for (int r = 0; r < R; ++r) accs[set][r] = mfma4(v, xf[r][ri.jt], accs[set][r]);
         }
-      });
-      double lqsel = 0.0;
+        // under those MFMAs: the previous cluster's tail and this cluster's deferred squares
+        if constexpr (n == 1) {
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const double dd = mfma4(1.0, d2[r], 0.0);  // sum over the four hi lanes, total in every lane
-        double cjk;
-        if constexpr (ONEGRP) cjk = ctl[k];
-        else if constexpr (CTLDS) cjk = ctl[grp[r] * K + k];
-        else cjk = a.ctab[(int64_t)grp[r] * K + k];
-        const double lq = cjk - 0.5 * dd;
-        if (hi == r) lqsel = lq;
-      }
-      mymx = fmax(mymx, lqsel);
-      qt[k * QS + tid] = lqsel;  // (this lane's own slot: no barrier needed before it reads it back)
+          for (int r = 0; r < R; ++r) d2P[r] = fma(accP[r], accP[r], d2P[r]);
+        }
+        if constexpr (n == 3) t = mfma4(selA[0], d2P[0], cP);
+        if constexpr (n == 4) {
+          t = mfma4(selA[1], d2P[1], t);
+#pragma unroll
+          for (int r = 0; r < R; ++r) d2[r] = accs[0][r] * accs[0][r];  // tile row 0
+        }
+        if constexpr (n == 6) t = mfma4(selA[2], d2P[2], t);
+        if constexpr (n == 7) {
+          t = mfma4(selA[3], d2P[3], t);
+#pragma unroll
+          for (int r = 0; r < R; ++r) d2[r] = fma(accs[1][r], accs[1][r], d2[r]);  // tile row 1
+        }
+        if constexpr (n == 11) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) d2[r] = fma(accs[0][r], accs[0][r], d2[r]);  // tile row 2
+        }
+        if constexpr (n == 12) {  // log q~ of cluster k - 1 for this lane's row: its own slot (no barrier before it reads it back)
+          mymx = max_raw(mymx, t);
+          *qslot = t;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+#pragma unroll
+      for (int r = 0; r < R; ++r) accP[r] = accs[1][r], d2P[r] = d2[r];  // tile row 3 is squared under the next cluster
+      cP = cK;
+    }
+    {  // the last cluster's tail
+#pragma unroll
+      for (int r = 0; r < R; ++r) d2P[r] = fma(accP[r], accP[r], d2P[r]);
+      double t = mfma4(selA[0], d2P[0], cP);
+#pragma unroll
+      for (int r = 1; r < R; ++r) t = mfma4(selA[r], d2P[r], t);
+      mymx = fmax(mymx, t);
+      qt[(size_t)(K - 1) * QS + tid] = t;
     }
     // logsumexp and normalisation in the reference's order: max, sum exp(x - max), log + max, exp(x - logZ)
     {
-      // (without LL_k: ONE exponential per entry -- e = exp(log q~ - max) goes back into the lane's slot and q = e / sum(e);
-      //  the same sum and logZ, q within 2 ulp of exp(log q~ - logZ))
-      double s = 0.0;
-      const bool onexp = !a.want_ll;
-      for (int k = 0; k < K; ++k) {
-        const double e = exp(qt[k * QS + tid] - mymx);
-        s += e;
-        if (onexp) qt[k * QS + tid] = e;
-      }
-      const double logZ = log(s) + mymx;
-      const double inv = 1.0 / s;
-      double* qp = a.qZ + row0 + tid;
-      for (int k = 0; k < K; ++k) {
-        const double lq = qt[k * QS + tid];
-        double q = onexp ? lq * inv : exp(lq - logZ);
-        if (!myok || !myrow) q = 0.0;
-        if (myok) qp[(int64_t)k * a.ldq] = q;
-        qt[k * QS + tid] = q;
-        if (a.want_ll) {  // wave-uniform
-          double cjk;
-          if constexpr (ONEGRP) cjk = ctl[k];
-          else if constexpr (CTLDS) cjk = ctl[mygrp * K + k];
-          else cjk = a.ctab[(int64_t)mygrp * K + k];
-          const double ll = wave_sum(q > 0.0 ? q * (lq - cjk) : 0.0);
+      double* const ql = qt + tid;
+      double* const qp = a.qZ + row0 + tid;
+      const bool live = myok && myrow;
+      if constexpr (!WANT_LL) {
+        // ONE exponential per entry -- e = exp(log q~ - max) stays in registers and q = e / sum(e); the same sum and
+        // logZ, q within 2 ulp of exp(log q~ - logZ).  Four entries at a time: four independent polynomial chains.
+        double e[4 * NQ], s = 0.0;
+        static_for<NQ>([&](auto cc) {
+          constexpr int c = cc;
+          if (4 * c < K) {  // (uniform)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int kk = 4 * c + j;
+              const double x = exp(ql[kk * QS] - mymx);
+              e[kk] = kk < K ? x : 0.0;  // (slots of clusters >= K hold zeros, not log q~)
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s += e[4 * c + j];
+          }
+        });
+        const double inv = 1.0 / s;
+        static_for<NQ>([&](auto cc) {
+          constexpr int c = cc;
+          if (4 * c < K) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int kk = 4 * c + j;
+              const double q = live ? e[kk] * inv : 0.0;
+              if (kk < K) {
+                if (myok) qp[(int64_t)kk * a.ldq] = q;
+                ql[kk * QS] = q;
+              }
+            }
+          }
+        });
+        if (live) fz += log(s) + mymx;
+      } else {
+        double s = 0.0;
+        for (int k = 0; k < K; ++k) s += exp(ql[k * QS] - mymx);
+        const double logZ = log(s) + mymx;
+        for (int k = 0; k < K; ++k) {
+          const double lq = ql[k * QS];
+          double q = exp(lq - logZ);
+          if (!live) q = 0.0;
+          if (myok) qp[(int64_t)k * a.ldq] = q;
+          ql[k * QS] = q;
+          const double ll = wave_sum(q > 0.0 ? q * (lq - cjk_of(k)) : 0.0);
           if (lane == 0) llw[wave * K + k] += ll;
         }
+        if (live) fz += logZ;
       }
-      if (myok && myrow) fz += logZ;
     }
     __syncthreads();
 
@@ -241,35 +316,53 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
     {
       // a step's four rows are {t, t + 8, t + 4, t + 12} of a 16-row block: the two rows of a half-wave then lie 32 banks
       // apart (8 x 36 dwords), which every fragment of the step needs -- the 8-bank patch operands and the 32-bank s_k
-      // tile alike -- and in the q table 16 dwords apart, between the 4-dword steps of consecutive clusters (FUSED_QS)
-      const int rsub = 8 * (hi & 1) + 4 * (hi >> 1);
+      // tile alike -- and in the q table 16 dwords apart, between the 4-dword steps of consecutive clusters (FUSED_QS).
+      // Step s4 of wave w is row block s4, rows w + {0, 8, 4, 12}: every address is a per-lane base + a compile-time offset.
+      const int rsub = 8 * (hi & 1) + 4 * (hi >> 1) + wave;
       const double* xu = xt + rsub * LD + lo2;        // + 4 ia
       const double* xw = xt + rsub * LD + blk;        // + 4 ja
       const double* xs = xt + rsub * LD + 4 * blk + lo2;
       const double* x1 = xt + rsub * LD + ONE;
       const double* qb = qt + lo2 * QS + rsub;
-#pragma unroll 2
-      for (int s4 = 0; s4 < FUSED_ROWS / 16; ++s4) {
-        const int st = 4 * s4 + wave, rbase = (st >> 2) * 16 + (st & 3), ro = rbase * LD;
-        double qa[NQ];
+      // software pipeline: the operands of step s4 + 1 (q of the cluster quads, the four x fragments of either role, the
+      // s_k fragment and the ones) are read while step s4's products and MFMAs issue -- left to itself hipcc reads them
+      // right in front of their use and every step starts with an exposed LDS round trip
+      struct StepOps {
+        double qa[NQ], u[4], w[4], s, one;
+      };
+      auto load = [&](auto sc, StepOps& o) {
+        constexpr int s4 = decltype(sc)::value, ro = s4 * 16 * LD;
 #pragma unroll
-        for (int c = 0; c < NQ; ++c) qa[c] = qb[4 * c * QS + rbase];
-        const double one = x1[ro];
+        for (int c = 0; c < NQ; ++c) o.qa[c] = qb[4 * c * QS + s4 * 16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o.u[i] = xu[ro + 4 * i], o.w[i] = xw[ro + 4 * i];
+        o.s = xs[ro];
+        o.one = x1[ro];
+      };
+      StepOps cur;
+      load(std::integral_constant<int, 0>{}, cur);
+      static_for<FUSED_ROWS / 16>([&](auto sc) {
+        constexpr int s4 = sc;
+        StepOps nxt = cur;
+        if constexpr (s4 + 1 < FUSED_ROWS / 16) load(std::integral_constant<int, s4 + 1>{}, nxt);
+        __builtin_amdgcn_sched_barrier(0);
         static_for<NTL>([&](auto tc) {
           constexpr int t = tc;
           double p;
           if constexpr (t < 10) {
             constexpr int ja = t < 1 ? 0 : t < 3 ? 1 : t < 6 ? 2 : 3, ia = t - ja * (ja + 1) / 2;
-            p = xu[ro + 4 * ia] * xw[ro + 4 * ja];
+            p = cur.u[ia] * cur.w[ja];
           } else if constexpr (t == 10) {
-            p = xs[ro];
+            p = cur.s;
           } else {
-            p = one;
+            p = cur.one;
           }
 #pragma unroll
-          for (int c = 0; c < NQ; ++c) acc[t][c] = mfma4(qa[c], p, acc[t][c]);
+          for (int c = 0; c < NQ; ++c) acc[t][c] = mfma4(cur.qa[c], p, acc[t][c]);
         });
-      }
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+      });
     }
     __syncthreads();  // the next tile overwrites xt and qt
   }
@@ -316,7 +409,7 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
   if (lane == 0) fzw[wave] = fz;
   __syncthreads();
   for (int k = tid; k < K; k += 256)
-    rec[K * SS + 1 + k] = a.want_ll ? llw[k] + llw[K + k] + llw[2 * K + k] + llw[3 * K + k] : 0.0;
+    rec[K * SS + 1 + k] = WANT_LL ? llw[k] + llw[K + k] + llw[2 * K + k] + llw[3 * K + k] : 0.0;
   if (tid == 0) rec[K * SS] = -(fzw[0] + fzw[1] + fzw[2] + fzw[3]);  // cluster.cpp:137 returns -sum(logZ)
 }
 
@@ -358,28 +451,33 @@ int fused_plan(int DP, int64_t nrg, int K) {
   return (int)std::min<int64_t>(ntile, (int64_t)cus * per_cu);
 }
 
-hipError_t launch_fused(const FusedLaunch& a, hipStream_t stream) {
-  if (a.DP != 16 || a.grid <= 0) return hipErrorInvalidValue;
-  const size_t shmem = fused_lds_bytes(a.DP, a.K);
-  static LdsGrant grants[9];
+template <int CPW, int GRP>
+static hipError_t launch_fused_t(const FusedLaunch& a, hipStream_t stream, size_t shmem) {
   auto go = [&](auto kern, LdsGrant& g) {
     if (hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(kern), shmem, g); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)a.grid), dim3(256), shmem, stream, a);
     return hipGetLastError();
   };
+  static LdsGrant grants[2];
+  return a.want_ll ? go(fused_small_kernel<16, CPW, GRP, true>, grants[1]) : go(fused_small_kernel<16, CPW, GRP, false>, grants[0]);
+}
+
+hipError_t launch_fused(const FusedLaunch& a, hipStream_t stream) {
+  if (a.DP != 16 || a.grid <= 0) return hipErrorInvalidValue;
+  const size_t shmem = fused_lds_bytes(a.DP, a.K);
   if (!a.rginfo) {
-    if (a.K <= 4) return go(fused_small_kernel<16, 1, 0>, grants[3]);
-    if (a.K <= 8) return go(fused_small_kernel<16, 2, 0>, grants[4]);
-    return go(fused_small_kernel<16, 4, 0>, grants[5]);
+    if (a.K <= 4) return launch_fused_t<1, 0>(a, stream, shmem);
+    if (a.K <= 8) return launch_fused_t<2, 0>(a, stream, shmem);
+    return launch_fused_t<4, 0>(a, stream, shmem);
   }
   if ((int64_t)a.ngroups * a.K <= FUSED_CT_CAP) {
-    if (a.K <= 4) return go(fused_small_kernel<16, 1, 1>, grants[6]);
-    if (a.K <= 8) return go(fused_small_kernel<16, 2, 1>, grants[7]);
-    return go(fused_small_kernel<16, 4, 1>, grants[8]);
+    if (a.K <= 4) return launch_fused_t<1, 1>(a, stream, shmem);
+    if (a.K <= 8) return launch_fused_t<2, 1>(a, stream, shmem);
+    return launch_fused_t<4, 1>(a, stream, shmem);
   }
-  if (a.K <= 4) return go(fused_small_kernel<16, 1, 2>, grants[0]);
-  if (a.K <= 8) return go(fused_small_kernel<16, 2, 2>, grants[1]);
-  return go(fused_small_kernel<16, 4, 2>, grants[2]);
+  if (a.K <= 4) return launch_fused_t<1, 2>(a, stream, shmem);
+  if (a.K <= 8) return launch_fused_t<2, 2>(a, stream, shmem);
+  return launch_fused_t<4, 2>(a, stream, shmem);
 }
 
 }  // namespace lck

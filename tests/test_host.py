@@ -1,6 +1,7 @@
 """Host-side pieces of the product (no GPU): the C-ABI library loads, exports
 every declared symbol, and its M-step arithmetic equals the oracle's."""
 import ctypes as C
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -8,6 +9,8 @@ from scipy.special import digamma
 
 import lc_oracle as o
 from libcluster_amd import capi
+
+ROOT = Path(__file__).resolve().parents[1]
 
 
 def test_library_exports_every_declared_symbol(lib):
@@ -147,3 +150,52 @@ def test_statistics_kernel_selection_is_a_function_of_the_shape(lib, monkeypatch
     assert fn(64, 8) == per and fn(64, 16) == per and fn(64, 24) == per and fn(64, 33) == per and fn(64, 48) == per
     assert fn(80, 32) == per and fn(96, 32) == per and fn(112, 32) == per   # (their 8-quad instances spill)
     assert fn(16, 32) == per and fn(256, 32) == per
+
+
+def test_roofline_traffic_json_is_generated_from_the_committed_summaries():
+    """bench.py's roofline.traffic comes from profiles/rNN_pmc_traffic.json; that file is the output of
+    tools/pmc_traffic.py over the TRAFFIC lines of the rocprofv3 summaries committed next to it (round 3's table was
+    maintained by hand and drifted from its profiles).  The newest JSON must be exactly what its summaries say, and
+    every bench configuration with a summary of that round must be in it."""
+    import json
+    import re
+    import subprocess
+    import sys
+
+    prof = ROOT / "profiles"
+    files = sorted(prof.glob("r[0-9][0-9]_pmc_traffic.json"))
+    assert files
+    newest = files[-1]
+    rnd = newest.name[:3]
+    if int(rnd[1:]) < 4:
+        pytest.skip("no generated traffic table yet (rounds 1-3 typed theirs)")
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / "pmc_traffic.py"), rnd, "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    d = json.loads(newest.read_text())
+    for f in prof.glob(f"{rnd}_*_rocprof_summary.txt"):
+        line = [ln for ln in f.read_text().splitlines() if ln.startswith("TRAFFIC ")]
+        if not line:
+            continue
+        inst = json.loads(line[-1][8:])
+        users = [k for k, v in d.items() if isinstance(v, dict) and v.get("_summary") == f.name]
+        assert users, f.name
+        for name, e in inst.items():
+            fam = name.split("<")[0]
+            # the same number the human-readable part of the summary prints (GB per launch, three decimals)
+            txt = f.read_text()
+            m = re.search(re.escape("[" + name + "]") + r".*?HBM read\s+\(FETCH_SIZE\*1024\*2\)\s+([0-9.]+) GB", txt, re.S)
+            if m:
+                assert abs(float(m.group(1)) * 1e9 - e["read_bytes"]) <= 6e5, (name, m.group(1), e)
+            assert any(fam in d[u] for u in users)
+
+
+def test_estep_kernel_isa_keeps_the_promises_its_inline_asm_relies_on():
+    """estep_kernel writes M0 and loads c_jk in inline asm that hipcc's waitcnt pass cannot see (lc_kernels_estep.hip);
+    tools/check_isa.py compiles the device code and asserts on the ISA of every instance: no scratch, M0 named only by
+    the LDS-direct load pairs, nothing touching an asm load's destination before its s_waitcnt vmcnt(0)."""
+    import subprocess
+    import sys
+
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / "check_isa.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "estep_kernel instances: ok" in r.stdout

@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""Build-time checks on the generated gfx950 ISA of estep_kernel (tools/check_isa.py [file.s]).
+
+The kernel's cluster loop does three things behind the compiler's back (lc_kernels_estep.hip):
+  * it writes M0 in inline asm for `global_load_lds_dwordx4` (hipcc refuses M0 in a clobber list: "reserved register");
+  * it loads c_jk with inline-asm `global_load_dwordx2`, invisible to hipcc's s_waitcnt insertion, and waits for them
+    in a later asm statement -- correct only while no copy / spill / use of those registers lands in between;
+  * its register budget (three waves per SIMD at D = 64) has no room for scratch.
+This script compiles the device code to assembly (or reads a given .s) and asserts, for every estep_kernel instance:
+  1. private_segment_fixed_size == 0 (no scratch, no spills);
+  2. every instruction that names m0 is an `s_mov_b32 m0, ...` directly followed by a `global_load_lds_dwordx4`
+     (nothing else in the kernel depends on M0, so writing it unannounced is safe);
+  3. between an inline-asm `global_load_dwordx2 vA, vOff, s[..]` and the next `s_waitcnt vmcnt(0)` no instruction reads
+     or writes the destination registers vA.
+Exit status 0 = all hold.  Run by tests/test_host.py (CPU: hipcc cross-compiles)."""
+import re
+import subprocess
+import sys
+import tempfile
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def device_asm() -> str:
+    sys.path.insert(0, str(ROOT))
+    from libcluster_amd import build as b
+
+    with tempfile.TemporaryDirectory() as td:
+        out = Path(td) / "estep.s"
+        cmd = [b._hipcc(), f"--offload-arch={b.ARCH}", *b.DEVICE_FLAGS, "-O3", "-std=c++17", "-fPIC", f"-I{ROOT / 'include'}",
+               "-S", "--cuda-device-only", str(b.CSRC / "lc_kernels_estep.hip"), "-o", str(out)]
+        subprocess.run(cmd, check=True, capture_output=True)
+        return out.read_text()
+
+
+def regs(tok: str):
+    """VGPR numbers named by one operand token (v12, v[4:5]); empty for anything else."""
+    m = re.fullmatch(r"v(\d+)", tok)
+    if m:
+        return {int(m.group(1))}
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    return set()
+
+
+def operands(line: str):
+    body = line.split(";")[0].strip()
+    if not body or body.endswith(":") or body.startswith("."):
+        return None, []
+    parts = body.split(None, 1)
+    ops = [t.strip() for t in re.split(r",\s*|\s+", parts[1])] if len(parts) > 1 else []
+    return parts[0], ops
+
+
+def check(asm: str):
+    problems, seen = [], 0
+    scratch = dict(re.findall(r"\.amdhsa_kernel\s+(\S+)\s+\.amdhsa_group_segment_fixed_size\s+\d+\s+"
+                              r"\.amdhsa_private_segment_fixed_size\s+(\d+)", asm))
+    for name, sz in scratch.items():
+        if "estep_kernel" in name and int(sz) != 0:
+            problems.append(f"{name}: {sz} bytes of scratch")
+    if not any("estep_kernel" in n for n in scratch):
+        problems.append("no .amdhsa_kernel descriptor of an estep_kernel instance found")
+    for m in re.finditer(r"^(_ZN3lck12estep_kernel\w+):[^\n]*\n(.*?)\n\.Lfunc_end\d+:", asm, re.S | re.M):
+        name, body = m.group(1), m.group(2).splitlines()
+        seen += 1
+        ins = [(i, *operands(ln)) for i, ln in enumerate(body)]
+        ins = [(i, op, ops) for i, op, ops in ins if op]
+        for n, (i, op, ops) in enumerate(ins):
+            if any(o == "m0" for o in ops):
+                nxt = ins[n + 1][1] if n + 1 < len(ins) else ""
+                if not (op == "s_mov_b32" and ops and ops[0] == "m0" and nxt.startswith("global_load_lds_dwordx4")):
+                    problems.append(f"{name}: `{body[i].strip()}` names m0 outside the LDS-direct load pair")
+        pending = set()  # destination registers of asm loads not yet waited for
+        for n, (i, op, ops) in enumerate(ins):
+            if op == "s_waitcnt" and any(o.startswith("vmcnt(0)") for o in ops):
+                pending = set()
+                continue
+            touched = set().union(*[regs(o) for o in ops]) if ops else set()
+            if pending & touched:
+                problems.append(f"{name}: `{body[i].strip()}` touches {sorted(pending & touched)} before the s_waitcnt vmcnt(0) "
+                                "that covers their inline-asm load")
+            # the c_jk loads: scalar-base form with a VGPR offset (compiler-generated loads of this kernel use either
+            # `off` or a 64-bit VGPR address; hipcc's own waitcnt pass covers those)
+            if op == "global_load_dwordx2" and len(ops) >= 3 and re.fullmatch(r"v\d+", ops[1]) and ops[2].startswith("s["):
+                pending |= regs(ops[0])
+    if seen == 0:
+        problems.append("no estep_kernel instance found in the assembly")
+    return problems, seen
+
+
+def main():
+    asm = Path(sys.argv[1]).read_text() if len(sys.argv) > 1 else device_asm()
+    problems, seen = check(asm)
+    for p in problems:
+        print("ISA check:", p)
+    print(f"checked {seen} estep_kernel instances: {'FAILED' if problems else 'ok'}")
+    sys.exit(1 if problems else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -17,10 +17,18 @@ if ks.exists():
         out.append("%-78s %6s %12.3f %12.4f %8s" % (r["Name"][:78], r["Calls"], float(r["TotalDurationNs"]) / 1e6,
                                                     float(r["AverageNs"]) / 1e6, r["Percentage"]))
 log = root / "kt.log"
+iters = None  # VBEM iterations of the profiled run (timed + warm-up): launches per step = calls / iters
 if log.exists():
     for line in open(log):
         if line.startswith("{"):
             out.append("\n== bench.py line of the profiled run ==\n" + line.strip())
+            try:
+                import json as _json
+
+                _d = _json.loads(line)
+                iters = int(_d["steps"]) + int(_d["warmup"])
+            except Exception:  # noqa: BLE001
+                pass
 
 
 def short(n):
@@ -70,4 +78,29 @@ for s, d in agg.items():
         out.append(f"  -> HBM read  (FETCH_SIZE*1024*2)  {m['FETCH_SIZE'] * 1024 * 2 / 1e9:.3f} GB per launch")
     if "WRITE_SIZE" in m:
         out.append(f"  -> HBM write (WRITE_SIZE*1024)    {m['WRITE_SIZE'] * 1024 / 1e9:.3f} GB per launch (uncalibrated)")
+# machine-readable: HBM bytes per launch (read = FETCH_SIZE KiB x 1024 x 2 on gfx950, write = WRITE_SIZE KiB x 1024, per
+# /opt/skills/guides/MI355X_MICROARCH.md "HBM") and launches per VBEM iteration, per kernel instance.  tools/pmc_traffic.py
+# collects these sections into profiles/rNN_pmc_traffic.json (what bench.py prints as roofline.traffic); a CPU test
+# asserts that the JSON says what the summaries say.
+import json
+
+calls = {}
+if ks.exists():
+    for r in rows:
+        sname = short(r["Name"])
+        if sname:
+            calls[sname] = calls.get(sname, 0) + int(r["Calls"])
+traffic = {}
+for sname, d in agg.items():
+    m = {k: sum(v) / len(v) for k, v in d.items()}
+    if "FETCH_SIZE" not in m and "WRITE_SIZE" not in m:
+        continue
+    rd = m.get("FETCH_SIZE", 0.0) * 1024 * 2
+    wr = m.get("WRITE_SIZE", 0.0) * 1024
+    e = {"read_bytes": round(rd), "write_bytes": round(wr), "bytes_per_launch": round(rd + wr)}
+    if iters and sname in calls:
+        e["launches_per_step"] = calls[sname] / iters
+        e["total_ms_in_run"] = next((float(r["TotalDurationNs"]) / 1e6 for r in rows if short(r["Name"]) == sname), None)
+    traffic[sname] = e
+out.append("\n== traffic (machine-readable; tools/pmc_traffic.py) ==\nTRAFFIC " + json.dumps(traffic, sort_keys=True))
 print("\n".join(out))
