@@ -574,7 +574,11 @@ __host__ __device__ constexpr int ft_tpw(int DP, int NQ) {  // tiles of the full
 __host__ __device__ constexpr int ft_batch_rows(int DP) {
   return DP == 128 && ft_waves(DP) == 8 ? LC_FT_BR128 : DP > 96 ? 24 : DP == 64 && ft_waves(DP) == 8 ? LC_FT_BR64 : LC_FT_BR;
 }
-constexpr int FT_QLD = 36;  // row stride of the staged q quads: the two rows of a half-wave 8 banks apart
+// row stride of the staged q quads (32 or 64 cluster columns + 4): the rows of a half-wave 8 banks apart
+__host__ __device__ constexpr int ft_qld(int NQ) { return NQ > 8 ? 68 : 36; }
+// cluster range of one launch: 32 (up to 8 quads), or -- D = 128 -- 64 in ONE pass over X (16 quads, 4 tiles per wave:
+// one multiply per 16 MFMAs; config 5's K = 64 used to take two launches of 8 quads, each re-reading and re-staging X)
+inline int ft_range(int DP, int K) { return DP == 128 && K % 64 == 0 ? 64 : DP == 128 && K % 64 >= 57 ? 64 : 32; }
 inline bool ss_feat_eligible(int DP, int K) {
   static const int mode = getenv("LC_SS_FEAT") ? atoi(getenv("LC_SS_FEAT")) : 1;  // 0 off, 1 where it wins, 2 everywhere it exists
   if (mode == 0 || K <= 16 || DP < 32 || DP > 128) return false;
@@ -583,12 +587,12 @@ inline bool ss_feat_eligible(int DP, int K) {
   // 7-8 MFMAs): K = 28..32, 60..64, ...; a remainder launch with few quads costs a whole pass over X at a poor ratio
   // (K = 33: 6.8 against 5.8 ms at N = 2M), and with 5-6 quads the two kernels are level
   const int rem = K % 32;
-  return LC_SS_FEAT_WIDTHS(DP) && (rem == 0 || rem >= 28);
+  return LC_SS_FEAT_WIDTHS(DP) && (rem == 0 || rem >= 28 || (ft_range(DP, K) == 64 && K >= 57));
 }
 template <int DP, int NQ>
 __global__ void __launch_bounds__(64 * ft_waves(DP), 2) suffstat_feat_kernel(SuffstatLaunch a) {
   constexpr int FTW = ft_waves(DP);
-  constexpr int BR = ft_batch_rows(DP), LD = lds_row_stride(DP), QLD = FT_QLD, XBUF = BR * LD, QBUF = BR * QLD;
+  constexpr int BR = ft_batch_rows(DP), LD = lds_row_stride(DP), QLD = ft_qld(NQ), XBUF = BR * LD, QBUF = BR * QLD;
   constexpr int TPW = ft_tpw(DP, NQ), TILES = ft_tiles(DP), NPATCH = (DP / 4) * (DP / 4 + 1) / 2, NSL = ft_nslice(DP, NQ);
   constexpr int ONE = DP;  // column of the staged rows that holds 1.0
   static_assert(LD > DP, "the staged rows need a spare column");
@@ -651,16 +655,17 @@ __global__ void __launch_bounds__(64 * ft_waves(DP), 2) suffstat_feat_kernel(Suf
 
   // ---- staging: registers hold the next batch while the current one is consumed.
   // X batch: thread -> 16 bytes of NPRE consecutive rows (row group tid / TPR, column pair tid % TPR): one address
-  // register on either side, the rows are immediate offsets.  q batch: thread -> (cluster tid % 32, row quad tid / 32):
-  // clusters fastest, so that the 16-lane groups of a ds_write_b64 fill one LDS row (rows fastest would put all the row
-  // quads of a group on one bank)
+  // register on either side, the rows are immediate offsets.  q batch: thread -> (cluster tid % QCL, row quad tid / QCL),
+  // QCL = 32 or 64 cluster columns: clusters fastest, so that the 16-lane groups of a ds_write_b64 fill one LDS row (rows
+  // fastest would put all the row quads of a group on one bank)
   constexpr int NTHR = 64 * FTW;
   constexpr int TPR = DP / 2, NV2 = BR * TPR, NPRE = (NV2 + NTHR - 1) / NTHR;  // double2 per row / per batch / per thread
   constexpr int RPP = NTHR / TPR;                                               // rows covered by one pass of the block
   static_assert(NTHR % TPR == 0 || NPRE * NTHR >= NV2, "staging");
-  static_assert(BR / 4 <= NTHR / 32 && 2 * BR <= NTHR, "q staging / ones column");
+  constexpr int QCL = NQ > 8 ? 64 : 32;
+  static_assert(BR / 4 <= NTHR / QCL && 2 * BR <= NTHR, "q staging / ones column");
   double pre[NPRE][2], qpre[4];
-  const int qcl = tid & 31, qrq = tid >> 5;
+  const int qcl = tid % QCL, qrq = tid / QCL;
   const bool qthr = qrq < BR / 4;
   const int xr0 = tid / TPR, xc2 = tid % TPR;  // (DP = 80, 112: 256 is not a multiple of TPR -- the generic index below)
   double* const qdst = qbuf + (4 * qrq) * QLD + qcl;
@@ -716,9 +721,12 @@ __global__ void __launch_bounds__(64 * ft_waves(DP), 2) suffstat_feat_kernel(Suf
   // run (rows past the chunk end were staged as zeros with q = 0): nothing in the loop depends on run-time counts.  The next tile's fragments -- behind the last tile the next step's first tile and its
   // q quads -- are issued BEFORE this tile's MFMAs and arrive under them (two register sets that swap roles; the fences
   // keep hipcc from sinking the reads to their uses).
+  // 16 quads: two sets of q quads would be 64 registers next to 128 of accumulators -- ONE set, refilled in place during
+  // the step's last tile (quad c's register takes the next step's quad c right behind the MFMA that read it)
+  constexpr bool ONEQ = NQ > 8;
   auto batch = [&](auto bsel, auto ntsel) {
     constexpr int B = decltype(bsel)::value, XO = B * XBUF, QO = B * QBUF, NT = decltype(ntsel)::value;
-    double qa[2][NQ], u[2], w[2];
+    double qa[ONEQ ? 1 : 2][NQ], u[2], w[2];
     u[0] = pu[0][XO];
     w[0] = pw[0][XO];
 #pragma unroll
@@ -729,19 +737,35 @@ __global__ void __launch_bounds__(64 * ft_waves(DP), 2) suffstat_feat_kernel(Suf
       for (int t = 0; t < NT; ++t) {
         const int cur = (st * NT + t) & 1, nxt = cur ^ 1;
         const double p = u[cur] * w[cur];
+        const bool refill = t + 1 == NT && st + 1 < BR / 4;
         if (t + 1 < NT) {
           u[nxt] = pu[t + 1][XO + st * 4 * LD];
           w[nxt] = pw[t + 1][XO + st * 4 * LD];
         } else if (st + 1 < BR / 4) {
           u[nxt] = pu[0][XO + (st + 1) * 4 * LD];
           w[nxt] = pw[0][XO + (st + 1) * 4 * LD];
+          if constexpr (!ONEQ) {
 #pragma unroll
-          for (int c = 0; c < NQ; ++c) qa[(st + 1) & 1][c] = pq[QO + (st + 1) * 4 * QLD + 4 * c];
+            for (int c = 0; c < NQ; ++c) qa[(st + 1) & 1][c] = pq[QO + (st + 1) * 4 * QLD + 4 * c];
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (ONEQ) {
 #pragma unroll
-        for (int c = 0; c < NQ; ++c) acc[t][c] = mfma4(qa[st & 1][c], p, acc[t][c]);
-        __builtin_amdgcn_sched_barrier(0);
+          for (int c4 = 0; c4 < NQ; c4 += 4) {
+#pragma unroll
+            for (int c = c4; c < c4 + 4; ++c) acc[t][c] = mfma4(qa[0][c], p, acc[t][c]);
+            if (refill) {
+#pragma unroll
+              for (int c = c4; c < c4 + 4; ++c) qa[0][c] = pq[QO + (st + 1) * 4 * QLD + 4 * c];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < NQ; ++c) acc[t][c] = mfma4(qa[st & 1][c], p, acc[t][c]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
   };
@@ -794,7 +818,7 @@ __global__ void __launch_bounds__(64 * ft_waves(DP), 2) suffstat_feat_kernel(Suf
 template <int DP, int NQ>
 static hipError_t launch_ss_feat_q(const SuffstatLaunch& b, hipStream_t stream) {
   constexpr int BR = ft_batch_rows(DP), LD = lds_row_stride(DP);
-  const size_t shmem = (size_t)(2 * BR * LD + 2 * BR * FT_QLD) * sizeof(double);
+  const size_t shmem = (size_t)(2 * BR * LD + 2 * BR * ft_qld(NQ)) * sizeof(double);
   auto kern = suffstat_feat_kernel<DP, NQ>;
   static LdsGrant grant;
   if (hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(kern), shmem, grant); e != hipSuccess) return e;
@@ -808,10 +832,18 @@ static hipError_t launch_ss_feat_d(const SuffstatLaunch& a, hipStream_t stream) 
   // re-reads X, which an MFMA-bound pass affords.
   SuffstatLaunch b = a;
   if (b.KR < a.K) b.KR = a.K;
-  for (int k0 = 0; k0 < a.K; k0 += 32) {
+  const int range = ft_range(DP, a.K);
+  for (int k0 = 0; k0 < a.K; k0 += range) {
     b.klast0 = k0;
-    const int nq = ((a.K - k0 < 32 ? a.K - k0 : 32) + 3) / 4;
+    const int nq = ((a.K - k0 < range ? a.K - k0 : range) + 3) / 4;
     hipError_t e = hipErrorInvalidValue;
+    if constexpr (DP == 128) {
+      if (nq > 8) {
+        e = launch_ss_feat_q<DP, 16>(b, stream);
+        if (e != hipSuccess) return e;
+        continue;
+      }
+    }
     switch (nq) {
       case 1: case 2: e = launch_ss_feat_q<DP, 2>(b, stream); break;
       case 3: case 4: e = launch_ss_feat_q<DP, 4>(b, stream); break;
