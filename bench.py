@@ -319,6 +319,52 @@ def model_selection(capi, device, stream, N=10_000_000, D=64, Kt=32):
             "free_energy": F}
 
 
+def dropin_call(capi, device, N=10_000_000, D=64, Kt=32):
+    """The call a libcluster user makes (cluster.cpp:636-664 `learnVDP(X, qZ, weights, clusters)`, python/libclusterpy.cpp:
+    135-158): ONE learnVDP on a HOST matrix -- upload, the whole model selection on the device, the responsibilities and
+    the posterior back -- timed end to end through libcluster_amd.learnVDP (ctypes over the C ABI, what the C++ facade of
+    include/libcluster.h calls too).  Plus the two PCIe legs on their own: lc_ctx_set_data of the same pageable array and
+    lc_ctx_get_qz_all of an N x K matrix, with the GB/s they reach.  Host memory: X 5.1 GB + qZ 2.6 GB."""
+    import libcluster_amd as lc
+
+    rng = np.random.default_rng(11)
+    mu = rng.normal(0, 4.0, (Kt, D))
+    sd = rng.uniform(0.7, 1.3, (Kt, 1))
+    X = np.empty((N, D))
+    piece = 1_000_000
+    for r0 in range(0, N, piece):  # (in pieces: no N x D temporaries next to X)
+        z = rng.integers(0, Kt, min(piece, N - r0))
+        X[r0:r0 + z.size] = mu[z] + rng.standard_normal((z.size, D)) * sd[z]
+    nthreads = max(1, min(32, len(os.sched_getaffinity(0))))
+    lc.learnVDP(X[:200_000], nthreads=nthreads, device=device)  # (loads the kernels; the timed call is the full one)
+    t0 = time.perf_counter()
+    F, qZ, w, means, covs, info = lc.learnVDP(X, nthreads=nthreads, device=device, return_info=True)
+    dt = time.perf_counter() - t0
+    K = info["K"]
+    out = {"workload": f"learnVDP(X) on a host numpy matrix N={N} D={D} ({Kt} true clusters): upload + model selection + "
+                       "qZ / weights / means / covariances back (libcluster_amd.learnVDP over the C ABI)",
+           "seconds": dt, "K_found": K, "rounds": len(info["rounds"]), "free_energy": float(F),
+           "qZ_shape": list(qZ.shape), "row_sums_ok": bool(np.allclose(qZ[:: max(1, N // 1000)].sum(1), 1.0, atol=1e-9))}
+    del qZ, w, means, covs, info
+    with capi.Context(device) as ctx:
+        ctx.set_data(X[:1000])  # (page-locked staging buffers exist from here on)
+        t0 = time.perf_counter()
+        ctx.set_data(X)
+        ctx.synchronize()
+        up = time.perf_counter() - t0
+        ctx.fill_qz(K, 1.0 / K)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        q = ctx.get_qz([N])[0]
+        down = time.perf_counter() - t0
+        out.update({"h2d_seconds": up, "h2d_GBps": X.nbytes / up / 1e9, "d2h_seconds": down,
+                    "d2h_GBps": q.nbytes / down / 1e9, "h2d_bytes": int(X.nbytes), "d2h_bytes": int(q.nbytes),
+                    "pcie_note": "pageable numpy arrays, row-major; packed / unpacked through two page-locked 32 MB buffers "
+                                 "(lc_ctx_set_data / lc_ctx_get_qz_all), d2h includes the device-side transpose and the "
+                                 "allocation of the result"})
+    return out
+
+
 def measure(capi, cfg, steps, warmup, rank, world, local_rank, stream, nthreads, comm=None, dist=None, torch=None):
     """Synthesise the workload in HBM, run `warmup` untimed and `steps` timed VBEM iterations; returns everything the
     JSON line needs plus the live context / model (for the CPU baseline)."""
@@ -592,6 +638,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the host-matrix learnVDP call (needs ~9 GB of host memory)")
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
     ap.add_argument("--parity-rows", type=int, default=1_000_000, help="N_par of SURVEY 8(d)")
     ap.add_argument("--comm", default="native", choices=["native", "torch"],
@@ -723,6 +770,11 @@ def main():
                 x2.close()
             line["other_configs"] = others
             line["model_selection"] = model_selection(capi, local_rank, stream)
+            if not args.no_dropin:
+                try:
+                    line["dropin_call"] = dropin_call(capi, local_rank)
+                except MemoryError as e:  # (a host with less than ~10 GB to spare: the line says so instead of dying)
+                    line["dropin_call"] = {"skipped": f"not enough host memory for a 10M x 64 matrix: {e}"}
         print(json.dumps(line), flush=True)
     if model is not None:
         model.close()

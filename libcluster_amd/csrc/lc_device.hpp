@@ -30,6 +30,54 @@ __device__ __forceinline__ double max_raw(double a, double b) {
   return a;
 }
 
+// exp(x) for x <= 0 (log q~ - max in the normalisation sweeps; -inf allowed), 1 ulp: 2^(n / 64) from a 64-entry table the
+// kernel keeps in LDS (fill_exp_table) times a degree-5 polynomial on |r| <= ln 2 / 128 -- 16 VALU instructions and one
+// LDS read against the 26 of the library exp, in kernels whose normalisation is bound by fp64 issue (one exponential per
+// responsibility: K of them per row).  Reference: probutils::logsumexp / vbexpectation's exp() calls
+// (src/probutils.cpp:146, src/cluster.cpp:130-131); the result differs from libm's by at most one unit in the last place.
+static __constant__ double LC_EXP2_TAB[64] = {
+    0x1.0000000000000p+0, 0x1.02c9a3e778061p+0, 0x1.059b0d3158574p+0, 0x1.0874518759bc8p+0,
+    0x1.0b5586cf9890fp+0, 0x1.0e3ec32d3d1a2p+0, 0x1.11301d0125b51p+0, 0x1.1429aaea92de0p+0,
+    0x1.172b83c7d517bp+0, 0x1.1a35beb6fcb75p+0, 0x1.1d4873168b9aap+0, 0x1.2063b88628cd6p+0,
+    0x1.2387a6e756238p+0, 0x1.26b4565e27cddp+0, 0x1.29e9df51fdee1p+0, 0x1.2d285a6e4030bp+0,
+    0x1.306fe0a31b715p+0, 0x1.33c08b26416ffp+0, 0x1.371a7373aa9cbp+0, 0x1.3a7db34e59ff7p+0,
+    0x1.3dea64c123422p+0, 0x1.4160a21f72e2ap+0, 0x1.44e086061892dp+0, 0x1.486a2b5c13cd0p+0,
+    0x1.4bfdad5362a27p+0, 0x1.4f9b2769d2ca7p+0, 0x1.5342b569d4f82p+0, 0x1.56f4736b527dap+0,
+    0x1.5ab07dd485429p+0, 0x1.5e76f15ad2148p+0, 0x1.6247eb03a5585p+0, 0x1.6623882552225p+0,
+    0x1.6a09e667f3bcdp+0, 0x1.6dfb23c651a2fp+0, 0x1.71f75e8ec5f74p+0, 0x1.75feb564267c9p+0,
+    0x1.7a11473eb0187p+0, 0x1.7e2f336cf4e62p+0, 0x1.82589994cce13p+0, 0x1.868d99b4492edp+0,
+    0x1.8ace5422aa0dbp+0, 0x1.8f1ae99157736p+0, 0x1.93737b0cdc5e5p+0, 0x1.97d829fde4e50p+0,
+    0x1.9c49182a3f090p+0, 0x1.a0c667b5de565p+0, 0x1.a5503b23e255dp+0, 0x1.a9e6b5579fdbfp+0,
+    0x1.ae89f995ad3adp+0, 0x1.b33a2b84f15fbp+0, 0x1.b7f76f2fb5e47p+0, 0x1.bcc1e904bc1d2p+0,
+    0x1.c199bdd85529cp+0, 0x1.c67f12e57d14bp+0, 0x1.cb720dcef9069p+0, 0x1.d072d4a07897cp+0,
+    0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,
+    0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0};
+__device__ __forceinline__ void fill_exp_table(double* etab, int tid, int nthreads) {
+  for (int i = tid; i < 64; i += nthreads) etab[i] = LC_EXP2_TAB[i];
+}
+__device__ __forceinline__ double exp_nonpos(double x, const double* etab) {
+  x = max_raw(x, -750.0);  // (exp(-750) = 0; keeps n finite for x = -inf)
+  const double n = __builtin_rint(x * 0x1.71547652b82fep+6);      // 64 / ln 2
+  double r = fma(n, -0x1.62e42fef00000p-7, x);                    // ln 2 / 64, 33 significant bits: n * C1 is exact
+  r = fma(n, -0x1.473de6af278edp-40, r);
+  double q = fma(r, 1.0 / 120.0, 1.0 / 24.0);
+  q = fma(q, r, 1.0 / 6.0);
+  q = fma(q, r, 0.5);
+  const double p = fma(q, r * r, r);                               // e^r - 1
+  const int ni = (int)n;
+  const double T = etab[ni & 63];
+  return ldexp(fma(T, p, T), ni >> 6);
+}
+// 1 / s for s > 0, finite (a row's sum of exponentials, >= 1): hardware estimate + two Newton steps, < 1 ulp off the
+// correctly rounded quotient -- 5 instructions against the 12 of an IEEE division
+__device__ __forceinline__ double rcp_pos(double s) {
+  double y = __builtin_amdgcn_rcp(s);
+  double e = fma(-s, y, 1.0);
+  y = fma(y, e, y);
+  e = fma(-s, y, 1.0);
+  return fma(y, e, y);
+}
+
 // n-th read of a cluster's parameter stream (for it: -b[it], tile(it,0), ..., tile(it,it)):
 // .jt < 0: element of the -b vector (offset in doubles from Pb), else of tile (it,jt) (from Pt)
 struct RdInfo {

@@ -467,6 +467,7 @@ __global__ void __launch_bounds__(256, 2)
   double* lls = fzw + 4;                      // [KT][256]: running q * data term per lane (split-ordering term)
   double* lqs = lls + (size_t)KT * 256;       // [KT][R][256] (KTM == 0): every lane's own log q~ slots
   double* ctl = lqs + (KTM == 0 ? (size_t)KT * R * 256 : 0);  // [EDM_CT_CAP] (GRP == 1): the table c_jk
+  double* etab = ctl + (CTLDS ? EDM_CT_CAP : 0);              // [64]: 2^(j / 64) for exp_nonpos
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lo4 = lane & 15, hi = lane >> 4;
   {
@@ -477,11 +478,13 @@ __global__ void __launch_bounds__(256, 2)
     // in tile_const is a vector load at the head of every cluster tile, and the vector-memory counter retires in order:
     // waiting for it is waiting for the next tile's rows issued just before it (an HBM round trip per cluster tile --
     // the kernel's "half of the wave time waiting").  With several groups the table is still read there.
-    for (int i = tid; i < 4 * KT; i += 256) cst[i] = i < K ? constk[i] + (rginfo ? 0.0 : ctab[i]) : 0.0;
+    // (clusters past K -- the padding of the last cluster tile -- carry -inf: they drop out of max and sum by themselves)
+    for (int i = tid; i < 4 * KT; i += 256) cst[i] = i < K ? constk[i] + (rginfo ? 0.0 : ctab[i]) : -INFINITY;
     for (int i = tid; i < DP; i += 256) mul[i] = QUAD ? mu[i] : 0.0;
     if constexpr (CTLDS)
       for (int i = tid; i < ngroups * K; i += 256) ctl[i] = ctab[i];
     for (int it = 0; it < KT; ++it) lls[it * 256 + tid] = 0.0;
+    fill_exp_table(etab, tid, 256);
   }
   __syncthreads();
   const double* Pt = wl + (lane & 3) + 4 * hi;  // this lane's element of every 4x4 tile
@@ -548,33 +551,38 @@ __global__ void __launch_bounds__(256, 2)
     double mx[R], lq[NLQ][R];
 #pragma unroll
     for (int r = 0; r < R; ++r) mx[r] = -INFINITY;
-    // one cluster tile (4 clusters) and one half of the features: out += W_tile[half] . f for the wave's R row groups
-    auto half_tile = [&](int it, int half, double (&out)[R]) {
+    // one cluster tile (4 clusters) and one half of the features: out += W_tile[half] . f for the wave's R row groups.
+    // The weight-tile reads run PFH ahead of their MFMAs ACROSS cluster tiles (the ring is handed from one call to the
+    // next: the last PFH reads of tile `it` are the first of tile it + 1 of the same half, NTF tiles further on), fenced
+    // so that hipcc does not sink them to their uses -- a ring restarted per half tile exposed an LDS round trip sixteen
+    // times per 32-row tile.  The accumulators start from `out` (the MFMA's C operand): no add behind the chain.
+    constexpr int PFH = NT < PF ? NT : PF;
+    auto ring_start = [&](int it, int half, double (&ring)[PFH]) {
       const double* Pi = Pt + ((size_t)it * NTF + (size_t)half * NT) * 16;
-      double acc[R];
-#pragma unroll
-      for (int r = 0; r < R; ++r) acc[r] = 0.0;
-      constexpr int PFH = NT < PF ? NT : PF;
-      double ring[PFH];
       static_for<PFH>([&](auto ic) { ring[ic] = Pi[ic * 16]; });
+    };
+    auto half_tile = [&](int it, int half, double (&out)[R], double (&ring)[PFH]) {
+      const double* Pi = Pt + ((size_t)it * NTF + (size_t)half * NT) * 16;
       static_for<NT>([&](auto jc) {
         constexpr int jt = jc;
         const double v = ring[jt % PFH];
-        if constexpr (jt + PFH < NT) ring[jt % PFH] = Pi[(jt + PFH) * 16];
+        constexpr int m = jt + PFH;  // (past this tile: the same half of the next cluster tile; past the last one: unused)
+        ring[jt % PFH] = Pi[(m < NT ? m : NTF + (m - NT)) * 16];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = mfma4(v, f[r][jt], acc[r]);
+        for (int r = 0; r < R; ++r) out[r] = mfma4(v, f[r][jt], out[r]);
+        __builtin_amdgcn_sched_barrier(0);
       });
-#pragma unroll
-      for (int r = 0; r < R; ++r) out[r] += acc[r];
     };
     // constants of a cluster tile: E[log weight] + per-cluster constant; clusters past K (padding of the last tile)
     // drop out as -inf
     auto tile_const = [&](int it, double (&out)[R]) {
       const int k = 4 * it + hi;
-      const double ck = cst[k];
+      const double ck = cst[k];  // (-inf for k >= K)
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        if constexpr (CTLDS) out[r] = k < K ? ctl[grp[r] * K + k] + ck : -INFINITY;
+        if constexpr (ONEGRP) out[r] = ck;
+        else if constexpr (CTLDS) out[r] = k < K ? ctl[grp[r] * K + k] + ck : -INFINITY;
         else out[r] = k < K ? (rginfo ? ctab[(int64_t)grp[r] * K + k] + ck : ck) : -INFINITY;
       }
     };
@@ -582,17 +590,19 @@ __global__ void __launch_bounds__(256, 2)
       const int k = 4 * it + hi;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        mx[r] = fmax(mx[r], v[r]);
+        mx[r] = max_raw(mx[r], v[r]);
         if (raw && k < K && rgok[r]) qZ[(int64_t)k * ldq + (rg0 + r) * RG + lo4] = v[r];
       }
     };
     // the half of the weights that multiplies x' (QUAD: tiles NT..2NT-1; otherwise the only half)
+    double ring[PFH];
     if constexpr (REGS) {
+      ring_start(0, QUAD ? 1 : 0, ring);
 #pragma unroll
       for (int it = 0; it < KTM; ++it) {
         if (it < KT) {  // block-uniform
           tile_const(it, lq[it]);
-          half_tile(it, QUAD ? 1 : 0, lq[it]);
+          half_tile(it, QUAD ? 1 : 0, lq[it], ring);
           if constexpr (!QUAD) tile_done(it, lq[it]);
         } else {
 #pragma unroll
@@ -603,7 +613,8 @@ __global__ void __launch_bounds__(256, 2)
 #pragma unroll 1
       for (int it = 0; it < KT; ++it) {
         tile_const(it, lq[0]);
-        half_tile(it, QUAD ? 1 : 0, lq[0]);
+        ring_start(it, QUAD ? 1 : 0, ring);  // (any K: the ring restarts per cluster tile here)
+        half_tile(it, QUAD ? 1 : 0, lq[0], ring);
         if constexpr (!QUAD) tile_done(it, lq[0]);
         if (QUAD || !raw) {
 #pragma unroll
@@ -617,10 +628,11 @@ __global__ void __launch_bounds__(256, 2)
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) f[r][jt] *= f[r][jt];
       if constexpr (REGS) {
+        ring_start(0, 0, ring);
 #pragma unroll
         for (int it = 0; it < KTM; ++it) {
           if (it < KT) {
-            half_tile(it, 0, lq[it]);
+            half_tile(it, 0, lq[it], ring);
             tile_done(it, lq[it]);
           }
         }
@@ -629,7 +641,8 @@ __global__ void __launch_bounds__(256, 2)
         for (int it = 0; it < KT; ++it) {
 #pragma unroll
           for (int r = 0; r < R; ++r) lq[0][r] = lqme[(it * R + r) * 256];
-          half_tile(it, 0, lq[0]);
+          ring_start(it, 0, ring);
+          half_tile(it, 0, lq[0], ring);
           tile_done(it, lq[0]);
           if (!raw) {
 #pragma unroll
@@ -641,6 +654,63 @@ __global__ void __launch_bounds__(256, 2)
     if (raw) continue;
     // logsumexp (probutils.cpp:141-150): max, sum exp(x - max), log + max; q = exp(x - max) / sum = exp(x - logZ)
     // (cluster.cpp:130-131) with ONE exponential per entry -- e is kept (registers or the lane's slot) and scaled
+    if constexpr (PLAIN && REGS) {
+      // The VBEM iterations' instance: everything but the MFMAs is fp64 issue (an fp64 VALU instruction costs the matrix
+      // pipe ~ 11 clocks), so the sweep spends as few as it can -- the table exponential (16 instructions
+      // for 26), a Newton reciprocal (5 for 12), and ONE logarithm per lane instead of one per row group: log Z is only
+      // needed for F_z, the four `hi` lanes of a row all hold its sum, so lane (lo4, hi) takes row group hi's.
+      double mm[R], se[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        double m = mx[r];
+        m = max_raw(m, __shfl_xor(m, 16));
+        m = max_raw(m, __shfl_xor(m, 32));
+        mm[r] = m;
+        se[r] = 0.0;
+      }
+      // cluster tiles in pairs: 2 R exponentials per basic block -- independent chains that fill each other's latency
+      // (one block per (tile, row group) is a 21-instruction dependent chain with an LDS wait in the middle, at two waves
+      // per SIMD).  A tile past the last one holds -inf (exp = 0): the odd tile of the last pair needs no test.
+#pragma unroll
+      for (int it = 0; it < KTM; it += 2) {
+        if (it < KT) {  // block-uniform
+#pragma unroll
+          for (int j = 0; j < 2 && it + j < KTM; ++j)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+              const double e = exp_nonpos(lq[it + j][r] - mm[r], etab);
+              se[r] += e;
+              lq[it + j][r] = e;
+            }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) se[r] = sum_over_hi(se[r]);
+      {
+        double sl = se[0], ml = mm[0];
+        bool okl = rgok[0] && rowok[0];
+#pragma unroll
+        for (int r = 1; r < R; ++r)
+          if (hi == r) sl = se[r], ml = mm[r], okl = rgok[r] && rowok[r];
+        const double lz = log(sl) + ml;
+        if (hi < R && okl) fz += lz;
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const double inv = rcp_pos(se[r]);
+#pragma unroll
+        for (int it = 0; it < KTM; ++it) {
+          const int k = 4 * it + hi;
+          const bool kin = k < K;
+          double q = lq[it][r] * inv;
+          if (!rowok[r] || !kin) q = 0.0;
+          // (unconditional store: see the general path below)
+          double* dst = kin && rgok[r] ? qZ + ((int64_t)k * ldq + (rg0 + r) * RG + lo4) : sink + tid;
+          *dst = q;
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       double m = mx[r];
@@ -717,7 +787,7 @@ __global__ void __launch_bounds__(256, 2)
 
 static size_t edm_lds_bytes(int NT, int NTF, int KT, int R, bool slots, bool table = false) {
   return ((size_t)KT * NTF * 16 + 4 * KT + 4 * NT + 4 + (size_t)KT * 256 + (slots ? (size_t)KT * R * 256 : 0) +
-          (table ? EDM_CT_CAP : 0)) * sizeof(double);
+          (table ? EDM_CT_CAP : 0) + 64) * sizeof(double);
 }
 
 template <int NT, bool QUAD, int R, int KTM>

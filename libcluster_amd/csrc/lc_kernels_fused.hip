@@ -82,6 +82,7 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
   // issued AFTER the next tile's prefetch, and the vector-memory counter retires in order: every wait for a constant was
   // a wait for the prefetch (an HBM round trip per tile, exposed).  With several groups the table is still read there.
   double* ctl = fzw + 4;               // [FUSED_CT_CAP]: the table c_jk when it fits (J x K entries), else unused
+  double* etab = ctl + FUSED_CT_CAP;   // [64]: 2^(j / 64) for exp_nonpos
   const int ctrows = ONEGRP ? 1 : a.ngroups;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave-uniform: its arithmetic belongs on the scalar unit)
@@ -92,6 +93,7 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
     for (int i = tid; i < ctrows * K; i += 256) ctl[i] = a.ctab[i];
   for (int i = tid; i < 4 * NQ * QS; i += 256) qt[i] = 0.0;
   xt[tid * LD + ONE] = 1.0;  // (the staging below writes columns 0 .. DP - 1 only)
+  fill_exp_table(etab, tid, 256);
   double acc[NTL][NQ];
 #pragma unroll
   for (int t = 0; t < NTL; ++t)
@@ -261,7 +263,8 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
       const bool live = myok && myrow;
       if constexpr (!WANT_LL) {
         // ONE exponential per entry -- e = exp(log q~ - max) stays in registers and q = e / sum(e); the same sum and
-        // logZ, q within 2 ulp of exp(log q~ - logZ).  Four entries at a time: four independent polynomial chains.
+        // logZ, q within a few ulp of exp(log q~ - logZ).  Four entries at a time: four independent polynomial chains
+        // (the table exponential and the Newton reciprocal of lc_device.hpp: this sweep is bound by fp64 issue).
         double e[4 * NQ], s = 0.0;
         static_for<NQ>([&](auto cc) {
           constexpr int c = cc;
@@ -269,14 +272,14 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const int kk = 4 * c + j;
-              const double x = exp(ql[kk * QS] - mymx);
+              const double x = exp_nonpos(ql[kk * QS] - mymx, etab);
               e[kk] = kk < K ? x : 0.0;  // (slots of clusters >= K hold zeros, not log q~)
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) s += e[4 * c + j];
           }
         });
-        const double inv = 1.0 / s;
+        const double inv = rcp_pos(s);
         static_for<NQ>([&](auto cc) {
           constexpr int c = cc;
           if (4 * c < K) {
@@ -416,7 +419,7 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
 static size_t fused_lds_bytes(int DP, int K) {
   const int NT = DP / 4, PS = NT * (NT + 1) / 2 * 16 + DP;
   const int NQ = K <= 4 ? 1 : K <= 8 ? 2 : 4;  // the instance launch_fused picks
-  return ((size_t)FUSED_ROWS * (DP + 2) + (size_t)K * PS + (size_t)4 * NQ * FUSED_QS + 4 * K + 4 + FUSED_CT_CAP) * sizeof(double);
+  return ((size_t)FUSED_ROWS * (DP + 2) + (size_t)K * PS + (size_t)4 * NQ * FUSED_QS + 4 * K + 4 + FUSED_CT_CAP + 64) * sizeof(double);
 }
 
 // does this shape have a fused path?  (a property of (DP, K) alone: every rank of a distributed run must take the same

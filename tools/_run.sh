@@ -1,9 +1,6 @@
-mkdir -p gpurun_out/r04e
-python tools/ssfeat_check.py > gpurun_out/r04e/ssfeat.log 2>&1
-tail -45 gpurun_out/r04e/ssfeat.log
-python bench.py --config 5 --steps 5 --warmup 1 --no-cpu-baseline --no-parity > gpurun_out/r04e/bench5.log 2>&1
-python - <<'PY'
-import json
-l=[x for x in open('gpurun_out/r04e/bench5.log') if x.startswith('{')][-1]
-d=json.loads(l); print(d['ms_per_step'], d['kernels'], d['roofline']['estep_frac'], d['roofline']['suffstat_frac'])
-PY
+mkdir -p gpurun_out/r04g
+python -m pytest tests/test_gpu_families.py -m gpu -x -q > gpurun_out/r04g/pytest.log 2>&1; echo "rc=$?" >> gpurun_out/r04g/pytest.log
+tail -3 gpurun_out/r04g/pytest.log
+LC_VARIANT_REPEAT=2 python tools/variants.py run --fam ng --iters 12 fused_v2 > gpurun_out/r04g/var_ng.log 2>&1
+LC_VARIANT_REPEAT=2 python tools/variants.py run --fam eg --iters 12 fused_v2 > gpurun_out/r04g/var_eg.log 2>&1
+cat gpurun_out/r04g/var_ng.log gpurun_out/r04g/var_eg.log
