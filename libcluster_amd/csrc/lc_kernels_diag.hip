@@ -556,7 +556,8 @@ __global__ void __launch_bounds__(256, 2)
     // next: the last PFH reads of tile `it` are the first of tile it + 1 of the same half, NTF tiles further on), fenced
     // so that hipcc does not sink them to their uses -- a ring restarted per half tile exposed an LDS round trip sixteen
     // times per 32-row tile.  The accumulators start from `out` (the MFMA's C operand): no add behind the chain.
-    constexpr int PFH = NT < PF ? NT : PF;
+    constexpr int PFH = NT % 8 == 0 ? 8 : 4;  // a divisor of NT: the ring's slots line up from one cluster tile to the next
+    static_assert(NT % PFH == 0 && PFH <= NT, "ring slots");
     auto ring_start = [&](int it, int half, double (&ring)[PFH]) {
       const double* Pi = Pt + ((size_t)it * NTF + (size_t)half * NT) * 16;
       static_for<PFH>([&](auto ic) { ring[ic] = Pi[ic * 16]; });

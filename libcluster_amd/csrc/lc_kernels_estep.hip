@@ -67,7 +67,8 @@ __global__ void __launch_bounds__(WAVES * 64, EstepOcc<DP>::BLOCKS) estep_kernel
   double* fzw = llw + WAVES * a.K; // [WAVES]
   // lq_lds (four row groups per wave, where every lane owns one row outright, and K small enough): log q~ waits in
   // LDS for the normalisation, [K][threads], instead of making a round trip through the qZ buffer
-  double* lql = fzw + WAVES;
+  double* etab = fzw + WAVES;      // [64]: 2^(j / 64) for exp_nonpos (the normalisation sweep)
+  double* lql = etab + 64;
   const bool lqm = R == 4 && a.lq_lds != 0;
   int* klist = reinterpret_cast<int*>(lql + (lqm ? (size_t)a.K * NTHR : 0));  // sparse mode: [K] active clusters of this block, [K] flags,
   int* kflag = klist + a.K;                          // [WAVES*R] groups of the block's row groups, [1] count
@@ -77,6 +78,7 @@ __global__ void __launch_bounds__(WAVES * 64, EstepOcc<DP>::BLOCKS) estep_kernel
   const int lo4 = lane & 15, hi = lane >> 4;
   const int K = a.K;
   const int64_t rg0 = ((int64_t)blockIdx.x * WAVES + wave) * R;
+  fill_exp_table(etab, tid, NTHR);  // (read after the cluster loop's barriers)
   constexpr bool ROWLANES = R == 4;  // four row groups per wave: lane (lo4, hi) can own row group hi outright
 
   double xf[R][NT];
@@ -328,14 +330,14 @@ __global__ void __launch_bounds__(WAVES * 64, EstepOcc<DP>::BLOCKS) estep_kernel
     double s = 0.0;
     if (myok) {
 #pragma unroll 8
-      for (int k = 0; k < K; ++k) s += exp((lqm ? lql[k * NTHR + tid] : qp[(int64_t)k * a.ldq]) - mymx);
+      for (int k = 0; k < K; ++k) s += exp_nonpos((lqm ? lql[k * NTHR + tid] : qp[(int64_t)k * a.ldq]) - mymx, etab);
     }
     const double logZ = log(s) + mymx;
     for (int k = 0; k < K; ++k) {
       double ll = 0.0;
       if (myok) {
         const double lq = lqm ? lql[k * NTHR + tid] : qp[(int64_t)k * a.ldq];
-        double q = exp(lq - logZ);
+        double q = exp_nonpos(lq - logZ, etab);
         if (!myrow) q = 0.0;
         qp[(int64_t)k * a.ldq] = q;
         if (a.ll_part && q > 0.0) ll = q * (lq - a.ctab[(int64_t)mygrp * K + k]);
@@ -354,7 +356,7 @@ __global__ void __launch_bounds__(WAVES * 64, EstepOcc<DP>::BLOCKS) estep_kernel
     if (rgok[r]) {
       const double* qp = a.qZ + (rg0 + r) * RG + lo4;
 #pragma unroll 8
-      for (int k = hi; k < K; k += 4) s += exp(qp[(int64_t)k * a.ldq] - mx[r]);
+      for (int k = hi; k < K; k += 4) s += exp_nonpos(qp[(int64_t)k * a.ldq] - mx[r], etab);
     }
     s = sum_over_hi(s);
     logZ[r] = log(s) + mx[r];
@@ -368,7 +370,7 @@ __global__ void __launch_bounds__(WAVES * 64, EstepOcc<DP>::BLOCKS) estep_kernel
         if (rgok[r]) {
           double* qp = a.qZ + (int64_t)k * a.ldq + (rg0 + r) * RG + lo4;
           const double lq = *qp;
-          double q = exp(lq - logZ[r]);
+          double q = exp_nonpos(lq - logZ[r], etab);
           if (!rowok[r]) q = 0.0;
           *qp = q;
           if (a.ll_part && q > 0.0) ll += q * (lq - a.ctab[(int64_t)grp[r] * K + k]);
@@ -690,7 +692,7 @@ int64_t estep_grid(int DP, int64_t nrg) {
 template <int DP, bool SPARSE>
 static hipError_t launch_estep_s(const EstepLaunch& a, hipStream_t stream) {
   constexpr int R = EstepCfg<DP>::R, WAVES = EstepCfg<DP>::WAVES;
-  size_t shmem = (size_t)(2 * pstride(DP) + WAVES * a.K + WAVES) * sizeof(double) +
+  size_t shmem = (size_t)(2 * pstride(DP) + WAVES * a.K + WAVES + 64) * sizeof(double) +
                  (size_t)(2 * a.K + WAVES * R + 2) * sizeof(int);
   EstepLaunch b = a;
   static const bool no_lql = getenv("LC_ES_NOLQL") != nullptr;  // tuning knob: log q~ through the qZ buffer everywhere
