@@ -920,7 +920,11 @@ hipError_t launch_estep_diag(const DiagEstepLaunch& a, hipStream_t stream) {
 // X batches (BR rows) and the slice's q columns are staged through LDS, next batch in flight in registers,
 // the same scheme as suffstat_kernel.
 constexpr int SD_QMAX = 64;  // clusters per block
-template <int DP, bool SECOND>
+// RS (row classes: 1, 2 or 4) is a template parameter so that a wave's steps of a batch are a compile-time list: the
+// operands of its next step (NB x fragments, CT q fragments) are read while the current step's MFMAs issue (fenced;
+// hipcc reads them right in front of their use otherwise, and every step of 32 MFMAs started with an exposed LDS round
+// trip: DGMM statistics 2.05 ms at 58 % of the pipe).
+template <int DP, bool SECOND, int RS>
 __global__ void __launch_bounds__(256, 2) suffstat_diag_kernel(DiagStatLaunch a) {
   constexpr int NB = DP / 16, CT = 4;
   constexpr int BR = DP <= 64 ? 32 : 16;
@@ -933,7 +937,7 @@ __global__ void __launch_bounds__(256, 2) suffstat_diag_kernel(DiagStatLaunch a)
   double* qbuf = lds + 2 * XBUF;     // [2][SD_QMAX][QLD]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lo2 = lane & 3, blk = (lane >> 2) & 3, hi = lane >> 4, lo4 = lane & 15;
-  const int K = a.K, RS = a.rsplit;
+  const int K = a.K;
   const int chunk = blockIdx.x / a.nslice, slice = blockIdx.x % a.nslice;
   const int kb0 = slice * SD_QMAX;
   const int kc = (K - kb0) < SD_QMAX ? (K - kb0) : SD_QMAX;     // clusters of this block
@@ -1003,23 +1007,47 @@ __global__ void __launch_bounds__(256, 2) suffstat_diag_kernel(DiagStatLaunch a)
     if (active) {
       const double* xb = xbuf + buf * XBUF + hi * LD + 4 * blk + lo2;
       const double* qb = qbuf + buf * SD_QMAX * QLD + (group * 16 + lo2) * QLD + hi;
-      // rows past the chunk end were staged as zeros with q = 0, so every step runs
-      for (int st = rcls; st < BR / 4; st += RS) {
-        double xf[NB], x2[NB];
+      // rows past the chunk end were staged as zeros with q = 0, so every step runs: steps rcls, rcls + RS, ...
+      constexpr int NST = BR / 4 / RS;
+      const double* xs = xb + rcls * 4 * LD;
+      const double* qs = qb + rcls * 4;
+      constexpr bool PIPE = DP <= 96;  // (the second operand set spills next to 128 accumulator registers at D = 112, 128)
+      double xf[PIPE ? 2 : 1][NB], qv[PIPE ? 2 : 1][CT];
 #pragma unroll
-        for (int jb = 0; jb < NB; ++jb) {
-          xf[jb] = xb[st * 4 * LD + 16 * jb];
-          if (SECOND) x2[jb] = xf[jb] * xf[jb];
+      for (int jb = 0; jb < NB; ++jb) xf[0][jb] = xs[16 * jb];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) qv[0][c] = qs[4 * c * QLD];
+#pragma unroll
+      for (int i = 0; i < NST; ++i) {
+        const int cur = PIPE ? (i & 1) : 0, nxt = PIPE ? (cur ^ 1) : 0;
+        if (PIPE && i + 1 < NST) {
+#pragma unroll
+          for (int jb = 0; jb < NB; ++jb) xf[nxt][jb] = xs[(i + 1) * RS * 4 * LD + 16 * jb];
+#pragma unroll
+          for (int c = 0; c < CT; ++c) qv[nxt][c] = qs[4 * c * QLD + (i + 1) * RS * 4];
         }
+        if constexpr (PIPE) __builtin_amdgcn_sched_barrier(0);
+        double x2[NB];
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb)
+          if (SECOND) x2[jb] = xf[cur][jb] * xf[cur][jb];
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
-          const double q = qb[4 * c * QLD + st * 4];
+          const double q = qv[cur][c];
           nacc[c] += q;
 #pragma unroll
           for (int jb = 0; jb < NB; ++jb) {
-            acc1[c][jb] = mfma4(q, xf[jb], acc1[c][jb]);
+            acc1[c][jb] = mfma4(q, xf[cur][jb], acc1[c][jb]);
             if (SECOND) acc2[c][jb] = mfma4(q, x2[jb], acc2[c][jb]);
           }
+        }
+        if constexpr (PIPE) {
+          __builtin_amdgcn_sched_barrier(0);
+        } else if (i + 1 < NST) {
+#pragma unroll
+          for (int jb = 0; jb < NB; ++jb) xf[0][jb] = xs[(i + 1) * RS * 4 * LD + 16 * jb];
+#pragma unroll
+          for (int c = 0; c < CT; ++c) qv[0][c] = qs[4 * c * QLD + (i + 1) * RS * 4];
         }
       }
     }
@@ -1053,23 +1081,27 @@ int suffstat_diag_rsplit(int K) {  // row classes per block: waves left over by 
   return groups >= 3 ? 1 : groups == 2 ? 2 : 4;
 }
 
-template <int DP>
-static hipError_t launch_sd_t(const DiagStatLaunch& a, hipStream_t stream) {
+template <int DP, int RS>
+static hipError_t launch_sd_r(const DiagStatLaunch& a, hipStream_t stream) {
   constexpr int BR = DP <= 64 ? 32 : 16;
   const size_t shmem = (size_t)(2 * BR * lds_row_stride(DP) + 2 * SD_QMAX * (BR + 4)) * sizeof(double);
   static LdsGrant grants[2];
-  if (hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(suffstat_diag_kernel<DP, true>), shmem, grants[0]);
+  if (hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(suffstat_diag_kernel<DP, true, RS>), shmem, grants[0]);
       e != hipSuccess)
     return e;
-  if (hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(suffstat_diag_kernel<DP, false>), shmem, grants[1]);
+  if (hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(suffstat_diag_kernel<DP, false, RS>), shmem, grants[1]);
       e != hipSuccess)
     return e;
   const dim3 grid((unsigned)(a.nchunks * a.nslice));
   if (a.second)
-    hipLaunchKernelGGL((suffstat_diag_kernel<DP, true>), grid, dim3(256), shmem, stream, a);
+    hipLaunchKernelGGL((suffstat_diag_kernel<DP, true, RS>), grid, dim3(256), shmem, stream, a);
   else
-    hipLaunchKernelGGL((suffstat_diag_kernel<DP, false>), grid, dim3(256), shmem, stream, a);
+    hipLaunchKernelGGL((suffstat_diag_kernel<DP, false, RS>), grid, dim3(256), shmem, stream, a);
   return hipGetLastError();
+}
+template <int DP>
+static hipError_t launch_sd_t(const DiagStatLaunch& a, hipStream_t stream) {
+  return a.rsplit == 1 ? launch_sd_r<DP, 1>(a, stream) : a.rsplit == 2 ? launch_sd_r<DP, 2>(a, stream) : launch_sd_r<DP, 4>(a, stream);
 }
 
 hipError_t launch_suffstat_diag(const DiagStatLaunch& a0, hipStream_t stream) {
