@@ -426,6 +426,7 @@ void Context::get_rows(int j, int64_t row0, int64_t n, double* out) const {
 // ---------------------------------------------------------------------------
 void Context::ensure_qz(QZ& q, int K, bool preserve) {
   use_device();
+  q.hash_ok = false;  // (whoever asks for the buffer is about to write it; estep_cache and the split helpers re-validate)
   if (K <= q.cap && q.buf.p) return;
   int newcap = std::max(K, q.cap > 0 ? q.cap + std::max(4, q.cap / 2) : K);
   DevBuf<double> nb;
@@ -452,6 +453,7 @@ void Context::qz_set(int j, const double* q, int K, int64_t rs, int64_t cs) {
   use_device();
   if (j < 0 || j >= J_) throw std::invalid_argument("group index out of range");
   if (K < 1) throw std::invalid_argument("K must be >= 1");
+  qz_[cur_].hash_ok = false;
   if (K != qz_[cur_].K) {
     ensure_qz(qz_[cur_], K, false);
     // a new K invalidates every group: start from zeros
@@ -626,6 +628,7 @@ void Context::qz_keep_columns(const std::vector<int>& keep) {
                             hipMemcpyDeviceToDevice, stream_));
   }
   q.K = (int)keep.size();
+  q.hash_ok = false;  // (columns moved: the rows' fingerprints weigh every value by its column)
 }
 
 void Context::qz_clone_to_alt() {
@@ -637,6 +640,11 @@ void Context::qz_clone_to_alt() {
   LC_HIP(hipMemcpyAsync(a.buf.p, qz_[cur_].buf.p, (size_t)NP_ * Ksave * sizeof(double), hipMemcpyDeviceToDevice,
                         stream_));
   LC_HIP(hipMemsetAsync(a.buf.p + (size_t)NP_ * Ksave, 0, (size_t)NP_ * sizeof(double), stream_));
+  if (qz_[cur_].hash_ok && NP_ > 0) {  // the copy is what the original is: so are its rows' fingerprints
+    a.hash.reserve((size_t)NP_);
+    LC_HIP(hipMemcpyAsync(a.hash.p, qz_[cur_].hash.p, (size_t)NP_ * sizeof(int64_t), hipMemcpyDeviceToDevice, stream_));
+    a.hash_ok = true;
+  }
 }
 
 void Context::qz_swap_alt() { cur_ ^= 1; }
@@ -764,10 +772,12 @@ void Context::qz_split_from(const Context& sub, const RowSelection& sel, int k) 
   QZ& q = qz_[cur_];
   if (k < 0 || k >= q.K) throw std::invalid_argument("split column out of range");
   if (sub.qz_[sub.cur_].K < 2) throw std::invalid_argument("sub-problem has no second column");
+  const bool hashed = q.hash_ok;  // (a new zero column leaves a row's fingerprint as it is; rewritten rows are marked)
   if (q.K + 1 > q.cap) ensure_qz(q, q.K + 1, true);
+  q.hash_ok = hashed;
   LC_HIP(hipMemsetAsync(q.buf.p + (size_t)NP_ * q.K, 0, (size_t)NP_ * sizeof(double), stream_));
   LC_HIP(lck::launch_aug_from_sub(q.buf.p, NP_, k, q.K, sel.idx.p, sel.M, sel.starts_d.p, sub.goff_d_.p, J_,
-                                  sub.qz_[sub.cur_].buf.p + (size_t)sub.NP_, stream_));
+                                  sub.qz_[sub.cur_].buf.p + (size_t)sub.NP_, stream_, hashed ? q.hash.p : nullptr));
   q.K += 1;
 }
 
@@ -1464,6 +1474,7 @@ int Context::estep_cache(int K, const double* A, const double* m, const double* 
   dc_K_ = K;
   // constants + normalisation
   const bool have_old = qz_[cur_].K == K;  // the buffer holds K columns of q_old
+  const bool hashed_old = have_old && qz_[cur_].hash_ok;
   ensure_qz(qz_[cur_], K, false);
   qz_[cur_].K = K;
   const int64_t grid = lck::softmax_cached_grid(NP_);
@@ -1499,10 +1510,19 @@ int Context::estep_cache(int K, const double* A, const double* m, const double* 
       dq_.reserve((size_t)NP_ * std::max(K, dc_cap_));  // (as wide as the slab: re-allocated only when that grows)
       amax_.reserve((size_t)NP_);
       a.dq = dq_.p;
-      a.ldd = NP_;
+      a.ldd = K;  // row-major [NP x K]
+      dq_ld_ = K;
       a.amax = amax_.p;
       a.dq_tol = delta_tol;
       dq_tol_ = delta_tol;
+      static const bool no_hash = std::getenv("LC_SPLIT_NO_QHASH") != nullptr;  // (A/B timing: read every old value)
+      if (!no_hash) {
+        qz_[cur_].hash.reserve((size_t)NP_);
+        a.qhash = qz_[cur_].hash.p;
+        a.qhash_in = hashed_old ? 1 : 0;
+        static const bool trace = std::getenv("LC_TRACE_PHASES") != nullptr;
+        if (trace) std::cerr << "[cache] sweep K " << K << ", fingerprints " << (hashed_old ? "compared" : "written") << std::endl;
+      }
     }
     EvPair ev{};
     if (timing_) {
@@ -1532,6 +1552,7 @@ int Context::estep_cache(int K, const double* A, const double* m, const double* 
   if (Fz) *Fz = hred_[0];
   if (LLk) std::copy(hred_.begin() + 1, hred_.begin() + 1 + K, LLk);
   if (delta) dq_K_ = K;  // (a rank without rows keeps an empty delta and still joins delta_suffstat's sums)
+  qz_[cur_].hash_ok = delta && NP_ > 0 && qz_[cur_].hash.p != nullptr && std::getenv("LC_SPLIT_NO_QHASH") == nullptr;
   return nch;
 }
 
@@ -1557,7 +1578,7 @@ bool Context::delta_suffstat(int K1, double max_frac, double* dNk, double* dxs, 
   q.K = K1;
   if (sub.NP_ > 0) {
     LC_HIP(hipMemsetAsync(q.buf.p, 0, (size_t)sub.NP_ * K1 * sizeof(double), stream_));  // padding rows carry nothing
-    LC_HIP(lck::launch_gather_cols(dq_.p, NP_, K1, sel.idx.p, sel.M, sel.starts_d.p, sub.goff_d_.p, J_, q.buf.p,
+    LC_HIP(lck::launch_gather_rowmajor(dq_.p, dq_ld_, K1, sel.idx.p, sel.M, sel.starts_d.p, sub.goff_d_.p, J_, q.buf.p,
                                    sub.NP_, stream_));
   }
   sub.suffstat(nullptr, dNk, dxs, dxxs, dNjk);

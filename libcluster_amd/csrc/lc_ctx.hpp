@@ -269,6 +269,11 @@ class Context {
     DevBuf<double> buf;
     int cap = 0;  // columns allocated
     int K = 0;    // columns in use
+    // cluster(): a 64-bit fingerprint per row of what the buffer holds (softmax_cached_kernel keeps it, and skips the
+    // old values of the rows it leaves unchanged).  Every other writer of the buffer goes through ensure_qz(), which
+    // clears hash_ok; qz_clone_to_alt copies it, qz_split_from marks the rows it rewrites.
+    DevBuf<int64_t> hash;
+    bool hash_ok = false;
   };
   void ensure_qz(QZ& q, int K, bool preserve);
   void build_layout(int J, const int64_t* Nj, int D);
@@ -315,6 +320,7 @@ class Context {
   DevBuf<double> dq_, amax_;  // estep_cache(delta_tol): q_new - q_old [K x NP] (moved rows), per-row max |.|
   double dq_tol_ = 0.0;
   int dq_K_ = 0;
+  int64_t dq_ld_ = 0;  // row stride of dq_ (row-major: a moved row's differences are contiguous)
   int64_t delta_rows_ = 0;
   int cur_ = 0;
 

@@ -216,14 +216,18 @@ hipError_t launch_transpose_qz(const double* qZ, int64_t ldq, int K, int64_t NP,
 // dst[c, gathered row of p] = src[c, idx[p]] for K columns (column-major, leading dimensions lds / ldd)
 hipError_t launch_gather_cols(const double* src, int64_t lds, int K, const int64_t* idx, int64_t M, const int64_t* starts,
                               const int64_t* goff_sub, int J, double* dst, int64_t ldd, hipStream_t stream);
+hipError_t launch_gather_rowmajor(const double* src, int64_t lds, int K, const int64_t* idx, int64_t M,
+                                  const int64_t* starts, const int64_t* goff_sub, int J, double* dst, int64_t ldd,
+                                  hipStream_t stream);
 hipError_t launch_gather_rows(const double* X, int DP, const int64_t* idx, int64_t M, const int64_t* starts,
                               const int64_t* goff_sub, int J, double* Xdst, hipStream_t stream);
 hipError_t launch_split_init(const double* X, int DP, int D, int64_t NP, const int* rginfo, int64_t nrows,
                              const double* mv, double* q, int64_t ldq, int mode, const double* thr,
                              hipStream_t stream);
+// qhash (or nullptr): the rows it rewrites lose their fingerprint (CachedNormLaunch::qhash)
 hipError_t launch_aug_from_sub(double* q, int64_t ldq, int k, int K, const int64_t* idx, int64_t M,
                                const int64_t* starts, const int64_t* goff_sub, int J, const double* qsub1,
-                               hipStream_t stream);
+                               hipStream_t stream, int64_t* qhash = nullptr);
 
 // split search: normalise K columns of log q~ = c_jk + (cached | freshly computed) -0.5 d^2 (softmax_cached_kernel)
 struct CachedNormLaunch {
@@ -241,11 +245,18 @@ struct CachedNormLaunch {
   double* fz_part;       // [softmax_cached_grid(NP)]
   // optional (both or neither): how far this E-step moved the responsibilities it overwrites
   double* ll_part = nullptr;  // [softmax_cached_grid(NP) x K] or nullptr: sum_n q_nk (log q~_nk - c_jk) partials
-  double* dq = nullptr;    // [K x ldd] q_new - q_old, written for the rows with amax > dq_tol only
+  double* dq = nullptr;    // [NP x ldd], ROW-major (ldd >= K): q_new - q_old, written for the rows with amax > dq_tol only
   double dq_tol = 0.0;
   int64_t ldd = 0;
   double* amax = nullptr;  // [NP] max_j |q_new - q_old| of the row
+  // optional, with dq: a 64-bit fingerprint of every row of qZ (QHASH_NONE: unknown).  The sweep writes the fingerprint of
+  // what it leaves in a row; with qhash_in it first compares: a row whose new values have the fingerprint of the old
+  // ones is unchanged and its K old values are not even read (between the candidates of a split round that is almost
+  // every row: half of the sweep's traffic)
+  int64_t* qhash = nullptr;  // [NP]
+  int qhash_in = 0;          // the fingerprints describe the responsibilities being overwritten
 };
+constexpr int64_t QHASH_NONE = (int64_t)0x8000000000000000ull;
 int64_t softmax_cached_grid(int64_t NP);
 int softmax_cached_max_k();  // widest K the sweep is built for
 hipError_t launch_softmax_cached(const CachedNormLaunch& a, hipStream_t stream);

@@ -344,6 +344,28 @@ __global__ void __launch_bounds__(256) gather_cols_kernel(const double* src, int
   for (int c = 0; c < K; ++c) dst[(int64_t)c * ldd + d] = src[(int64_t)c * lds + s];
 }
 
+// the same from a ROW-major table (row stride lds): one thread per (selected row, column) -- a row's K values are
+// contiguous on the source side, the K columns of the gathered layout on the destination side
+__global__ void __launch_bounds__(256) gather_rowmajor_kernel(const double* src, int64_t lds, int K, const int64_t* idx,
+                                                              int64_t M, const int64_t* starts, const int64_t* goff_sub,
+                                                              int J, double* dst, int64_t ldd) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= M * K) return;
+  const int64_t p = t / K;
+  const int c = (int)(t % K);
+  const int64_t d = sel_dst_row(p, starts, goff_sub, J);
+  dst[(int64_t)c * ldd + d] = src[idx[p] * lds + c];
+}
+hipError_t launch_gather_rowmajor(const double* src, int64_t lds, int K, const int64_t* idx, int64_t M,
+                                  const int64_t* starts, const int64_t* goff_sub, int J, double* dst, int64_t ldd,
+                                  hipStream_t stream) {
+  if (M <= 0 || K <= 0) return hipSuccess;
+  const int64_t n = M * K;
+  hipLaunchKernelGGL(gather_rowmajor_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, lds, K, idx, M,
+                     starts, goff_sub, J, dst, ldd);
+  return hipGetLastError();
+}
+
 hipError_t launch_gather_cols(const double* src, int64_t lds, int K, const int64_t* idx, int64_t M, const int64_t* starts,
                               const int64_t* goff_sub, int J, double* dst, int64_t ldd, hipStream_t stream) {
   if (M <= 0 || K <= 0) return hipSuccess;
@@ -434,7 +456,7 @@ hipError_t launch_split_init(const double* X, int DP, int D, int64_t NP, const i
 // second refined responsibility exceeds 0.5 moves its column-k mass to the new column K
 __global__ void __launch_bounds__(256) aug_from_sub_kernel(double* q, int64_t ldq, int k, int K, const int64_t* idx,
                                                            int64_t M, const int64_t* starts, const int64_t* goff_sub,
-                                                           int J, const double* qsub1) {
+                                                           int J, const double* qsub1, int64_t* qhash) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= M) return;
   const int64_t sub = sel_dst_row(p, starts, goff_sub, J);
@@ -442,15 +464,16 @@ __global__ void __launch_bounds__(256) aug_from_sub_kernel(double* q, int64_t ld
     const int64_t r = idx[p];
     q[(int64_t)K * ldq + r] = q[(int64_t)k * ldq + r];
     q[(int64_t)k * ldq + r] = 0.0;
+    if (qhash) qhash[r] = QHASH_NONE;  // (the row no longer is what its fingerprint says)
   }
 }
 
 hipError_t launch_aug_from_sub(double* q, int64_t ldq, int k, int K, const int64_t* idx, int64_t M,
                                const int64_t* starts, const int64_t* goff_sub, int J, const double* qsub1,
-                               hipStream_t stream) {
+                               hipStream_t stream, int64_t* qhash) {
   if (M <= 0) return hipSuccess;
   hipLaunchKernelGGL(aug_from_sub_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, stream, q, ldq, k, K, idx, M,
-                     starts, goff_sub, J, qsub1);
+                     starts, goff_sub, J, qsub1, qhash);
   return hipGetLastError();
 }
 
@@ -606,7 +629,10 @@ template <int KT>
 __global__ void __launch_bounds__(256) softmax_cached_kernel(CachedNormLaunch a) {
   __shared__ double fzw[4];
   __shared__ double llw[4 * KT];
+  __shared__ double etab[64];  // 2^(j / 64) for exp_nonpos
   const int tid = threadIdx.x, K = a.K;
+  fill_exp_table(etab, tid, 256);
+  __syncthreads();
   const int64_t row = (int64_t)blockIdx.x * 256 + tid;
   const bool inb = row < a.NP;
   const int64_t rr = inb ? row : 0;  // (out-of-range lanes load row 0 and write nothing)
@@ -649,18 +675,24 @@ __global__ void __launch_bounds__(256) softmax_cached_kernel(CachedNormLaunch a)
 #pragma unroll
   for (int j = 0; j < KT; ++j)
     if (j < K) {
-      const double e = exp(v[j] - mx);
+      const double e = exp_nonpos(v[j] - mx, etab);
       s += e;
       if (onexp) v[j] = e;
     }
   const double logZ = log(s) + mx;
-  const double inv = 1.0 / s;
+  const double inv = rcp_pos(s);
 #pragma unroll
   for (int j = 0; j < KT; ++j)
     if (j < K) {
       const double lq = v[j];
-      double q = onexp ? lq * inv : exp(lq - logZ);
-      if (!ok) q = 0.0;
+      double q = onexp ? lq * inv : exp_nonpos(lq - logZ, etab);
+      // Responsibilities below 2^-300 are stored as zero.  A row that belongs to one cluster has q = 1 there and
+      // e^-(hundreds) everywhere else; those specks change in their last bits with every change of any weight, so that
+      // every row "changed" in every sweep of a split candidate (all K old values read, all K new ones written: 3 x 2.6
+      // GB per sweep at K = 33) although nothing above 1e-90 moved.  Flushed, such a row comes out bit for bit as it
+      // was, its fingerprint matches and the sweep touches nothing of it.  The mass dropped from any statistic is below
+      // 1e-90 of the row's; the reference itself loses everything below e^-745 (exp underflow, probutils.cpp:146).
+      if (!ok || q < 0x1p-300) q = 0.0;
       v[j] = q;
       if (a.ll_part) {  // the data term of the split ordering (cluster.cpp:407-410), as estep_kernel's sweep forms it
         const double ll = wave_sum(q > 0.0 ? q * (lq - crow[j]) : 0.0);
@@ -672,34 +704,45 @@ __global__ void __launch_bounds__(256) softmax_cached_kernel(CachedNormLaunch a)
     // whose K values all come out bit for bit as they were is not written at all, its q_new - q_old only when some
     // |.| exceeds dq_tol (delta_suffstat never looks at the other rows).  Between the candidates of a split round
     // almost every row is of the first kind.
-    // (the old values pass through eight registers at a time: the new ones already hold 2 KT)
+    // Fingerprint of the row's new values: sum_j bits(q_j) * M_j (mod 2^64, M_j odd; a zero entry adds nothing, so K
+    // columns and K + 1 columns with q_K = 0 agree).  Equal to the stored fingerprint of the old values: the row is
+    // unchanged (up to a 2^-64 coincidence) and its old values are not read at all.
+    int64_t h = 0;
+    bool same = false;
+    if (a.qhash) {
+      uint64_t acc = 0;
+#pragma unroll
+      for (int j = 0; j < KT; ++j)
+        if (j < K) acc += (uint64_t)__double_as_longlong(v[j]) * (0x9E3779B97F4A7C15ull * (uint64_t)(2 * j + 1));
+      h = (int64_t)acc;
+      if (h == QHASH_NONE) h = 1;
+      if (a.qhash_in && inb) same = a.qhash[row] == h;
+    }
+    // A row that did change: its old values pass through eight registers at a time; every entry that differs is
+    // written at once (with the specks flushed, a row of the cluster being split changes in two or three columns, not in
+    // all K: 33 partial-line writes per such row were a third of a candidate's sweep), and the row's differences go to
+    // the row-major table in the same pass (delta_suffstat reads them only where amax > dq_tol).
     double am = 0.0;
-    bool any = false;
+    if (!same && inb) {
 #pragma unroll
-    for (int jb = 0; jb < KT; jb += 8) {
-      double o[8];
+      for (int jb = 0; jb < KT; jb += 8) {
+        double o[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (jb + u < KT && jb + u < K) o[u] = a.qZ[(int64_t)(jb + u) * a.ldq + rr];
+        for (int u = 0; u < 8; ++u)
+          if (jb + u < KT && jb + u < K) o[u] = a.qZ[(int64_t)(jb + u) * a.ldq + row];
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (jb + u < KT && jb + u < K) {
-          const double dd = v[jb + u] - o[u];
-          am = fmax(am, fabs(dd));
-          any = any || dd != 0.0;
-        }
+        for (int u = 0; u < 8; ++u)
+          if (jb + u < KT && jb + u < K) {
+            const double dd = v[jb + u] - o[u];
+            am = fmax(am, fabs(dd));
+            if (dd != 0.0) a.qZ[(int64_t)(jb + u) * a.ldq + row] = v[jb + u];
+            a.dq[row * a.ldd + jb + u] = dd;
+          }
+      }
     }
     if (inb) {
       a.amax[row] = am;
-      if (any) {
-        const bool moved = am > a.dq_tol;
-#pragma unroll
-        for (int j = 0; j < KT; ++j)
-          if (j < K) {
-            if (moved) a.dq[(int64_t)j * a.ldd + row] = v[j] - a.qZ[(int64_t)j * a.ldq + row];
-            a.qZ[(int64_t)j * a.ldq + row] = v[j];
-          }
-      }
+      if (a.qhash && !same) a.qhash[row] = h;
     }
   } else if (inb) {
 #pragma unroll

@@ -455,7 +455,6 @@ __global__ void __launch_bounds__(256, 2)
   double* const ll_part = PLAIN ? nullptr : ll_part_;
   constexpr int DP = NT * 4;
   constexpr int NTF = QUAD ? 2 * NT : NT;  // feature tiles per cluster tile
-  constexpr int PF = NTF < 8 ? NTF : 8;    // weight-tile reads in flight ahead of their MFMAs
   constexpr bool REGS = KTM > 0;
   constexpr int NLQ = REGS ? KTM : 1;
   extern __shared__ __attribute__((aligned(16))) double lds[];
