@@ -724,14 +724,18 @@ __global__ void __launch_bounds__(256) softmax_cached_kernel(CachedNormLaunch a)
     // the row-major table in the same pass (delta_suffstat reads them only where amax > dq_tol).
     double am = 0.0;
     if (!same && inb) {
+      // (all K old values in ONE batch of loads: nearly every wave holds a changed row or two, and with eight registers at
+      //  a time it walked five dependent memory round trips for them -- 1.83 against 1.23 ms for a candidate's sweep at
+      //  K = 33, tools/smc_probe.hip; the 2 KT extra registers cost the unchanged-rows stream 8 %)
+      constexpr int OB = KT;
 #pragma unroll
-      for (int jb = 0; jb < KT; jb += 8) {
-        double o[8];
+      for (int jb = 0; jb < KT; jb += OB) {
+        double o[OB];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < OB; ++u)
           if (jb + u < KT && jb + u < K) o[u] = a.qZ[(int64_t)(jb + u) * a.ldq + row];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < OB; ++u)
           if (jb + u < KT && jb + u < K) {
             const double dd = v[jb + u] - o[u];
             am = fmax(am, fabs(dd));

@@ -39,11 +39,14 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  for (int mode = 0; mode < 4; ++mode) {  // 0: plain (writes q), 1: moves reported, 2: moves + LL_k, 3: a split candidate's E-step
+  int64_t* qh;
+  CK(hipMalloc(&qh, NP * 8));
+  for (int mode = 0; mode < 6; ++mode) {  // 0: plain (writes q), 1: moves reported, 2: moves + LL_k, 3: a split candidate's E-step, 4: 1 with row fingerprints, 5: 3 with them
     lck::CachedNormLaunch a{};
     a.dcache = slab; a.ldc = NP; a.fresh = nullptr; a.ldf = 0; a.colmap = nullptr; a.ctab = ctab; a.K = K;
     a.rginfo = nullptr; a.nrows = NP; a.NP = NP; a.qZ = q; a.ldq = NP; a.fz_part = fz;
-    if (mode >= 1) { a.dq = dq; a.ldd = NP; a.amax = amax; a.dq_tol = 8.9e-16; }
+    if (mode >= 1) { a.dq = dq; a.ldd = K; a.amax = amax; a.dq_tol = 8.9e-16; }
+    if (mode >= 4) { a.qhash = qh; a.qhash_in = 1; }
     if (mode == 2) a.ll_part = ll;
     // mode 3: c_6 alternates between launches -- every row's (tiny) q_6 changes in its low bits, the rows of cluster 5
     // (1 / K of all; cluster 6 is their close second) move by O(1)
@@ -53,7 +56,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(ctab2, c.data(), K * 8, hipMemcpyHostToDevice));
     c[6 % K] -= 3.0;
     auto go = [&](int r) {
-      a.ctab = mode == 3 && (r & 1) ? ctab2 : ctab;
+      a.ctab = (mode == 3 || mode == 5) && (r & 1) ? ctab2 : ctab;
       CK(lck::launch_softmax_cached(a, 0));
     };
     for (int w = 0; w < 2; ++w) go(w);
