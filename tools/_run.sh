@@ -1,2 +1,12 @@
-for i in 1 2 3; do python tools/_ms.py 2>&1 | grep MS; done
-python -m pytest tests/test_gpu_splitsearch.py -m gpu -x -q 2>&1 | tail -2
+cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
+bash tools/profile_round.sh r04_ns > /dev/null 2>&1
+bash tools/profile_round.sh r04_c2 --config 2 --steps 200 --warmup 20 > /dev/null 2>&1
+bash tools/profile_round.sh r04_c5 --config 5 > /dev/null 2>&1
+bash tools/profile_round.sh r04_dgmm --config dgmm > /dev/null 2>&1
+bash tools/profile_round.sh r04_bemm --config bemm > /dev/null 2>&1
+bash tools/profile_round.sh r04_wide --config wide256 > /dev/null 2>&1
+for t in ns c2 c5 dgmm bemm wide; do python tools/summarize_prof.py gpurun_out/prof_r04_$t > gpurun_out/prof_r04_$t/summary.txt 2>&1; done
+mkdir -p gpurun_out/prof_r04_learn
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r04_learn/kt -o kt -- python3 tools/learn_bench.py 10000000 64 32 > gpurun_out/prof_r04_learn/kt.log 2>&1
+tail -3 gpurun_out/prof_r04_learn/kt.log
+grep -h "MFMA pipe busy\|^\[" gpurun_out/prof_r04_*/summary.txt
