@@ -963,10 +963,50 @@ int suffstat_plan(int DP, int64_t NP, int K, int64_t* chunk_rows) {
   int64_t maxchunks = std::max<int64_t>((NP + 1023) / 1024, std::min<int64_t>((NP + 255) / 256, 512));
   if (want > maxchunks) want = maxchunks;
   if (want < 1) want = 1;
-  int64_t rows = (NP + want - 1) / want;
-  rows = (rows + SS_BR - 1) / SS_BR * SS_BR;  // whole staging batches
+  auto plan = [&](int64_t w, int64_t* rows_out) {
+    int64_t rows = (NP + w - 1) / w;
+    rows = (rows + SS_BR - 1) / SS_BR * SS_BR;  // whole staging batches
+    *rows_out = rows;
+    return (NP + rows - 1) / rows;
+  };
+  int64_t rows = 0;
+  int64_t n = plan(want, &rows);
+  // Feature-GEMM launches put nslice blocks on every chunk and one (8 waves) or two (4 waves) blocks on a CU: a grid
+  // whose last round of resident blocks is half empty loses that much of the launch.  Config 5 (D = 128, K = 64: 17 blocks
+  // per chunk) ran 127 chunks = 2159 blocks = 8.43 rounds of 256 -- 6 % of the pass idle; 120 chunks are 7.97 rounds.
+  // Among the chunk counts down to 80 % of the wanted one, take the fullest last round (the larger count on ties).
+  if (DP <= 128 && ss_feat_eligible(DP, K) && NP >= 64 * 1024) {
+    const int range = ft_range(DP, K), nq = ((K < range ? K : range) + 3) / 4;
+    int nslice = 0;
+    switch (DP) {
+      case 32: nslice = nq > 7 ? ft_nslice(32, 8) : nq > 6 ? ft_nslice(32, 7) : nq > 5 ? ft_nslice(32, 6) : ft_nslice(32, 5); break;
+      case 48: nslice = nq > 7 ? ft_nslice(48, 8) : nq > 6 ? ft_nslice(48, 7) : nq > 5 ? ft_nslice(48, 6) : ft_nslice(48, 5); break;
+      case 64: nslice = nq > 7 ? ft_nslice(64, 8) : nq > 6 ? ft_nslice(64, 7) : nq > 5 ? ft_nslice(64, 6) : ft_nslice(64, 5); break;
+      case 128: nslice = nq > 8 ? ft_nslice(128, 16) : nq > 7 ? ft_nslice(128, 8) : nq > 6 ? ft_nslice(128, 7) : nq > 5 ? ft_nslice(128, 6) : ft_nslice(128, 5); break;
+    }
+    if (nslice > 0) {
+      static int cus = 0;
+      if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+      }
+      const int64_t slots = (int64_t)cus * (ft_waves(DP) == 8 ? 1 : 2);
+      auto fill = [&](int64_t chunks) {
+        const int64_t blocks = chunks * nslice, rounds = (blocks + slots - 1) / slots;
+        return (double)blocks / (double)(rounds * slots);
+      };
+      double best = fill(n);
+      for (int64_t w = want - 1; w >= 1 && w * 5 >= want * 4 && best < 0.985; --w) {
+        int64_t r2 = 0;
+        const int64_t n2 = plan(w, &r2);
+        if (fill(n2) > best + 1e-9) best = fill(n2), n = n2, rows = r2;
+      }
+    }
+  }
   *chunk_rows = rows;
-  return (int)((NP + rows - 1) / rows);
+  return (int)n;
 }
 
 template <int DP, int CPW, bool SKIP, int HALF, int PAN = 0, bool RSP = false>

@@ -1,12 +1,11 @@
-cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-bash tools/profile_round.sh r04_ns > /dev/null 2>&1
-bash tools/profile_round.sh r04_c2 --config 2 --steps 200 --warmup 20 > /dev/null 2>&1
-bash tools/profile_round.sh r04_c5 --config 5 > /dev/null 2>&1
-bash tools/profile_round.sh r04_dgmm --config dgmm > /dev/null 2>&1
-bash tools/profile_round.sh r04_bemm --config bemm > /dev/null 2>&1
-bash tools/profile_round.sh r04_wide --config wide256 > /dev/null 2>&1
-for t in ns c2 c5 dgmm bemm wide; do python tools/summarize_prof.py gpurun_out/prof_r04_$t > gpurun_out/prof_r04_$t/summary.txt 2>&1; done
-mkdir -p gpurun_out/prof_r04_learn
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r04_learn/kt -o kt -- python3 tools/learn_bench.py 10000000 64 32 > gpurun_out/prof_r04_learn/kt.log 2>&1
-tail -3 gpurun_out/prof_r04_learn/kt.log
-grep -h "MFMA pipe busy\|^\[" gpurun_out/prof_r04_*/summary.txt
+mkdir -p gpurun_out/r04y
+python bench.py --config 5 --steps 5 --warmup 1 --no-cpu-baseline --no-parity > gpurun_out/r04y/bench5.log 2>&1
+python - <<'PY'
+import json
+l=[x for x in open('gpurun_out/r04y/bench5.log') if x.startswith('{')][-1]
+d=json.loads(l); print(d['ms_per_step'], d['kernels']['estep_ms'], d['kernels']['suffstat_ms'], d['roofline']['estep_frac'], d['roofline']['suffstat_frac'])
+PY
+python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py -m gpu -x -q 2>&1 | tail -2
+python tools/ssfeat_check.py 2>&1 | tail -20
+(python tools/fuzz_parity.py 1200 101; LC_FUZZ_CACHE=1 python tools/fuzz_learn.py 500 103; python tools/fuzz_learn.py 500 107; python tools/fuzz_kernels.py 300 109) > gpurun_out/r04y/fuzz.log 2>&1
+tail -12 gpurun_out/r04y/fuzz.log
