@@ -493,7 +493,30 @@ __global__ void __launch_bounds__(256, 2)
   // the next tile's rows are in flight while the current one is computed (registers: R x NT fragments)
   double xn[R][NT];
   int infon[R];
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);  // (wave-uniform: its arithmetic belongs on the scalar unit)
+  const int lane_x = lo4 * DP + 4 * hi;                     // this lane's offset inside a row group's 16 x DP block
   auto fetch = [&](int64_t tile) {
+    if constexpr (ONEGRP) {
+      // one group: everything about a tile's row groups but the lane's own offset is uniform -- a scalar base per row
+      // group and a 32-bit lane offset (the general form below costs ~ 40 VALU instructions of 64-bit address and
+      // bounds arithmetic per row group and tile)
+      const int64_t rg0 = (tile * 4 + wave_u) * R;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int64_t rg = rg0 + r;
+        const bool ok = tile < ntile && rg < nrg;
+        const int64_t rem = nrows - rg * RG;
+        infon[r] = !ok ? -1 : rem >= RG ? RG : (rem > 0 ? (int)rem : 0);
+        const double* xr = X + (ok ? rg : 0) * (int64_t)(RG * DP) + lane_x;
+#pragma unroll
+        for (int q = 0; q < NT / 4; ++q) {
+          const double2* p2 = reinterpret_cast<const double2*>(xr + 16 * q);
+          const double2 v0 = p2[0], v1 = p2[1];
+          xn[r][4 * q] = v0.x, xn[r][4 * q + 1] = v0.y, xn[r][4 * q + 2] = v1.x, xn[r][4 * q + 3] = v1.y;
+        }
+      }
+      return;
+    }
     const int64_t rg0 = (tile * 4 + wave) * R;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -955,25 +978,43 @@ __global__ void __launch_bounds__(256, 2) suffstat_diag_kernel(DiagStatLaunch a)
   }
 
   double pre[NPRE][2], qpre[NQ];
+  // Staging addresses = a UNIFORM base per batch (scalar registers) + per-lane offsets that are fixed for the whole
+  // chunk.  Formed inside the batch loop -- (b0 + row) * ldx, (kb0 + kk) * ldq + b0 + r, idx / BR, the bounds -- they
+  // were ~ 150 VALU instructions per thread and batch, 37 per 32-MFMA step: the kernel sat at 59 % of the pipe for them
+  // (PMC: 146 M non-MFMA VALU instructions per launch at D = 64, K = 32 against 160 M MFMAs).
+  int xoff[NPRE], xlds[NPRE], xrow[NPRE];
+#pragma unroll
+  for (int i = 0; i < NPRE; ++i) {
+    const int idx = tid + i * 256;  // double2 index inside the batch, row-major [BR][DP/2]
+    const int row = idx / (DP / 2), c2 = idx % (DP / 2);
+    xrow[i] = idx < NV2 ? row : BR;  // (BR: never inside a batch)
+    xoff[i] = row * (int)a.ldx + 2 * c2;
+    xlds[i] = row * LD + 2 * c2;
+  }
+  static_assert(256 % BR == 0, "a thread stages the same row of every q column it takes");
+  const int qr = tid % BR, qk0 = tid / BR;                  // q element i of this thread: cluster qk0 + i * (256 / BR), row qr
+  const int64_t qoff = (int64_t)qk0 * a.ldq + qr;
+  const int qlds0 = qk0 * QLD + qr;
   auto gload = [&](int64_t b0) {
+    const int64_t left64 = r1 - b0;
+    const int left = left64 < BR ? (int)left64 : BR;  // rows of this batch inside the chunk
+    const double* xb = a.X + b0 * a.ldx + a.col0;     // uniform
 #pragma unroll
     for (int i = 0; i < NPRE; ++i) {
-      const int idx = tid + i * 256;  // double2 index inside the batch, row-major [BR][DP/2]
-      const int row = idx / (DP / 2), c2 = idx % (DP / 2);
       double2 v = make_double2(0.0, 0.0);
-      if (idx < NV2 && b0 + row < r1)
-        v = *reinterpret_cast<const double2*>(a.X + (b0 + row) * a.ldx + a.col0 + 2 * c2);
+      if (xrow[i] < left) v = *reinterpret_cast<const double2*>(xb + xoff[i]);
       pre[i][0] = v.x;
       pre[i][1] = v.y;
     }
+    const bool qrow = qr < left;
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
-      const int idx = tid + i * 256;  // [SD_QMAX][BR]
-      const int kk = idx / BR, r = idx % BR;
+      const int kk = qk0 + i * (256 / BR);
+      const double* qc = a.qZ + ((int64_t)(kb0 + i * (256 / BR)) * a.ldq + b0);  // uniform
       double q = 0.0;
-      if (kk < kc && b0 + r < r1) {
-        q = a.qZ[(int64_t)(kb0 + kk) * a.ldq + b0 + r];
-        if (a.smask && !a.smask[(int64_t)(a.rginfo[(b0 + r) >> 4] >> 5) * K + kb0 + kk]) q = 0.0;
+      if (kk < kc && qrow) {
+        q = qc[qoff];
+        if (a.smask && !a.smask[(int64_t)(a.rginfo[(b0 + qr) >> 4] >> 5) * K + kb0 + kk]) q = 0.0;
       }
       qpre[i] = q;
     }
@@ -981,17 +1022,11 @@ __global__ void __launch_bounds__(256, 2) suffstat_diag_kernel(DiagStatLaunch a)
   auto lstore = [&](int buf) {
     double* xb = xbuf + buf * XBUF;
 #pragma unroll
-    for (int i = 0; i < NPRE; ++i) {
-      const int idx = tid + i * 256;
-      const int row = idx / (DP / 2), c2 = idx % (DP / 2);
-      if (idx < NV2) *reinterpret_cast<double2*>(xb + row * LD + 2 * c2) = make_double2(pre[i][0], pre[i][1]);
-    }
-    double* qb = qbuf + buf * SD_QMAX * QLD;
+    for (int i = 0; i < NPRE; ++i)
+      if (xrow[i] < BR) *reinterpret_cast<double2*>(xb + xlds[i]) = make_double2(pre[i][0], pre[i][1]);
+    double* qb = qbuf + buf * SD_QMAX * QLD + qlds0;
 #pragma unroll
-    for (int i = 0; i < NQ; ++i) {
-      const int idx = tid + i * 256;
-      qb[(idx / BR) * QLD + idx % BR] = qpre[i];
-    }
+    for (int i = 0; i < NQ; ++i) qb[i * (256 / BR) * QLD] = qpre[i];
   };
 
   if (r0 < r1) {

@@ -586,8 +586,14 @@ inline bool ss_feat_eligible(int DP, int K) {
   // measured (tools/ssfeat_check.py, MI355X): it wins where EVERY launch carries 7 or 8 cluster quads (one multiply per
   // 7-8 MFMAs): K = 28..32, 60..64, ...; a remainder launch with few quads costs a whole pass over X at a poor ratio
   // (K = 33: 6.8 against 5.8 ms at N = 2M), and with 5-6 quads the two kernels are level
+  // round 4, with chunk counts that fill the last round of resident blocks (suffstat_plan): at D <= 64 a remainder launch
+  // of 1 ... 7 quads pays as soon as it carries a whole quad's worth of clusters (D = 64: K = 36 +2 %, 40 +9 %, 48 +2 %,
+  // 56 +17 %; D = 48, K = 48 +12 %; D = 32, K = 40 +21 %; K = 33 still loses 12 %); D = 128 keeps the round-3 rule
+  // (K = 40 level, 48 -5 %) next to the 64-cluster ranges
   const int rem = K % 32;
-  return LC_SS_FEAT_WIDTHS(DP) && (rem == 0 || rem >= 28 || (ft_range(DP, K) == 64 && K >= 57));
+  if (!LC_SS_FEAT_WIDTHS(DP)) return false;
+  if (DP == 128) return rem == 0 || rem >= 28 || (ft_range(DP, K) == 64 && K >= 57);
+  return rem == 0 || rem >= 4;
 }
 template <int DP, int NQ>
 __global__ void __launch_bounds__(64 * ft_waves(DP), 2) suffstat_feat_kernel(SuffstatLaunch a) {

@@ -138,8 +138,8 @@ def test_ng_and_eg_mstep_match_oracle(lib):
 
 def test_statistics_kernel_selection_is_a_function_of_the_shape(lib, monkeypatch):
     """lc_statistics_kernel_name (no device needed): the dense Gauss-Wishart statistics pass runs as the feature GEMM
-    where every launch carries 7-8 cluster quads at a width it was measured to win at, as the per-cluster kernel
-    elsewhere -- a property of (D, K) alone, so every rank of a sharded run takes the same kernel."""
+    where it was measured to win (the widths with instances that do not spill; cluster counts whose remainder launch
+    carries at least four clusters), as the per-cluster kernel elsewhere -- a property of (D, K) alone, so every rank of a sharded run takes the same kernel."""
     monkeypatch.delenv("LC_SS_FEAT", raising=False)
     fn = lib.lc_statistics_kernel_name
     fn.restype = C.c_char_p
@@ -147,7 +147,12 @@ def test_statistics_kernel_selection_is_a_function_of_the_shape(lib, monkeypatch
     feat, per = b"suffstat_feat_kernel", b"suffstat_kernel"
     assert fn(64, 32) == feat and fn(61, 30) == feat and fn(64, 28) == feat and fn(64, 64) == feat
     assert fn(128, 64) == feat and fn(32, 32) == feat and fn(48, 29) == feat
-    assert fn(64, 8) == per and fn(64, 16) == per and fn(64, 24) == per and fn(64, 33) == per and fn(64, 48) == per
+    # round 4 (chunk counts that fill the last round of resident blocks): at D <= 64 a remainder launch pays from four
+    # clusters on; D = 128 takes 64 clusters in one pass for K mod 64 in {0, 57 ... 63}
+    assert fn(64, 24) == feat and fn(64, 48) == feat and fn(64, 36) == feat and fn(32, 40) == feat
+    assert fn(128, 60) == feat and fn(128, 128) == feat and fn(128, 121) == feat
+    assert fn(128, 40) == per and fn(128, 48) == per
+    assert fn(64, 8) == per and fn(64, 16) == per and fn(64, 33) == per and fn(64, 35) == per
     assert fn(80, 32) == per and fn(96, 32) == per and fn(112, 32) == per   # (their 8-quad instances spill)
     assert fn(16, 32) == per and fn(256, 32) == per
 

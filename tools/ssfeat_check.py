@@ -17,7 +17,7 @@ CASES = [(1000, 64, 17), (4099, 64, 20), (777, 50, 24), (30001, 64, 29), (65536,
          (3001, 112, 40), (6000, 128, 32), (5001, 128, 64), (2000, 100, 65), (3000, 64, 64), (2500, 64, 45),
          # D = 128: ranges of 64 clusters in one pass (16 quads), full and ragged, one and two ranges
          (3000, 128, 57), (2777, 120, 60), (2100, 128, 128), (1900, 128, 121)]
-TIMING = [(4000000, 32, 32), (4000000, 32, 40), (2000000, 48, 32), (2000000, 48, 48), (2000000, 64, 32), (2000000, 64, 28),
+TIMING = [(2000000, 64, 17), (2000000, 64, 20), (2000000, 64, 24), (4000000, 32, 20), (2000000, 48, 24), (4000000, 32, 32), (4000000, 32, 40), (2000000, 48, 32), (2000000, 48, 48), (2000000, 64, 32), (2000000, 64, 28),
           (2000000, 64, 33), (2000000, 64, 36), (2000000, 64, 40), (2000000, 64, 48), (2000000, 64, 56), (2000000, 64, 64),
           (1000000, 128, 32), (1000000, 128, 28), (1000000, 128, 40), (1000000, 128, 48), (1000000, 128, 64)]
 
