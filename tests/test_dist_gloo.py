@@ -73,11 +73,12 @@ def _worker(rank, world, port, N, D, K, iters, out):
         dist.destroy_process_group()
 
 
-def test_two_rank_gloo_em_matches_single_process(tmp_path, lib):
+@pytest.mark.parametrize("world", [2, 8])  # (8: the world the driver's scaling run ends at; unequal shards of 62 / 63 rows)
+def test_two_rank_gloo_em_matches_single_process(tmp_path, lib, world):
     import torch.multiprocessing as mp
 
     out = str(tmp_path / "f.npy")
-    mp.spawn(_worker, args=(2, _free_port(), 501, 5, 3, 3, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), 501, 5, 3, 3, out), nprocs=world, join=True)
     F = np.load(out)
     np.testing.assert_allclose(F[0], F[1], rtol=1e-11)
 
