@@ -56,7 +56,10 @@ __device__ __forceinline__ void fill_exp_table(double* etab, int tid, int nthrea
   for (int i = tid; i < 64; i += nthreads) etab[i] = LC_EXP2_TAB[i];
 }
 __device__ __forceinline__ double exp_nonpos(double x, const double* etab) {
-  x = max_raw(x, -750.0);  // (exp(-750) = 0; keeps n finite for x = -inf)
+  // (exp(-750) = 0; keeps n finite for x = -inf.  fmax, not the asm max_raw: the argument is the result of a subtraction,
+  //  which hipcc knows to be canonical -- one v_max_f64 -- and inline asm counts as convergent, which keeps the sweeps'
+  //  run-time loops from being unrolled)
+  x = fmax(x, -750.0);
   const double n = __builtin_rint(x * 0x1.71547652b82fep+6);      // 64 / ln 2
   double r = fma(n, -0x1.62e42fef00000p-7, x);                    // ln 2 / 64, 33 significant bits: n * C1 is exact
   r = fma(n, -0x1.473de6af278edp-40, r);
