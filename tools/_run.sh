@@ -1,4 +1,6 @@
-python -m pytest tests/test_gpu_parity.py tests/test_gpu_families.py tests/test_gpu_splitsearch.py -m gpu -x -q 2>&1 | tail -2
-LC_VARIANT_REPEAT=3 python tools/variants.py run --iters 12 pre_fmax
-LC_VARIANT_REPEAT=2 python tools/variants.py run --fam ng --iters 12 pre_fmax
-LC_VARIANT_REPEAT=2 python tools/variants.py run --shape "1000000,16,8" --iters 300 pre_fmax
+mkdir -p gpurun_out/r04z
+python bench.py --steps 20 --warmup 5 > gpurun_out/r04z/bench_line.json 2> gpurun_out/r04z/bench_err.log
+tail -c 200 gpurun_out/r04z/bench_line.json
+python -m pytest tests -m gpu -x -q > gpurun_out/r04z/pytest_full.log 2>&1; echo "rc=$?" >> gpurun_out/r04z/pytest_full.log
+tail -3 gpurun_out/r04z/pytest_full.log
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
