@@ -234,6 +234,7 @@ Context::~Context() {
     (void)hipEventDestroy(p.a);
     (void)hipEventDestroy(p.b);
   }
+  for (hipEvent_t e : evpool_) (void)hipEventDestroy(e);
 }
 
 void Context::synchronize() const {
@@ -788,8 +789,8 @@ void Context::allreduce(double* dbuf, int64_t count) {
   if (!comm_ && !ar_fn_) return;
   EvPair ev{};
   if (timing_) {  // events around the exchange step: the sum plus the wait for the slowest rank
-    LC_HIP(hipEventCreate(&ev.a));
-    LC_HIP(hipEventCreate(&ev.b));
+    ev.a = timing_event();
+    ev.b = timing_event();
     ev.kind = 3;
     LC_HIP(hipEventRecord(ev.a, stream_));
   }
@@ -918,8 +919,8 @@ void Context::estep(int K, const double* A, const double* m, const double* c, do
     if (c[t] == -std::numeric_limits<double>::infinity()) a.sparse = 1;
   EvPair ev{};
   if (timing_) {
-    LC_HIP(hipEventCreate(&ev.a));
-    LC_HIP(hipEventCreate(&ev.b));
+    ev.a = timing_event();
+    ev.b = timing_event();
     ev.kind = 0;
     LC_HIP(hipEventRecord(ev.a, stream_));
   }
@@ -1002,8 +1003,8 @@ bool Context::estep_suffstat_fused(int K, const double* A, const double* m, cons
   a.ngroups = J_;
   EvPair ev{};
   if (timing_) {
-    LC_HIP(hipEventCreate(&ev.a));
-    LC_HIP(hipEventCreate(&ev.b));
+    ev.a = timing_event();
+    ev.b = timing_event();
     ev.kind = 2;
     LC_HIP(hipEventRecord(ev.a, stream_));
   }
@@ -1203,8 +1204,8 @@ void Context::suffstat(const unsigned char* smask, double* Nk, double* xs, doubl
     a.chunk_rows = chunk_rows;
     EvPair ev{};
     if (timing_) {
-      LC_HIP(hipEventCreate(&ev.a));
-      LC_HIP(hipEventCreate(&ev.b));
+      ev.a = timing_event();
+      ev.b = timing_event();
       ev.kind = 1;
       LC_HIP(hipEventRecord(ev.a, stream_));
     }
@@ -1526,8 +1527,8 @@ int Context::estep_cache(int K, const double* A, const double* m, const double* 
     }
     EvPair ev{};
     if (timing_) {
-      LC_HIP(hipEventCreate(&ev.a));
-      LC_HIP(hipEventCreate(&ev.b));
+      ev.a = timing_event();
+      ev.b = timing_event();
       ev.kind = 0;
       LC_HIP(hipEventRecord(ev.a, stream_));
     }
@@ -1735,8 +1736,8 @@ void Context::estep_diag(int K, const double* av, const double* w2, const double
   }
   EvPair ev{};
   if (timing_) {
-    LC_HIP(hipEventCreate(&ev.a));
-    LC_HIP(hipEventCreate(&ev.b));
+    ev.a = timing_event();
+    ev.b = timing_event();
     ev.kind = 0;
     LC_HIP(hipEventRecord(ev.a, stream_));
   }
@@ -1806,8 +1807,8 @@ void Context::suffstat_diag(const unsigned char* smask, double* Nk, double* xs, 
     a.second = xxs ? 1 : 0;
     EvPair ev{};
     if (timing_) {
-      LC_HIP(hipEventCreate(&ev.a));
-      LC_HIP(hipEventCreate(&ev.b));
+      ev.a = timing_event();
+      ev.b = timing_event();
       ev.kind = 1;
       LC_HIP(hipEventRecord(ev.a, stream_));
     }
@@ -1871,11 +1872,31 @@ KernelTimes Context::timing_get() {
       times_.suffstat_ms += ms;
       times_.suffstat_calls += 1;
     }
-    (void)hipEventDestroy(p.a);
-    (void)hipEventDestroy(p.b);
+    evpool_.push_back(p.a);  // (back to the pool: creating an event costs microseconds, and a timed iteration of the
+    evpool_.push_back(p.b);  //  small configuration lasts 180 of them)
   }
   pending_.clear();
   return times_;
+}
+
+hipEvent_t Context::timing_event() {
+  if (!evpool_.empty()) {
+    hipEvent_t e = evpool_.back();
+    evpool_.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  LC_HIP(hipEventCreate(&e));
+  return e;
+}
+
+void Context::timing_prepare(int events) {
+  use_device();
+  while ((int)evpool_.size() < events) {
+    hipEvent_t e = nullptr;
+    LC_HIP(hipEventCreate(&e));
+    evpool_.push_back(e);
+  }
 }
 
 void Context::timing_reset() {

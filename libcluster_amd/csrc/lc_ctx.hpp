@@ -252,7 +252,10 @@ class Context {
   }
 
   // ---- timing ---------------------------------------------------------------
-  void timing_enable(bool on) { timing_ = on; }
+  void timing_enable(bool on) {
+    timing_ = on;
+    if (on) timing_prepare(1024);  // (two events per timed launch: created here, outside anybody's timed region)
+  }
   bool timing_enabled() const { return timing_; }
   void timing_host_phases(double stats_ms, double mstep_ms, double estep_ms, double fenergy_ms) {  // one VBEM iteration
     times_.host_stats_ms += stats_ms;
@@ -262,6 +265,7 @@ class Context {
     times_.host_iters += 1;
   }
   KernelTimes timing_get();  // resolves pending events (synchronises the stream)
+  void timing_prepare(int events);  // events created ahead of a timed region (they are recycled afterwards)
   void timing_reset();
 
  private:
@@ -338,6 +342,8 @@ class Context {
     int kind;
   };
   std::vector<EvPair> pending_;
+  std::vector<hipEvent_t> evpool_;  // recycled timing events
+  hipEvent_t timing_event();
   KernelTimes times_;
 };
 
