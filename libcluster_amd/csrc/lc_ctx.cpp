@@ -988,6 +988,7 @@ bool Context::estep_suffstat_fused(int K, const double* A, const double* m, cons
   double* njk_d = ssout_.p + nrec;
   lck::FusedLaunch a;
   a.DP = DP;
+  a.D = D;
   a.X = X_.p;
   a.nrg = nrg;
   a.rginfo = J_ > 1 ? rginfo_.p : nullptr;

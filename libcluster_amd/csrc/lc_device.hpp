@@ -24,7 +24,10 @@ __device__ __forceinline__ double mfma4(double a, double b, double c) {
 }
 
 // max without the canonicalising self-max hipcc puts in front of fmax (three v_max_f64 per call where one does;
-// the operands here are never signalling NaNs)
+// the operands here are never signalling NaNs).  NOT for an operand that an MFMA has just written: the hazard recogniser
+// does not look inside inline asm, so the wait states an MFMA result needs before a VALU read are not inserted in front
+// of it -- use fmax there (seen as NaN rows out of the half-width fused instance, whose last chain link sits right in
+// front of the max).
 __device__ __forceinline__ double max_raw(double a, double b) {
   asm("v_max_f64 %0, %1, %2" : "=v"(a) : "v"(a), "v"(b));
   return a;

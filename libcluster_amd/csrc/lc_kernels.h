@@ -79,6 +79,7 @@ hipError_t launch_estep(const EstepLaunch& a, hipStream_t stream);
 // ---- small observations: E-step + the next iteration's statistics in one persistent pass (lc_kernels_fused.hip) ----
 struct FusedLaunch {
   int DP;
+  int D = 16;            // observation width before padding (D <= 8: the half-width instance)
   const double* X;       // [NP x DP]
   int64_t nrg;           // row groups (NP / 16)
   const int* rginfo;     // [nrg] or nullptr (single group)

@@ -613,7 +613,7 @@ __global__ void __launch_bounds__(256, 2)
       const int k = 4 * it + hi;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        mx[r] = max_raw(mx[r], v[r]);
+        mx[r] = fmax(mx[r], v[r]);  // (v is an MFMA result: see max_raw)
         if (raw && k < K && rgok[r]) qZ[(int64_t)k * ldq + (rg0 + r) * RG + lo4] = v[r];
       }
     };

@@ -49,16 +49,21 @@ constexpr int FUSED_QS = FUSED_ROWS + 2;  // q table: 258 doubles per cluster = 
 // four chained MFMAs  t = sum_r A_r d2_r + c  with selector operands A_r[i][.] = -1/2 [i == r]  leave
 // log q~ = c - d^2 / 2 of row group `hi` in lane (lo4, hi) directly: no select, no branch, no VALU; (iii) c_k is read at
 // the head of the cluster it belongs to and rides into the chain as its C operand.
-template <int DP, int CPW, int GRP, bool WANT_LL>
+// NTA: tile rows of the whitener / 4-column blocks of X that are not identically zero: 4, or 2 for D <= 8 (the layout is
+// the DP = 16 one either way -- `Xcat`'s two columns are padded eightfold -- but the tiles of rows and columns 8 ... 15 are
+// zeros there: the E-step half then walks 5 of a cluster's 14 reads (20 + 4 MFMAs instead of 40 + 4) and the statistics
+// half 5 of its 12 feature tiles; what is left out is written as zeros).
+template <int DP, int CPW, int GRP, bool WANT_LL, int NTA = 4>
 __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
   constexpr bool ONEGRP = GRP == 0, CTLDS = GRP != 2;
+  static_assert(NTA == 2 || NTA == 4, "active tile rows");
   FusedLaunch a = a_;
   if constexpr (ONEGRP) a.rginfo = nullptr;
   static_assert(DP == 16, "one 16 x 16 block of S_k (the general blocking lives in suffstat_kernel)");
   constexpr int NT = DP / 4;
   constexpr int NTILES = NT * (NT + 1) / 2;
-  constexpr int NREAD = NTILES + NT;
-  constexpr int PF = 7;
+  constexpr int NREAD = NTA * (NTA + 1) / 2 + NTA;  // reads of the first NTA tile rows: a prefix of the cluster's stream
+  constexpr int PF = NTA == 4 ? 7 : 5;
   static_assert(NREAD % PF == 0, "the ring's slots must line up from one cluster to the next");
   constexpr int PS = NTILES * 16 + DP;
   // row stride of the staged tile (36 dwords).  E-step half: a half-wave reads rows lo4 = 0..15 at two columns -- 36 lo4
@@ -69,6 +74,8 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
   constexpr int R = 4;
   static_assert(4 * CPW <= FUSED_KMAX, "statistics accumulators");
   constexpr int NQ = CPW, NTL = 12;    // cluster quads; feature tiles: 10 patches (ia <= ja), s_k, N_k
+  // active feature tiles: the patches with ja < NTA (the first NTA (NTA + 1) / 2 of the enumeration), then s_k and N_k
+  constexpr int NPA = NTA * (NTA + 1) / 2, NTLA = NPA + 2;
   constexpr int QS = FUSED_QS;         // row stride of the q table: consecutive clusters 8 banks apart
   constexpr int ONE = DP;              // column of the staged tile that holds 1.0
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -94,9 +101,9 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
   for (int i = tid; i < 4 * NQ * QS; i += 256) qt[i] = 0.0;
   xt[tid * LD + ONE] = 1.0;  // (the staging below writes columns 0 .. DP - 1 only)
   fill_exp_table(etab, tid, 256);
-  double acc[NTL][NQ];
+  double acc[NTLA][NQ];  // [patches | s_k | N_k]
 #pragma unroll
-  for (int t = 0; t < NTL; ++t)
+  for (int t = 0; t < NTLA; ++t)
 #pragma unroll
     for (int c = 0; c < NQ; ++c) acc[t][c] = 0.0;
   // selector operands of the lane-sum chain: A_r[i = lo2][k = hi] = -1/2 [lo2 == r]
@@ -174,7 +181,7 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
     for (int r = 0; r < R; ++r) {
       const double* xr = xt + (wave * 64 + r * 16 + lo4) * LD + hi;
 #pragma unroll
-      for (int jt = 0; jt < NT; ++jt) xf[r][jt] = xr[4 * jt];
+      for (int jt = 0; jt < NT; ++jt) xf[r][jt] = jt < NTA ? xr[4 * jt] : 0.0;
     }
     // the constant of cluster k for this lane's row group
     auto cjk_of = [&](int k) -> double {
@@ -221,30 +228,28 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
 #pragma unroll
           for (int r = 0; r < R; ++r) d2P[r] = fma(accP[r], accP[r], d2P[r]);
         }
-        if constexpr (n == 3) t = mfma4(selA[0], d2P[0], cP);
-        if constexpr (n == 4) {
-          t = mfma4(selA[1], d2P[1], t);
+        // the four links of the previous cluster's lane-sum chain (NTA = 4: behind reads 3, 4, 6, 7; NTA = 2: 2, 3, 4, 4)
+        constexpr int L0 = NTA == 4 ? 3 : 2, L1 = NTA == 4 ? 4 : 3, L2 = NTA == 4 ? 6 : 4, L3 = NTA == 4 ? 7 : 4;
+        if constexpr (n == L0) t = mfma4(selA[0], d2P[0], cP);
+        if constexpr (n == L1) t = mfma4(selA[1], d2P[1], t);
+        if constexpr (n == L2) t = mfma4(selA[2], d2P[2], t);
+        if constexpr (n == L3) t = mfma4(selA[3], d2P[3], t);
+        // tile row it - 1 is squared behind tile (it, 1), under the MFMAs of row it (the last row waits for the next cluster)
+        if constexpr (ri.jt == 1 && ri.it >= 1) {
+          constexpr int pset = (ri.it - 1) & 1;
 #pragma unroll
-          for (int r = 0; r < R; ++r) d2[r] = accs[0][r] * accs[0][r];  // tile row 0
+          for (int r = 0; r < R; ++r)
+            d2[r] = ri.it == 1 ? accs[pset][r] * accs[pset][r] : fma(accs[pset][r], accs[pset][r], d2[r]);
         }
-        if constexpr (n == 6) t = mfma4(selA[2], d2P[2], t);
-        if constexpr (n == 7) {
-          t = mfma4(selA[3], d2P[3], t);
-#pragma unroll
-          for (int r = 0; r < R; ++r) d2[r] = fma(accs[1][r], accs[1][r], d2[r]);  // tile row 1
-        }
-        if constexpr (n == 11) {
-#pragma unroll
-          for (int r = 0; r < R; ++r) d2[r] = fma(accs[0][r], accs[0][r], d2[r]);  // tile row 2
-        }
-        if constexpr (n == 12) {  // log q~ of cluster k - 1 for this lane's row: its own slot (no barrier before it reads it back)
-          mymx = max_raw(mymx, t);
+        if constexpr (n == NREAD - 2 + (NTA == 2 ? 1 : 0)) {  // log q~ of cluster k - 1 for this lane's row: its own slot (no barrier before it reads it back)
+          mymx = fmax(mymx, t);  // (fmax, not the asm max_raw: t comes straight out of an MFMA, and the compiler only counts the
+                                 //  wait states between an MFMA and its reader for instructions it emitted itself)
           *qslot = t;
         }
         __builtin_amdgcn_sched_barrier(0);
       });
 #pragma unroll
-      for (int r = 0; r < R; ++r) accP[r] = accs[1][r], d2P[r] = d2[r];  // tile row 3 is squared under the next cluster
+      for (int r = 0; r < R; ++r) accP[r] = accs[(NTA - 1) & 1][r], d2P[r] = d2[r];  // the last tile row is squared under the next cluster
       cP = cK;
     }
     {  // the last cluster's tail
@@ -331,14 +336,14 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
       // s_k fragment and the ones) are read while step s4's products and MFMAs issue -- left to itself hipcc reads them
       // right in front of their use and every step starts with an exposed LDS round trip
       struct StepOps {
-        double qa[NQ], u[4], w[4], s, one;
+        double qa[NQ], u[NTA], w[NTA], s, one;
       };
       auto load = [&](auto sc, StepOps& o) {
         constexpr int s4 = decltype(sc)::value, ro = s4 * 16 * LD;
 #pragma unroll
         for (int c = 0; c < NQ; ++c) o.qa[c] = qb[4 * c * QS + s4 * 16];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o.u[i] = xu[ro + 4 * i], o.w[i] = xw[ro + 4 * i];
+        for (int i = 0; i < NTA; ++i) o.u[i] = xu[ro + 4 * i], o.w[i] = xw[ro + 4 * i];
         o.s = xs[ro];
         o.one = x1[ro];
       };
@@ -349,13 +354,13 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
         StepOps nxt = cur;
         if constexpr (s4 + 1 < FUSED_ROWS / 16) load(std::integral_constant<int, s4 + 1>{}, nxt);
         __builtin_amdgcn_sched_barrier(0);
-        static_for<NTL>([&](auto tc) {
+        static_for<NTLA>([&](auto tc) {
           constexpr int t = tc;
           double p;
-          if constexpr (t < 10) {
+          if constexpr (t < NPA) {
             constexpr int ja = t < 1 ? 0 : t < 3 ? 1 : t < 6 ? 2 : 3, ia = t - ja * (ja + 1) / 2;
             p = cur.u[ia] * cur.w[ja];
-          } else if constexpr (t == 10) {
+          } else if constexpr (t == NPA) {
             p = cur.s;
           } else {
             p = cur.one;
@@ -383,8 +388,11 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
         for (int t = 0; t < NTL; ++t)
 #pragma unroll
           for (int c = 0; c < NQ; ++c) {
+            // record tile t: patch t (t < 10), s_k (10), N_k (11) <- accumulator slot; the tiles left out are zeros
+            const int slot = t < NPA ? t : t == 10 ? NPA : t == 11 ? NPA + 1 : -1;
+            const double v = slot >= 0 ? acc[slot >= 0 ? slot : 0][c] : 0.0;
             double* r = red + (t * NQ + c) * 64 + lane;
-            *r = w == 0 ? acc[t][c] : *r + acc[t][c];
+            *r = w == 0 ? v : *r + v;
           }
       }
       __syncthreads();
@@ -461,7 +469,10 @@ static hipError_t launch_fused_t(const FusedLaunch& a, hipStream_t stream, size_
     hipLaunchKernelGGL(kern, dim3((unsigned)a.grid), dim3(256), shmem, stream, a);
     return hipGetLastError();
   };
-  static LdsGrant grants[2];
+  static LdsGrant grants[4];
+  static const bool full_only = getenv("LC_FUSED_FULL") != nullptr;  // (A/B: the full-width instance at every D)
+  if (a.D <= 8 && !full_only)  // (columns 8 ... 15 of the padded layout are zeros: the half-width instance)
+    return a.want_ll ? go(fused_small_kernel<16, CPW, GRP, true, 2>, grants[3]) : go(fused_small_kernel<16, CPW, GRP, false, 2>, grants[2]);
   return a.want_ll ? go(fused_small_kernel<16, CPW, GRP, true>, grants[1]) : go(fused_small_kernel<16, CPW, GRP, false>, grants[0]);
 }
 

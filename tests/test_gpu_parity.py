@@ -465,6 +465,42 @@ def test_randomised_kernel_fuzz():
     assert "60 cases" in r.stdout and " 0 failures" in r.stdout
 
 
+@pytest.mark.parametrize("D", [2, 5, 8, 9])
+def test_fused_pass_on_hard_labels_after_a_split(D):
+    """One VBEM iteration from hard labels with one cluster cut in two along its principal axis (what model selection
+    hands the fused pass): at D <= 8 this is the half-width instance, whose last lane-sum link sits right in front of
+    the row maximum -- an MFMA result read too early there once gave NaN rows in this very case."""
+    rng = np.random.default_rng(3)
+    K, N = 3, 2000
+    mu = rng.normal(0, 5, (K, D))
+    z = rng.integers(0, K, N)
+    X = mu[z] + rng.normal(size=(N, D))
+    idx = np.flatnonzero(z == 0)
+    Xk = X[idx] - X[idx].mean(0)
+    v = np.linalg.eigh(np.atleast_2d(np.cov(Xk.T)))[1][:, -1]
+    qa = np.zeros((N, K + 1))
+    qa[np.arange(N), z] = 1.0
+    mv = idx[Xk @ v < 0]
+    qa[mv, K], qa[mv, 0] = 1.0, 0.0
+    w = o.StickBreak()
+    cl = [o.GaussWish(1.0, D) for _ in range(K + 1)]
+    w.update(o.updateSS(X, qa, cl))
+    for c in cl:
+        c.update()
+    qref, _ = o.vbexpectation(X, w, cl)
+    with capi.Context(0) as ctx:
+        ctx.set_data(X)
+        ctx.set_qz(qa)
+        F, tr, m = ctx.vbem(capi.W_STICKBREAK, fixed_iters=1)
+        q1 = ctx.get_qz([N])[0]
+        Nk, xs, xxs, _ = ctx.suffstat()
+        m.close()
+    assert np.isfinite(q1).all() and np.isfinite(tr).all()
+    assert_q_close(q1, qref)
+    np.testing.assert_allclose(Nk, qref.sum(0), rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(xs, qref.T @ X, rtol=1e-9, atol=1e-9)
+
+
 def test_mahaldist_matches_numpy():
     """probutils::mahaldist (probutils.cpp:113-138) on the GPU: ragged groups, narrow and wide D, SPD A; non-PD is
     refused."""

@@ -197,10 +197,13 @@ def test_roofline_traffic_json_is_generated_from_the_committed_summaries():
 def test_estep_kernel_isa_keeps_the_promises_its_inline_asm_relies_on():
     """estep_kernel writes M0 and loads c_jk in inline asm that hipcc's waitcnt pass cannot see (lc_kernels_estep.hip);
     tools/check_isa.py compiles the device code and asserts on the ISA of every instance: no scratch, M0 named only by
-    the LDS-direct load pairs, nothing touching an asm load's destination before its s_waitcnt vmcnt(0)."""
+    the LDS-direct load pairs, nothing touching an asm load's destination before its s_waitcnt vmcnt(0); and, over the
+    estep / fused / diag kernels, no inline-asm statement reading an MFMA result inside the MFMA's hazard window (the
+    compiler does not count wait states for asm: the round-4 NaN rows of the half-width fused instance)."""
     import subprocess
     import sys
 
     r = subprocess.run([sys.executable, str(ROOT / "tools" / "check_isa.py")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "estep_kernel instances: ok" in r.stdout
+    assert "inline-asm statements behind MFMAs in 3 files: ok" in r.stdout

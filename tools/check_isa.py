@@ -12,6 +12,11 @@ This script compiles the device code to assembly (or reads a given .s) and asser
      (nothing else in the kernel depends on M0, so writing it unannounced is safe);
   3. between an inline-asm `global_load_dwordx2 vA, vOff, s[..]` and the next `s_waitcnt vmcnt(0)` no instruction reads
      or writes the destination registers vA.
+And for every kernel of lc_kernels_estep / _fused / _diag.hip:
+  4. no inline-asm statement reads a VGPR that a v_mfma wrote fewer than MFMA_WAIT wait states earlier.  The hazard
+     recogniser counts the wait states between an MFMA and a VALU reader only for instructions it emitted itself; an
+     asm `v_max_f64` right behind the last link of an MFMA chain read a stale register (NaN rows out of the half-width
+     fused instance, round 4).  MFMA results go through compiler-generated instructions (fmax) before any asm sees them.
 Exit status 0 = all hold.  Run by tests/test_host.py (CPU: hipcc cross-compiles)."""
 import re
 import subprocess
@@ -22,16 +27,60 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
 
 
-def device_asm() -> str:
+MFMA_WAIT = 19  # the longest MFMA -> VALU-read distance of the CDNA3/4 hazard tables (16-pass); the 4x4x4 f64 needs fewer
+ASM_FILES = ("lc_kernels_estep.hip", "lc_kernels_fused.hip", "lc_kernels_diag.hip")
+
+
+def device_asm(name="lc_kernels_estep.hip", src=None) -> str:
     sys.path.insert(0, str(ROOT))
     from libcluster_amd import build as b
 
     with tempfile.TemporaryDirectory() as td:
-        out = Path(td) / "estep.s"
+        out = Path(td) / "k.s"
         cmd = [b._hipcc(), f"--offload-arch={b.ARCH}", *b.DEVICE_FLAGS, "-O3", "-std=c++17", "-fPIC", f"-I{ROOT / 'include'}",
-               "-S", "--cuda-device-only", str(b.CSRC / "lc_kernels_estep.hip"), "-o", str(out)]
+               f"-I{b.CSRC}", "-S", "--cuda-device-only", str(src or b.CSRC / name), "-o", str(out)]
         subprocess.run(cmd, check=True, capture_output=True)
         return out.read_text()
+
+
+def check_mfma_into_asm(asm: str):
+    """Check 4 over every function of one assembly file -> (problems, number of asm statements looked at)."""
+    problems, nasm = [], 0
+    for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)\n\.Lfunc_end\d+:", asm, re.S | re.M):
+        name, body = m.group(1), m.group(2).splitlines()
+        recent = []  # (registers written by an MFMA, wait states since)
+        in_asm = False
+        for ln in body:
+            t = ln.strip()
+            if t.startswith(";;#ASMSTART"):
+                in_asm = True
+                continue
+            if t.startswith(";;#ASMEND"):
+                in_asm = False
+                continue
+            op, ops = operands(ln)
+            if not op:
+                continue
+            if in_asm:
+                nasm += 1
+                # stores have no destination; everything else writes its first operand and reads the rest
+                srcs = ops if op.startswith(("global_store", "ds_write", "buffer_store")) else ops[1:]
+                read = set().union(*[regs(o) for o in srcs]) if srcs else set()
+                for wr, age in recent:
+                    if wr & read and age < MFMA_WAIT:
+                        problems.append(f"{name}: inline asm `{t}` reads v{sorted(wr & read)} {age} wait states after the MFMA that "
+                                        f"wrote them (needs {MFMA_WAIT} or a compiler-generated reader in between)")
+            step = 1
+            if op == "s_nop" and ops and ops[0].isdigit():
+                step = int(ops[0]) + 1
+            recent = [(wr, age + step) for wr, age in recent if age + step < MFMA_WAIT]
+            if op.startswith("v_mfma") and ops:
+                recent.append((regs(ops[0]), 0))
+            elif not in_asm and ops:
+                # a compiler-generated instruction that overwrites an MFMA result ends that result's hazard window
+                w = regs(ops[0])
+                recent = [(wr - w, age) for wr, age in recent if wr - w]
+    return problems, nasm
 
 
 def regs(tok: str):
@@ -92,11 +141,31 @@ def check(asm: str):
 
 
 def main():
-    asm = Path(sys.argv[1]).read_text() if len(sys.argv) > 1 else device_asm()
-    problems, seen = check(asm)
+    if len(sys.argv) > 2 and sys.argv[1] == "--mfma-asm":  # check 4 alone, on a given source file (or .s)
+        p = Path(sys.argv[2])
+        problems, nasm = check_mfma_into_asm(p.read_text() if p.suffix == ".s" else device_asm(src=p))
+        for q in problems:
+            print("ISA check:", q)
+        print(f"checked {nasm} inline-asm statements behind MFMAs: {'FAILED' if problems else 'ok'}")
+        sys.exit(1 if problems else 0)
+    if len(sys.argv) > 1:
+        asms = {"given": Path(sys.argv[1]).read_text()}
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+
+        with ThreadPoolExecutor(len(ASM_FILES)) as ex:
+            asms = dict(zip(ASM_FILES, ex.map(device_asm, ASM_FILES)))
+    first = next(iter(asms.values()))
+    problems, seen = check(first)
+    nasm = 0
+    for name, asm in asms.items():
+        p4, n4 = check_mfma_into_asm(asm)
+        problems += [f"[{name}] {q}" for q in p4]
+        nasm += n4
     for p in problems:
         print("ISA check:", p)
     print(f"checked {seen} estep_kernel instances: {'FAILED' if problems else 'ok'}")
+    print(f"checked {nasm} inline-asm statements behind MFMAs in {len(asms)} files: {'FAILED' if problems else 'ok'}")
     sys.exit(1 if problems else 0)
 
 
