@@ -952,7 +952,9 @@ __global__ void __launch_bounds__(256, 2) suffstat_diag_kernel(DiagStatLaunch a)
   constexpr int BR = DP <= 64 ? 32 : 16;
   constexpr int LD = lds_row_stride(DP), XBUF = BR * LD;
   constexpr int NV2 = BR * DP / 2, NPRE = (NV2 + 255) / 256;   // double2 per thread and batch
-  constexpr int NQ = SD_QMAX * BR / 256;                       // q elements per thread and batch
+  constexpr int QCAP = SD_QMAX / RS;                           // clusters a block with RS row classes can hold (suffstat_diag_rsplit)
+  constexpr int NQ = QCAP * BR / 256;                          // q elements per thread and batch
+  static_assert(NQ >= 1 && NQ * 256 == QCAP * BR, "whole q columns per thread");
   constexpr int QLD = BR + 4;                                  // padded q column stride: conflict-free A fragments
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* xbuf = lds;                // [2][BR][LD]
@@ -977,7 +979,14 @@ __global__ void __launch_bounds__(256, 2) suffstat_diag_kernel(DiagStatLaunch a)
     for (int jb = 0; jb < NB; ++jb) acc1[c][jb] = acc2[c][jb] = 0.0;
   }
 
-  double pre[NPRE][2], qpre[NQ];
+  // Two batches in flight (DP <= 96: the second register set spills next to 128 accumulator registers beyond): with
+  // one, a block asked for batch b + 1 at the top of batch b and needed it ~ 1 us of MFMAs later -- about one HBM round
+  // trip under load, so the kernel sat at 3.8 TB/s waiting for its single batch.  Set (b & 1) now receives batch b + 2
+  // while batch b is multiplied out of LDS and batch b + 1 moves from the other set into the other LDS buffer; the batch
+  // loop is unrolled twice so that set and buffer are compile-time names (registers, not scratch).
+  constexpr bool DEEP = DP <= 96;
+  constexpr int NSET = DEEP ? 2 : 1, AHEAD = DEEP ? 2 : 1;
+  double pre[NSET][NPRE][2], qpre[NSET][NQ];
   // Staging addresses = a UNIFORM base per batch (scalar registers) + per-lane offsets that are fixed for the whole
   // chunk.  Formed inside the batch loop -- (b0 + row) * ldx, (kb0 + kk) * ldq + b0 + r, idx / BR, the bounds -- they
   // were ~ 150 VALU instructions per thread and batch, 37 per 32-MFMA step: the kernel sat at 59 % of the pipe for them
@@ -995,99 +1004,137 @@ __global__ void __launch_bounds__(256, 2) suffstat_diag_kernel(DiagStatLaunch a)
   const int qr = tid % BR, qk0 = tid / BR;                  // q element i of this thread: cluster qk0 + i * (256 / BR), row qr
   const int64_t qoff = (int64_t)qk0 * a.ldq + qr;
   const int qlds0 = qk0 * QLD + qr;
-  auto gload = [&](int64_t b0) {
+  // The loads of a batch are straight-line code without a use of what they return: a load under a branch (a row bound, a
+  // cluster bound, "is there another batch") makes the number of loads in flight a run-time quantity, and a select on a
+  // loaded value in front of the MFMAs is a wait for it -- either way the compiler ends up at `s_waitcnt vmcnt(0)` before
+  // the older set is used: one batch in flight again.  So every load is issued always -- a lane outside the batch (or a
+  // batch outside the chunk: left <= 0) reads a valid stand-in address -- and the zeros for such lanes are chosen when the
+  // set is stored to LDS, a batch later.
+  auto rows_left = [&](int64_t b0) {
     const int64_t left64 = r1 - b0;
-    const int left = left64 < BR ? (int)left64 : BR;  // rows of this batch inside the chunk
-    const double* xb = a.X + b0 * a.ldx + a.col0;     // uniform
+    return left64 < BR ? (left64 > 0 ? (int)left64 : 0) : BR;  // rows of this batch inside the chunk
+  };
+  auto gload = [&](auto sc, int64_t b0) {
+    constexpr int S = decltype(sc)::value;
+    const int left = rows_left(b0);
+    const double* xb = a.X + (left > 0 ? b0 * a.ldx : 0) + a.col0;  // uniform
+    const int64_t qb0 = left > 0 ? b0 : 0;                          // uniform
 #pragma unroll
     for (int i = 0; i < NPRE; ++i) {
-      double2 v = make_double2(0.0, 0.0);
-      if (xrow[i] < left) v = *reinterpret_cast<const double2*>(xb + xoff[i]);
-      pre[i][0] = v.x;
-      pre[i][1] = v.y;
+      const double2 v = *reinterpret_cast<const double2*>(xb + (xrow[i] < left ? xoff[i] : 0));
+      pre[S][i][0] = v.x;
+      pre[S][i][1] = v.y;
     }
     const bool qrow = qr < left;
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
-      const int kk = qk0 + i * (256 / BR);
-      const double* qc = a.qZ + ((int64_t)(kb0 + i * (256 / BR)) * a.ldq + b0);  // uniform
-      double q = 0.0;
-      if (kk < kc && qrow) {
-        q = qc[qoff];
-        if (a.smask && !a.smask[(int64_t)(a.rginfo[(b0 + qr) >> 4] >> 5) * K + kb0 + kk]) q = 0.0;
-      }
-      qpre[i] = q;
+      // (an offset chosen per lane, not a pointer: hipcc turns `*(in ? p : q)` with a uniform q into a branch around a
+      //  scalar load of *q and a copy into the destination -- which waits for every vector load in flight)
+      const bool in = qrow && qk0 + i * (256 / BR) < kc;
+      const int64_t off = in ? (int64_t)(kb0 + i * (256 / BR)) * a.ldq + qb0 + qoff : (int64_t)qr;
+      qpre[S][i] = a.qZ[off];
     }
   };
-  auto lstore = [&](int buf) {
+  // (b0: first row of the batch being stored -- the sparse mask is looked up here, where its two dependent loads delay
+  //  nothing but the sparse runs themselves)
+  auto lstore = [&](auto sc, int buf, int64_t b0) {
+    constexpr int S = decltype(sc)::value;
+    const int left = rows_left(b0);
     double* xb = xbuf + buf * XBUF;
 #pragma unroll
-    for (int i = 0; i < NPRE; ++i)
-      if (xrow[i] < BR) *reinterpret_cast<double2*>(xb + xlds[i]) = make_double2(pre[i][0], pre[i][1]);
+    for (int i = 0; i < NPRE; ++i) {
+      const bool in = xrow[i] < left;
+      // (a compile-time "always" wherever it is one: a set register whose store stands under a branch counts as never
+      //  waited for, and the next write to it -- hipcc reuses them as address temporaries -- waits for everything)
+      if ((i + 1) * 256 <= NV2 || xrow[i] < BR)
+        *reinterpret_cast<double2*>(xb + xlds[i]) = make_double2(in ? pre[S][i][0] : 0.0, in ? pre[S][i][1] : 0.0);
+    }
+    const bool qrow = qr < left;
+    int64_t g = 0;
+    if (a.smask && qrow) g = a.rginfo[(b0 + qr) >> 4] >> 5;
     double* qb = qbuf + buf * SD_QMAX * QLD + qlds0;
 #pragma unroll
-    for (int i = 0; i < NQ; ++i) qb[i * (256 / BR) * QLD] = qpre[i];
+    for (int i = 0; i < NQ; ++i) {
+      const int kk = qk0 + i * (256 / BR);
+      bool in = qrow && kk < kc;
+      if (a.smask && in) in = a.smask[g * K + kb0 + kk] != 0;
+      qb[i * (256 / BR) * QLD] = in ? qpre[S][i] : 0.0;
+    }
   };
-
-  if (r0 < r1) {
-    gload(r0);
-    lstore(0);
-  }
-  __syncthreads();
-  int buf = 0;
-  for (int64_t b0 = r0; b0 < r1; b0 += BR, buf ^= 1) {
-    const bool more = b0 + BR < r1;
-    if (more) gload(b0 + BR);
-    if (active) {
-      const double* xb = xbuf + buf * XBUF + hi * LD + 4 * blk + lo2;
-      const double* qb = qbuf + buf * SD_QMAX * QLD + (group * 16 + lo2) * QLD + hi;
-      // rows past the chunk end were staged as zeros with q = 0, so every step runs: steps rcls, rcls + RS, ...
-      constexpr int NST = BR / 4 / RS;
-      const double* xs = xb + rcls * 4 * LD;
-      const double* qs = qb + rcls * 4;
-      constexpr bool PIPE = DP <= 96;  // (the second operand set spills next to 128 accumulator registers at D = 112, 128)
-      double xf[PIPE ? 2 : 1][NB], qv[PIPE ? 2 : 1][CT];
+  // the MFMAs of one batch out of LDS buffer `buf`
+  auto multiply = [&](int buf) {
+    const double* xb = xbuf + buf * XBUF + hi * LD + 4 * blk + lo2;
+    const double* qb = qbuf + buf * SD_QMAX * QLD + (group * 16 + lo2) * QLD + hi;
+    // rows past the chunk end were staged as zeros with q = 0, so every step runs: steps rcls, rcls + RS, ...
+    constexpr int NST = BR / 4 / RS;
+    const double* xs = xb + rcls * 4 * LD;
+    const double* qs = qb + rcls * 4;
+    constexpr bool PIPE = DP <= 96;  // (the second operand set spills next to 128 accumulator registers at D = 112, 128)
+    double xf[PIPE ? 2 : 1][NB], qv[PIPE ? 2 : 1][CT];
 #pragma unroll
-      for (int jb = 0; jb < NB; ++jb) xf[0][jb] = xs[16 * jb];
+    for (int jb = 0; jb < NB; ++jb) xf[0][jb] = xs[16 * jb];
 #pragma unroll
-      for (int c = 0; c < CT; ++c) qv[0][c] = qs[4 * c * QLD];
+    for (int c = 0; c < CT; ++c) qv[0][c] = qs[4 * c * QLD];
 #pragma unroll
-      for (int i = 0; i < NST; ++i) {
-        const int cur = PIPE ? (i & 1) : 0, nxt = PIPE ? (cur ^ 1) : 0;
-        if (PIPE && i + 1 < NST) {
+    for (int i = 0; i < NST; ++i) {
+      const int cur = PIPE ? (i & 1) : 0, nxt = PIPE ? (cur ^ 1) : 0;
+      if (PIPE && i + 1 < NST) {
 #pragma unroll
-          for (int jb = 0; jb < NB; ++jb) xf[nxt][jb] = xs[(i + 1) * RS * 4 * LD + 16 * jb];
+        for (int jb = 0; jb < NB; ++jb) xf[nxt][jb] = xs[(i + 1) * RS * 4 * LD + 16 * jb];
 #pragma unroll
-          for (int c = 0; c < CT; ++c) qv[nxt][c] = qs[4 * c * QLD + (i + 1) * RS * 4];
-        }
-        if constexpr (PIPE) __builtin_amdgcn_sched_barrier(0);
-        double x2[NB];
+        for (int c = 0; c < CT; ++c) qv[nxt][c] = qs[4 * c * QLD + (i + 1) * RS * 4];
+      }
+      if constexpr (PIPE) __builtin_amdgcn_sched_barrier(0);
+      double x2[NB];
 #pragma unroll
-        for (int jb = 0; jb < NB; ++jb)
-          if (SECOND) x2[jb] = xf[cur][jb] * xf[cur][jb];
+      for (int jb = 0; jb < NB; ++jb)
+        if (SECOND) x2[jb] = xf[cur][jb] * xf[cur][jb];
 #pragma unroll
-        for (int c = 0; c < CT; ++c) {
-          const double q = qv[cur][c];
-          nacc[c] += q;
+      for (int c = 0; c < CT; ++c) {
+        const double q = qv[cur][c];
+        nacc[c] += q;
 #pragma unroll
-          for (int jb = 0; jb < NB; ++jb) {
-            acc1[c][jb] = mfma4(q, xf[cur][jb], acc1[c][jb]);
-            if (SECOND) acc2[c][jb] = mfma4(q, x2[jb], acc2[c][jb]);
-          }
-        }
-        if constexpr (PIPE) {
-          __builtin_amdgcn_sched_barrier(0);
-        } else if (i + 1 < NST) {
-#pragma unroll
-          for (int jb = 0; jb < NB; ++jb) xf[0][jb] = xs[(i + 1) * RS * 4 * LD + 16 * jb];
-#pragma unroll
-          for (int c = 0; c < CT; ++c) qv[0][c] = qs[4 * c * QLD + (i + 1) * RS * 4];
+        for (int jb = 0; jb < NB; ++jb) {
+          acc1[c][jb] = mfma4(q, xf[cur][jb], acc1[c][jb]);
+          if (SECOND) acc2[c][jb] = mfma4(q, x2[jb], acc2[c][jb]);
         }
       }
+      if constexpr (PIPE) {
+        __builtin_amdgcn_sched_barrier(0);
+      } else if (i + 1 < NST) {
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb) xf[0][jb] = xs[(i + 1) * RS * 4 * LD + 16 * jb];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) qv[0][c] = qs[4 * c * QLD + (i + 1) * RS * 4];
+      }
     }
-    if (more) lstore(buf ^ 1);
-    __syncthreads();
+  };
+  using Set0 = std::integral_constant<int, 0>;
+  using Set1 = std::integral_constant<int, NSET - 1>;
+
+  if (r0 < r1) {
+    gload(Set0{}, r0);
+    lstore(Set0{}, 0, r0);
+    if constexpr (DEEP) gload(Set1{}, r0 + BR);
   }
+  __syncthreads();
+  // batch b0 sits in LDS buffer `buf`; batch b0 + BR is in flight into (DEEP) or about to be asked for from (otherwise)
+  // the registers; `into` receives batch b0 + AHEAD BR, `from` is stored to the other LDS buffer behind the MFMAs.
+  // No branch around the loads or the stores, and the loop takes batches in pairs with the odd one behind it: two paths
+  // that meet with different numbers of loads in flight leave the compiler one safe count for the next wait -- zero.
+  // (A batch past the end of the chunk is loaded from stand-in addresses and stored as zeros that nobody reads.)
+  auto batch = [&](auto into, auto from, int64_t b0, int buf) {
+    gload(into, b0 + AHEAD * BR);
+    if (active) multiply(buf);
+    lstore(from, buf ^ 1, b0 + BR);
+    __syncthreads();
+  };
+  int64_t b0 = r0;
+  for (; b0 + BR < r1; b0 += 2 * BR) {
+    batch(Set0{}, Set1{}, b0, 0);
+    batch(Set1{}, Set0{}, b0 + BR, 1);
+  }
+  if (b0 < r1 && active) multiply(0);
   if (!active) return;
 
   // output lane (lo2, blk, hi) of accumulator (c, jb): cluster 4 c + hi, dimension 16 jb + 4 blk + lo2
