@@ -971,13 +971,11 @@ __global__ void __launch_bounds__(256, 2) suffstat_diag_kernel(DiagStatLaunch a)
   const int64_t r0 = (int64_t)chunk * a.chunk_rows;
   const int64_t r1 = (r0 + a.chunk_rows) < a.NP ? (r0 + a.chunk_rows) : a.NP;
 
-  double acc1[CT][NB], acc2[CT][NB], nacc[CT];
+  double acc1[CT][NB], acc2[CT][NB];
 #pragma unroll
-  for (int c = 0; c < CT; ++c) {
-    nacc[c] = 0.0;
+  for (int c = 0; c < CT; ++c)
 #pragma unroll
     for (int jb = 0; jb < NB; ++jb) acc1[c][jb] = acc2[c][jb] = 0.0;
-  }
 
   // Two batches in flight (DP <= 96: the second register set spills next to 128 accumulator registers beyond): with
   // one, a block asked for batch b + 1 at the top of batch b and needed it ~ 1 us of MFMAs later -- about one HBM round
@@ -987,6 +985,17 @@ __global__ void __launch_bounds__(256, 2) suffstat_diag_kernel(DiagStatLaunch a)
   constexpr bool DEEP = DP <= 96;
   constexpr int NSET = DEEP ? 2 : 1, AHEAD = DEEP ? 2 : 1;
   double pre[NSET][NPRE][2], qpre[NSET][NQ];
+  // N_k is summed where q is staged (NQ adds per thread and batch) and not next to the MFMAs, where the A fragment is
+  // replicated over the four MFMA blocks and every lane added CT values per 4-row step: four times the additions, at
+  // the fp64 VALU's price in matrix-pipe time (16 of a wave's 48 non-MFMA fp64 instructions per batch at D = 64)
+  // (where NQ more registers would spill -- a block of more than 32 clusters at D >= 64, D >= 112 -- the sum stays in the
+  //  step loop)
+  constexpr bool NSTAGE = DP <= 96 && !(DP >= 64 && RS == 1);
+  double nq[NSTAGE ? NQ : 1], nacc[NSTAGE ? 1 : CT];
+#pragma unroll
+  for (int i = 0; i < (NSTAGE ? NQ : 1); ++i) nq[i] = 0.0;
+#pragma unroll
+  for (int c = 0; c < (NSTAGE ? 1 : CT); ++c) nacc[c] = 0.0;
   // Staging addresses = a UNIFORM base per batch (scalar registers) + per-lane offsets that are fixed for the whole
   // chunk.  Formed inside the batch loop -- (b0 + row) * ldx, (kb0 + kk) * ldq + b0 + r, idx / BR, the bounds -- they
   // were ~ 150 VALU instructions per thread and batch, 37 per 32-MFMA step: the kernel sat at 59 % of the pipe for them
@@ -1043,11 +1052,11 @@ __global__ void __launch_bounds__(256, 2) suffstat_diag_kernel(DiagStatLaunch a)
     double* xb = xbuf + buf * XBUF;
 #pragma unroll
     for (int i = 0; i < NPRE; ++i) {
-      const bool in = xrow[i] < left;
       // (a compile-time "always" wherever it is one: a set register whose store stands under a branch counts as never
-      //  waited for, and the next write to it -- hipcc reuses them as address temporaries -- waits for everything)
+      //  waited for, and the next write to it -- hipcc reuses them as address temporaries -- waits for everything.
+      //  A row past the end of the chunk keeps what its stand-in address held -- observations, finite: its q is zero)
       if ((i + 1) * 256 <= NV2 || xrow[i] < BR)
-        *reinterpret_cast<double2*>(xb + xlds[i]) = make_double2(in ? pre[S][i][0] : 0.0, in ? pre[S][i][1] : 0.0);
+        *reinterpret_cast<double2*>(xb + xlds[i]) = make_double2(pre[S][i][0], pre[S][i][1]);
     }
     const bool qrow = qr < left;
     int64_t g = 0;
@@ -1058,7 +1067,9 @@ __global__ void __launch_bounds__(256, 2) suffstat_diag_kernel(DiagStatLaunch a)
       const int kk = qk0 + i * (256 / BR);
       bool in = qrow && kk < kc;
       if (a.smask && in) in = a.smask[g * K + kb0 + kk] != 0;
-      qb[i * (256 / BR) * QLD] = in ? qpre[S][i] : 0.0;
+      const double q = in ? qpre[S][i] : 0.0;
+      qb[i * (256 / BR) * QLD] = q;
+      if constexpr (NSTAGE) nq[i] += q;  // N_k: every responsibility passes through exactly one thread's hands here
     }
   };
   // the MFMAs of one batch out of LDS buffer `buf`
@@ -1092,7 +1103,7 @@ __global__ void __launch_bounds__(256, 2) suffstat_diag_kernel(DiagStatLaunch a)
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
         const double q = qv[cur][c];
-        nacc[c] += q;
+        if constexpr (!NSTAGE) nacc[c] += q;
 #pragma unroll
         for (int jb = 0; jb < NB; ++jb) {
           acc1[c][jb] = mfma4(q, xf[cur][jb], acc1[c][jb]);
@@ -1135,17 +1146,34 @@ __global__ void __launch_bounds__(256, 2) suffstat_diag_kernel(DiagStatLaunch a)
     batch(Set1{}, Set0{}, b0 + BR, 1);
   }
   if (b0 < r1 && active) multiply(0);
+  // record layout: [N_k | x_s (DPT) | xx_s (DPT)]; a launch over the column block [col0, col0 + DP) fills its part
+  const int64_t SS = 1 + 2 * (int64_t)a.DPT;
+  // N_k of the chunk: the BR threads that staged a cluster's rows sit in consecutive lanes; the sum goes to the record of
+  // row class 0, the other row classes' records carry zero (the fold adds all of them)
+  if (NSTAGE && a.col0 == 0) {
+#pragma unroll
+    for (int i = 0; i < (NSTAGE ? NQ : 1); ++i) {
+      double v = nq[i];
+#pragma unroll
+      for (int m = BR / 2; m > 0; m >>= 1) v += __shfl_xor(v, m);
+      const int kk = qk0 + i * (256 / BR);
+      if (qr == 0 && kk < kc) {
+#pragma unroll
+        for (int rc = 0; rc < RS; ++rc) a.partial[((int64_t)(chunk * RS + rc) * K + kb0 + kk) * SS] = rc == 0 ? v : 0.0;
+      }
+    }
+  }
   if (!active) return;
 
   // output lane (lo2, blk, hi) of accumulator (c, jb): cluster 4 c + hi, dimension 16 jb + 4 blk + lo2
-  // record layout: [N_k | x_s (DPT) | xx_s (DPT)]; a launch over the column block [col0, col0 + DP) fills its part
-  const int64_t SS = 1 + 2 * (int64_t)a.DPT;
   double* rec = a.partial + ((int64_t)(chunk * RS + rcls) * K + kb0 + group * 16) * SS;
 #pragma unroll
   for (int c = 0; c < CT; ++c) {
-    // N_k: this lane summed q[row class hi][cluster 4 c + lo2] (replicated over blk)
-    const double n = sum_over_hi(nacc[c]);
-    if (a.col0 == 0 && hi == 0 && blk == 0 && group * 16 + 4 * c + lo2 < kc) rec[(int64_t)(4 * c + lo2) * SS] = n;
+    if constexpr (!NSTAGE) {
+      // N_k: this lane summed q[row class hi][cluster 4 c + lo2] (replicated over blk)
+      const double n = sum_over_hi(nacc[c]);
+      if (a.col0 == 0 && hi == 0 && blk == 0 && group * 16 + 4 * c + lo2 < kc) rec[(int64_t)(4 * c + lo2) * SS] = n;
+    }
     if (group * 16 + 4 * c + hi < kc) {
       double* out = rec + (int64_t)(4 * c + hi) * SS;
 #pragma unroll
