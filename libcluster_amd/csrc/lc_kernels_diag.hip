@@ -1023,25 +1023,53 @@ __global__ void __launch_bounds__(256, 2) suffstat_diag_kernel(DiagStatLaunch a)
     const int64_t left64 = r1 - b0;
     return left64 < BR ? (left64 > 0 ? (int)left64 : 0) : BR;  // rows of this batch inside the chunk
   };
-  auto gload = [&](auto sc, int64_t b0) {
+  // Whole batches (all but the last ones of a chunk) are loaded without any per-batch address arithmetic on the vector
+  // unit: X as  uniform base + a 32-bit byte offset fixed per lane, q as  uniform base + a 64-bit offset fixed per lane
+  // that already holds the stand-in of a lane without a cluster (one add per load).  Before this the selects and shifts
+  // of the general form were 40 of a wave's 50 32-bit VALU instructions per batch, next to 128 MFMAs.
+  // (Not where the offsets' registers would spill: the instances that keep N_k in the step loop.)
+  constexpr bool WHOLE = NSTAGE;
+  unsigned xbyte[WHOLE ? NPRE : 1];
+  int64_t qfix[WHOLE ? NQ : 1];  // element offset from qZ + (first row of the batch)
+  if constexpr (WHOLE) {
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) xbyte[i] = xrow[i] < BR ? (unsigned)xoff[i] * 8u : 0u;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i)
+      qfix[i] = qk0 + i * (256 / BR) < kc ? (int64_t)(kb0 + i * (256 / BR)) * a.ldq + qoff : (int64_t)qr;
+  }
+  auto gload = [&](auto whole, auto sc, int64_t b0) {
     constexpr int S = decltype(sc)::value;
-    const int left = rows_left(b0);
-    const double* xb = a.X + (left > 0 ? b0 * a.ldx : 0) + a.col0;  // uniform
-    const int64_t qb0 = left > 0 ? b0 : 0;                          // uniform
+    if constexpr (WHOLE && decltype(whole)::value) {
+      const char* xc = reinterpret_cast<const char*>(a.X + b0 * a.ldx + a.col0);  // uniform
+      const double* qc = a.qZ + b0;                                                // uniform
 #pragma unroll
-    for (int i = 0; i < NPRE; ++i) {
-      const double2 v = *reinterpret_cast<const double2*>(xb + (xrow[i] < left ? xoff[i] : 0));
-      pre[S][i][0] = v.x;
-      pre[S][i][1] = v.y;
-    }
-    const bool qrow = qr < left;
+      for (int i = 0; i < NPRE; ++i) {
+        const double2 v = *reinterpret_cast<const double2*>(xc + xbyte[i]);
+        pre[S][i][0] = v.x;
+        pre[S][i][1] = v.y;
+      }
 #pragma unroll
-    for (int i = 0; i < NQ; ++i) {
-      // (an offset chosen per lane, not a pointer: hipcc turns `*(in ? p : q)` with a uniform q into a branch around a
-      //  scalar load of *q and a copy into the destination -- which waits for every vector load in flight)
-      const bool in = qrow && qk0 + i * (256 / BR) < kc;
-      const int64_t off = in ? (int64_t)(kb0 + i * (256 / BR)) * a.ldq + qb0 + qoff : (int64_t)qr;
-      qpre[S][i] = a.qZ[off];
+      for (int i = 0; i < NQ; ++i) qpre[S][i] = qc[qfix[i]];
+    } else {
+      const int left = rows_left(b0);
+      const double* xb = a.X + (left > 0 ? b0 * a.ldx : 0) + a.col0;  // uniform
+      const int64_t qb0 = left > 0 ? b0 : 0;                          // uniform
+#pragma unroll
+      for (int i = 0; i < NPRE; ++i) {
+        const double2 v = *reinterpret_cast<const double2*>(xb + (xrow[i] < left ? xoff[i] : 0));
+        pre[S][i][0] = v.x;
+        pre[S][i][1] = v.y;
+      }
+      const bool qrow = qr < left;
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) {
+        // (an offset chosen per lane, not a pointer: hipcc turns `*(in ? p : q)` with a uniform q into a branch around a
+        //  scalar load of *q and a copy into the destination -- which waits for every vector load in flight)
+        const bool in = qrow && qk0 + i * (256 / BR) < kc;
+        const int64_t off = in ? (int64_t)(kb0 + i * (256 / BR)) * a.ldq + qb0 + qoff : (int64_t)qr;
+        qpre[S][i] = a.qZ[off];
+      }
     }
   };
   // (b0: first row of the batch being stored -- the sparse mask is looked up here, where its two dependent loads delay
@@ -1123,27 +1151,35 @@ __global__ void __launch_bounds__(256, 2) suffstat_diag_kernel(DiagStatLaunch a)
   using Set0 = std::integral_constant<int, 0>;
   using Set1 = std::integral_constant<int, NSET - 1>;
 
+  using Whole = std::true_type;
+  using Any = std::false_type;
   if (r0 < r1) {
-    gload(Set0{}, r0);
+    gload(Any{}, Set0{}, r0);
     lstore(Set0{}, 0, r0);
-    if constexpr (DEEP) gload(Set1{}, r0 + BR);
+    if constexpr (DEEP) gload(Any{}, Set1{}, r0 + BR);
   }
   __syncthreads();
   // batch b0 sits in LDS buffer `buf`; batch b0 + BR is in flight into (DEEP) or about to be asked for from (otherwise)
   // the registers; `into` receives batch b0 + AHEAD BR, `from` is stored to the other LDS buffer behind the MFMAs.
-  // No branch around the loads or the stores, and the loop takes batches in pairs with the odd one behind it: two paths
-  // that meet with different numbers of loads in flight leave the compiler one safe count for the next wait -- zero.
-  // (A batch past the end of the chunk is loaded from stand-in addresses and stored as zeros that nobody reads.)
-  auto batch = [&](auto into, auto from, int64_t b0, int buf) {
-    gload(into, b0 + AHEAD * BR);
+  // No branch around the loads or the stores, and the loops take batches in pairs with the odd one behind them: two
+  // paths that meet with different numbers of loads in flight leave the compiler one safe count for the next wait --
+  // zero.  (A batch past the end of the chunk is loaded from stand-in addresses and stored as zeros that nobody reads.)
+  auto batch = [&](auto whole, auto into, auto from, int64_t b0, int buf) {
+    gload(whole, into, b0 + AHEAD * BR);
     if (active) multiply(buf);
     lstore(from, buf ^ 1, b0 + BR);
     __syncthreads();
   };
   int64_t b0 = r0;
+  if constexpr (WHOLE) {
+    for (; b0 + (AHEAD + 2) * BR <= r1; b0 += 2 * BR) {  // both batches this pair asks for are whole
+      batch(Whole{}, Set0{}, Set1{}, b0, 0);
+      batch(Whole{}, Set1{}, Set0{}, b0 + BR, 1);
+    }
+  }
   for (; b0 + BR < r1; b0 += 2 * BR) {
-    batch(Set0{}, Set1{}, b0, 0);
-    batch(Set1{}, Set0{}, b0 + BR, 1);
+    batch(Any{}, Set0{}, Set1{}, b0, 0);
+    batch(Any{}, Set1{}, Set0{}, b0 + BR, 1);
   }
   if (b0 < r1 && active) multiply(0);
   // record layout: [N_k | x_s (DPT) | xx_s (DPT)]; a launch over the column block [col0, col0 + DP) fills its part
