@@ -501,6 +501,52 @@ def test_fused_pass_on_hard_labels_after_a_split(D):
     np.testing.assert_allclose(xs, qref.T @ X, rtol=1e-9, atol=1e-9)
 
 
+def test_half_width_fused_instance_equals_the_full_width_one():
+    """D <= 8 takes fused_small_kernel's half-width instance; LC_FUSED_FULL=1 (read once per process) takes the full-width
+    one on the same padded layout.  The columns left out are zeros, so both must give the same F trace, responsibilities
+    and statistics to rounding (in practice: to the last bit)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    child = (
+        "import sys, json, numpy as np\n"
+        f"sys.path.insert(0, {str(root)!r})\n"
+        "from libcluster_amd import capi\n"
+        "out = []\n"
+        "for D, K, N, J in ((3, 4, 5000, 1), (8, 16, 7001, 1), (5, 7, 4000, 3)):\n"
+        "    rng = np.random.default_rng(D * 100 + K)\n"
+        "    X = [rng.normal(size=(N // J, D)) * 1.3 + rng.integers(0, K, (N // J, 1)) for _ in range(J)]\n"
+        "    q0 = [rng.dirichlet(np.ones(K) * 0.4, x.shape[0]) for x in X]\n"
+        "    with capi.Context(0) as ctx:\n"
+        "        ctx.set_data(X); ctx.set_qz(q0)\n"
+        "        F, tr, m = ctx.vbem(capi.W_GDIRICHLET if J > 1 else capi.W_STICKBREAK, fixed_iters=6)\n"
+        "        q = ctx.get_qz([x.shape[0] for x in X])\n"
+        "        Nk, xs, xxs, _ = ctx.suffstat()\n"
+        "        m.close()\n"
+        "    out.append([tr.tolist(), [float(np.sum(a * np.arange(1, a.size + 1).reshape(a.shape))) for a in q], Nk.tolist(), float(xs.sum()), float(xxs.sum())])\n"
+        "print('RESULT', json.dumps(out))\n"
+    )
+    res = []
+    for full in (False, True):
+        env = dict(os.environ)
+        env.pop("LC_FUSED_FULL", None)
+        if full:
+            env["LC_FUSED_FULL"] = "1"
+        r = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+        res.append(json.loads(line[7:]))
+    for half, fullw in zip(*res):
+        np.testing.assert_allclose(half[0], fullw[0], rtol=1e-13)
+        np.testing.assert_allclose(half[1], fullw[1], rtol=1e-12)
+        np.testing.assert_allclose(half[2], fullw[2], rtol=1e-12)
+        np.testing.assert_allclose(half[3:], fullw[3:], rtol=1e-11)
+
+
 def test_mahaldist_matches_numpy():
     """probutils::mahaldist (probutils.cpp:113-138) on the GPU: ragged groups, narrow and wide D, SPD A; non-PD is
     refused."""

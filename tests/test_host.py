@@ -207,3 +207,33 @@ def test_estep_kernel_isa_keeps_the_promises_its_inline_asm_relies_on():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "estep_kernel instances: ok" in r.stdout
     assert "inline-asm statements behind MFMAs in 3 files: ok" in r.stdout
+
+
+def test_isa_checker_sees_an_asm_read_inside_an_mfma_hazard_window():
+    """The checker itself, on assembly written for the purpose: an inline-asm v_max_f64 that reads an accumulator three
+    instructions behind the MFMA that wrote it is reported; the same read behind a compiler-generated instruction that
+    overwrote the register, or far enough behind the MFMA, is not."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("check_isa", ROOT / "tools" / "check_isa.py")
+    ci = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ci)
+    head = "_Z4kernv: ; @kern\n"
+    tail = "\n.Lfunc_end0:\n"
+    bad = head + """	v_mfma_f64_4x4x4_4b_f64 v[10:11], v[2:3], v[4:5], v[10:11]
+	s_nop 1
+	;;#ASMSTART
+	v_max_f64 v[20:21], v[20:21], v[10:11]
+	;;#ASMEND""" + tail
+    problems, nasm = ci.check_mfma_into_asm(bad)
+    assert nasm == 1 and len(problems) == 1 and "v[10, 11]" in problems[0]
+    rewritten = head + """	v_mfma_f64_4x4x4_4b_f64 v[10:11], v[2:3], v[4:5], v[10:11]
+	v_max_f64 v[10:11], v[10:11], v[10:11]
+	;;#ASMSTART
+	v_max_f64 v[20:21], v[20:21], v[10:11]
+	;;#ASMEND""" + tail
+    assert ci.check_mfma_into_asm(rewritten) == ([], 1)
+    far = head + "\tv_mfma_f64_4x4x4_4b_f64 v[10:11], v[2:3], v[4:5], v[10:11]\n" + "\ts_nop 7\n" * 3 + """	;;#ASMSTART
+	v_max_f64 v[20:21], v[20:21], v[10:11]
+	;;#ASMEND""" + tail
+    assert ci.check_mfma_into_asm(far) == ([], 1)
