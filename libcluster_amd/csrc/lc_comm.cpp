@@ -1,5 +1,7 @@
 #include "lc_comm.hpp"
 
+#include "lc_kernels.h"  // rank_order_sum
+
 #include <dlfcn.h>
 #include <fcntl.h>
 #include <rccl/rccl.h>  // types and enums only: every call goes through the lazily bound table below
@@ -41,6 +43,7 @@ struct RcclApi {
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -87,9 +90,10 @@ RcclApi& rccl() {
     api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
     api.CommAbort = reinterpret_cast<decltype(api.CommAbort)>(sym("ncclCommAbort"));
     api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
+    api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
     api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
     if (!api.GetUniqueId || !api.CommInitRank || !api.CommInitAll || !api.CommDestroy || !api.CommAbort ||
-        !api.AllReduce || !api.GetErrorString) {
+        !api.AllReduce || !api.AllGather || !api.GetErrorString) {
       dlclose(api.handle);
       api.handle = nullptr;
     }
@@ -107,9 +111,20 @@ void nccl_ok(ncclResult_t r, const char* what) {
   if (r != ncclSuccess) fail(std::string(what) + ": " + rccl().GetErrorString(r));
 }
 
+// LIBCLUSTER_COMM=rccl-gather: the sum over ranks in a FIXED order.  ncclAllReduce adds in the order of its ring / tree
+// (chosen per message size and topology), so the low bits of the statistics -- and, through `Fsplit < F`
+// (cluster.cpp:473-479), in principle a split decision -- may depend on the number of GPUs.  Here every rank gathers all
+// ranks' buffers (ncclAllGather: W x 1 - 8.5 MB, nothing at xGMI rates) and adds them itself, rank 0 first, with the
+// very additions of the host transport (HostComm::allreduce_sum): an N-GPU run then equals the host-transport run and,
+// with it, every other placement of the same shards, bit for bit.  Default stays ncclAllReduce (one pass, no W-fold buffer).
+bool rccl_gather_mode() {
+  const char* e = std::getenv("LIBCLUSTER_COMM");
+  return e && std::string(e) == "rccl-gather";
+}
+
 class RcclComm final : public Comm {
  public:
-  RcclComm(ncclComm_t c, int rank, int world, int device) : comm_(c), device_(device) {
+  RcclComm(ncclComm_t c, int rank, int world, int device) : comm_(c), device_(device), gather_(rccl_gather_mode()) {
     rank_ = rank;
     world_ = world;
   }
@@ -119,11 +134,29 @@ class RcclComm final : public Comm {
       (void)hipSetDevice(device_);
       (void)rccl().CommDestroy(c);
     }
+    if (gbuf_) {
+      (void)hipSetDevice(device_);
+      (void)hipFree(gbuf_);
+    }
   }
   void allreduce_sum(double* dbuf, int64_t count, hipStream_t stream) override {
     if (count <= 0) return;
     ncclComm_t c = comm_.load();
     if (!c) fail("communicator was aborted");
+    if (gather_) {
+      const size_t need = (size_t)world_ * (size_t)count;
+      if (need > gcap_) {  // (grow-only; the stream may still be reading the old block)
+        hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize");
+        if (gbuf_) hip_ok(hipFree(gbuf_), "hipFree(gather buffer)");
+        gbuf_ = nullptr;
+        gcap_ = 0;
+        hip_ok(hipMalloc(reinterpret_cast<void**>(&gbuf_), need * sizeof(double)), "hipMalloc(gather buffer)");
+        gcap_ = need;
+      }
+      nccl_ok(rccl().AllGather(dbuf, gbuf_, (size_t)count, ncclDouble, c, stream), "ncclAllGather");
+      hip_ok(lck::launch_rank_order_sum(gbuf_, world_, count, dbuf, stream), "rank_order_sum");
+      return;
+    }
     // in place, on the caller's stream: ordered with the kernels that produced dbuf and with the copy that reads it
     nccl_ok(rccl().AllReduce(dbuf, dbuf, (size_t)count, ncclDouble, ncclSum, c, stream), "ncclAllReduce");
   }
@@ -131,11 +164,14 @@ class RcclComm final : public Comm {
     ncclComm_t c = comm_.exchange(nullptr);
     if (c) (void)rccl().CommAbort(c);
   }
-  const char* kind() const override { return "rccl"; }
+  const char* kind() const override { return gather_ ? "rccl-gather" : "rccl"; }
 
  private:
   std::atomic<ncclComm_t> comm_{nullptr};
   int device_ = 0;
+  bool gather_ = false;
+  double* gbuf_ = nullptr;  // [world][count] in gather mode
+  size_t gcap_ = 0;
 };
 
 // ---------------------------------------------------------------------------------------------------------------

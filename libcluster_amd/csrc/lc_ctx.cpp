@@ -425,9 +425,21 @@ void Context::get_rows(int j, int64_t row0, int64_t n, double* out) const {
 // ---------------------------------------------------------------------------
 // qZ
 // ---------------------------------------------------------------------------
+#ifdef LC_TEST_HOOKS
+// tests (LC_TEST_QHASH_KEEP_STALE): the writers of qZ "forget" what they owe the row fingerprints -- ensure_qz and
+// qz_keep_columns leave hash_ok standing, qz_split_from does not mark the rows it rewrites.  The fingerprint check of
+// LC_TEST_VERIFY_QHASH (estep_cache) has to notice.
+static bool test_keep_stale() {
+  static const bool on = std::getenv("LC_TEST_QHASH_KEEP_STALE") != nullptr;
+  return on;
+}
+#endif
 void Context::ensure_qz(QZ& q, int K, bool preserve) {
   use_device();
   q.hash_ok = false;  // (whoever asks for the buffer is about to write it; estep_cache and the split helpers re-validate)
+#ifdef LC_TEST_HOOKS
+  if (test_keep_stale() && q.hash.p) q.hash_ok = true;
+#endif
   if (K <= q.cap && q.buf.p) return;
   int newcap = std::max(K, q.cap > 0 ? q.cap + std::max(4, q.cap / 2) : K);
   DevBuf<double> nb;
@@ -630,6 +642,9 @@ void Context::qz_keep_columns(const std::vector<int>& keep) {
   }
   q.K = (int)keep.size();
   q.hash_ok = false;  // (columns moved: the rows' fingerprints weigh every value by its column)
+#ifdef LC_TEST_HOOKS
+  if (test_keep_stale() && q.hash.p) q.hash_ok = true;
+#endif
 }
 
 void Context::qz_clone_to_alt() {
@@ -776,9 +791,13 @@ void Context::qz_split_from(const Context& sub, const RowSelection& sel, int k) 
   const bool hashed = q.hash_ok;  // (a new zero column leaves a row's fingerprint as it is; rewritten rows are marked)
   if (q.K + 1 > q.cap) ensure_qz(q, q.K + 1, true);
   q.hash_ok = hashed;
+  bool mark = hashed;
+#ifdef LC_TEST_HOOKS
+  if (test_keep_stale()) mark = false;
+#endif
   LC_HIP(hipMemsetAsync(q.buf.p + (size_t)NP_ * q.K, 0, (size_t)NP_ * sizeof(double), stream_));
   LC_HIP(lck::launch_aug_from_sub(q.buf.p, NP_, k, q.K, sel.idx.p, sel.M, sel.starts_d.p, sub.goff_d_.p, J_,
-                                  sub.qz_[sub.cur_].buf.p + (size_t)sub.NP_, stream_, hashed ? q.hash.p : nullptr));
+                                  sub.qz_[sub.cur_].buf.p + (size_t)sub.NP_, stream_, mark ? q.hash.p : nullptr));
   q.K += 1;
 }
 
@@ -1477,6 +1496,23 @@ int Context::estep_cache(int K, const double* A, const double* m, const double* 
   // constants + normalisation
   const bool have_old = qz_[cur_].K == K;  // the buffer holds K columns of q_old
   const bool hashed_old = have_old && qz_[cur_].hash_ok;
+#ifdef LC_TEST_HOOKS
+  // tests: before the sweep trusts the stored fingerprints, recompute every one of them from the buffer.  Any writer of
+  // qZ that left hash_ok standing over rows it changed (without marking them QHASH_NONE) is caught here, on whatever
+  // path a learner reached it.
+  static const bool verify = std::getenv("LC_TEST_VERIFY_QHASH") != nullptr;
+  if (verify && hashed_old && NP_ > 0) {
+    DevBuf<int64_t> bad;
+    bad.reserve(1);
+    LC_HIP(hipMemsetAsync(bad.p, 0, sizeof(int64_t), stream_));
+    LC_HIP(lck::launch_qhash_verify(qz_[cur_].buf.p, NP_, K, NP_, qz_[cur_].hash.p, reinterpret_cast<unsigned long long*>(bad.p), stream_));
+    unsigned long long nbad = 0;
+    LC_HIP(hipMemcpyAsync(&nbad, bad.p, sizeof(nbad), hipMemcpyDeviceToHost, stream_));
+    LC_HIP(hipStreamSynchronize(stream_));
+    if (nbad) throw std::runtime_error("LC_TEST_VERIFY_QHASH: " + std::to_string(nbad) + " rows carry a fingerprint that is not theirs (K = " + std::to_string(K) + ")");
+    std::cerr << "[cache] fingerprints verified, K " << K << std::endl;
+  }
+#endif
   ensure_qz(qz_[cur_], K, false);
   qz_[cur_].K = K;
   const int64_t grid = lck::softmax_cached_grid(NP_);
@@ -1906,3 +1942,21 @@ void Context::timing_reset() {
 }
 
 }  // namespace lcc
+
+#ifdef LC_TEST_HOOKS
+// libcluster_hip_testhooks.so only (tests/test_gpu_comm.py): the device-side rank-order sum of LIBCLUSTER_COMM=rccl-gather
+// on host data -- `world` blocks of `count` doubles in, `count` out.  0 on success, the HIP error code otherwise.
+extern "C" __attribute__((visibility("default"))) int lc_test_rank_order_sum(const double* in, int world, long long count, double* out) {
+  if (!in || !out || world < 1 || count < 1) return -1;
+  double *din = nullptr, *dout = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&din), (size_t)world * (size_t)count * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&dout), (size_t)count * sizeof(double));
+  if (e == hipSuccess) e = hipMemcpy(din, in, (size_t)world * (size_t)count * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = lck::launch_rank_order_sum(din, world, count, dout, nullptr);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(out, dout, (size_t)count * sizeof(double), hipMemcpyDeviceToHost);
+  if (din) (void)hipFree(din);
+  if (dout) (void)hipFree(dout);
+  return (int)e;
+}
+#endif

@@ -10,6 +10,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <type_traits>
@@ -18,6 +19,23 @@
 #include "lc_kernels.h"
 
 namespace lck {
+
+// Compute units of the CURRENT device (a process may hold contexts on several, and learn_sharded drives its shards from
+// concurrent threads: one relaxed atomic slot per device, filled by whoever asks first -- every writer stores the same
+// value).  256 when the query fails.
+inline int current_device_cus() {
+  static std::atomic<int> cus_of[32];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) dev = -1;
+  int cus = dev >= 0 ? cus_of[dev].load(std::memory_order_relaxed) : 0;
+  if (cus <= 0) {
+    hipDeviceProp_t p;
+    if (dev >= 0 && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+    if (dev >= 0) cus_of[dev].store(cus, std::memory_order_relaxed);
+  }
+  return cus;
+}
 
 __device__ __forceinline__ double mfma4(double a, double b, double c) {
   return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
@@ -29,7 +47,10 @@ __device__ __forceinline__ double mfma4(double a, double b, double c) {
 // of it -- use fmax there (seen as NaN rows out of the half-width fused instance, whose last chain link sits right in
 // front of the max).
 __device__ __forceinline__ double max_raw(double a, double b) {
-  asm("v_max_f64 %0, %1, %2" : "=v"(a) : "v"(a), "v"(b));
+  // ("+v": the result goes into the register that holds `a` -- with a separate "=v" output the allocator may hand the asm a
+  //  freshly freed register that an in-flight MFMA still reads as SrcC or is about to write, and no wait states are
+  //  inserted for asm in that direction either; tools/check_isa.py looks at both directions)
+  asm("v_max_f64 %0, %0, %1" : "+v"(a) : "v"(b));
   return a;
 }
 
@@ -82,6 +103,27 @@ __device__ __forceinline__ double rcp_pos(double s) {
   y = fma(y, e, y);
   e = fma(-s, y, 1.0);
   return fma(y, e, y);
+}
+
+// Fingerprint of one row of responsibilities (softmax_cached_kernel writes and compares them; qhash_verify_kernel
+// recomputes them in the tests): a multiplicative chain over the NON-ZERO entries,
+//   h <- (h ^ (bits(q_j) + C (j + 1))) * G;  h ^= h >> 32      (mod 2^64, G odd)
+// A zero entry leaves h as it is, so K columns and K + 1 columns with q_K = 0 agree; every other entry is mixed in
+// together with its column, so a label that moves from one column to another changes the fingerprint.  (Round 4 summed
+// bits(q_j) * G (2 j + 1): LINEAR in the bit patterns -- two rows collided whenever sum_j (2 j + 1) dbits_j = 0, e.g.
+// column 0 up by 3 ulp and column 1 down by 1, which few-ulp moves between the sweeps of a split round do produce.
+// In the chain a change of any entry reaches every later step through a product and an xor: no small integer relation
+// between the entries' moves survives.)
+constexpr uint64_t QHASH_SEED = 0x243F6A8885A308D3ull;
+__device__ __forceinline__ uint64_t qhash_step(uint64_t acc, double q, int j) {
+  const uint64_t b = (uint64_t)__double_as_longlong(q);  // (q >= +0: a zero is the all-zero pattern)
+  uint64_t t = (acc ^ (b + 0xD6E8FEB86659FD93ull * (uint64_t)(j + 1))) * 0x9E3779B97F4A7C15ull;
+  t ^= t >> 32;
+  return b ? t : acc;
+}
+__device__ __forceinline__ int64_t qhash_finish(uint64_t acc) {
+  const int64_t h = (int64_t)acc;
+  return h == QHASH_NONE ? 1 : h;
 }
 
 // n-th read of a cluster's parameter stream (for it: -b[it], tile(it,0), ..., tile(it,it)):

@@ -258,6 +258,12 @@ struct CachedNormLaunch {
   int qhash_in = 0;          // the fingerprints describe the responsibilities being overwritten
 };
 constexpr int64_t QHASH_NONE = (int64_t)0x8000000000000000ull;
+// out[i] = ((in[0][i] + in[1][i]) + in[2][i]) + ... over `world` blocks of `count` doubles, rank 0 first: the additions of
+// the host transport (lc_comm.cpp, HostComm::allreduce_sum), on the device, behind ncclAllGather (LIBCLUSTER_COMM=rccl-gather)
+hipError_t launch_rank_order_sum(const double* gathered, int world, int64_t count, double* out, hipStream_t stream);
+// tests: rows whose stored fingerprint is neither QHASH_NONE nor that of the K values in the buffer are counted in *bad
+hipError_t launch_qhash_verify(const double* qZ, int64_t ldq, int K, int64_t NP, const int64_t* qhash,
+                               unsigned long long* bad, hipStream_t stream);
 int64_t softmax_cached_grid(int64_t NP);
 int softmax_cached_max_k();  // widest K the sweep is built for
 hipError_t launch_softmax_cached(const CachedNormLaunch& a, hipStream_t stream);

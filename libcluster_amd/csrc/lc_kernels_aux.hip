@@ -686,13 +686,15 @@ __global__ void __launch_bounds__(256) softmax_cached_kernel(CachedNormLaunch a)
     if (j < K) {
       const double lq = v[j];
       double q = onexp ? lq * inv : exp_nonpos(lq - logZ, etab);
-      // Responsibilities below 2^-300 are stored as zero.  A row that belongs to one cluster has q = 1 there and
+      // In the moved-row sweeps (a.dq: cluster()'s split search with the distance cache; never a plain E-step, which is
+      // cluster.cpp:130-131 to the letter like the other E-step kernels): responsibilities below 2^-300 are stored as
+      // zero -- a deliberate deviation from the reference, DESIGN 4.4.  A row that belongs to one cluster has q = 1 there and
       // e^-(hundreds) everywhere else; those specks change in their last bits with every change of any weight, so that
       // every row "changed" in every sweep of a split candidate (all K old values read, all K new ones written: 3 x 2.6
       // GB per sweep at K = 33) although nothing above 1e-90 moved.  Flushed, such a row comes out bit for bit as it
       // was, its fingerprint matches and the sweep touches nothing of it.  The mass dropped from any statistic is below
       // 1e-90 of the row's; the reference itself loses everything below e^-745 (exp underflow, probutils.cpp:146).
-      if (!ok || q < 0x1p-300) q = 0.0;
+      if (!ok || (a.dq && q < 0x1p-300)) q = 0.0;
       v[j] = q;
       if (a.ll_part) {  // the data term of the split ordering (cluster.cpp:407-410), as estep_kernel's sweep forms it
         const double ll = wave_sum(q > 0.0 ? q * (lq - crow[j]) : 0.0);
@@ -704,18 +706,16 @@ __global__ void __launch_bounds__(256) softmax_cached_kernel(CachedNormLaunch a)
     // whose K values all come out bit for bit as they were is not written at all, its q_new - q_old only when some
     // |.| exceeds dq_tol (delta_suffstat never looks at the other rows).  Between the candidates of a split round
     // almost every row is of the first kind.
-    // Fingerprint of the row's new values: sum_j bits(q_j) * M_j (mod 2^64, M_j odd; a zero entry adds nothing, so K
-    // columns and K + 1 columns with q_K = 0 agree).  Equal to the stored fingerprint of the old values: the row is
-    // unchanged (up to a 2^-64 coincidence) and its old values are not read at all.
+    // Fingerprint of the row's new values (qhash_step, lc_device.hpp).  Equal to the stored fingerprint of the old
+    // values: the row is unchanged (up to a 2^-64 coincidence) and its old values are not read at all.
     int64_t h = 0;
     bool same = false;
     if (a.qhash) {
-      uint64_t acc = 0;
+      uint64_t acc = QHASH_SEED;
 #pragma unroll
       for (int j = 0; j < KT; ++j)
-        if (j < K) acc += (uint64_t)__double_as_longlong(v[j]) * (0x9E3779B97F4A7C15ull * (uint64_t)(2 * j + 1));
-      h = (int64_t)acc;
-      if (h == QHASH_NONE) h = 1;
+        if (j < K) acc = qhash_step(acc, v[j], j);
+      h = qhash_finish(acc);
       if (a.qhash_in && inb) same = a.qhash[row] == h;
     }
     // A row that did change: its old values pass through eight registers at a time; every entry that differs is
@@ -761,6 +761,44 @@ __global__ void __launch_bounds__(256) softmax_cached_kernel(CachedNormLaunch a)
     for (int j = tid; j < K; j += 256)
       a.ll_part[(int64_t)blockIdx.x * K + j] = llw[j] + llw[KT + j] + llw[2 * KT + j] + llw[3 * KT + j];
 }
+// Tests (libcluster_hip_testhooks.so, LC_TEST_VERIFY_QHASH): does every stored fingerprint describe the row it belongs
+// to?  Counts the rows whose fingerprint is neither QHASH_NONE nor that of the K values in the buffer.
+__global__ void __launch_bounds__(256) qhash_verify_kernel(const double* __restrict__ qZ, int64_t ldq, int K, int64_t NP,
+                                                           const int64_t* __restrict__ qhash, unsigned long long* bad) {
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (row >= NP) return;
+  const int64_t stored = qhash[row];
+  if (stored == QHASH_NONE) return;
+  uint64_t acc = QHASH_SEED;
+  for (int j = 0; j < K; ++j) acc = qhash_step(acc, qZ[(int64_t)j * ldq + row], j);
+  if (qhash_finish(acc) != stored) atomicAdd(bad, 1ull);
+}
+hipError_t launch_qhash_verify(const double* qZ, int64_t ldq, int K, int64_t NP, const int64_t* qhash,
+                               unsigned long long* bad, hipStream_t stream) {
+  if (NP <= 0 || K <= 0) return hipSuccess;
+  hipLaunchKernelGGL(qhash_verify_kernel, dim3((unsigned)((NP + 255) / 256)), dim3(256), 0, stream, qZ, ldq, K, NP, qhash, bad);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The sum over ranks in rank order (LIBCLUSTER_COMM=rccl-gather, lc_comm.cpp): one thread per element, W strided reads.
+// __fadd_rn-style plain additions, never contracted: the same bits as the host transport's loop.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) rank_order_sum_kernel(const double* __restrict__ g, int world, int64_t count,
+                                                             double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  double s = g[i];
+  for (int r = 1; r < world; ++r) s = __dadd_rn(s, g[(int64_t)r * count + i]);
+  out[i] = s;
+}
+hipError_t launch_rank_order_sum(const double* gathered, int world, int64_t count, double* out, hipStream_t stream) {
+  if (count <= 0 || world < 1) return hipSuccess;
+  hipLaunchKernelGGL(rank_order_sum_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, gathered, world,
+                     count, out);
+  return hipGetLastError();
+}
+
 int64_t softmax_cached_grid(int64_t NP) { return (NP + 255) / 256; }
 int softmax_cached_max_k() { return 72; }
 hipError_t launch_softmax_cached(const CachedNormLaunch& a, hipStream_t stream) {

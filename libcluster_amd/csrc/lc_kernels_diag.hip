@@ -836,13 +836,7 @@ static hipError_t launch_edm_k(const DiagEstepLaunch& a, hipStream_t stream) {
     return e;
   const int64_t ntile = (a.nrg + 4 * R - 1) / (4 * R);
   const int64_t nslots = estep_diag_grid(a.nrg);
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    hipDeviceProp_t p;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
-    if (cus <= 0) cus = 256;
-  }
+  const int cus = current_device_cus();
   // persistent blocks (the weights are staged once per block): as many as are resident, a few tiles each
   const int per_cu = shmem <= 80 * 1024 ? 2 : 1;
   int64_t grid = std::min<int64_t>(std::min<int64_t>(ntile, nslots), (int64_t)cus * per_cu);
@@ -1067,7 +1061,8 @@ __global__ void __launch_bounds__(256, 2) suffstat_diag_kernel(DiagStatLaunch a)
         // (an offset chosen per lane, not a pointer: hipcc turns `*(in ? p : q)` with a uniform q into a branch around a
         //  scalar load of *q and a copy into the destination -- which waits for every vector load in flight)
         const bool in = qrow && qk0 + i * (256 / BR) < kc;
-        const int64_t off = in ? (int64_t)(kb0 + i * (256 / BR)) * a.ldq + qb0 + qoff : (int64_t)qr;
+        // (the stand-in stays inside the smallest buffer there is -- 16 padded rows of one cluster -- and differs by lane)
+        const int64_t off = in ? (int64_t)(kb0 + i * (256 / BR)) * a.ldq + qb0 + qoff : (int64_t)(qr & 15);
         qpre[S][i] = a.qZ[off];
       }
     }
@@ -1082,7 +1077,10 @@ __global__ void __launch_bounds__(256, 2) suffstat_diag_kernel(DiagStatLaunch a)
     for (int i = 0; i < NPRE; ++i) {
       // (a compile-time "always" wherever it is one: a set register whose store stands under a branch counts as never
       //  waited for, and the next write to it -- hipcc reuses them as address temporaries -- waits for everything.
-      //  A row past the end of the chunk keeps what its stand-in address held -- observations, finite: its q is zero)
+      //  A row past the end of the chunk keeps what its stand-in address held -- observations of the chunk's first rows --
+      //  and its q is zero: 0 * x adds nothing as long as x is finite.  A non-finite observation poisons the statistics
+      //  of every cluster here exactly as it does in the reference, where its responsibilities are NaN in every column:
+      //  cluster.cpp:120-131 on a NaN / Inf row)
       if ((i + 1) * 256 <= NV2 || xrow[i] < BR)
         *reinterpret_cast<double2*>(xb + xlds[i]) = make_double2(pre[S][i][0], pre[S][i][1]);
     }

@@ -23,6 +23,8 @@
 #include "lc_device.hpp"
 
 #include <algorithm>
+#include <cstdio>
+#include <vector>
 
 namespace lck {
 
@@ -53,6 +55,12 @@ constexpr int FUSED_QS = FUSED_ROWS + 2;  // q table: 258 doubles per cluster = 
 // the DP = 16 one either way -- `Xcat`'s two columns are padded eightfold -- but the tiles of rows and columns 8 ... 15 are
 // zeros there: the E-step half then walks 5 of a cluster's 14 reads (20 + 4 MFMAs instead of 40 + 4) and the statistics
 // half 5 of its 12 feature tiles; what is left out is written as zeros).
+#ifdef LC_FUSED_TL
+__device__ long long* g_fused_tl;
+#define TL() do { if (lane == 0 && tli < 62) { g_fused_tl[((size_t)blockIdx.x * 4 + wave) * 128 + tli] = wall_clock64(); g_fused_tl[((size_t)blockIdx.x * 4 + wave) * 128 + 64 + tli] = clock64(); } ++tli; } while (0)
+#else
+#define TL() do {} while (0)
+#endif
 template <int DP, int CPW, int GRP, bool WANT_LL, int NTA = 4>
 __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
   constexpr bool ONEGRP = GRP == 0, CTLDS = GRP != 2;
@@ -94,6 +102,14 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave-uniform: its arithmetic belongs on the scalar unit)
   const int lo4 = lane & 15, hi = lane >> 4, blk = (lane >> 2) & 3, lo2 = lane & 3;
+#ifdef LC_FUSED_TL
+  int tli = 0;
+  if (lane == 0) {
+    g_fused_tl[((size_t)blockIdx.x * 4 + wave) * 128 + 62] = __builtin_amdgcn_s_getreg(63492);  // HW_ID
+    g_fused_tl[((size_t)blockIdx.x * 4 + wave) * 128 + 63] = __builtin_amdgcn_s_getreg(63508);  // XCC_ID
+  }
+#endif
+  TL();
   for (int i = tid; i < K * PS; i += 256) par[i] = a.params[i];
   for (int i = tid; i < 4 * K; i += 256) llw[i] = 0.0;
   if constexpr (CTLDS)
@@ -137,6 +153,7 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
   };
   fetch(blockIdx.x);
   __syncthreads();
+  TL();
   // n-th read of cluster `kk`'s parameter stream relative to the running pointers of the current cluster
   const double* Pt = par + (lane & 3) + 4 * hi;  // this lane's element of every 4x4 tile (cluster 0)
   const double* Pb = par + NTILES * 16 + hi;     // this lane's element of every 4-vector of -b (cluster 0)
@@ -149,7 +166,14 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
 #pragma unroll
     for (int i = 0; i < NPRE; ++i) *reinterpret_cast<double2*>(xstage + i * (256 / C2) * LD) = pre[i];
     __syncthreads();
+    TL();
 
+#ifdef LC_FX_PRIO
+#define FX_PRIO() do { if ((((unsigned)(wall_clock64() >> LC_FX_PRIO) ^ (blockIdx.x >> 8)) & 1u) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); } while (0)
+#else
+#define FX_PRIO() do {} while (0)
+#endif
+    FX_PRIO();
     // ---- E-step half: this wave's 64 rows as four row groups; lane (lo4, hi) owns row 16 hi + lo4 = row `tid` of the tile
     // (a table entry is read BEFORE the next tile's prefetch goes out: it is waited for at once, and the vector-memory
     //  counter retires in order)
@@ -261,6 +285,8 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
       mymx = fmax(mymx, t);
       qt[(size_t)(K - 1) * QS + tid] = t;
     }
+    TL();
+    FX_PRIO();
     // logsumexp and normalisation in the reference's order: max, sum exp(x - max), log + max, exp(x - logZ)
     {
       double* const ql = qt + tid;
@@ -316,7 +342,10 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
         if (live) fz += logZ;
       }
     }
+    TL();
     __syncthreads();
+    TL();
+    FX_PRIO();
 
     // ---- statistics half: this wave's 16 of the tile's 64 four-row steps, all feature tiles, all cluster quads.
     // Tile t < 10 is the patch (ia, ja): x[row][4 ia + lo2] * x[row][4 ja + blk] -- two lane-dependent base pointers and
@@ -354,26 +383,35 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
         StepOps nxt = cur;
         if constexpr (s4 + 1 < FUSED_ROWS / 16) load(std::integral_constant<int, s4 + 1>{}, nxt);
         __builtin_amdgcn_sched_barrier(0);
+        // ALL of the step's products first, then all of its MFMAs: next to the matrix pipe a VALU instruction is paid per
+        // switch between the two kinds, not per instruction (tools/mfma_batch_probe.hip: ~ 12 clocks each when they stand
+        // alone between MFMAs, ~ 5 in a group of eight)
+        double p[NTLA];
         static_for<NTLA>([&](auto tc) {
           constexpr int t = tc;
-          double p;
           if constexpr (t < NPA) {
             constexpr int ja = t < 1 ? 0 : t < 3 ? 1 : t < 6 ? 2 : 3, ia = t - ja * (ja + 1) / 2;
-            p = cur.u[ia] * cur.w[ja];
+            p[t] = cur.u[ia] * cur.w[ja];
           } else if constexpr (t == NPA) {
-            p = cur.s;
+            p[t] = cur.s;
           } else {
-            p = cur.one;
+            p[t] = cur.one;
           }
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<NTLA>([&](auto tc) {
+          constexpr int t = tc;
 #pragma unroll
-          for (int c = 0; c < NQ; ++c) acc[t][c] = mfma4(cur.qa[c], p, acc[t][c]);
+          for (int c = 0; c < NQ; ++c) acc[t][c] = mfma4(cur.qa[c], p[t], acc[t][c]);
         });
         __builtin_amdgcn_sched_barrier(0);
         cur = nxt;
       });
     }
+    TL();
     __syncthreads();  // the next tile overwrites xt and qt
   }
+  TL();
 
   // ---- one partial record per (block, cluster): [N_k, s_k(DP), S_k(DP x DP)].  The four waves' accumulators meet in
   // LDS in wave order (fixed: deterministic); then every thread writes its share of the 12 x NQ x 64 entries.
@@ -422,6 +460,7 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
   for (int k = tid; k < K; k += 256)
     rec[K * SS + 1 + k] = WANT_LL ? llw[k] + llw[K + k] + llw[2 * K + k] + llw[3 * K + k] : 0.0;
   if (tid == 0) rec[K * SS] = -(fzw[0] + fzw[1] + fzw[2] + fzw[3]);  // cluster.cpp:137 returns -sum(logZ)
+  TL();
 }
 
 static size_t fused_lds_bytes(int DP, int K) {
@@ -445,17 +484,7 @@ bool fused_eligible(int DP, int K) {
 // number of persistent blocks (= partial records per cluster, fz / ll partial slots)
 int fused_plan(int DP, int64_t nrg, int K) {
   if (!fused_eligible(DP, K) || nrg <= 0) return 0;
-  // compute units of the CURRENT device (a process may hold contexts on several)
-  static int cus_of[16] = {};
-  int dev = 0, cus = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;
-  if (dev >= 0) cus = cus_of[dev];
-  if (!cus) {
-    hipDeviceProp_t p;
-    if (dev >= 0 && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
-    if (cus <= 0) cus = 256;
-    if (dev >= 0) cus_of[dev] = cus;
-  }
+  const int cus = current_device_cus();
   const int64_t ntile = (nrg * RG + FUSED_ROWS - 1) / FUSED_ROWS;
   const size_t lds = fused_lds_bytes(DP, K);
   const int per_cu = lds <= 80 * 1024 ? 2 : 1;
@@ -476,7 +505,45 @@ static hipError_t launch_fused_t(const FusedLaunch& a, hipStream_t stream, size_
   return a.want_ll ? go(fused_small_kernel<16, CPW, GRP, true>, grants[1]) : go(fused_small_kernel<16, CPW, GRP, false>, grants[0]);
 }
 
+#ifdef LC_FUSED_TL
+static void fused_tl_hook(const FusedLaunch& a, hipStream_t stream, bool after) {
+  static long long* buf = nullptr;
+  static int launches = 0;
+  const size_t n = (size_t)a.grid * 4 * 128;
+  if (!after) {
+    if (!buf) {
+      hipMalloc(&buf, n * sizeof(long long));
+      hipMemcpyToSymbol(HIP_SYMBOL(g_fused_tl), &buf, sizeof(buf));
+    }
+    return;
+  }
+  if (++launches == 60 && getenv("LC_FUSED_TL_OUT")) {
+    hipStreamSynchronize(stream);
+    std::vector<long long> h(n);
+    hipMemcpy(h.data(), buf, n * sizeof(long long), hipMemcpyDeviceToHost);
+    FILE* f = fopen(getenv("LC_FUSED_TL_OUT"), "w");
+    for (int b = 0; b < a.grid; ++b)
+      for (int w = 0; w < 4; ++w) {
+        fprintf(f, "%d %d", b, w);
+        for (int i = 0; i < 128; ++i) fprintf(f, " %lld", h[((size_t)b * 4 + w) * 128 + i]);
+        fprintf(f, "\n");
+      }
+    fclose(f);
+  }
+}
+#endif
+static hipError_t launch_fused_impl(const FusedLaunch& a, hipStream_t stream);
 hipError_t launch_fused(const FusedLaunch& a, hipStream_t stream) {
+#ifdef LC_FUSED_TL
+  fused_tl_hook(a, stream, false);
+  hipError_t e = launch_fused_impl(a, stream);
+  fused_tl_hook(a, stream, true);
+  return e;
+#else
+  return launch_fused_impl(a, stream);
+#endif
+}
+static hipError_t launch_fused_impl(const FusedLaunch& a, hipStream_t stream) {
   if (a.DP != 16 || a.grid <= 0) return hipErrorInvalidValue;
   const size_t shmem = fused_lds_bytes(a.DP, a.K);
   if (!a.rginfo) {

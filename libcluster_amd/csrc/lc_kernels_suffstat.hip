@@ -557,6 +557,9 @@ __host__ __device__ constexpr int ft_tpw_max(int DP, int NQ) {
 #ifndef LC_FT_BR
 #define LC_FT_BR 32
 #endif
+#ifndef LC_FT_GROUP
+#define LC_FT_GROUP 1
+#endif
 #ifndef LC_FT_BR64
 #define LC_FT_BR64 48
 #endif
@@ -732,6 +735,59 @@ __global__ void __launch_bounds__(64 * ft_waves(DP), 2) suffstat_feat_kernel(Suf
   constexpr bool ONEQ = NQ > 8;
   auto batch = [&](auto bsel, auto ntsel) {
     constexpr int B = decltype(bsel)::value, XO = B * XBUF, QO = B * QBUF, NT = decltype(ntsel)::value;
+#if LC_FT_GROUP > 1
+    if constexpr (!ONEQ) {
+      // Tiles in groups of G: the group's products first, then its G x NQ MFMAs.  Next to the matrix pipe a VALU
+      // instruction is paid per switch between the two kinds, not per instruction (tools/mfma_batch_probe.hip: ~ 12 clocks
+      // for a lone multiply between MFMAs, 8 each in pairs, 6.5 in threes); the fragments of the next group are read into
+      // the registers the multiplies have just freed and arrive under the MFMAs.
+      constexpr int G = LC_FT_GROUP, TOT = (BR / 4) * NT;
+      double qa[2][NQ], u[G], w[G], pp[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+        if (g < TOT) {
+          u[g] = pu[g % NT][XO + (g / NT) * 4 * LD];
+          w[g] = pw[g % NT][XO + (g / NT) * 4 * LD];
+        }
+#pragma unroll
+      for (int c = 0; c < NQ; ++c) qa[0][c] = pq[QO + 4 * c];
+#pragma unroll
+      for (int st = 0; st < BR / 4; ++st) {
+        // (groups never straddle a step: the step's q quads change there)
+#pragma unroll
+        for (int t0 = 0; t0 < NT; t0 += G) {
+          const int ng = NT - t0 < G ? NT - t0 : G;
+#pragma unroll
+          for (int g = 0; g < G; ++g)
+            if (g < ng) pp[g] = u[g] * w[g];
+          // the next group: the rest of this step, or the head of the next one (and then its q quads as well)
+          const int nt0 = t0 + G < NT ? t0 + G : 0, nst = t0 + G < NT ? st : st + 1;
+          if (nst < BR / 4) {
+            const int nng = NT - nt0 < G ? NT - nt0 : G;
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+              if (g < nng) {
+                u[g] = pu[nt0 + g][XO + nst * 4 * LD];
+                w[g] = pw[nt0 + g][XO + nst * 4 * LD];
+              }
+            if (nst != st) {
+#pragma unroll
+              for (int c = 0; c < NQ; ++c) qa[nst & 1][c] = pq[QO + nst * 4 * QLD + 4 * c];
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int g = 0; g < G; ++g)
+            if (g < ng) {
+#pragma unroll
+              for (int c = 0; c < NQ; ++c) acc[t0 + g][c] = mfma4(qa[st & 1][c], pp[g], acc[t0 + g][c]);
+            }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      return;
+    }
+#endif
     double qa[ONEQ ? 1 : 2][NQ], u[2], w[2];
     u[0] = pu[0][XO];
     w[0] = pw[0][XO];
@@ -991,13 +1047,7 @@ int suffstat_plan(int DP, int64_t NP, int K, int64_t* chunk_rows) {
       case 128: nslice = nq > 8 ? ft_nslice(128, 16) : nq > 7 ? ft_nslice(128, 8) : nq > 6 ? ft_nslice(128, 7) : nq > 5 ? ft_nslice(128, 6) : ft_nslice(128, 5); break;
     }
     if (nslice > 0) {
-      static int cus = 0;
-      if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-      }
+      const int cus = current_device_cus();
       const int64_t slots = (int64_t)cus * (ft_waves(DP) == 8 ? 1 : 2);
       auto fill = [&](int64_t chunks) {
         const int64_t blocks = chunks * nslice, rounds = (blocks + slots - 1) / slots;

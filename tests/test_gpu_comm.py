@@ -11,6 +11,7 @@ The loop being distributed: src/cluster.cpp:207-223 (single-process OpenMP in th
 import os
 import signal
 import subprocess
+import sys
 from pathlib import Path
 
 import numpy as np
@@ -427,3 +428,79 @@ def test_sharded_model_selection_on_cached_distances_equals_one_gpu(lib, sharded
             np.testing.assert_allclose(b, a, atol=1e-9)
     else:
         np.testing.assert_allclose(q2, q1, atol=1e-9)
+
+
+_GATHER_SNIPPET = r"""
+import sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from libcluster_amd import capi
+rng = np.random.default_rng(9)
+mu = rng.normal(0, 6.0, (5, 16))
+X = mu[rng.integers(0, 5, 20000)] + rng.normal(size=(20000, 16))
+q0 = np.random.default_rng(1).dirichlet(np.ones(5), X.shape[0])
+with capi.Context(0) as ctx:
+    ctx.set_data(X)
+    ctx.set_qz(q0)
+    ctx.comm_init_rccl(capi.comm_unique_id(), 0, 1)
+    print("KIND", ctx.comm_info()["kind"])
+    v = ctx.allreduce([1.5, -2.0, 3.25])
+    assert list(v) == [1.5, -2.0, 3.25], v
+    big = rng.normal(size=300000)          # (the gather buffer grows between calls)
+    assert np.array_equal(ctx.allreduce(big), big)
+    F, tr, m = ctx.vbem(capi.W_STICKBREAK, fixed_iters=4)
+    m.close()
+    ctx.comm_free()
+print("TRACE", " ".join(float(f).hex() for f in tr))
+"""
+
+
+@pytest.mark.gpu
+def test_rccl_gather_mode_world_of_one_inside_the_em_loop(lib):
+    """LIBCLUSTER_COMM=rccl-gather: ncclAllGather + the rank-order sum kernel instead of ncclAllReduce (lc_comm.cpp), so
+    that the sum over ranks does not depend on RCCL's ring order.  With one rank it is an identity: the trace of a VBEM
+    run must equal the default transport's bit for bit.  (More than one RCCL rank needs more than one GPU; the order of
+    the additions is tested separately below, against the host transport's loop.)"""
+    from libcluster_amd import capi
+
+    if not capi.rccl_available():
+        pytest.skip("librccl could not be loaded on this box")
+    outs = {}
+    for mode in ("", "rccl-gather"):
+        e = dict(os.environ)
+        e.pop("LIBCLUSTER_COMM", None)
+        if mode:
+            e["LIBCLUSTER_COMM"] = mode
+        r = subprocess.run([sys.executable, "-c", _GATHER_SNIPPET.format(root=str(ROOT))], capture_output=True, text=True,
+                           timeout=600, env=e, cwd=str(ROOT))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs[mode] = r.stdout
+    assert "KIND rccl\n" in outs[""] and "KIND rccl-gather\n" in outs["rccl-gather"]
+    tr = {k: [ln for ln in v.splitlines() if ln.startswith("TRACE ")][-1] for k, v in outs.items()}
+    assert tr[""] == tr["rccl-gather"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,count", [(1, 7), (2, 1000), (8, 4097), (8, 1100000), (5, 263)])
+def test_rank_order_sum_kernel_adds_like_the_host_transport(lib, world, count):
+    """The device half of LIBCLUSTER_COMM=rccl-gather (rank_order_sum_kernel) against the additions of the host
+    transport (HostComm::allreduce_sum: slot 0, then += slot 1, 2, ... -- tests/test_gpu_comm.py's 8-rank runs pin that
+    path to one rank): values that differ by many orders of magnitude, so that any other order of the additions, or a
+    fused multiply-add, changes the low bits."""
+    import ctypes as C
+
+    hooked = C.CDLL(str(ROOT / "libcluster_amd" / "lib" / "libcluster_hip_testhooks.so"))
+    fn = hooked.lc_test_rank_order_sum
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_longlong, C.c_void_p]
+    fn.restype = C.c_int
+    rng = np.random.default_rng(world * 1000 + count)
+    slots = rng.normal(size=(world, count)) * 10.0 ** rng.integers(-12, 12, size=(world, count))
+    slots = np.ascontiguousarray(slots)
+    out = np.empty(count)
+    assert fn(slots.ctypes.data, world, count, out.ctypes.data) == 0
+    want = slots[0].copy()
+    for r in range(1, world):
+        want += slots[r]
+    assert np.array_equal(out, want)
+    if world > 2:  # (the check can tell orders apart on this input)
+        assert not np.array_equal(out, slots[::-1].cumsum(axis=0)[-1]) or count < 64

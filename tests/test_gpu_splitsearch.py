@@ -107,7 +107,11 @@ if J == 1:
     F, q, w, means, covs, info = lc.learnVDP(Xs[0], return_info=True)
 else:
     F, q, w, means, covs, info = lc.learnGMC(Xs, return_info=True)
-print(json.dumps(dict(F=F, K=info["K"], rounds=[[k, list(map(float, t))] for k, t in info["rounds"]])))
+import hashlib
+qs = [q] if J == 1 else list(q)
+sha = hashlib.sha256(b"".join(np.ascontiguousarray(a, dtype=np.float64).tobytes() for a in qs)).hexdigest()
+print(json.dumps(dict(F=F, K=info["K"], rounds=[[k, list(map(float, t))] for k, t in info["rounds"]], qsha=sha,
+                      Fhex=float(F).hex())))
 """
 
 
@@ -118,6 +122,8 @@ def _run_snippet(env, **kw):
     e.update(env)
     r = subprocess.run([sys.executable, "-c", _SNIPPET.format(root=str(ROOT), **kw)], capture_output=True, text=True,
                        timeout=600, env=e, cwd=str(ROOT))
+    if env.get("_EXPECT_FAILURE"):
+        return dict(rc=r.returncode, _stderr=r.stderr)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
     out["_stderr"] = r.stderr
@@ -173,3 +179,36 @@ def test_model_selection_carries_on_when_the_distance_cache_does_not_fit(lib):
     assert a["K"] == b["K"] >= 6 and [k for k, _ in a["rounds"]] == [k for k, _ in b["rounds"]]
     for (_, x), (_, y) in zip(a["rounds"], b["rounds"]):
         np.testing.assert_allclose(x, y, rtol=1e-10)
+
+
+_FP_CASES = [dict(seed=6, K=6, D=24, N=5000, J=1, scale=2.0), dict(seed=7, K=7, D=33, N=4000, J=1, scale=6.0),
+             dict(seed=8, K=5, D=20, N=1500, J=3, scale=3.0), dict(seed=9, K=9, D=40, N=30000, J=1, scale=1.2)]
+
+
+@pytest.mark.parametrize("kw", _FP_CASES)
+def test_row_fingerprints_change_no_bit_of_the_result(lib, kw):
+    """The moved-row sweeps skip a row whose new responsibilities carry the fingerprint of the old ones
+    (softmax_cached_kernel, qhash_step).  With LC_SPLIT_NO_QHASH every old value is read and compared instead: the two
+    runs must agree in every bit of qZ and F -- a fingerprint collision (round 4's linear sum had systematic ones: ADVICE
+    r4) leaves a row with stale values and shows here."""
+    a = _run_snippet({"LC_SPLIT_DELTA_FORCE": "1"}, **kw)
+    b = _run_snippet({"LC_SPLIT_DELTA_FORCE": "1", "LC_SPLIT_NO_QHASH": "1"}, **kw)
+    assert a["K"] == b["K"] and a["rounds"] == b["rounds"]
+    assert a["Fhex"] == b["Fhex"] and a["qsha"] == b["qsha"]
+
+
+@pytest.mark.parametrize("kw", _FP_CASES)
+def test_every_writer_of_the_responsibilities_keeps_the_fingerprints_honest(lib, kw):
+    """Test-hooks library, LC_TEST_VERIFY_QHASH: before a sweep trusts the stored fingerprints, every one of them is
+    recomputed from the buffer (qhash_verify_kernel) and a row whose fingerprint is not its own aborts the learner.  This
+    covers every writer of qZ on the paths cluster() really takes (qz_set, the E-step kernels, split_init, keep_columns,
+    clone / swap): each must clear hash_ok or mark the rows it rewrites.  LC_TEST_QHASH_KEEP_STALE makes ensure_qz
+    "forget" to clear the flag -- the same run must then fail, which shows the check has teeth."""
+    hooked = str(ROOT / "libcluster_amd" / "lib" / "libcluster_hip_testhooks.so")
+    env = {"LC_LIB_PATH": hooked, "LC_TEST_VERIFY_QHASH": "1", "LC_SPLIT_DELTA_FORCE": "1"}
+    ok = _run_snippet(env, **kw)
+    assert ok["_stderr"].count("fingerprints verified") >= 3, ok["_stderr"][-1500:]
+    plain = _run_snippet({"LC_SPLIT_DELTA_FORCE": "1"}, **kw)
+    assert plain["qsha"] == ok["qsha"] and plain["Fhex"] == ok["Fhex"]
+    bad = _run_snippet(dict(env, LC_TEST_QHASH_KEEP_STALE="1", _EXPECT_FAILURE="1"), **kw)
+    assert bad["rc"] != 0 and "fingerprint that is not theirs" in bad["_stderr"], bad["_stderr"][-1500:]

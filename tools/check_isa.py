@@ -17,6 +17,10 @@ And for every kernel of lc_kernels_estep / _fused / _diag.hip:
      recogniser counts the wait states between an MFMA and a VALU reader only for instructions it emitted itself; an
      asm `v_max_f64` right behind the last link of an MFMA chain read a stale register (NaN rows out of the half-width
      fused instance, round 4).  MFMA results go through compiler-generated instructions (fmax) before any asm sees them.
+     The other direction as well (round 5): no inline-asm statement WRITES a VGPR that an MFMA inside that window has as
+     its destination or reads as SrcC (an asm output the register allocator placed in a just-freed register).
+     The walk is linear over the text of a function and does not follow branches: a hazard across a loop back-edge is
+     outside what it sees.
 Exit status 0 = all hold.  Run by tests/test_host.py (CPU: hipcc cross-compiles)."""
 import re
 import subprocess
@@ -48,7 +52,8 @@ def check_mfma_into_asm(asm: str):
     problems, nasm = [], 0
     for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)\n\.Lfunc_end\d+:", asm, re.S | re.M):
         name, body = m.group(1), m.group(2).splitlines()
-        recent = []  # (registers written by an MFMA, wait states since)
+        recent = []    # (registers written by an MFMA, wait states since)
+        recent_c = []  # (registers an MFMA reads as SrcC, wait states since)
         in_asm = False
         for ln in body:
             t = ln.strip()
@@ -66,16 +71,27 @@ def check_mfma_into_asm(asm: str):
                 # stores have no destination; everything else writes its first operand and reads the rest
                 srcs = ops if op.startswith(("global_store", "ds_write", "buffer_store")) else ops[1:]
                 read = set().union(*[regs(o) for o in srcs]) if srcs else set()
+                wrote = set() if op.startswith(("global_store", "ds_write", "buffer_store", "s_")) or not ops else regs(ops[0])
                 for wr, age in recent:
                     if wr & read and age < MFMA_WAIT:
                         problems.append(f"{name}: inline asm `{t}` reads v{sorted(wr & read)} {age} wait states after the MFMA that "
                                         f"wrote them (needs {MFMA_WAIT} or a compiler-generated reader in between)")
+                    if wr & wrote and age < MFMA_WAIT:
+                        problems.append(f"{name}: inline asm `{t}` writes v{sorted(wr & wrote)} {age} wait states after an MFMA whose "
+                                        f"destination they are (no wait states are inserted for asm in this direction either)")
+                for rd, age in recent_c:
+                    if rd & wrote and age < MFMA_WAIT:
+                        problems.append(f"{name}: inline asm `{t}` writes v{sorted(rd & wrote)} {age} wait states after an MFMA that "
+                                        f"reads them as SrcC")
             step = 1
             if op == "s_nop" and ops and ops[0].isdigit():
                 step = int(ops[0]) + 1
             recent = [(wr, age + step) for wr, age in recent if age + step < MFMA_WAIT]
+            recent_c = [(rd, age + step) for rd, age in recent_c if age + step < MFMA_WAIT]
             if op.startswith("v_mfma") and ops:
                 recent.append((regs(ops[0]), 0))
+                if len(ops) >= 4 and regs(ops[3]):
+                    recent_c.append((regs(ops[3]), 0))
             elif not in_asm and ops:
                 # a compiler-generated instruction that overwrites an MFMA result ends that result's hazard window
                 w = regs(ops[0])
