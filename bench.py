@@ -453,8 +453,9 @@ def measure(capi, cfg, steps, warmup, rank, world, local_rank, stream, nthreads,
         fn.argtypes = [__import__("ctypes").c_int, __import__("ctypes").c_int]
         ssname = fn(D, K).decode()
     dom = "estep_kernel" if est >= sst else ssname
-    if family != "GaussWish":
-        dom = dom.replace("_kernel", "_diag_kernel")
+    if family != "GaussWish":  # the names rocprofv3 lists: the matrix-pipe E-step where the context took it (every launch here)
+        dom = ("estep_diag_mfma_kernel" if ka.get("estep_diag_mfma_calls", 0) > 0 else "estep_diag_kernel") if est >= sst \
+            else "suffstat_diag_kernel"
     dom_ms = max(est, sst)
     dom_fl = fl["estep"] if est >= sst else fl["suffstat"]
     fused = kt.get("fused_calls", 0)
@@ -474,7 +475,11 @@ def measure(capi, cfg, steps, warmup, rank, world, local_rank, stream, nthreads,
                      "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
                      "alg_flops_per_launch": dom_fl, "avg_launch_ms": dom_ms,
                      "estep_frac": fl["estep"] / (est * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if est > 0 else None,
-                     "suffstat_frac": fl["suffstat"] / (sst * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if sst > 0 else None},
+                     "suffstat_frac": fl["suffstat"] / (sst * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if sst > 0 else None,
+                     # the other roof of the same launch (report both): X read once + one q column per
+                     # cluster written (E-step, fused pass) or read (statistics) = 8 N (D + K) algorithmic bytes
+                     "alg_bytes_per_launch": 8.0 * N * (D + K),
+                     "hbm_frac": 8.0 * N * (D + K) / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if dom_ms > 0 else None},
         "config": {"workload": cfg["label"], "rows_per_gpu": N, "D": D, "K": K, "weights": cfg["w"],
                    "seed": cfg["seed"], "groups_per_gpu": J,
                    "parallelism": (f"rows sharded x{world}" if J == 1 else f"whole groups sharded x{world}")

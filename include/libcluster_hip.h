@@ -209,8 +209,10 @@ int lc_ctx_timing_get_fused(lc_ctx* ctx, double* fused_ms, int64_t* fused_calls)
  *   6 allreduce_ms  7 allreduce_calls   (events around the exchange step: the sum + the wait for the slowest rank)
  *   8 host_stats_ms  9 host_mstep_ms  10 host_estep_ms  11 host_fenergy_ms  12 host_iters
  *     (host wall time per phase of the VBEM iterations: statistics pass + weights update, cluster M-step + parameter
- *      packing, E-step, free energy) */
-#define LC_TIMING_FIELDS 13
+ *      packing, E-step, free energy)
+ *   13 estep_diag_mfma_calls  (separable families: how many of the estep_calls took estep_diag_mfma_kernel, the
+ *      matrix-pipe form of NormGamma / ExpGamma::Eloglike, distributions.cpp:483-492, 568-581; the rest ran estep_diag_kernel) */
+#define LC_TIMING_FIELDS 14
 int lc_ctx_timing_get_all(lc_ctx* ctx, double* out, int n);
 
 /* ======================================================================== *

@@ -507,7 +507,7 @@ class Context:
 
     TIMING_FIELDS = ("estep_ms", "estep_calls", "suffstat_ms", "suffstat_calls", "fused_ms", "fused_calls",
                      "allreduce_ms", "allreduce_calls", "host_stats_ms", "host_mstep_ms", "host_estep_ms",
-                     "host_fenergy_ms", "host_iters")
+                     "host_fenergy_ms", "host_iters", "estep_diag_mfma_calls")
 
     def timing_get_all(self):
         """Kernel, collective and host-phase times since the last reset (lc_ctx_timing_get_all)."""

@@ -715,7 +715,7 @@ int lc_ctx_timing_get_all(lc_ctx* ctx, double* out, int n) {
     const double v[LC_TIMING_FIELDS] = {t.estep_ms, (double)t.estep_calls, t.suffstat_ms, (double)t.suffstat_calls,
                                         t.fused_ms, (double)t.fused_calls, t.allreduce_ms, (double)t.allreduce_calls,
                                         t.host_stats_ms, t.host_mstep_ms, t.host_estep_ms, t.host_fenergy_ms,
-                                        (double)t.host_iters};
+                                        (double)t.host_iters, (double)t.estep_diag_mfma_calls};
     for (int i = 0; i < n && i < LC_TIMING_FIELDS; ++i) out[i] = v[i];
   });
 }

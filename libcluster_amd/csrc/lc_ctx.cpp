@@ -953,7 +953,7 @@ void Context::estep(int K, const double* A, const double* m, const double* c, do
     return;
   }
   hred_.resize((size_t)1 + K);
-  static const bool direct_env = [] { const char* e = std::getenv("LC_DIRECT_HOST"); return !e || std::atoi(e) != 0; }();
+  constexpr bool direct_env = true;  // (the copy-back command instead: measured slower)
   if (direct_env && !distributed() && grid > 0) {
     // nothing to sum over ranks: the folds write F_z (and LL_k) straight into the page-locked host buffer
     redtmp_.reserve((size_t)lck::REDUCE_TMP_ELEMS * 64);
@@ -1033,14 +1033,31 @@ bool Context::estep_suffstat_fused(int K, const double* A, const double* m, cons
     LC_HIP(hipEventRecord(ev.b, stream_));
     pending_.push_back(ev);
   }
-  hss_.resize(nout);
+  hss_.resize(nout + 1);  // (+ the completion flag of the signalling fold)
   // nothing to sum over ranks: the fold writes straight into the pinned host buffer (coherent, device-visible
-  // memory; visible after the stream synchronises) and the copy-back command drops off the iteration's critical path
-  static const bool direct_env = [] { const char* e = std::getenv("LC_FUSED_DIRECT_HOST"); return !e || std::atoi(e) != 0; }();
+  // memory) and the copy-back command drops off the iteration's critical path
+  constexpr bool direct_env = true;  // (the copy-back command instead: 0.258 against 0.247 ms per iteration in round 2)
   const bool direct = direct_env && !distributed() && grid > 0;
+  // ... and when the fold is the last command of the iteration (one group: no count block behind it) the host waits for
+  // its completion flag in that buffer, not for the stream: hipStreamSynchronize's wake-up is a third of what an
+  // iteration at N = 1M spends outside the kernel (LC_FUSED_SPIN=0 restores it)
+  static const bool spin_env = [] { const char* e = std::getenv("LC_FUSED_SPIN"); return !e || std::atoi(e) != 0; }();
+  const bool spin = direct && !own_counts && spin_env;
+  unsigned long long* flag = reinterpret_cast<unsigned long long*>(hss_.data() + nout);
   double* dst = direct ? hss_.data() : ssout_.p;
   if (grid > 0) {
-    LC_HIP(lck::launch_reduce_partials(sspart_.p, grid, W, dst, stream_));
+    if (spin) {
+      if (!fold_ticket_.p) {
+        fold_ticket_.reserve(1);
+        LC_HIP(hipMemsetAsync(fold_ticket_.p, 0, sizeof(int), stream_));
+      }
+      fold_seq_ += 1;
+      __atomic_store_n(flag, 0ull, __ATOMIC_RELEASE);  // (a recycled page-locked block may hold an old run's sequence number)
+      LC_HIP(lck::launch_reduce_partials_signal(sspart_.p, grid, W, dst, reinterpret_cast<unsigned*>(fold_ticket_.p), flag,
+                                                fold_seq_, stream_));
+    } else {
+      LC_HIP(lck::launch_reduce_partials(sspart_.p, grid, W, dst, stream_));
+    }
     if (own_counts) {
       redtmp_.reserve((size_t)lck::REDUCE_TMP_ELEMS * 64);
       LC_HIP(lck::launch_group_colsum(qz_[cur_].buf.p, NP_, K, goff_d_.p, J_, direct ? dst + nrec : njk_d, stream_,
@@ -1055,7 +1072,22 @@ bool Context::estep_suffstat_fused(int K, const double* A, const double* m, cons
     LC_HIP(hipMemcpyAsync(hss_.data(), ssout_.p, nout * sizeof(double), hipMemcpyDeviceToHost, stream_));
   }
   run_overlap();
-  LC_HIP(hipStreamSynchronize(stream_));
+  if (spin) {
+    // (the flag follows the sums through the same queue of posted writes; a stream that has drained without it -- an
+    //  error -- falls through to the synchronisation, which reports it)
+    bool seen = false;
+    for (unsigned i = 0; !seen; ++i) {
+      seen = __atomic_load_n(flag, __ATOMIC_ACQUIRE) == fold_seq_;
+      if (!seen && (i & 0xffffu) == 0xffffu && hipStreamQuery(stream_) != hipErrorNotReady) break;
+      __builtin_ia32_pause();
+    }
+    if (!seen) {
+      LC_HIP(hipStreamSynchronize(stream_));
+      if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != fold_seq_) throw HipFailure("the fused pass finished without its completion flag");
+    }
+  } else {
+    LC_HIP(hipStreamSynchronize(stream_));
+  }
   for (int k = 0; k < K; ++k) {
     const double* rec = hss_.data() + (size_t)k * SS;
     if (Nk) Nk[k] = rec[0];
@@ -1166,7 +1198,7 @@ void Context::suffstat(const unsigned char* smask, double* Nk, double* xs, doubl
   // Nothing to sum over ranks, one group, no mask: the fold of the per-chunk records writes straight into the page-locked
   // host buffer (device-visible; complete when the stream synchronises) -- no fill and no copy-back command, which
   // count where a pass lasts 0.1 ms (the sub-problems of the split search run thousands of them)
-  static const bool direct_env = [] { const char* e = std::getenv("LC_DIRECT_HOST"); return !e || std::atoi(e) != 0; }();
+  constexpr bool direct_env = true;  // (the copy-back command instead: measured slower)
   const bool direct = direct_env && !distributed() && !own_counts && NP_ > 0;
   hss_.resize(nout);
   if (NP_ > 0) {
@@ -1290,7 +1322,7 @@ void Context::suffstat(const unsigned char* smask, double* Nk, double* xs, doubl
 }
 
 bool Context::dcache_eligible(int K) const {
-  static const bool off = std::getenv("LC_SPLIT_NO_DCACHE") != nullptr || std::getenv("LC_SPLIT_NO_DELTA") != nullptr;
+  static const bool off = lck::test_switch("LC_SPLIT_NO_DCACHE") != nullptr || lck::test_switch("LC_SPLIT_NO_DELTA") != nullptr;
   // (the normalisation sweep keeps a row's K values in registers)
   return !off && DP_ <= lck::GW_MAX_DP && K >= 1 && K <= lck::softmax_cached_max_k() && !lck::fused_eligible(DP_, K);
 }
@@ -1522,7 +1554,7 @@ int Context::estep_cache(int K, const double* A, const double* m, const double* 
   const bool delta = delta_tol >= 0.0 && have_old;
   const int nred = LLk ? 1 + K : 1;
   hred_.resize((size_t)nred);
-  static const bool direct_env = [] { const char* e = std::getenv("LC_DIRECT_HOST"); return !e || std::atoi(e) != 0; }();
+  constexpr bool direct_env = true;  // (the copy-back command instead: measured slower)
   const bool direct = direct_env && !distributed() && NP_ > 0;
   if (NP_ > 0) {
     hpack_.assign((size_t)J_ * K, 0.0);
@@ -1553,7 +1585,7 @@ int Context::estep_cache(int K, const double* A, const double* m, const double* 
       a.amax = amax_.p;
       a.dq_tol = delta_tol;
       dq_tol_ = delta_tol;
-      static const bool no_hash = std::getenv("LC_SPLIT_NO_QHASH") != nullptr;  // (A/B timing: read every old value)
+      static const bool no_hash = lck::test_switch("LC_SPLIT_NO_QHASH") != nullptr;  // (tests: read every old value)
       if (!no_hash) {
         qz_[cur_].hash.reserve((size_t)NP_);
         a.qhash = qz_[cur_].hash.p;
@@ -1590,7 +1622,7 @@ int Context::estep_cache(int K, const double* A, const double* m, const double* 
   if (Fz) *Fz = hred_[0];
   if (LLk) std::copy(hred_.begin() + 1, hred_.begin() + 1 + K, LLk);
   if (delta) dq_K_ = K;  // (a rank without rows keeps an empty delta and still joins delta_suffstat's sums)
-  qz_[cur_].hash_ok = delta && NP_ > 0 && qz_[cur_].hash.p != nullptr && std::getenv("LC_SPLIT_NO_QHASH") == nullptr;
+  qz_[cur_].hash_ok = delta && NP_ > 0 && qz_[cur_].hash.p != nullptr && lck::test_switch("LC_SPLIT_NO_QHASH") == nullptr;
   return nch;
 }
 
@@ -1669,7 +1701,7 @@ void Context::estep_diag(int K, const double* av, const double* w2, const double
   // the centre (the mean of the cluster centres): the absolute error of log q~ is then about D * cond * 2^-53.
   size_t wt_off = 0, mu_off = 0, ck_off = 0;
   {
-    static const int force = std::getenv("LC_ED_MFMA") ? std::atoi(std::getenv("LC_ED_MFMA")) : -1;  // 0 never, 1 always
+    static const int force = lck::test_switch("LC_ED_MFMA") ? std::atoi(lck::test_switch("LC_ED_MFMA")) : -1;  // (tests: 0 never, 1 always)
     const int64_t nw = lck::estep_diag_mfma_weights(DP, K, mode);
     bool use = nw > 0 && force != 0;
     std::vector<double> muv((size_t)DP, 0.0);
@@ -1692,6 +1724,7 @@ void Context::estep_diag(int K, const double* av, const double* w2, const double
       if (!(cond <= 4096.0) && force != 1) use = false;  // (NaN-safe)
     }
     if (use) {
+      if (timing_) times_.estep_diag_mfma_calls += 1;
       const int NT = DP / 4, NTF = mode == 2 ? NT : 2 * NT, KT = (K + 3) / 4;
       const size_t base = hpack_.size();
       mu_off = base;
@@ -1942,6 +1975,17 @@ void Context::timing_reset() {
 }
 
 }  // namespace lcc
+
+namespace lck {
+const char* test_switch(const char* name) {
+#ifdef LC_TEST_HOOKS
+  return std::getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
+}  // namespace lck
 
 #ifdef LC_TEST_HOOKS
 // libcluster_hip_testhooks.so only (tests/test_gpu_comm.py): the device-side rank-order sum of LIBCLUSTER_COMM=rccl-gather

@@ -88,6 +88,7 @@ void cache_release_thread();
 struct KernelTimes {
   double estep_ms = 0, suffstat_ms = 0, fused_ms = 0;  // fused: E-step + statistics in one launch (small observations)
   int64_t estep_calls = 0, suffstat_calls = 0, fused_calls = 0;
+  int64_t estep_diag_mfma_calls = 0;  // separable families: E-step launches that took estep_diag_mfma_kernel (of estep_calls)
   // the exchange step (events around the collective on the context's stream: the sum itself plus the wait for the
   // slowest rank to arrive) and the host's wall time per phase of a VBEM iteration (vbem): what a multi-GPU run
   // needs to tell a slow collective from a slow M-step from a straggling rank
@@ -334,6 +335,8 @@ class Context {
   DevBuf<int64_t> seloff_;
   DevBuf<double> mv_;
   PinnedBuf hpack_, hred_, hss_;
+  DevBuf<int> fold_ticket_;          // ticket counter of the signalling fold (estep_suffstat_fused)
+  unsigned long long fold_seq_ = 0;  // last sequence number handed to it
   std::function<void()> overlap_;
 
   bool timing_ = false;

@@ -133,6 +133,11 @@ bool env_on(const char* name) {
   const char* e = std::getenv(name);
   return e && *e && !(e[0] == '0' && e[1] == 0);
 }
+// the same for the switches of the test suite (the split search's literal schedule): libcluster_hip_testhooks.so only
+bool test_on(const char* name) {
+  const char* e = lck::test_switch(name);
+  return e && *e && !(e[0] == '0' && e[1] == 0);
+}
 
 // Run fn(k) for k in [0,n) on up to nthreads host threads.  Exceptions are collected and the first one
 // re-thrown on the calling thread.
@@ -216,7 +221,7 @@ double vbem(lcc::Context& ctx, Model& model, const VbemOptions& opt) {
   bool have_delta = false;
   int chain = 0;
   // LC_SPLIT_DELTA_FORCE=1 (tests): stay on the cache and on moved-row statistics however much moves
-  static const bool inc_force = env_on("LC_SPLIT_DELTA_FORCE");
+  static const bool inc_force = test_on("LC_SPLIT_DELTA_FORCE");
 
   double F = std::numeric_limits<double>::max(), Fold;
   int i = 0, done = 0;
@@ -423,7 +428,7 @@ bool finish_stats(lcc::Context& ctx, StatsBlock& s) {
   if (s.K < 1) return false;
   if (!s.pending) return true;
   s.pending = false;
-  static const bool inc_force = env_on("LC_SPLIT_DELTA_FORCE");
+  static const bool inc_force = test_on("LC_SPLIT_DELTA_FORCE");
   const int K = s.K;
   std::vector<double> dN(K), dx(s.xs.size()), dxx(s.xxs.size()), dNj(s.Njk.size());
   if (ctx.delta_pending() != K || s.chain >= CHAIN_CAP ||
@@ -515,7 +520,7 @@ static bool split_gr(lcc::Context& ctx, Model& model, std::vector<int>& tally, d
   // Statistics of the round's converged qZ (K columns), known after the first candidate's full-data iteration: a
   // candidate changes two columns of qZ (auglabels moves mass from column k to the new column K), so every later
   // candidate recomputes those two only.  Not in sparse mode (the masks depend on all columns).
-  static const bool no_incremental = env_on("LC_SPLIT_FULL_STATS");
+  static const bool no_incremental = test_on("LC_SPLIT_FULL_STATS");
   // ... known already when the round's VBEM could follow the rows its last E-step moved (cluster())
   StatsBlock round_stats;
   if (model.final_stats.K == K && !opt.sparse && !no_incremental) round_stats = model.final_stats;
@@ -700,9 +705,9 @@ double cluster(lcc::Context& ctx, Model& model, const ClusterOptions& opt) {
   double F = 0.0;
   // Gauss-Wishart, dense: E-steps through the distance cache, statistics from the moved rows (VbemOptions::inc);
   // LC_SPLIT_NO_DELTA=1 restores full passes everywhere but the two-column statistics of the split candidates
-  static const bool no_delta = env_on("LC_SPLIT_NO_DELTA") || env_on("LC_SPLIT_NO_DCACHE");
+  static const bool no_delta = test_on("LC_SPLIT_NO_DELTA") || test_on("LC_SPLIT_NO_DCACHE");
   static const double delta_tol = [] {
-    const char* e = std::getenv("LC_SPLIT_DELTA_TOL");
+    const char* e = lck::test_switch("LC_SPLIT_DELTA_TOL");
     return e ? std::atof(e) : 0x1p-50;
   }();
   IncState inc;
@@ -754,7 +759,7 @@ double cluster(lcc::Context& ctx, Model& model, const ClusterOptions& opt) {
     vo.trace = &tr;
     // the split ordering needs the data term LL_k of the converged responsibilities (cluster.cpp:407-410): it comes out
     // of the last iteration's E-step (a by-product of the normalisation sweep) instead of a full extra pass per round
-    static const bool ll_extra_pass = env_on("LC_LL_EXTRA_PASS");  // (the round-1 behaviour, for A/B timing)
+    static const bool ll_extra_pass = test_on("LC_LL_EXTRA_PASS");  // (tests: the round-1 behaviour)
     vo.want_ll = !ll_extra_pass;
     F = vbem(ctx, model, vo);
     model.next_stats.K = 0;

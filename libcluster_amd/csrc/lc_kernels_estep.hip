@@ -695,8 +695,7 @@ static hipError_t launch_estep_s(const EstepLaunch& a, hipStream_t stream) {
   size_t shmem = (size_t)(2 * pstride(DP) + WAVES * a.K + WAVES + 64) * sizeof(double) +
                  (size_t)(2 * a.K + WAVES * R + 2) * sizeof(int);
   EstepLaunch b = a;
-  static const bool no_lql = getenv("LC_ES_NOLQL") != nullptr;  // tuning knob: log q~ through the qZ buffer everywhere
-  if (R == 4 && !a.raw && !no_lql && shmem + (size_t)a.K * WAVES * 64 * sizeof(double) <= 40 * 1024) {  // (four blocks per CU still fit; at 74 KB, K = 32, the lost occupancy costs 8 %)
+  if (R == 4 && !a.raw && shmem + (size_t)a.K * WAVES * 64 * sizeof(double) <= 40 * 1024) {  // (four blocks per CU still fit; at 74 KB, K = 32, the lost occupancy costs 8 %)
     b.lq_lds = 1;  // log q~ stays in LDS until the normalisation
     shmem += (size_t)a.K * WAVES * 64 * sizeof(double);
   }

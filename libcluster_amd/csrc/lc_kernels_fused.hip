@@ -23,8 +23,6 @@
 #include "lc_device.hpp"
 
 #include <algorithm>
-#include <cstdio>
-#include <vector>
 
 namespace lck {
 
@@ -51,27 +49,21 @@ constexpr int FUSED_QS = FUSED_ROWS + 2;  // q table: 258 doubles per cluster = 
 // four chained MFMAs  t = sum_r A_r d2_r + c  with selector operands A_r[i][.] = -1/2 [i == r]  leave
 // log q~ = c - d^2 / 2 of row group `hi` in lane (lo4, hi) directly: no select, no branch, no VALU; (iii) c_k is read at
 // the head of the cluster it belongs to and rides into the chain as its C operand.
-// NTA: tile rows of the whitener / 4-column blocks of X that are not identically zero: 4, or 2 for D <= 8 (the layout is
+// NTA: tile rows of the whitener / 4-column blocks of X that are not identically zero: 4, 2 for D <= 8, 1 for D <= 4 (the layout is
 // the DP = 16 one either way -- `Xcat`'s two columns are padded eightfold -- but the tiles of rows and columns 8 ... 15 are
 // zeros there: the E-step half then walks 5 of a cluster's 14 reads (20 + 4 MFMAs instead of 40 + 4) and the statistics
 // half 5 of its 12 feature tiles; what is left out is written as zeros).
-#ifdef LC_FUSED_TL
-__device__ long long* g_fused_tl;
-#define TL() do { if (lane == 0 && tli < 62) { g_fused_tl[((size_t)blockIdx.x * 4 + wave) * 128 + tli] = wall_clock64(); g_fused_tl[((size_t)blockIdx.x * 4 + wave) * 128 + 64 + tli] = clock64(); } ++tli; } while (0)
-#else
-#define TL() do {} while (0)
-#endif
 template <int DP, int CPW, int GRP, bool WANT_LL, int NTA = 4>
-__global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
+__global__ void __launch_bounds__(256, CPW == 4 ? 1 : 2) fused_small_kernel(FusedLaunch a_) {
   constexpr bool ONEGRP = GRP == 0, CTLDS = GRP != 2;
-  static_assert(NTA == 2 || NTA == 4, "active tile rows");
+  static_assert(NTA == 1 || NTA == 2 || NTA == 4, "active tile rows");
   FusedLaunch a = a_;
   if constexpr (ONEGRP) a.rginfo = nullptr;
   static_assert(DP == 16, "one 16 x 16 block of S_k (the general blocking lives in suffstat_kernel)");
   constexpr int NT = DP / 4;
   constexpr int NTILES = NT * (NT + 1) / 2;
   constexpr int NREAD = NTA * (NTA + 1) / 2 + NTA;  // reads of the first NTA tile rows: a prefix of the cluster's stream
-  constexpr int PF = NTA == 4 ? 7 : 5;
+  constexpr int PF = NTA == 4 ? 7 : NTA == 2 ? 5 : 2;
   static_assert(NREAD % PF == 0, "the ring's slots must line up from one cluster to the next");
   constexpr int PS = NTILES * 16 + DP;
   // row stride of the staged tile (36 dwords).  E-step half: a half-wave reads rows lo4 = 0..15 at two columns -- 36 lo4
@@ -83,7 +75,11 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
   static_assert(4 * CPW <= FUSED_KMAX, "statistics accumulators");
   constexpr int NQ = CPW, NTL = 12;    // cluster quads; feature tiles: 10 patches (ia <= ja), s_k, N_k
   // active feature tiles: the patches with ja < NTA (the first NTA (NTA + 1) / 2 of the enumeration), then s_k and N_k
-  constexpr int NPA = NTA * (NTA + 1) / 2, NTLA = NPA + 2;
+  // N_k: with LL_k the twelfth feature tile (1 * 1); in the plain instance the sweep adds every
+  // responsibility it forms to a per-lane sum instead (one add per entry in a phase that is VALU anyway, against two
+  // MFMAs per 4-row step: 8 % of the statistics half at D = 16, 20 % at D <= 8), folded once at the end of the kernel
+  constexpr bool NK_MFMA = WANT_LL;
+  constexpr int NPA = NTA * (NTA + 1) / 2, NTLA = NPA + 1 + (NK_MFMA ? 1 : 0);
   constexpr int QS = FUSED_QS;         // row stride of the q table: consecutive clusters 8 banks apart
   constexpr int ONE = DP;              // column of the staged tile that holds 1.0
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -102,14 +98,6 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave-uniform: its arithmetic belongs on the scalar unit)
   const int lo4 = lane & 15, hi = lane >> 4, blk = (lane >> 2) & 3, lo2 = lane & 3;
-#ifdef LC_FUSED_TL
-  int tli = 0;
-  if (lane == 0) {
-    g_fused_tl[((size_t)blockIdx.x * 4 + wave) * 128 + 62] = __builtin_amdgcn_s_getreg(63492);  // HW_ID
-    g_fused_tl[((size_t)blockIdx.x * 4 + wave) * 128 + 63] = __builtin_amdgcn_s_getreg(63508);  // XCC_ID
-  }
-#endif
-  TL();
   for (int i = tid; i < K * PS; i += 256) par[i] = a.params[i];
   for (int i = tid; i < 4 * K; i += 256) llw[i] = 0.0;
   if constexpr (CTLDS)
@@ -130,15 +118,21 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
     asm volatile("" : "+v"(selA[r]));  // (four registers for the whole kernel, not a compare + select per use)
   }
   double fz = 0.0;
-  const int64_t NP = a.nrg * RG;
-  const int64_t ntile = (NP + FUSED_ROWS - 1) / FUSED_ROWS;
-  // register double-buffer for the next tile of X (coalesced double2 pieces; rows past the end as zeros)
+  double nk[NK_MFMA ? 1 : 4 * NQ];  // this lane's share of N_k (plain instance)
+#pragma unroll
+  for (int i = 0; i < (NK_MFMA ? 1 : 4 * NQ); ++i) nk[i] = 0.0;
+  // Every block takes the same share of the row groups (+- 1), whole tiles of 16 row groups and ONE partial tile at the
+  // end (round 5: dealing whole tiles left 3907 of them on 512 blocks at N = 1M -- eight rounds for 7.63 tiles' worth of
+  // work; a partial tile costs its share: waves drop row groups in the E-step half, the statistics half drops steps).
+  const int64_t g0 = a.nrg * (int64_t)blockIdx.x / gridDim.x, g1 = a.nrg * ((int64_t)blockIdx.x + 1) / gridDim.x;
+  const int nmy = (int)((g1 - g0 + FUSED_ROWS / RG - 1) / (FUSED_ROWS / RG));  // this block's tiles
+  // register double-buffer for the next tile of X (coalesced double2 pieces; rows past the block's share as zeros)
   constexpr int C2 = DP / 2, NPRE = FUSED_ROWS * C2 / 256;
   double2 pre[NPRE];
-  auto fetch = [&](int64_t tile) {
-    const int64_t r0 = tile * FUSED_ROWS;
-    const int64_t left = tile < ntile ? NP - r0 : 0;
-    const double2* X2 = reinterpret_cast<const double2*>(a.X) + (tile < ntile ? r0 : 0) * C2;
+  auto fetch = [&](int t) {
+    const int64_t rg = g0 + (int64_t)t * (FUSED_ROWS / RG);
+    const int64_t left = t < nmy ? (g1 - rg) * RG : 0;
+    const double2* X2 = reinterpret_cast<const double2*>(a.X) + (t < nmy ? rg * RG : 0) * C2;
     if (left >= FUSED_ROWS) {  // (uniform) a whole tile: no per-load bounds
 #pragma unroll
       for (int i = 0; i < NPRE; ++i) pre[i] = X2[tid + i * 256];
@@ -151,42 +145,37 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
       }
     }
   };
-  fetch(blockIdx.x);
+  fetch(0);
   __syncthreads();
-  TL();
   // n-th read of cluster `kk`'s parameter stream relative to the running pointers of the current cluster
   const double* Pt = par + (lane & 3) + 4 * hi;  // this lane's element of every 4x4 tile (cluster 0)
   const double* Pb = par + NTILES * 16 + hi;     // this lane's element of every 4-vector of -b (cluster 0)
   double* const xstage = xt + (tid / C2) * LD + 2 * (tid % C2);
-  for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
-    const int64_t row0 = tile * FUSED_ROWS;
+  for (int tile = 0; tile < nmy; ++tile) {
+    const int64_t row0 = (g0 + (int64_t)tile * (FUSED_ROWS / RG)) * RG;
     // ---- the tile of X -> LDS (its loads were issued a whole tile ago)
     // (one 16-byte store per piece: its 8-lane groups fill one row's 128 bytes; two 8-byte stores put two rows, 36 dwords
     //  apart, into a 16-lane group: a 2-way conflict on the 32 write banks)
 #pragma unroll
     for (int i = 0; i < NPRE; ++i) *reinterpret_cast<double2*>(xstage + i * (256 / C2) * LD) = pre[i];
     __syncthreads();
-    TL();
-
-#ifdef LC_FX_PRIO
-#define FX_PRIO() do { if ((((unsigned)(wall_clock64() >> LC_FX_PRIO) ^ (blockIdx.x >> 8)) & 1u) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); } while (0)
-#else
-#define FX_PRIO() do {} while (0)
-#endif
-    FX_PRIO();
-    // ---- E-step half: this wave's 64 rows as four row groups; lane (lo4, hi) owns row 16 hi + lo4 = row `tid` of the tile
+    // ---- E-step half: the tile's row groups are dealt to the waves in turn (wave w: groups w, w + 4, w + 8, w + 12); lane
+    // (lo4, hi) owns row lo4 of the wave's group `hi` = row 16 (4 hi + w) + lo4 of the tile.  A partial tile of L row
+    // groups leaves wave w with nr = ceil((L - w) / 4) of them: the pass below exists for 1 ... 4 row groups.
     // (a table entry is read BEFORE the next tile's prefetch goes out: it is waited for at once, and the vector-memory
     //  counter retires in order)
-    const int64_t left = NP - row0;  // padded rows from here on (a multiple of 16)
-    const bool myok = tid < left;    // this lane's row group exists
+    const int L = (int)std::min<int64_t>(FUSED_ROWS / RG, g1 - row0 / RG);  // row groups in this tile (uniform)
+    const int nr = __builtin_amdgcn_readfirstlane(L - wave > 0 ? (L - wave + 3) / 4 : 0);
+    const int rowi = 16 * (4 * hi + wave) + lo4;
+    const bool myok = 4 * hi + wave < L;  // this lane's row group exists
     bool myrow;
     int mygrp = 0;
     if constexpr (ONEGRP) {
-      myrow = row0 + tid < a.nrows;
+      myrow = row0 + rowi < a.nrows;
     } else {
       int info = 0;
       if (myok) {
-        const int64_t rg = row0 / RG + (tid >> 4);
+        const int64_t rg = row0 / RG + 4 * hi + wave;
         if (a.rginfo) {
           info = a.rginfo[rg];
         } else {
@@ -199,98 +188,113 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
       myrow = lo4 < (info & 31);
       __builtin_amdgcn_sched_barrier(0);
     }
-    fetch(tile + gridDim.x);  // in flight during both halves of this tile
-    double xf[R][NT];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const double* xr = xt + (wave * 64 + r * 16 + lo4) * LD + hi;
-#pragma unroll
-      for (int jt = 0; jt < NT; ++jt) xf[r][jt] = jt < NTA ? xr[4 * jt] : 0.0;
-    }
+    fetch(tile + 1);  // in flight during both halves of this tile
     // the constant of cluster k for this lane's row group
     auto cjk_of = [&](int k) -> double {
       if constexpr (ONEGRP) return ctl[k];
       else if constexpr (CTLDS) return ctl[mygrp * K + k];
       else return a.ctab[(int64_t)mygrp * K + k];
     };
-    double ring[PF];
-    static_for<PF>([&](auto ic) {
-      constexpr RdInfo ri = rd_info(ic);
-      ring[ic] = ri.jt < 0 ? Pb[ri.off] : Pt[ri.off];
-    });
-    // carried from cluster k - 1 into cluster k's pass: its last tile row (not yet squared), its partial squared norms
-    // and its constant (-inf before the first cluster: that pass's "log q~" is -inf and changes nothing)
-    double accP[R], d2P[R], cP = -INFINITY, mymx = -INFINITY;
+    double mymx = -INFINITY;
+    auto estep_pass = [&](auto rrc) {
+      constexpr int RR = decltype(rrc)::value;  // row groups of this wave in this tile
+      double xf[RR][NT];
 #pragma unroll
-    for (int r = 0; r < R; ++r) accP[r] = 0.0, d2P[r] = 0.0;
-    for (int k = 0; k < K; ++k) {
-      const double* Ptk = Pt + (size_t)k * PS;
-      const double* Pbk = Pb + (size_t)k * PS;
-      const double cK = cjk_of(k);
-      double* const qslot = qt + (size_t)(k > 0 ? k - 1 : 0) * QS + tid;  // (k = 0 writes -inf where cluster 0 lands next)
-      double d2[R], accs[2][R], t = 0.0;
-      static_for<NREAD>([&](auto nc) {
-        constexpr int n = nc;
-        constexpr RdInfo ri = rd_info(n);
-        constexpr int set = ri.it & 1;
-        const double v = ring[n % PF];
-        {  // the read PF ahead: of this cluster, or already of the next one
-          constexpr int m = n + PF;
-          constexpr RdInfo rn = rd_info(m < NREAD ? m : m - NREAD);
-          constexpr int over = m < NREAD ? 0 : PS;
-          ring[n % PF] = rn.jt < 0 ? Pbk[rn.off + over] : Ptk[rn.off + over];
-        }
-        if constexpr (ri.jt < 0) {
+      for (int r = 0; r < RR; ++r) {
+        const double* xr = xt + (16 * (4 * r + wave) + lo4) * LD + hi;
 #pragma unroll
-          for (int r = 0; r < R; ++r) accs[set][r] = v;  // y starts at -b: y = A x - b
-        } else {
-#pragma unroll
-          for (int r = 0; r < R; ++r) accs[set][r] = mfma4(v, xf[r][ri.jt], accs[set][r]);
-        }
-        // under those MFMAs: the previous cluster's tail and this cluster's deferred squares
-        if constexpr (n == 1) {
-#pragma unroll
-          for (int r = 0; r < R; ++r) d2P[r] = fma(accP[r], accP[r], d2P[r]);
-        }
-        // the four links of the previous cluster's lane-sum chain (NTA = 4: behind reads 3, 4, 6, 7; NTA = 2: 2, 3, 4, 4)
-        constexpr int L0 = NTA == 4 ? 3 : 2, L1 = NTA == 4 ? 4 : 3, L2 = NTA == 4 ? 6 : 4, L3 = NTA == 4 ? 7 : 4;
-        if constexpr (n == L0) t = mfma4(selA[0], d2P[0], cP);
-        if constexpr (n == L1) t = mfma4(selA[1], d2P[1], t);
-        if constexpr (n == L2) t = mfma4(selA[2], d2P[2], t);
-        if constexpr (n == L3) t = mfma4(selA[3], d2P[3], t);
-        // tile row it - 1 is squared behind tile (it, 1), under the MFMAs of row it (the last row waits for the next cluster)
-        if constexpr (ri.jt == 1 && ri.it >= 1) {
-          constexpr int pset = (ri.it - 1) & 1;
-#pragma unroll
-          for (int r = 0; r < R; ++r)
-            d2[r] = ri.it == 1 ? accs[pset][r] * accs[pset][r] : fma(accs[pset][r], accs[pset][r], d2[r]);
-        }
-        if constexpr (n == NREAD - 2 + (NTA == 2 ? 1 : 0)) {  // log q~ of cluster k - 1 for this lane's row: its own slot (no barrier before it reads it back)
-          mymx = fmax(mymx, t);  // (fmax, not the asm max_raw: t comes straight out of an MFMA, and the compiler only counts the
-                                 //  wait states between an MFMA and its reader for instructions it emitted itself)
-          *qslot = t;
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        for (int jt = 0; jt < NT; ++jt) xf[r][jt] = jt < NTA ? xr[4 * jt] : 0.0;
+      }
+      double ring[PF];
+      static_for<PF>([&](auto ic) {
+        constexpr RdInfo ri = rd_info(ic);
+        ring[ic] = ri.jt < 0 ? Pb[ri.off] : Pt[ri.off];
       });
+      // carried from cluster k - 1 into cluster k's pass: its last tile row (not yet squared), its partial squared norms
+      // and its constant (-inf before the first cluster: that pass's "log q~" is -inf and changes nothing)
+      double accP[RR], d2P[RR], cP = -INFINITY;
 #pragma unroll
-      for (int r = 0; r < R; ++r) accP[r] = accs[(NTA - 1) & 1][r], d2P[r] = d2[r];  // the last tile row is squared under the next cluster
-      cP = cK;
+      for (int r = 0; r < RR; ++r) accP[r] = 0.0, d2P[r] = 0.0;
+      for (int k = 0; k < K; ++k) {
+        const double* Ptk = Pt + (size_t)k * PS;
+        const double* Pbk = Pb + (size_t)k * PS;
+        const double cK = cjk_of(k);
+        double* const qslot = qt + (size_t)(k > 0 ? k - 1 : 0) * QS + tid;  // (k = 0 writes -inf where cluster 0 lands next)
+        double d2[RR], accs[2][RR], t = 0.0;
+#pragma unroll
+        for (int r = 0; r < RR; ++r) d2[r] = 0.0;  // (NTA = 1: no tile row is squared inside the pass)
+        static_for<NREAD>([&](auto nc) {
+          constexpr int n = nc;
+          constexpr RdInfo ri = rd_info(n);
+          constexpr int set = ri.it & 1;
+          const double v = ring[n % PF];
+          {  // the read PF ahead: of this cluster, or already of the next one
+            constexpr int m = n + PF;
+            constexpr RdInfo rn = rd_info(m < NREAD ? m : m - NREAD);
+            constexpr int over = m < NREAD ? 0 : PS;
+            ring[n % PF] = rn.jt < 0 ? Pbk[rn.off + over] : Ptk[rn.off + over];
+          }
+          if constexpr (ri.jt < 0) {
+#pragma unroll
+            for (int r = 0; r < RR; ++r) accs[set][r] = v;  // y starts at -b: y = A x - b
+          } else {
+#pragma unroll
+            for (int r = 0; r < RR; ++r) accs[set][r] = mfma4(v, xf[r][ri.jt], accs[set][r]);
+          }
+          // under those MFMAs: the previous cluster's tail and this cluster's deferred squares
+          if constexpr (n == 1) {
+#pragma unroll
+            for (int r = 0; r < RR; ++r) d2P[r] = fma(accP[r], accP[r], d2P[r]);
+          }
+          // the links of the previous cluster's lane-sum chain, one per row group (NTA = 4: behind reads 3, 4, 6, 7;
+          // NTA = 2: 2, 3, 4, 4;
+          // NTA = 1: all behind read 1, the only tile)
+          constexpr int L0 = NTA == 4 ? 3 : NTA == 2 ? 2 : 1, L1 = NTA == 4 ? 4 : NTA == 2 ? 3 : 1, L2 = NTA == 4 ? 6 : NTA == 2 ? 4 : 1,
+                        L3 = NTA == 4 ? 7 : NTA == 2 ? 4 : 1;
+          if constexpr (n == L0) t = mfma4(selA[0], d2P[0], cP);
+          if constexpr (n == L1 && RR > 1) t = mfma4(selA[1], d2P[RR > 1 ? 1 : 0], t);
+          if constexpr (n == L2 && RR > 2) t = mfma4(selA[2], d2P[RR > 2 ? 2 : 0], t);
+          if constexpr (n == L3 && RR > 3) t = mfma4(selA[3], d2P[RR > 3 ? 3 : 0], t);
+          // tile row it - 1 is squared behind tile (it, 1), under the MFMAs of row it (the last row waits for the next cluster)
+          if constexpr (ri.jt == 1 && ri.it >= 1) {
+            constexpr int pset = (ri.it - 1) & 1;
+#pragma unroll
+            for (int r = 0; r < RR; ++r)
+              d2[r] = ri.it == 1 ? accs[pset][r] * accs[pset][r] : fma(accs[pset][r], accs[pset][r], d2[r]);
+          }
+          if constexpr (n == NREAD - (NTA == 4 ? 2 : 1)) {  // log q~ of cluster k - 1 for this lane's row: its own slot (no barrier before it reads it back)
+            mymx = fmax(mymx, t);  // (fmax, not the asm max_raw: t comes straight out of an MFMA, and the compiler only counts the
+                                   //  wait states between an MFMA and its reader for instructions it emitted itself)
+            *qslot = t;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        });
+#pragma unroll
+        for (int r = 0; r < RR; ++r) accP[r] = accs[(NTA - 1) & 1][r], d2P[r] = d2[r];  // the last tile row is squared under the next cluster
+        cP = cK;
+      }
+      {  // the last cluster's tail
+#pragma unroll
+        for (int r = 0; r < RR; ++r) d2P[r] = fma(accP[r], accP[r], d2P[r]);
+        double t = mfma4(selA[0], d2P[0], cP);
+#pragma unroll
+        for (int r = 1; r < RR; ++r) t = mfma4(selA[r], d2P[r], t);
+        mymx = fmax(mymx, t);
+        qt[(size_t)(K - 1) * QS + tid] = t;
+      }
+    };
+    // (lanes whose row group does not exist -- hi >= nr -- come out of the chain with log q~ = c_k: finite, and unused)
+    if (nr == 4) estep_pass(std::integral_constant<int, 4>{});
+    else if (nr == 3) estep_pass(std::integral_constant<int, 3>{});
+    else if (nr == 2) estep_pass(std::integral_constant<int, 2>{});
+    else if (nr == 1) estep_pass(std::integral_constant<int, 1>{});
+    else {  // no row group of this wave in the tile: its slots of the table are zeros for the statistics half
+      for (int k = 0; k < K; ++k) qt[(size_t)k * QS + tid] = 0.0;
     }
-    {  // the last cluster's tail
-#pragma unroll
-      for (int r = 0; r < R; ++r) d2P[r] = fma(accP[r], accP[r], d2P[r]);
-      double t = mfma4(selA[0], d2P[0], cP);
-#pragma unroll
-      for (int r = 1; r < R; ++r) t = mfma4(selA[r], d2P[r], t);
-      mymx = fmax(mymx, t);
-      qt[(size_t)(K - 1) * QS + tid] = t;
-    }
-    TL();
-    FX_PRIO();
     // logsumexp and normalisation in the reference's order: max, sum exp(x - max), log + max, exp(x - logZ)
-    {
-      double* const ql = qt + tid;
-      double* const qp = a.qZ + row0 + tid;
+    if (nr > 0) {
+      double* const ql = qt + tid;  // (the table is indexed by owner thread: 64 consecutive slots per wave, no bank shared)
+      double* const qp = a.qZ + row0 + rowi;
       const bool live = myok && myrow;
       if constexpr (!WANT_LL) {
         // ONE exponential per entry -- e = exp(log q~ - max) stays in registers and q = e / sum(e); the same sum and
@@ -318,6 +322,7 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
             for (int j = 0; j < 4; ++j) {
               const int kk = 4 * c + j;
               const double q = live ? e[kk] * inv : 0.0;
+              if constexpr (!NK_MFMA) nk[kk] += q;  // (slots of clusters >= K add zeros)
               if (kk < K) {
                 if (myok) qp[(int64_t)kk * a.ldq] = q;
                 ql[kk * QS] = q;
@@ -342,10 +347,7 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
         if (live) fz += logZ;
       }
     }
-    TL();
     __syncthreads();
-    TL();
-    FX_PRIO();
 
     // ---- statistics half: this wave's 16 of the tile's 64 four-row steps, all feature tiles, all cluster quads.
     // Tile t < 10 is the patch (ia, ja): x[row][4 ia + lo2] * x[row][4 ja + blk] -- two lane-dependent base pointers and
@@ -365,27 +367,22 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
       // s_k fragment and the ones) are read while step s4's products and MFMAs issue -- left to itself hipcc reads them
       // right in front of their use and every step starts with an exposed LDS round trip
       struct StepOps {
-        double qa[NQ], u[NTA], w[NTA], s, one;
+        double qa[NQ], u[NTA], w[NTA], s, one = 0.0;
       };
-      auto load = [&](auto sc, StepOps& o) {
-        constexpr int s4 = decltype(sc)::value, ro = s4 * 16 * LD;
+      // (row block s4 = row group s4 of the tile belongs to wave s4 % 4 as its group s4 / 4: the slots of its rows in the
+      //  table -- indexed by owner thread -- start at 64 (s4 % 4) + 16 (s4 / 4))
+      auto load = [&](int ro, int qo, StepOps& o) {
 #pragma unroll
-        for (int c = 0; c < NQ; ++c) o.qa[c] = qb[4 * c * QS + s4 * 16];
+        for (int c = 0; c < NQ; ++c) o.qa[c] = qb[4 * c * QS + qo];
 #pragma unroll
         for (int i = 0; i < NTA; ++i) o.u[i] = xu[ro + 4 * i], o.w[i] = xw[ro + 4 * i];
         o.s = xs[ro];
-        o.one = x1[ro];
+        if constexpr (NK_MFMA) o.one = x1[ro];
       };
-      StepOps cur;
-      load(std::integral_constant<int, 0>{}, cur);
-      static_for<FUSED_ROWS / 16>([&](auto sc) {
-        constexpr int s4 = sc;
-        StepOps nxt = cur;
-        if constexpr (s4 + 1 < FUSED_ROWS / 16) load(std::integral_constant<int, s4 + 1>{}, nxt);
-        __builtin_amdgcn_sched_barrier(0);
-        // ALL of the step's products first, then all of its MFMAs: next to the matrix pipe a VALU instruction is paid per
-        // switch between the two kinds, not per instruction (tools/mfma_batch_probe.hip: ~ 12 clocks each when they stand
-        // alone between MFMAs, ~ 5 in a group of eight)
+      // ALL of a step's products first, then all of its MFMAs: next to the matrix pipe a VALU instruction is paid per
+      // switch between the two kinds, not per instruction (tools/mfma_batch_probe.hip: ~ 12 clocks each when they stand
+      // alone between MFMAs, ~ 5 in a group of eight)
+      auto multiply = [&](const StepOps& cur) {
         double p[NTLA];
         static_for<NTLA>([&](auto tc) {
           constexpr int t = tc;
@@ -404,14 +401,33 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
 #pragma unroll
           for (int c = 0; c < NQ; ++c) acc[t][c] = mfma4(cur.qa[c], p[t], acc[t][c]);
         });
-        __builtin_amdgcn_sched_barrier(0);
-        cur = nxt;
-      });
+      };
+      StepOps cur;
+      load(0, 0, cur);
+      if (L == FUSED_ROWS / 16) {  // (uniform) a whole tile: every offset a compile-time constant
+        static_for<FUSED_ROWS / 16>([&](auto sc) {
+          constexpr int s4 = sc, n4 = s4 + 1;
+          StepOps nxt = cur;
+          if constexpr (n4 < FUSED_ROWS / 16) load(n4 * 16 * LD, 64 * (n4 % 4) + 16 * (n4 / 4), nxt);
+          __builtin_amdgcn_sched_barrier(0);
+          multiply(cur);
+          __builtin_amdgcn_sched_barrier(0);
+          cur = nxt;
+        });
+      } else {  // the block's last tile: L < 16 row blocks, the same steps in a loop
+        for (int s4 = 0; s4 < L; ++s4) {
+          const int n4 = s4 + 1;
+          StepOps nxt = cur;
+          if (n4 < L) load(n4 * 16 * LD, 64 * (n4 % 4) + 16 * (n4 / 4), nxt);
+          __builtin_amdgcn_sched_barrier(0);
+          multiply(cur);
+          __builtin_amdgcn_sched_barrier(0);
+          cur = nxt;
+        }
+      }
     }
-    TL();
     __syncthreads();  // the next tile overwrites xt and qt
   }
-  TL();
 
   // ---- one partial record per (block, cluster): [N_k, s_k(DP), S_k(DP x DP)].  The four waves' accumulators meet in
   // LDS in wave order (fixed: deterministic); then every thread writes its share of the 12 x NQ x 64 entries.
@@ -427,7 +443,7 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
 #pragma unroll
           for (int c = 0; c < NQ; ++c) {
             // record tile t: patch t (t < 10), s_k (10), N_k (11) <- accumulator slot; the tiles left out are zeros
-            const int slot = t < NPA ? t : t == 10 ? NPA : t == 11 ? NPA + 1 : -1;
+            const int slot = t < NPA ? t : t == 10 ? NPA : t == 11 && NK_MFMA ? NPA + 1 : -1;
             const double v = slot >= 0 ? acc[slot >= 0 ? slot : 0][c] : 0.0;
             double* r = red + (t * NQ + c) * 64 + lane;
             *r = w == 0 ? v : *r + v;
@@ -449,10 +465,20 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
         out[1 + DP + gj * DP + gi] = v;
       } else if (t == 10) {
         out[1 + 4 * b + lo] = v;
-      } else if (b == 0 && lo == 0) {
+      } else if (NK_MFMA && b == 0 && lo == 0) {
         out[0] = v;
       }
     }
+  }
+  if constexpr (!NK_MFMA) {  // N_k: lanes (fixed butterfly), then the four waves in wave order (llw is unused without LL_k)
+#pragma unroll
+    for (int kk = 0; kk < 4 * NQ; ++kk) {
+      const double v = wave_sum(nk[kk]);
+      if (lane == 0 && kk < K) llw[wave * K + kk] = v;
+    }
+    __syncthreads();
+    for (int k = tid; k < K; k += 256) rec[(int64_t)k * SS] = ((llw[k] + llw[K + k]) + llw[2 * K + k]) + llw[3 * K + k];
+    __syncthreads();
   }
   fz = wave_sum(fz);
   if (lane == 0) fzw[wave] = fz;
@@ -460,7 +486,6 @@ __global__ void __launch_bounds__(256, 2) fused_small_kernel(FusedLaunch a_) {
   for (int k = tid; k < K; k += 256)
     rec[K * SS + 1 + k] = WANT_LL ? llw[k] + llw[K + k] + llw[2 * K + k] + llw[3 * K + k] : 0.0;
   if (tid == 0) rec[K * SS] = -(fzw[0] + fzw[1] + fzw[2] + fzw[3]);  // cluster.cpp:137 returns -sum(logZ)
-  TL();
 }
 
 static size_t fused_lds_bytes(int DP, int K) {
@@ -472,7 +497,7 @@ static size_t fused_lds_bytes(int DP, int K) {
 // does this shape have a fused path?  (a property of (DP, K) alone: every rank of a distributed run must take the same
 // branch whatever its share of the rows, an empty share included)
 bool fused_eligible(int DP, int K) {
-  static const bool off = getenv("LC_FUSED_SMALL") && atoi(getenv("LC_FUSED_SMALL")) == 0;
+  static const bool off = test_switch("LC_FUSED_SMALL") && atoi(test_switch("LC_FUSED_SMALL")) == 0;  // (tests: the two separate kernels)
   if (off || DP != 16 || K < 1 || K > FUSED_KMAX) return false;
   // the pass keeps a 256-row tile, all K parameter records and a K x 256 table in LDS (93 KB at K = 16): the answer must
   // also hold on the device at hand -- and be the same on every rank, so it is asked of the architecture the library is
@@ -498,52 +523,16 @@ static hipError_t launch_fused_t(const FusedLaunch& a, hipStream_t stream, size_
     hipLaunchKernelGGL(kern, dim3((unsigned)a.grid), dim3(256), shmem, stream, a);
     return hipGetLastError();
   };
-  static LdsGrant grants[4];
-  static const bool full_only = getenv("LC_FUSED_FULL") != nullptr;  // (A/B: the full-width instance at every D)
+  static LdsGrant grants[6];
+  static const bool full_only = test_switch("LC_FUSED_FULL") != nullptr;  // (tests: the full-width instance at every D)
+  if (a.D <= 4 && !full_only)  // (columns 4 ... 15 are zeros: one tile of the whitener, one patch of S_k -- the reference's own test data is D = 2)
+    return a.want_ll ? go(fused_small_kernel<16, CPW, GRP, true, 1>, grants[5]) : go(fused_small_kernel<16, CPW, GRP, false, 1>, grants[4]);
   if (a.D <= 8 && !full_only)  // (columns 8 ... 15 of the padded layout are zeros: the half-width instance)
     return a.want_ll ? go(fused_small_kernel<16, CPW, GRP, true, 2>, grants[3]) : go(fused_small_kernel<16, CPW, GRP, false, 2>, grants[2]);
   return a.want_ll ? go(fused_small_kernel<16, CPW, GRP, true>, grants[1]) : go(fused_small_kernel<16, CPW, GRP, false>, grants[0]);
 }
 
-#ifdef LC_FUSED_TL
-static void fused_tl_hook(const FusedLaunch& a, hipStream_t stream, bool after) {
-  static long long* buf = nullptr;
-  static int launches = 0;
-  const size_t n = (size_t)a.grid * 4 * 128;
-  if (!after) {
-    if (!buf) {
-      hipMalloc(&buf, n * sizeof(long long));
-      hipMemcpyToSymbol(HIP_SYMBOL(g_fused_tl), &buf, sizeof(buf));
-    }
-    return;
-  }
-  if (++launches == 60 && getenv("LC_FUSED_TL_OUT")) {
-    hipStreamSynchronize(stream);
-    std::vector<long long> h(n);
-    hipMemcpy(h.data(), buf, n * sizeof(long long), hipMemcpyDeviceToHost);
-    FILE* f = fopen(getenv("LC_FUSED_TL_OUT"), "w");
-    for (int b = 0; b < a.grid; ++b)
-      for (int w = 0; w < 4; ++w) {
-        fprintf(f, "%d %d", b, w);
-        for (int i = 0; i < 128; ++i) fprintf(f, " %lld", h[((size_t)b * 4 + w) * 128 + i]);
-        fprintf(f, "\n");
-      }
-    fclose(f);
-  }
-}
-#endif
-static hipError_t launch_fused_impl(const FusedLaunch& a, hipStream_t stream);
 hipError_t launch_fused(const FusedLaunch& a, hipStream_t stream) {
-#ifdef LC_FUSED_TL
-  fused_tl_hook(a, stream, false);
-  hipError_t e = launch_fused_impl(a, stream);
-  fused_tl_hook(a, stream, true);
-  return e;
-#else
-  return launch_fused_impl(a, stream);
-#endif
-}
-static hipError_t launch_fused_impl(const FusedLaunch& a, hipStream_t stream) {
   if (a.DP != 16 || a.grid <= 0) return hipErrorInvalidValue;
   const size_t shmem = fused_lds_bytes(a.DP, a.K);
   if (!a.rginfo) {

@@ -557,15 +557,14 @@ __host__ __device__ constexpr int ft_tpw_max(int DP, int NQ) {
 #ifndef LC_FT_BR
 #define LC_FT_BR 32
 #endif
-#ifndef LC_FT_GROUP
-#define LC_FT_GROUP 1
-#endif
 #ifndef LC_FT_BR64
 #define LC_FT_BR64 48
 #endif
 #ifndef LC_FT_BR128
 #define LC_FT_BR128 32
 #endif
+// tiles whose products are formed together in front of their MFMAs (suffstat_feat_kernel's step loop)
+__host__ __device__ constexpr int ft_group(int DP) { return DP == 48 || DP == 64 ? 2 : 1; }
 __host__ __device__ constexpr int ft_waves(int DP) { return DP == 64 ? LC_FT_WAVES64 : DP == 128 ? LC_FT_WAVES128 : 4; }
 __host__ __device__ constexpr int ft_nslice(int DP, int NQ) {  // blocks per row chunk
   return (ft_tiles(DP) + ft_waves(DP) * ft_tpw_max(DP, NQ) - 1) / (ft_waves(DP) * ft_tpw_max(DP, NQ));
@@ -583,7 +582,8 @@ __host__ __device__ constexpr int ft_qld(int NQ) { return NQ > 8 ? 68 : 36; }
 // one multiply per 16 MFMAs; config 5's K = 64 used to take two launches of 8 quads, each re-reading and re-staging X)
 inline int ft_range(int DP, int K) { return DP == 128 && K % 64 == 0 ? 64 : DP == 128 && K % 64 >= 57 ? 64 : 32; }
 inline bool ss_feat_eligible(int DP, int K) {
-  static const int mode = getenv("LC_SS_FEAT") ? atoi(getenv("LC_SS_FEAT")) : 1;  // 0 off, 1 where it wins, 2 everywhere it exists
+  // (tests, libcluster_hip_testhooks.so only: 0 off, 1 where it wins, 2 everywhere it exists)
+  static const int mode = test_switch("LC_SS_FEAT") ? atoi(test_switch("LC_SS_FEAT")) : 1;
   if (mode == 0 || K <= 16 || DP < 32 || DP > 128) return false;
   if (mode == 2) return true;
   // measured (tools/ssfeat_check.py, MI355X): it wins where EVERY launch carries 7 or 8 cluster quads (one multiply per
@@ -735,22 +735,25 @@ __global__ void __launch_bounds__(64 * ft_waves(DP), 2) suffstat_feat_kernel(Suf
   constexpr bool ONEQ = NQ > 8;
   auto batch = [&](auto bsel, auto ntsel) {
     constexpr int B = decltype(bsel)::value, XO = B * XBUF, QO = B * QBUF, NT = decltype(ntsel)::value;
-#if LC_FT_GROUP > 1
-    if constexpr (!ONEQ) {
+    if constexpr (!ONEQ && ft_group(DP) > 1) {
       // Tiles in groups of G: the group's products first, then its G x NQ MFMAs.  Next to the matrix pipe a VALU
       // instruction is paid per switch between the two kinds, not per instruction (tools/mfma_batch_probe.hip: ~ 12 clocks
-      // for a lone multiply between MFMAs, 8 each in pairs, 6.5 in threes); the fragments of the next group are read into
-      // the registers the multiplies have just freed and arrive under the MFMAs.
-      constexpr int G = LC_FT_GROUP, TOT = (BR / 4) * NT;
-      double qa[2][NQ], u[G], w[G], pp[G];
+      // for a lone multiply between MFMAs, 8 each in pairs, 5.7 in fours); the fragments of the next group are read into
+      // the registers the multiplies have just freed and arrive under the MFMAs.  ONE set of q quads, refilled in place
+      // during the last tile of a step (as the 16-quad instance does): the second set's 16 registers pay for the group.
+      // Measured (N = 10M, D = 64, K = 32; gpurun_out/r05e): pairs 21.61 -> 21.22 ms, threes 21.30, fours 21.51, fives 21.79
+      // -- the multiplies were a third of what the step loses, and larger groups expose the fragment reads; D = 48 gains
+      // 1 % with pairs, D = 32 and D = 128 nothing (ft_group).
+      constexpr int G = ft_group(DP), TOT = (BR / 4) * NT;
+      double qa[NQ], u[G], w[G], pp[G];
 #pragma unroll
       for (int g = 0; g < G; ++g)
-        if (g < TOT) {
-          u[g] = pu[g % NT][XO + (g / NT) * 4 * LD];
-          w[g] = pw[g % NT][XO + (g / NT) * 4 * LD];
+        if (g < TOT && g < NT) {
+          u[g] = pu[g][XO];
+          w[g] = pw[g][XO];
         }
 #pragma unroll
-      for (int c = 0; c < NQ; ++c) qa[0][c] = pq[QO + 4 * c];
+      for (int c = 0; c < NQ; ++c) qa[c] = pq[QO + 4 * c];
 #pragma unroll
       for (int st = 0; st < BR / 4; ++st) {
         // (groups never straddle a step: the step's q quads change there)
@@ -760,7 +763,7 @@ __global__ void __launch_bounds__(64 * ft_waves(DP), 2) suffstat_feat_kernel(Suf
 #pragma unroll
           for (int g = 0; g < G; ++g)
             if (g < ng) pp[g] = u[g] * w[g];
-          // the next group: the rest of this step, or the head of the next one (and then its q quads as well)
+          // the next group: the rest of this step, or the head of the next one
           const int nt0 = t0 + G < NT ? t0 + G : 0, nst = t0 + G < NT ? st : st + 1;
           if (nst < BR / 4) {
             const int nng = NT - nt0 < G ? NT - nt0 : G;
@@ -770,24 +773,31 @@ __global__ void __launch_bounds__(64 * ft_waves(DP), 2) suffstat_feat_kernel(Suf
                 u[g] = pu[nt0 + g][XO + nst * 4 * LD];
                 w[g] = pw[nt0 + g][XO + nst * 4 * LD];
               }
-            if (nst != st) {
-#pragma unroll
-              for (int c = 0; c < NQ; ++c) qa[nst & 1][c] = pq[QO + nst * 4 * QLD + 4 * c];
-            }
           }
+          const bool refill = nst != st && nst < BR / 4;
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int g = 0; g < G; ++g)
             if (g < ng) {
+              if (refill && g + 1 == ng) {
 #pragma unroll
-              for (int c = 0; c < NQ; ++c) acc[t0 + g][c] = mfma4(qa[st & 1][c], pp[g], acc[t0 + g][c]);
+                for (int c4 = 0; c4 < NQ; c4 += 4) {
+#pragma unroll
+                  for (int c = c4; c < c4 + 4 && c < NQ; ++c) acc[t0 + g][c] = mfma4(qa[c], pp[g], acc[t0 + g][c]);
+#pragma unroll
+                  for (int c = c4; c < c4 + 4 && c < NQ; ++c) qa[c] = pq[QO + nst * 4 * QLD + 4 * c];
+                  __builtin_amdgcn_sched_barrier(0);
+                }
+              } else {
+#pragma unroll
+                for (int c = 0; c < NQ; ++c) acc[t0 + g][c] = mfma4(qa[c], pp[g], acc[t0 + g][c]);
+              }
             }
           __builtin_amdgcn_sched_barrier(0);
         }
       }
       return;
     }
-#endif
     double qa[ONEQ ? 1 : 2][NQ], u[2], w[2];
     u[0] = pu[0][XO];
     w[0] = pw[0][XO];
@@ -949,10 +959,6 @@ template <>
 struct SSCfg<128> { static constexpr int CPW = 1; };
 
 static int ss_cpw(int DP, int K) {
-  if (const char* e = getenv("LC_SS_CPW")) {  // tuning knob
-    const int v = atoi(e);
-    if (v == 1 || (v == 2 && DP <= 64) || (v == 4 && DP <= 32)) return v;
-  }
   int cpw = DP == 16 ? SSCfg<16>::CPW : DP == 32 ? SSCfg<32>::CPW : DP == 48 ? SSCfg<48>::CPW : DP == 64 ? SSCfg<64>::CPW
                                                                                              : SSCfg<128>::CPW;  // (96, 128)
   // few clusters: spread them over more waves instead of stacking them in one
@@ -967,7 +973,6 @@ int suffstat_extra_records(int DP, int K, bool skip_or_items, int* klast0) {
   if (klast0) *klast0 = K;
   if (DP > 128 || skip_or_items || K < 1) return 0;
   if (ss_feat_eligible(DP, K)) return 0;  // (the feature-GEMM kernel covers any K of its range with the same 16 waves)
-  if (DP > 80 && getenv("LC_SS_WHOLE")) return 0;  // (the one-launch tuning variant has no row-split instance)
   const int cpw = ss_cpw(DP, K), kwaves = (K + cpw - 1) / cpw, nslice = (kwaves + 3) / 4;
   const int rs = ss_row_classes(kwaves - (nslice - 1) * 4);
   if (rs == 1) return 0;
@@ -1009,11 +1014,7 @@ int suffstat_plan(int DP, int64_t NP, int K, int64_t* chunk_rows) {
   // four blocks per resident slot: the hardware back-fills slots as blocks retire, which evens out the
   // per-CU / per-XCD speed differences (measured 25.7 -> 24.9 ms at N=10M, D=64, K=32), while the partial
   // records (chunks x K x (1 + DP + DP^2) doubles) stay below 1 GiB
-  int rounds = 4;
-  if (const char* e = getenv("LC_SS_ROUNDS")) {  // tuning knob
-    const int v = atoi(e);
-    if (v >= 1 && v <= 16) rounds = v;
-  }
+  const int rounds = 4;
   const int64_t rec = (int64_t)K * (1 + DP + (int64_t)DP * DP) * 8;
   // (wide records are large: allow 4 GiB of them so that the grid still covers the chip)
   const int64_t cap = ((int64_t)(DP > 128 ? 4 : 1) << 30) / rec;
@@ -1127,15 +1128,14 @@ static hipError_t launch_ss_wide(const SuffstatLaunch& a, hipStream_t stream) {
 
 template <int DP, int CPW, bool SKIP>
 static hipError_t launch_ss_s(const SuffstatLaunch& a, hipStream_t stream) {
-  if constexpr (DP > 80) {  // (at D = 64 the two-half variant is slower: 26.0 vs 23.6 ms)
-    static const bool whole = getenv("LC_SS_WHOLE") != nullptr;  // tuning knob: one launch, one wave per SIMD
-    if (!whole) {
-      hipError_t e = launch_ss_h<DP, CPW, SKIP, 1>(a, stream);
-      if (e != hipSuccess) return e;
-      return launch_ss_h<DP, CPW, SKIP, 2>(a, stream);
-    }
+  if constexpr (DP > 80) {  // (at D = 64 the two-half variant is slower: 26.0 vs 23.6 ms; one launch at one wave per SIMD
+                            //  measured 82.8 against 73.2 ms at D = 128: DESIGN 4.5.3)
+    hipError_t e = launch_ss_h<DP, CPW, SKIP, 1>(a, stream);
+    if (e != hipSuccess) return e;
+    return launch_ss_h<DP, CPW, SKIP, 2>(a, stream);
+  } else {
+    return launch_ss_h<DP, CPW, SKIP, 0>(a, stream);
   }
-  return launch_ss_h<DP, CPW, SKIP, 0>(a, stream);
 }
 
 template <int DP, int CPW>

@@ -534,8 +534,9 @@ def test_half_width_fused_instance_equals_the_full_width_one():
     for full in (False, True):
         env = dict(os.environ)
         env.pop("LC_FUSED_FULL", None)
-        if full:
+        if full:  # (a switch of the test-hooks build: lck::test_switch)
             env["LC_FUSED_FULL"] = "1"
+            env["LC_LIB_PATH"] = str(root / "libcluster_amd" / "lib" / "libcluster_hip_testhooks.so")
         r = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
@@ -699,7 +700,8 @@ def test_feature_gemm_statistics_at_every_width_and_cluster_range(lib):
 
     root = Path(__file__).resolve().parents[1]
     for mode in ("2", "0"):
-        e = dict(os.environ, LC_SS_FEAT=mode, LC_SSFEAT_NOTIME="1")
+        e = dict(os.environ, LC_SS_FEAT=mode, LC_SSFEAT_NOTIME="1",
+                 LC_LIB_PATH=str(root / "libcluster_amd" / "lib" / "libcluster_hip_testhooks.so"))  # (lck::test_switch)
         r = subprocess.run([sys.executable, str(root / "tools" / "ssfeat_check.py"), "child"], capture_output=True, text=True,
                            env=e, timeout=900, cwd=str(root))
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

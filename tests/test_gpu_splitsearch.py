@@ -17,11 +17,22 @@ import pytest
 
 ROOT = Path(__file__).resolve().parents[1]
 pytestmark = pytest.mark.gpu
+HOOKED = str(ROOT / "libcluster_amd" / "lib" / "libcluster_hip_testhooks.so")
+
+
+def _with_switches(env):
+    """The schedule switches (LC_SPLIT_*, LC_LL_EXTRA_PASS, LC_FUSED_SMALL, ...) exist in the test-hooks build of the library
+    only (lck::test_switch): a run that sets one loads that build."""
+    e = dict(env)
+    if any(k.startswith(("LC_SPLIT_", "LC_LL_", "LC_FUSED_", "LC_SS_", "LC_ED_")) for k in e):
+        e.setdefault("LC_LIB_PATH", HOOKED)
+    return e
+
 
 
 def _learn(args, env):
     e = dict(os.environ)
-    e.update(env)
+    e.update(_with_switches(env))
     r = subprocess.run([sys.executable, str(ROOT / "tools" / "learn_bench.py"), *args], capture_output=True, text=True,
                        timeout=600, env=e, cwd=str(ROOT))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
@@ -48,7 +59,7 @@ def _learn_trace(args, env):
     import json
 
     e = dict(os.environ)
-    e.update(env)
+    e.update(_with_switches(env))
     e["LC_LB_TRACE"] = "1"
     r = subprocess.run([sys.executable, str(ROOT / "tools" / "learn_bench.py"), *args], capture_output=True, text=True,
                        timeout=900, env=e, cwd=str(ROOT))
@@ -119,7 +130,7 @@ def _run_snippet(env, **kw):
     import json
 
     e = dict(os.environ)
-    e.update(env)
+    e.update(_with_switches(env))
     r = subprocess.run([sys.executable, "-c", _SNIPPET.format(root=str(ROOT), **kw)], capture_output=True, text=True,
                        timeout=600, env=e, cwd=str(ROOT))
     if env.get("_EXPECT_FAILURE"):
@@ -176,6 +187,11 @@ def test_model_selection_carries_on_when_the_distance_cache_does_not_fit(lib):
     # the shipped library has no fault hooks: the switch does nothing there
     c = _run_snippet({"LC_TEST_CACHE_NO_ROOM": "4", "LC_TRACE_PHASES": "1"}, **kw)
     assert "distance cache given up" not in c["_stderr"] and c["K"] == a["K"]
+    # ... and no schedule switches either (lck::test_switch): the literal schedule's launch count shows only in the hooks build
+    d = _learn(["60000", "24", "5"], {"LC_SPLIT_NO_DCACHE": "1", "LC_LIB_PATH": str(ROOT / "libcluster_amd" / "lib" / "libcluster_hip.so")})
+    e = _learn(["60000", "24", "5"], {})
+    f = _learn(["60000", "24", "5"], {"LC_SPLIT_NO_DCACHE": "1"})
+    assert d[4] == e[4] and f[4] > e[4], (d, e, f)
     assert a["K"] == b["K"] >= 6 and [k for k, _ in a["rounds"]] == [k for k, _ in b["rounds"]]
     for (_, x), (_, y) in zip(a["rounds"], b["rounds"]):
         np.testing.assert_allclose(x, y, rtol=1e-10)
@@ -204,8 +220,7 @@ def test_every_writer_of_the_responsibilities_keeps_the_fingerprints_honest(lib,
     covers every writer of qZ on the paths cluster() really takes (qz_set, the E-step kernels, split_init, keep_columns,
     clone / swap): each must clear hash_ok or mark the rows it rewrites.  LC_TEST_QHASH_KEEP_STALE makes ensure_qz
     "forget" to clear the flag -- the same run must then fail, which shows the check has teeth."""
-    hooked = str(ROOT / "libcluster_amd" / "lib" / "libcluster_hip_testhooks.so")
-    env = {"LC_LIB_PATH": hooked, "LC_TEST_VERIFY_QHASH": "1", "LC_SPLIT_DELTA_FORCE": "1"}
+    env = {"LC_LIB_PATH": HOOKED, "LC_TEST_VERIFY_QHASH": "1", "LC_SPLIT_DELTA_FORCE": "1"}
     ok = _run_snippet(env, **kw)
     assert ok["_stderr"].count("fingerprints verified") >= 3, ok["_stderr"][-1500:]
     plain = _run_snippet({"LC_SPLIT_DELTA_FORCE": "1"}, **kw)

@@ -40,5 +40,6 @@ if __name__ == "__main__":
                 env = dict(os.environ)
                 env.pop("LC_FUSED_FULL", None)
                 if full:
-                    env["LC_FUSED_FULL"] = "1"
+                    env["LC_FUSED_FULL"] = "1"  # (a switch of the test-hooks build: lck::test_switch)
+                    env["LC_LIB_PATH"] = str(__import__("pathlib").Path(__file__).resolve().parents[1] / "libcluster_amd" / "lib" / "libcluster_hip_testhooks.so")
                 subprocess.run([sys.executable, __file__, str(D), str(K)], env=env, check=False)

@@ -65,7 +65,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
 res = {}
 tim = {}
 for name, env in (("feat", {"LC_SS_FEAT": "2"}), ("percluster", {"LC_SS_FEAT": "0"})):
-    e = dict(os.environ, **env)
+    # (LC_SS_FEAT is a switch of the test-hooks build of the library: lck::test_switch)
+    e = dict(os.environ, LC_LIB_PATH=str(ROOT / "libcluster_amd" / "lib" / "libcluster_hip_testhooks.so"), **env)
     p = subprocess.run([sys.executable, __file__, "child"], capture_output=True, text=True, env=e, timeout=900)
     line = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")]
     if p.returncode or not line:
