@@ -64,8 +64,14 @@ CONFIGS = {
     # full covariances wider than 128 columns: estep_wide_kernel + panel launches of suffstat_kernel
     "wide256": dict(N=1_000_000, D=256, K=16, w="Dirichlet", seed=1008,
                     label="BGMM, wide observations: N=1M D=256 K=16 (chunk-streamed whitener, panel statistics)"),
+    # ragged cluster counts (model selection walks K = 1, 2, 3, ...: most of its rounds are NOT multiples of 32) and an
+    # in-between width: the statistics kernel selection of DESIGN 1 off its best shapes
+    "k20": dict(N=5_000_000, D=64, K=20, w="Dirichlet", seed=1020, label="BGMM N=5M D=64 K=20 (ragged cluster count)"),
+    "k40": dict(N=5_000_000, D=64, K=40, w="Dirichlet", seed=1040, label="BGMM N=5M D=64 K=40 (ragged cluster count)"),
+    "d96": dict(N=4_000_000, D=96, K=32, w="Dirichlet", seed=1096, label="BGMM N=4M D=96 K=32 (in-between width)"),
 }
-OTHER_CONFIGS = ["2", "3", "5", "dgmm", "bemm", "wide256"]  # short runs reported under "other_configs" of the default line
+# short runs reported under "other_configs" of the default line
+OTHER_CONFIGS = ["2", "3", "5", "dgmm", "bemm", "wide256", "k20", "k40", "d96"]
 
 
 def mixture(D, K, seed, family="GaussWish", overlap=False):
@@ -434,7 +440,9 @@ def measure(capi, cfg, steps, warmup, rank, world, local_rank, stream, nthreads,
         "estep_ms": ka["estep_ms"] / max(1, ka["estep_calls"]), "suffstat_ms": ka["suffstat_ms"] / max(1, ka["suffstat_calls"]),
         **({"fused_ms": ka["fused_ms"] / ka["fused_calls"]} if ka["fused_calls"] else {}),
         "allreduce_ms": ka["allreduce_ms"] / it, "allreduce_calls_per_step": ka["allreduce_calls"] / it,
-        "mstep_ms": (ka["host_mstep_ms"] + ka["host_fenergy_ms"]) / it,
+        # host phases of an iteration (vbem's own clocks): cluster M-step + E-step constants; the free-energy tail; the
+        # statistics phase's host share (weights update, unpacking) is inside wait_ms with the launches and the waits
+        "mstep_ms": ka["host_mstep_ms"] / it, "fenergy_ms": ka["host_fenergy_ms"] / it,
         "wait_ms": max(0.0, (ka["host_stats_ms"] + ka["host_estep_ms"]) / it - dev_ms),
         "mstep_threads": nthreads, "cpus": len(os.sched_getaffinity(0)),
     }
@@ -485,6 +493,11 @@ def measure(capi, cfg, steps, warmup, rank, world, local_rank, stream, nthreads,
                    "parallelism": (f"rows sharded x{world}" if J == 1 else f"whole groups sharded x{world}")
                    + ", all-reduce of suff-stats"},
     }
+    # where the host's wall time of a step goes (vbem's own clocks, ms per step): the statistics phase and the E-step phase
+    # include the wait for their kernels; mstep = cluster M-step + the E-step's constants, fenergy = the free-energy tail
+    res["host_phases_ms"] = {"stats_wall": ka["host_stats_ms"] / it, "mstep": ka["host_mstep_ms"] / it,
+                             "estep_wall": ka["host_estep_ms"] / it, "fenergy": ka["host_fenergy_ms"] / it,
+                             "kernels": dev_ms, "mstep_threads": nthreads, "cpus": len(os.sched_getaffinity(0))}
     if family != "GaussWish":
         # separable families: 8 (D + K) algorithmic bytes per row and launch (X read + q column written / read)
         gbs = 8.0 * N * (D + K) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
@@ -735,7 +748,7 @@ def main():
             "value": res["value"], "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic", "config": res["config"], "free_energy": res["free_energy"],
-            "kernels": res["kernels"], "roofline": res["roofline"],
+            "kernels": res["kernels"], "roofline": res["roofline"], "host_phases_ms": res["host_phases_ms"],
             **({"check": res["check"]} if "check" in res else {}),
         }
         N, D, K = cfg["N"], cfg["D"], cfg["K"]
@@ -771,7 +784,7 @@ def main():
                 put_traffic(r2["roofline"], name)
                 others.append({"config": name, "workload": c2["label"], "steps": st, "warmup": wu,
                                "value": r2["value"], "ms_per_step": r2["ms_per_step"], "kernels": r2["kernels"],
-                               "roofline": r2["roofline"]})
+                               "roofline": r2["roofline"], "host_phases_ms": r2["host_phases_ms"]})
                 if m2 is not None:
                     m2.close()
                 x2.close()

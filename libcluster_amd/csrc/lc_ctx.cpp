@@ -1033,31 +1033,14 @@ bool Context::estep_suffstat_fused(int K, const double* A, const double* m, cons
     LC_HIP(hipEventRecord(ev.b, stream_));
     pending_.push_back(ev);
   }
-  hss_.resize(nout + 1);  // (+ the completion flag of the signalling fold)
+  hss_.resize(nout);
   // nothing to sum over ranks: the fold writes straight into the pinned host buffer (coherent, device-visible
   // memory) and the copy-back command drops off the iteration's critical path
   constexpr bool direct_env = true;  // (the copy-back command instead: 0.258 against 0.247 ms per iteration in round 2)
   const bool direct = direct_env && !distributed() && grid > 0;
-  // ... and when the fold is the last command of the iteration (one group: no count block behind it) the host waits for
-  // its completion flag in that buffer, not for the stream: hipStreamSynchronize's wake-up is a third of what an
-  // iteration at N = 1M spends outside the kernel (LC_FUSED_SPIN=0 restores it)
-  static const bool spin_env = [] { const char* e = std::getenv("LC_FUSED_SPIN"); return !e || std::atoi(e) != 0; }();
-  const bool spin = direct && !own_counts && spin_env;
-  unsigned long long* flag = reinterpret_cast<unsigned long long*>(hss_.data() + nout);
   double* dst = direct ? hss_.data() : ssout_.p;
   if (grid > 0) {
-    if (spin) {
-      if (!fold_ticket_.p) {
-        fold_ticket_.reserve(1);
-        LC_HIP(hipMemsetAsync(fold_ticket_.p, 0, sizeof(int), stream_));
-      }
-      fold_seq_ += 1;
-      __atomic_store_n(flag, 0ull, __ATOMIC_RELEASE);  // (a recycled page-locked block may hold an old run's sequence number)
-      LC_HIP(lck::launch_reduce_partials_signal(sspart_.p, grid, W, dst, reinterpret_cast<unsigned*>(fold_ticket_.p), flag,
-                                                fold_seq_, stream_));
-    } else {
-      LC_HIP(lck::launch_reduce_partials(sspart_.p, grid, W, dst, stream_));
-    }
+    LC_HIP(lck::launch_reduce_partials(sspart_.p, grid, W, dst, stream_));
     if (own_counts) {
       redtmp_.reserve((size_t)lck::REDUCE_TMP_ELEMS * 64);
       LC_HIP(lck::launch_group_colsum(qz_[cur_].buf.p, NP_, K, goff_d_.p, J_, direct ? dst + nrec : njk_d, stream_,
@@ -1072,22 +1055,7 @@ bool Context::estep_suffstat_fused(int K, const double* A, const double* m, cons
     LC_HIP(hipMemcpyAsync(hss_.data(), ssout_.p, nout * sizeof(double), hipMemcpyDeviceToHost, stream_));
   }
   run_overlap();
-  if (spin) {
-    // (the flag follows the sums through the same queue of posted writes; a stream that has drained without it -- an
-    //  error -- falls through to the synchronisation, which reports it)
-    bool seen = false;
-    for (unsigned i = 0; !seen; ++i) {
-      seen = __atomic_load_n(flag, __ATOMIC_ACQUIRE) == fold_seq_;
-      if (!seen && (i & 0xffffu) == 0xffffu && hipStreamQuery(stream_) != hipErrorNotReady) break;
-      __builtin_ia32_pause();
-    }
-    if (!seen) {
-      LC_HIP(hipStreamSynchronize(stream_));
-      if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != fold_seq_) throw HipFailure("the fused pass finished without its completion flag");
-    }
-  } else {
-    LC_HIP(hipStreamSynchronize(stream_));
-  }
+  LC_HIP(hipStreamSynchronize(stream_));
   for (int k = 0; k < K; ++k) {
     const double* rec = hss_.data() + (size_t)k * SS;
     if (Nk) Nk[k] = rec[0];
@@ -1329,6 +1297,8 @@ bool Context::dcache_eligible(int K) const {
 
 void Context::dcache_invalidate() {
   dc_K_ = 0;
+  dc_slot_.clear();
+  std::fill(dc_used_.begin(), dc_used_.end(), (unsigned char)0);
   dc_saved_.clear();
   dc_journal_ = false;
   dq_K_ = 0;
@@ -1338,6 +1308,7 @@ void Context::dcache_release() {
   dcache_invalidate();
   dc_cap_ = 0;
   dc_room_K_ = 0;
+  dc_used_.clear();
   dc_slab_.release();
   dfresh_.release();
   dq_.release();
@@ -1346,28 +1317,42 @@ void Context::dcache_release() {
   dc_tagm_.clear();
 }
 
+int Context::dc_find_run(int n) const {
+  int run = 0;
+  for (int s = 0; s < dc_cap_; ++s) {
+    run = dc_used_[(size_t)s] ? 0 : run + 1;
+    if (run == n) return s - n + 1;
+  }
+  return -1;
+}
+
 void Context::dcache_journal_begin() {
-  dc_saved_.clear();
+  dcache_journal_end();  // (a journal left open: its old columns are no longer needed)
   dc_journal_ = true;
   dc_jK0_ = dc_K_;
 }
 
 void Context::dcache_journal_end() {
+  for (auto& sv : dc_saved_) dc_used_[(size_t)sv->slot] = 0;  // commit: the journaled contents go
   dc_saved_.clear();
   dc_journal_ = false;
 }
 
 void Context::dcache_rollback() {
   if (!dc_journal_) return;
-  use_device();
+  // back to the map of dcache_journal_begin: the trial's columns give their slots back, the journaled ones return
+  for (int k = dc_jK0_; k < dc_K_; ++k) dc_used_[(size_t)dc_slot_[(size_t)k]] = 0;
+  if ((int)dc_slot_.size() < dc_jK0_) dc_slot_.resize((size_t)dc_jK0_, -1);
   for (auto& sv : dc_saved_) {
-    if (NP_ > 0)
-      LC_HIP(hipMemcpyAsync(dc_slab_.p + (size_t)sv->col * NP_, sv->buf.p, (size_t)NP_ * sizeof(double),
-                            hipMemcpyDeviceToDevice, stream_));
+    const int cur = sv->col < dc_K_ ? dc_slot_[(size_t)sv->col] : -1;
+    if (cur >= 0 && cur != sv->slot) dc_used_[(size_t)cur] = 0;
+    dc_slot_[(size_t)sv->col] = sv->slot;
+    dc_used_[(size_t)sv->slot] = 1;
     dc_tagA_[(size_t)sv->col].swap(sv->A);
     dc_tagm_[(size_t)sv->col].swap(sv->m);
   }
   dc_K_ = dc_jK0_;
+  dc_slot_.resize((size_t)dc_K_);
   dc_saved_.clear();
   dc_journal_ = false;
 }
@@ -1394,18 +1379,47 @@ int Context::estep_cache(int K, const double* A, const double* m, const double* 
   if (stale_out) *stale_out = stale;
   const int nch = (int)changed.size();
   const size_t NPs = (size_t)std::max<int64_t>(NP_, 1);
-  // Is there room?  Asked once per width (before anything is touched), and answered by ALL ranks together: a grown
-  // slab lives next to the old one for a moment, the move of the responsibilities takes K more columns, the journal
-  // a few.
-  // (capacities grow geometrically and together: at tens of millions of rows every one of these blocks is past the
-  // block cache's limit, and a hipMalloc / hipFree of ten gigabytes costs seconds)
-  const int grown_cap = std::max(K + 8, 2 * dc_cap_);
-  if (K > dc_room_K_) {
-    const int newcap = K > dc_cap_ ? grown_cap : dc_cap_;
+  // ---- which slots the changed columns need (nothing is touched yet)
+  auto is_saved = [&](int k) {
+    for (auto& sv : dc_saved_)
+      if (sv->col == k) return true;
+    return false;
+  };
+  // a valid column of the journal's base that has not been journaled yet keeps its slot as it is (a rollback returns to
+  // it): the recomputed column needs a new one; so does a column that does not exist yet.  Everything else may be
+  // overwritten where it is.
+  std::vector<int> writable((size_t)nch, -1);
+  int new_needed = 0;
+  for (int t = 0; t < nch; ++t) {
+    const int k = changed[(size_t)t];
+    const bool exists = k < dc_K_ && k < (int)dc_slot_.size() && dc_slot_[(size_t)k] >= 0;
+    if (exists && !(dc_journal_ && k < dc_jK0_ && !is_saved(k))) writable[(size_t)t] = dc_slot_[(size_t)k];
+    else ++new_needed;
+  }
+  int used = 0;
+  for (unsigned char u : dc_used_) used += u ? 1 : 0;
+  // Is there room?  Asked before anything is touched, and answered by ALL ranks together (`changed` and the slot map are
+  // functions of the replicated M-step: every rank arrives at the same numbers): a grown slab lives next to the old one
+  // for a moment, the move of the responsibilities takes K more columns.
+  // (capacities grow geometrically: at tens of millions of rows every one of these blocks is past the block cache's
+  // limit, and a hipMalloc / hipFree of ten gigabytes costs seconds)
+  const bool grow = K > dc_cap_ || used + new_needed > dc_cap_;
+  const int grown_cap = std::max(std::max(K, used + new_needed) + 8, 2 * dc_cap_);
+  bool ask = K > dc_room_K_ || grow;
+#ifdef LC_TEST_HOOKS  // (libcluster_hip_testhooks.so only: the shipped library has no fault hooks)
+  // tests: the named rank "has no room" for the columns of a split trial (every rank reads the same environment, so every
+  // rank asks the question at the same E-step)
+  static const char* fail_rank = std::getenv("LC_TEST_JOURNAL_FAIL_RANK");
+  const bool trial = fail_rank && dc_journal_ && new_needed > 0;
+  ask = ask || trial;
+#endif
+  if (ask) {
+    const int newcap = grow ? grown_cap : dc_cap_;
     size_t need = 0;
-    if (K > dc_cap_) need += NPs * (size_t)newcap * sizeof(double);
+    if (grow) need += NPs * (size_t)newcap * sizeof(double);
     if (delta_tol >= 0.0 && dq_.cap < NPs * (size_t)newcap) need += NPs * (size_t)(newcap + 1) * sizeof(double);
     bool ok = true;
+    std::string why;
     size_t free_b = 0, total_b = 0;
     if (need > 0) {
       need += NPs * 4 * sizeof(double);
@@ -1415,90 +1429,76 @@ int Context::estep_cache(int K, const double* A, const double* m, const double* 
         LC_HIP(hipMemGetInfo(&free_b, &total_b));
       }
       ok = need <= free_b;
+      if (!ok) why = std::to_string(need) + " bytes needed, " + std::to_string(free_b) + " free on this rank";
     }
-#ifdef LC_TEST_HOOKS  // (libcluster_hip_testhooks.so only: the shipped library has no fault hooks)
+#ifdef LC_TEST_HOOKS
     static const char* fake = std::getenv("LC_TEST_CACHE_NO_ROOM");  // tests: pretend the device is full from this K on
-    if (fake && K >= std::atoi(fake)) ok = false;
+    if (fake && K >= std::atoi(fake)) ok = false, why = "LC_TEST_CACHE_NO_ROOM";
+    if (trial) {
+      const char* er = std::getenv("RANK");  // (hook-based runs have no communicator to ask)
+      if (std::atoi(fail_rank) == (comm_ ? comm_->rank() : er ? std::atoi(er) : 0)) ok = false, why = "LC_TEST_JOURNAL_FAIL_RANK";
+    }
 #endif
     if (allreduce_value(ok ? 0.0 : 1.0) > 0.0)
-      throw CacheNoRoom("no room for the distance cache at K = " + std::to_string(K) + ": " + std::to_string(need) +
-                        " bytes needed, " + std::to_string(free_b) + " free on this rank");
-    dc_room_K_ = K;
+      throw CacheNoRoom("no room for the distance cache at K = " + std::to_string(K) + (ok ? std::string(" on another rank") : ": " + why));
+    dc_room_K_ = std::max(dc_room_K_, K);
   }
-  // room for K columns (the valid ones move along when the slab grows)
-  if (K > dc_cap_) {
+  // room for K columns and the few a trial holds on to (the slab moves as a whole when it grows: slots keep their numbers)
+  if (grow) {
     const int newcap = grown_cap;
     static const bool trace = std::getenv("LC_TRACE_PHASES") != nullptr;
     if (trace) std::cerr << "[cache] slab " << dc_cap_ << " -> " << newcap << " columns" << std::endl;
     DevBuf<double> nb;
     nb.reserve(NPs * newcap);
-    if (dc_K_ > 0 && NP_ > 0)
-      LC_HIP(hipMemcpyAsync(nb.p, dc_slab_.p, (size_t)NP_ * dc_K_ * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+    if (dc_cap_ > 0 && NP_ > 0 && used > 0)
+      LC_HIP(hipMemcpyAsync(nb.p, dc_slab_.p, (size_t)NP_ * dc_cap_ * sizeof(double), hipMemcpyDeviceToDevice, stream_));
     LC_HIP(hipStreamSynchronize(stream_));
     std::swap(dc_slab_.p, nb.p);
     std::swap(dc_slab_.cap, nb.cap);
     std::swap(dc_slab_.device, nb.device);
     dc_cap_ = newcap;
+    dc_used_.resize((size_t)newcap, 0);
   }
   if ((int)dc_tagA_.size() < K) {
     dc_tagA_.resize((size_t)K);
     dc_tagm_.resize((size_t)K);
   }
-  // journal: what is about to be overwritten (a column is saved once per journal).  Two steps, because the outcome must
-  // be the same on every rank: reserve the columns (which ones is a function of the replicated M-step, hence the same
-  // list everywhere; under group sharding ranks hold different numbers of rows, so ONE of them may run out of memory),
-  // agree on success with one all-reduced flag, and only then copy.  A failure anywhere is CacheNoRoom everywhere, before
-  // anything has been overwritten: vbem falls back to the ordinary E-step on all ranks together.
-  if (dc_journal_) {
-    std::vector<std::unique_ptr<SavedColumn>> fresh;
-    bool ok = true;
-    std::string why;
-#ifdef LC_TEST_HOOKS
-    static const char* fail_rank = std::getenv("LC_TEST_JOURNAL_FAIL_RANK");  // tests: this rank cannot reserve
-#endif
-    for (int k : changed) {
-      if (k >= dc_K_ || k >= dc_jK0_) continue;  // nothing valid there / not part of the state to return to
-      bool done = false;
-      for (auto& sv : dc_saved_) done = done || sv->col == k;
-      if (done) continue;
-      auto sv = std::make_unique<SavedColumn>();
-      sv->col = k;
-      if (ok) {
-        try {
-#ifdef LC_TEST_HOOKS
-          if (fail_rank) {
-            const char* er = std::getenv("RANK");  // (hook-based runs have no communicator to ask)
-            if (std::atoi(fail_rank) == (comm_ ? comm_->rank() : er ? std::atoi(er) : 0)) throw HipFailure("LC_TEST_JOURNAL_FAIL_RANK");
-          }
-#endif
-          sv->buf.reserve(NPs);
-        } catch (const HipFailure& e) {
-          ok = false;
-          why = e.what();
-        }
-      }
-      fresh.push_back(std::move(sv));
-    }
-    if (!fresh.empty()) {
-      if (allreduce_value(ok ? 0.0 : 1.0) > 0.0)
-        throw CacheNoRoom("no room for the distance cache's journal" + (why.empty() ? std::string(" on another rank") : ": " + why));
-      for (auto& sv : fresh) {
-        const int k = sv->col;
-        if (NP_ > 0)
-          LC_HIP(hipMemcpyAsync(sv->buf.p, dc_slab_.p + (size_t)k * NP_, (size_t)NP_ * sizeof(double), hipMemcpyDeviceToDevice,
-                                stream_));
-        sv->A = dc_tagA_[(size_t)k];
-        sv->m = dc_tagm_[(size_t)k];
-        dc_saved_.push_back(std::move(sv));
-      }
+  auto journal_column = [&](int k) {  // by reference: the slot stays as it is, whoever changes the column moves it on
+    auto sv = std::make_unique<SavedColumn>();
+    sv->col = k;
+    sv->slot = dc_slot_[(size_t)k];
+    sv->A = dc_tagA_[(size_t)k];
+    sv->m = dc_tagm_[(size_t)k];
+    dc_saved_.push_back(std::move(sv));
+  };
+  // columns past K (a narrower model than the last call's): their slots are free again -- unless a journal returns to them
+  for (int k = K; k < dc_K_; ++k) {
+    if (dc_journal_ && k < dc_jK0_) {
+      if (!is_saved(k)) journal_column(k);
+    } else {
+      dc_used_[(size_t)dc_slot_[(size_t)k]] = 0;
     }
   }
-  // recompute: raw E-step (c = 0: the columns are -0.5 d^2), straight into the slab when the columns are adjacent
+  if ((int)dc_slot_.size() < K) dc_slot_.resize((size_t)K, -1);
+  // ---- where the recomputed columns go.  The raw E-step writes its columns side by side, so the changed columns need a
+  // RUN of slots: their own when those are writable and adjacent, else a free run (the writable old slots are given up
+  // first), else the scratch buffer and one copy per column.
   if (nch > 0) {
-    const bool adjacent = changed.back() - changed.front() + 1 == nch;
+    for (int t = 0; t < nch; ++t)
+      if (writable[(size_t)t] < 0 && changed[(size_t)t] < dc_K_ && changed[(size_t)t] < dc_jK0_ && dc_journal_ &&
+          dc_slot_[(size_t)changed[(size_t)t]] >= 0 && !is_saved(changed[(size_t)t]))
+        journal_column(changed[(size_t)t]);
+    bool inplace = writable[0] >= 0;
+    for (int t = 1; t < nch && inplace; ++t) inplace = writable[(size_t)t] == writable[0] + t;
+    int run = inplace ? writable[0] : -1;
+    if (!inplace) {
+      for (int t = 0; t < nch; ++t)
+        if (writable[(size_t)t] >= 0) dc_used_[(size_t)writable[(size_t)t]] = 0;
+      run = dc_find_run(nch);
+    }
     std::vector<double> A2, m2;
     const double *Ap = A + (size_t)changed.front() * AA, *mp = m + (size_t)changed.front() * D;
-    if (!adjacent) {
+    if (changed.back() - changed.front() + 1 != nch) {  // (the parameter records of the changed clusters, side by side)
       A2.resize((size_t)nch * AA);
       m2.resize((size_t)nch * D);
       for (int t = 0; t < nch; ++t) {
@@ -1507,16 +1507,31 @@ int Context::estep_cache(int K, const double* A, const double* m, const double* 
       }
       Ap = A2.data();
       mp = m2.data();
+    }
+    std::vector<int> dest((size_t)nch, -1);
+    if (run >= 0) {
+      for (int t = 0; t < nch; ++t) dest[(size_t)t] = run + t;
+    } else {  // no run of nch free slots: one slot each (there are enough: `grow` above), filled from the scratch buffer
+      for (int t = 0; t < nch; ++t) {
+        const int sl = dc_find_run(1);
+        if (sl < 0) throw std::logic_error("distance cache: no free column slot");
+        dest[(size_t)t] = sl;
+        dc_used_[(size_t)sl] = 1;
+      }
       dfresh_.reserve(NPs * nch);
+    }
+    for (int t = 0; t < nch; ++t) {
+      dc_used_[(size_t)dest[(size_t)t]] = 1;
+      dc_slot_[(size_t)changed[(size_t)t]] = dest[(size_t)t];
     }
     const std::vector<double> zero((size_t)J_ * nch, 0.0);
     double fz0 = 0.0;
-    double* target = adjacent ? dc_slab_.p + (size_t)changed.front() * NP_ : dfresh_.p;
+    double* target = run >= 0 ? dc_slab_.p + (size_t)run * NP_ : dfresh_.p;
     if (NP_ > 0) {
       estep(nch, Ap, mp, zero.data(), &fz0, nullptr, true, target);
-      if (!adjacent)
+      if (run < 0)
         for (int t = 0; t < nch; ++t)
-          LC_HIP(hipMemcpyAsync(dc_slab_.p + (size_t)changed[t] * NP_, dfresh_.p + (size_t)t * NP_,
+          LC_HIP(hipMemcpyAsync(dc_slab_.p + (size_t)dest[(size_t)t] * NP_, dfresh_.p + (size_t)t * NP_,
                                 (size_t)NP_ * sizeof(double), hipMemcpyDeviceToDevice, stream_));
     }
     for (int k : changed) {
@@ -1524,6 +1539,7 @@ int Context::estep_cache(int K, const double* A, const double* m, const double* 
       dc_tagm_[(size_t)k].assign(m + (size_t)k * D, m + (size_t)(k + 1) * D);
     }
   }
+  if (!dc_journal_ || K >= dc_jK0_) dc_slot_.resize((size_t)std::max(K, dc_journal_ ? dc_jK0_ : 0));
   dc_K_ = K;
   // constants + normalisation
   const bool have_old = qz_[cur_].K == K;  // the buffer holds K columns of q_old
@@ -1557,8 +1573,10 @@ int Context::estep_cache(int K, const double* A, const double* m, const double* 
   constexpr bool direct_env = true;  // (the copy-back command instead: measured slower)
   const bool direct = direct_env && !distributed() && NP_ > 0;
   if (NP_ > 0) {
-    hpack_.assign((size_t)J_ * K, 0.0);
+    // [c_jk table | the K slots of the clusters' columns (ints)] in one upload
+    hpack_.assign((size_t)J_ * K + (size_t)(K + 1) / 2, 0.0);
     std::memcpy(hpack_.data(), c, (size_t)J_ * K * sizeof(double));
+    std::memcpy(hpack_.data() + (size_t)J_ * K, dc_slot_.data(), (size_t)K * sizeof(int));
     params_.reserve(hpack_.size());
     LC_HIP(hipMemcpyAsync(params_.p, hpack_.data(), hpack_.size() * sizeof(double), hipMemcpyHostToDevice, stream_));
     lck::CachedNormLaunch a;
@@ -1566,7 +1584,7 @@ int Context::estep_cache(int K, const double* A, const double* m, const double* 
     a.ldc = NP_;
     a.fresh = nullptr;
     a.ldf = 0;
-    a.colmap = nullptr;
+    a.colmap = reinterpret_cast<const int*>(params_.p + (size_t)J_ * K);
     a.ctab = params_.p;
     a.K = K;
     a.rginfo = J_ > 1 ? rginfo_.p : nullptr;

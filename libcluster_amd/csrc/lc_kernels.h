@@ -151,10 +151,6 @@ hipError_t launch_reduce_records(const double* partial, int64_t n, int K, const 
 constexpr int REDUCE_TMP_ELEMS = 512;
 hipError_t launch_reduce_partials(const double* partial, int nparts, int64_t n, double* out, hipStream_t stream,
                                   double* tmp = nullptr);
-// the same 16 x 16 fold into page-locked host memory, plus a completion flag the host can spin on (single-rank fused pass):
-// the last block to finish writes `seq` to *flag (system scope) and zeroes *ticket (a device counter, zero before the first launch)
-hipError_t launch_reduce_partials_signal(const double* partial, int nparts, int64_t n, double* out, unsigned* ticket,
-                                         unsigned long long* flag, unsigned long long seq, hipStream_t stream);
 // out[j*K+k] = sum over rows of group j of qZ[k*ldq + row]; goff = padded row offsets [J+1]
 // tmp (optional, REDUCE_TMP_ELEMS * 64 doubles) and rows (total padded rows) enable the sliced path for few large groups
 hipError_t launch_group_colsum(const double* qZ, int64_t ldq, int K, const int64_t* goff, int J, double* out,

@@ -36,56 +36,6 @@ __global__ void __launch_bounds__(256) reduce_partials_kernel(const double* __re
   if (py == 0 && e < n) out[e] = sh[0][ex];
 }
 
-// The same fold for a host that waits on a flag instead of the stream (Context::estep_suffstat_fused, one rank): `out`
-// and `flag` live in page-locked host memory.  Every block makes its results visible system-wide and takes a ticket; the
-// block that takes the last one resets the ticket counter for the next launch and publishes `seq` -- the host has the
-// sums one PCIe write after the last block finished, without the wake-up latency of hipStreamSynchronize.
-__global__ void __launch_bounds__(256) reduce_partials_signal_kernel(const double* __restrict__ partial, int nparts, int64_t n,
-                                                                     double* __restrict__ out, unsigned* ticket,
-                                                                     unsigned long long* flag, unsigned long long seq) {
-  __shared__ double sh[16][17];
-  const int ex = threadIdx.x & 15, py = threadIdx.x >> 4;
-  const int64_t e = (int64_t)blockIdx.x * 16 + ex;
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  if (e < n) {
-    const double* p = partial + e;
-    int c = py;
-    for (; c + 48 < nparts; c += 64) {
-      s0 += p[(int64_t)c * n];
-      s1 += p[(int64_t)(c + 16) * n];
-      s2 += p[(int64_t)(c + 32) * n];
-      s3 += p[(int64_t)(c + 48) * n];
-    }
-    for (; c < nparts; c += 16) s0 += p[(int64_t)c * n];
-  }
-  sh[py][ex] = (s0 + s1) + (s2 + s3);
-  __syncthreads();
-  for (int w = 8; w > 0; w >>= 1) {
-    if (py < w) sh[py][ex] += sh[py + w][ex];
-    __syncthreads();
-  }
-  if (py == 0 && e < n) {
-    out[e] = sh[0][ex];
-    __threadfence_system();
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (old + 1 == gridDim.x) {
-      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __threadfence_system();
-      __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-  }
-}
-hipError_t launch_reduce_partials_signal(const double* partial, int nparts, int64_t n, double* out, unsigned* ticket,
-                                         unsigned long long* flag, unsigned long long seq, hipStream_t stream) {
-  if (n <= 0) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(reduce_partials_signal_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, stream, partial, nparts,
-                     n, out, ticket, flag, seq);
-  return hipGetLastError();
-}
-
 // few elements, many parts: one block per element, fixed-shape strided sum + tree
 __global__ void __launch_bounds__(256) reduce_cols_kernel(const double* partial, int nparts, int64_t n, double* out) {
   __shared__ double sh[256];

@@ -617,9 +617,38 @@ __global__ void __launch_bounds__(256, 2)
         if (raw && k < K && rgok[r]) qZ[(int64_t)k * ldq + (rg0 + r) * RG + lo4] = v[r];
       }
     };
+    // Two cluster tiles at a time (REGS): four accumulation chains (2 tiles x R row groups).  With R = 2 chains an MFMA's
+    // C operand is the result of the MFMA two instructions back, and hipcc fills the gap with `s_nop 1` behind every pair
+    // (6 % of the stream); the second ring of weight reads costs 16 registers.
+    // (two rings of PFP = 4 reads: a step is four MFMAs now, so four steps ahead is as far ahead in time as eight were)
+    constexpr int PFP = 4;
+    auto pair_start = [&](int it, int half, double (&r0)[PFP], double (&r1)[PFP]) {
+      const double* P0 = Pt + ((size_t)it * NTF + (size_t)half * NT) * 16;
+      static_for<PFP>([&](auto ic) { r0[ic] = P0[ic * 16], r1[ic] = P0[(NTF + ic) * 16]; });
+    };
+    auto half_pair = [&](int it, int half, double (&o0)[R], double (&o1)[R], double (&r0)[PFP], double (&r1)[PFP]) {
+      const double* P0 = Pt + ((size_t)it * NTF + (size_t)half * NT) * 16;
+      const double* P1 = P0 + (size_t)NTF * 16;
+      static_for<NT>([&](auto jc) {
+        constexpr int jt = jc;
+        const double v0 = r0[jt % PFP], v1 = r1[jt % PFP];
+        constexpr int m = jt + PFP;  // (past these tiles: the same half of the next PAIR; past the last one: unused)
+        r0[jt % PFP] = P0[(m < NT ? m : 2 * NTF + (m - NT)) * 16];
+        r1[jt % PFP] = P1[(m < NT ? m : 2 * NTF + (m - NT)) * 16];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < R; ++r) o0[r] = mfma4(v0, f[r][jt], o0[r]);
+#pragma unroll
+        for (int r = 0; r < R; ++r) o1[r] = mfma4(v1, f[r][jt], o1[r]);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    };
     // the half of the weights that multiplies x' (QUAD: tiles NT..2NT-1; otherwise the only half)
-    double ring[PFH];
-    if constexpr (REGS) {
+    // (where it pays and fits: the VBEM iterations' instances and the one-row-group widths, whose single chain stalls the
+    //  most; the instances that carry LL_k / raw output as well already spill without the second ring)
+    constexpr bool PAIR = REGS && (PLAIN || R == 1);
+    double ring[PFH], pr0[PFP], pr1[PFP];
+    if constexpr (REGS && !PAIR) {
       ring_start(0, QUAD ? 1 : 0, ring);
 #pragma unroll
       for (int it = 0; it < KTM; ++it) {
@@ -630,6 +659,31 @@ __global__ void __launch_bounds__(256, 2)
         } else {
 #pragma unroll
           for (int r = 0; r < R; ++r) lq[it][r] = -INFINITY;
+        }
+      }
+    } else if constexpr (REGS) {
+      static_assert(KTM % 2 == 0 && NT % PFP == 0, "cluster tiles in pairs");
+      pair_start(0, QUAD ? 1 : 0, pr0, pr1);
+#pragma unroll
+      for (int it = 0; it < KTM; it += 2) {
+        if (it + 1 < KT) {  // block-uniform
+          tile_const(it, lq[it]);
+          tile_const(it + 1, lq[it + 1]);
+          half_pair(it, QUAD ? 1 : 0, lq[it], lq[it + 1], pr0, pr1);
+          if constexpr (!QUAD) {
+            tile_done(it, lq[it]);
+            tile_done(it + 1, lq[it + 1]);
+          }
+        } else if (it < KT) {  // (an odd last tile, on its own ring)
+          tile_const(it, lq[it]);
+          ring_start(it, QUAD ? 1 : 0, ring);
+          half_tile(it, QUAD ? 1 : 0, lq[it], ring);
+          if constexpr (!QUAD) tile_done(it, lq[it]);
+#pragma unroll
+          for (int r = 0; r < R; ++r) lq[it + 1][r] = -INFINITY;
+        } else {
+#pragma unroll
+          for (int r = 0; r < R; ++r) lq[it][r] = -INFINITY, lq[it + 1][r] = -INFINITY;
         }
       }
     } else {
@@ -650,11 +704,25 @@ __global__ void __launch_bounds__(256, 2)
       for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) f[r][jt] *= f[r][jt];
-      if constexpr (REGS) {
+      if constexpr (REGS && !PAIR) {
         ring_start(0, 0, ring);
 #pragma unroll
         for (int it = 0; it < KTM; ++it) {
           if (it < KT) {
+            half_tile(it, 0, lq[it], ring);
+            tile_done(it, lq[it]);
+          }
+        }
+      } else if constexpr (REGS) {
+        pair_start(0, 0, pr0, pr1);
+#pragma unroll
+        for (int it = 0; it < KTM; it += 2) {
+          if (it + 1 < KT) {
+            half_pair(it, 0, lq[it], lq[it + 1], pr0, pr1);
+            tile_done(it, lq[it]);
+            tile_done(it + 1, lq[it + 1]);
+          } else if (it < KT) {
+            ring_start(it, 0, ring);
             half_tile(it, 0, lq[it], ring);
             tile_done(it, lq[it]);
           }

@@ -75,9 +75,9 @@ __global__ void __launch_bounds__(256, CPW == 4 ? 1 : 2) fused_small_kernel(Fuse
   static_assert(4 * CPW <= FUSED_KMAX, "statistics accumulators");
   constexpr int NQ = CPW, NTL = 12;    // cluster quads; feature tiles: 10 patches (ia <= ja), s_k, N_k
   // active feature tiles: the patches with ja < NTA (the first NTA (NTA + 1) / 2 of the enumeration), then s_k and N_k
-  // N_k: with LL_k the twelfth feature tile (1 * 1); in the plain instance the sweep adds every
-  // responsibility it forms to a per-lane sum instead (one add per entry in a phase that is VALU anyway, against two
-  // MFMAs per 4-row step: 8 % of the statistics half at D = 16, 20 % at D <= 8), folded once at the end of the kernel
+  // N_k: with LL_k the twelfth feature tile (1 * 1); in the plain instance the sweep adds every responsibility it forms
+  // to a per-lane sum instead (one add per entry in a phase that is VALU anyway, against two MFMAs per 4-row step: 8 % of
+  // the statistics half at D = 16, 20 % at D <= 8), folded once at the end of the kernel
   constexpr bool NK_MFMA = WANT_LL;
   constexpr int NPA = NTA * (NTA + 1) / 2, NTLA = NPA + 1 + (NK_MFMA ? 1 : 0);
   constexpr int QS = FUSED_QS;         // row stride of the q table: consecutive clusters 8 banks apart
@@ -121,18 +121,15 @@ __global__ void __launch_bounds__(256, CPW == 4 ? 1 : 2) fused_small_kernel(Fuse
   double nk[NK_MFMA ? 1 : 4 * NQ];  // this lane's share of N_k (plain instance)
 #pragma unroll
   for (int i = 0; i < (NK_MFMA ? 1 : 4 * NQ); ++i) nk[i] = 0.0;
-  // Every block takes the same share of the row groups (+- 1), whole tiles of 16 row groups and ONE partial tile at the
-  // end (round 5: dealing whole tiles left 3907 of them on 512 blocks at N = 1M -- eight rounds for 7.63 tiles' worth of
-  // work; a partial tile costs its share: waves drop row groups in the E-step half, the statistics half drops steps).
-  const int64_t g0 = a.nrg * (int64_t)blockIdx.x / gridDim.x, g1 = a.nrg * ((int64_t)blockIdx.x + 1) / gridDim.x;
-  const int nmy = (int)((g1 - g0 + FUSED_ROWS / RG - 1) / (FUSED_ROWS / RG));  // this block's tiles
-  // register double-buffer for the next tile of X (coalesced double2 pieces; rows past the block's share as zeros)
+  const int64_t NP = a.nrg * RG;
+  const int64_t ntile = (NP + FUSED_ROWS - 1) / FUSED_ROWS;
+  // register double-buffer for the next tile of X (coalesced double2 pieces; rows past the end as zeros)
   constexpr int C2 = DP / 2, NPRE = FUSED_ROWS * C2 / 256;
   double2 pre[NPRE];
-  auto fetch = [&](int t) {
-    const int64_t rg = g0 + (int64_t)t * (FUSED_ROWS / RG);
-    const int64_t left = t < nmy ? (g1 - rg) * RG : 0;
-    const double2* X2 = reinterpret_cast<const double2*>(a.X) + (t < nmy ? rg * RG : 0) * C2;
+  auto fetch = [&](int64_t tile) {
+    const int64_t r0 = tile * FUSED_ROWS;
+    const int64_t left = tile < ntile ? NP - r0 : 0;
+    const double2* X2 = reinterpret_cast<const double2*>(a.X) + (tile < ntile ? r0 : 0) * C2;
     if (left >= FUSED_ROWS) {  // (uniform) a whole tile: no per-load bounds
 #pragma unroll
       for (int i = 0; i < NPRE; ++i) pre[i] = X2[tid + i * 256];
@@ -145,37 +142,33 @@ __global__ void __launch_bounds__(256, CPW == 4 ? 1 : 2) fused_small_kernel(Fuse
       }
     }
   };
-  fetch(0);
+  fetch(blockIdx.x);
   __syncthreads();
   // n-th read of cluster `kk`'s parameter stream relative to the running pointers of the current cluster
   const double* Pt = par + (lane & 3) + 4 * hi;  // this lane's element of every 4x4 tile (cluster 0)
   const double* Pb = par + NTILES * 16 + hi;     // this lane's element of every 4-vector of -b (cluster 0)
   double* const xstage = xt + (tid / C2) * LD + 2 * (tid % C2);
-  for (int tile = 0; tile < nmy; ++tile) {
-    const int64_t row0 = (g0 + (int64_t)tile * (FUSED_ROWS / RG)) * RG;
+  for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const int64_t row0 = tile * FUSED_ROWS;
     // ---- the tile of X -> LDS (its loads were issued a whole tile ago)
     // (one 16-byte store per piece: its 8-lane groups fill one row's 128 bytes; two 8-byte stores put two rows, 36 dwords
     //  apart, into a 16-lane group: a 2-way conflict on the 32 write banks)
 #pragma unroll
     for (int i = 0; i < NPRE; ++i) *reinterpret_cast<double2*>(xstage + i * (256 / C2) * LD) = pre[i];
     __syncthreads();
-    // ---- E-step half: the tile's row groups are dealt to the waves in turn (wave w: groups w, w + 4, w + 8, w + 12); lane
-    // (lo4, hi) owns row lo4 of the wave's group `hi` = row 16 (4 hi + w) + lo4 of the tile.  A partial tile of L row
-    // groups leaves wave w with nr = ceil((L - w) / 4) of them: the pass below exists for 1 ... 4 row groups.
+    // ---- E-step half: this wave's 64 rows as four row groups; lane (lo4, hi) owns row 16 hi + lo4 = row `tid` of the tile
     // (a table entry is read BEFORE the next tile's prefetch goes out: it is waited for at once, and the vector-memory
     //  counter retires in order)
-    const int L = (int)std::min<int64_t>(FUSED_ROWS / RG, g1 - row0 / RG);  // row groups in this tile (uniform)
-    const int nr = __builtin_amdgcn_readfirstlane(L - wave > 0 ? (L - wave + 3) / 4 : 0);
-    const int rowi = 16 * (4 * hi + wave) + lo4;
-    const bool myok = 4 * hi + wave < L;  // this lane's row group exists
+    const int64_t left = NP - row0;  // padded rows from here on (a multiple of 16)
+    const bool myok = tid < left;    // this lane's row group exists
     bool myrow;
     int mygrp = 0;
     if constexpr (ONEGRP) {
-      myrow = row0 + rowi < a.nrows;
+      myrow = row0 + tid < a.nrows;
     } else {
       int info = 0;
       if (myok) {
-        const int64_t rg = row0 / RG + 4 * hi + wave;
+        const int64_t rg = row0 / RG + (tid >> 4);
         if (a.rginfo) {
           info = a.rginfo[rg];
         } else {
@@ -188,113 +181,109 @@ __global__ void __launch_bounds__(256, CPW == 4 ? 1 : 2) fused_small_kernel(Fuse
       myrow = lo4 < (info & 31);
       __builtin_amdgcn_sched_barrier(0);
     }
-    fetch(tile + 1);  // in flight during both halves of this tile
+    fetch(tile + gridDim.x);  // in flight during both halves of this tile
+    double xf[R][NT];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const double* xr = xt + (wave * 64 + r * 16 + lo4) * LD + hi;
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) xf[r][jt] = jt < NTA ? xr[4 * jt] : 0.0;
+    }
     // the constant of cluster k for this lane's row group
     auto cjk_of = [&](int k) -> double {
       if constexpr (ONEGRP) return ctl[k];
       else if constexpr (CTLDS) return ctl[mygrp * K + k];
       else return a.ctab[(int64_t)mygrp * K + k];
     };
-    double mymx = -INFINITY;
-    auto estep_pass = [&](auto rrc) {
-      constexpr int RR = decltype(rrc)::value;  // row groups of this wave in this tile
-      double xf[RR][NT];
+    double ring[PF];
+    static_for<PF>([&](auto ic) {
+      constexpr RdInfo ri = rd_info(ic);
+      ring[ic] = ri.jt < 0 ? Pb[ri.off] : Pt[ri.off];
+    });
+    // carried from cluster k - 1 into cluster k's pass: its last tile row (not yet squared), its partial squared norms
+    // and its constant (-inf before the first cluster: that pass's "log q~" is -inf and changes nothing)
+    double accP[R], d2P[R], cP = -INFINITY, mymx = -INFINITY;
 #pragma unroll
-      for (int r = 0; r < RR; ++r) {
-        const double* xr = xt + (16 * (4 * r + wave) + lo4) * LD + hi;
+    for (int r = 0; r < R; ++r) accP[r] = 0.0, d2P[r] = 0.0;
+    for (int k = 0; k < K; ++k) {
+      const double* Ptk = Pt + (size_t)k * PS;
+      const double* Pbk = Pb + (size_t)k * PS;
+      const double cK = cjk_of(k);
+      double* const qslot = qt + (size_t)(k > 0 ? k - 1 : 0) * QS + tid;  // (k = 0 writes -inf where cluster 0 lands next)
+      double d2[R], accs[2][R], t = 0.0;
+      if constexpr (NTA == 1) {  // (no tile row is squared inside the pass: the only one waits for the next cluster)
 #pragma unroll
-        for (int jt = 0; jt < NT; ++jt) xf[r][jt] = jt < NTA ? xr[4 * jt] : 0.0;
+        for (int r = 0; r < R; ++r) d2[r] = 0.0;
       }
-      double ring[PF];
-      static_for<PF>([&](auto ic) {
-        constexpr RdInfo ri = rd_info(ic);
-        ring[ic] = ri.jt < 0 ? Pb[ri.off] : Pt[ri.off];
+      static_for<NREAD>([&](auto nc) {
+        constexpr int n = nc;
+        constexpr RdInfo ri = rd_info(n);
+        constexpr int set = ri.it & 1;
+        const double v = ring[n % PF];
+        {  // the read PF ahead: of this cluster, or already of the next one
+          constexpr int m = n + PF;
+          constexpr RdInfo rn = rd_info(m < NREAD ? m : m - NREAD);
+          constexpr int over = m < NREAD ? 0 : PS;
+          ring[n % PF] = rn.jt < 0 ? Pbk[rn.off + over] : Ptk[rn.off + over];
+        }
+        if constexpr (ri.jt < 0) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) accs[set][r] = v;  // y starts at -b: y = A x - b
+        } else {
+#pragma unroll
+          for (int r = 0; r < R; ++r) accs[set][r] = mfma4(v, xf[r][ri.jt], accs[set][r]);
+        }
+        // under those MFMAs: the previous cluster's tail and this cluster's deferred squares
+        if constexpr (n == 1) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) d2P[r] = fma(accP[r], accP[r], d2P[r]);
+        }
+        // the four links of the previous cluster's lane-sum chain (NTA = 4: behind reads 3, 4, 6, 7; NTA = 2: 2, 3, 4, 4;
+        // NTA = 1: all behind read 1, the only tile)
+        constexpr int L0 = NTA == 4 ? 3 : NTA == 2 ? 2 : 1, L1 = NTA == 4 ? 4 : NTA == 2 ? 3 : 1, L2 = NTA == 4 ? 6 : NTA == 2 ? 4 : 1,
+                      L3 = NTA == 4 ? 7 : NTA == 2 ? 4 : 1;
+        if constexpr (n == L0) t = mfma4(selA[0], d2P[0], cP);
+        if constexpr (n == L1) t = mfma4(selA[1], d2P[1], t);
+        if constexpr (n == L2) t = mfma4(selA[2], d2P[2], t);
+        if constexpr (n == L3) t = mfma4(selA[3], d2P[3], t);
+        // tile row it - 1 is squared behind tile (it, 1), under the MFMAs of row it (the last row waits for the next cluster)
+        if constexpr (ri.jt == 1 && ri.it >= 1) {
+          constexpr int pset = (ri.it - 1) & 1;
+#pragma unroll
+          for (int r = 0; r < R; ++r)
+            d2[r] = ri.it == 1 ? accs[pset][r] * accs[pset][r] : fma(accs[pset][r], accs[pset][r], d2[r]);
+        }
+        if constexpr (n == NREAD - (NTA == 4 ? 2 : 1)) {  // log q~ of cluster k - 1 for this lane's row: its own slot (no barrier before it reads it back)
+          mymx = fmax(mymx, t);  // (fmax, not the asm max_raw: t comes straight out of an MFMA, and the compiler only counts the
+                                 //  wait states between an MFMA and its reader for instructions it emitted itself)
+          *qslot = t;
+        }
+        // within a step: its VALU instructions as ONE group ahead of the ring read and the MFMAs (hipcc otherwise splits a row's
+        // four squares around the MFMAs; next to the matrix pipe VALU work is paid per switch: tools/mfma_batch_probe.hip).
+        // K = 16, N = 4M: 1.092 -> 1.06 ms; level at K <= 8 (gpurun_out/r05i)
+        __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
       });
-      // carried from cluster k - 1 into cluster k's pass: its last tile row (not yet squared), its partial squared norms
-      // and its constant (-inf before the first cluster: that pass's "log q~" is -inf and changes nothing)
-      double accP[RR], d2P[RR], cP = -INFINITY;
 #pragma unroll
-      for (int r = 0; r < RR; ++r) accP[r] = 0.0, d2P[r] = 0.0;
-      for (int k = 0; k < K; ++k) {
-        const double* Ptk = Pt + (size_t)k * PS;
-        const double* Pbk = Pb + (size_t)k * PS;
-        const double cK = cjk_of(k);
-        double* const qslot = qt + (size_t)(k > 0 ? k - 1 : 0) * QS + tid;  // (k = 0 writes -inf where cluster 0 lands next)
-        double d2[RR], accs[2][RR], t = 0.0;
+      for (int r = 0; r < R; ++r) accP[r] = accs[(NTA - 1) & 1][r], d2P[r] = d2[r];  // the last tile row is squared under the next cluster
+      cP = cK;
+    }
+    {  // the last cluster's tail
 #pragma unroll
-        for (int r = 0; r < RR; ++r) d2[r] = 0.0;  // (NTA = 1: no tile row is squared inside the pass)
-        static_for<NREAD>([&](auto nc) {
-          constexpr int n = nc;
-          constexpr RdInfo ri = rd_info(n);
-          constexpr int set = ri.it & 1;
-          const double v = ring[n % PF];
-          {  // the read PF ahead: of this cluster, or already of the next one
-            constexpr int m = n + PF;
-            constexpr RdInfo rn = rd_info(m < NREAD ? m : m - NREAD);
-            constexpr int over = m < NREAD ? 0 : PS;
-            ring[n % PF] = rn.jt < 0 ? Pbk[rn.off + over] : Ptk[rn.off + over];
-          }
-          if constexpr (ri.jt < 0) {
+      for (int r = 0; r < R; ++r) d2P[r] = fma(accP[r], accP[r], d2P[r]);
+      double t = mfma4(selA[0], d2P[0], cP);
 #pragma unroll
-            for (int r = 0; r < RR; ++r) accs[set][r] = v;  // y starts at -b: y = A x - b
-          } else {
-#pragma unroll
-            for (int r = 0; r < RR; ++r) accs[set][r] = mfma4(v, xf[r][ri.jt], accs[set][r]);
-          }
-          // under those MFMAs: the previous cluster's tail and this cluster's deferred squares
-          if constexpr (n == 1) {
-#pragma unroll
-            for (int r = 0; r < RR; ++r) d2P[r] = fma(accP[r], accP[r], d2P[r]);
-          }
-          // the links of the previous cluster's lane-sum chain, one per row group (NTA = 4: behind reads 3, 4, 6, 7;
-          // NTA = 2: 2, 3, 4, 4;
-          // NTA = 1: all behind read 1, the only tile)
-          constexpr int L0 = NTA == 4 ? 3 : NTA == 2 ? 2 : 1, L1 = NTA == 4 ? 4 : NTA == 2 ? 3 : 1, L2 = NTA == 4 ? 6 : NTA == 2 ? 4 : 1,
-                        L3 = NTA == 4 ? 7 : NTA == 2 ? 4 : 1;
-          if constexpr (n == L0) t = mfma4(selA[0], d2P[0], cP);
-          if constexpr (n == L1 && RR > 1) t = mfma4(selA[1], d2P[RR > 1 ? 1 : 0], t);
-          if constexpr (n == L2 && RR > 2) t = mfma4(selA[2], d2P[RR > 2 ? 2 : 0], t);
-          if constexpr (n == L3 && RR > 3) t = mfma4(selA[3], d2P[RR > 3 ? 3 : 0], t);
-          // tile row it - 1 is squared behind tile (it, 1), under the MFMAs of row it (the last row waits for the next cluster)
-          if constexpr (ri.jt == 1 && ri.it >= 1) {
-            constexpr int pset = (ri.it - 1) & 1;
-#pragma unroll
-            for (int r = 0; r < RR; ++r)
-              d2[r] = ri.it == 1 ? accs[pset][r] * accs[pset][r] : fma(accs[pset][r], accs[pset][r], d2[r]);
-          }
-          if constexpr (n == NREAD - (NTA == 4 ? 2 : 1)) {  // log q~ of cluster k - 1 for this lane's row: its own slot (no barrier before it reads it back)
-            mymx = fmax(mymx, t);  // (fmax, not the asm max_raw: t comes straight out of an MFMA, and the compiler only counts the
-                                   //  wait states between an MFMA and its reader for instructions it emitted itself)
-            *qslot = t;
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        });
-#pragma unroll
-        for (int r = 0; r < RR; ++r) accP[r] = accs[(NTA - 1) & 1][r], d2P[r] = d2[r];  // the last tile row is squared under the next cluster
-        cP = cK;
-      }
-      {  // the last cluster's tail
-#pragma unroll
-        for (int r = 0; r < RR; ++r) d2P[r] = fma(accP[r], accP[r], d2P[r]);
-        double t = mfma4(selA[0], d2P[0], cP);
-#pragma unroll
-        for (int r = 1; r < RR; ++r) t = mfma4(selA[r], d2P[r], t);
-        mymx = fmax(mymx, t);
-        qt[(size_t)(K - 1) * QS + tid] = t;
-      }
-    };
-    // (lanes whose row group does not exist -- hi >= nr -- come out of the chain with log q~ = c_k: finite, and unused)
-    if (nr == 4) estep_pass(std::integral_constant<int, 4>{});
-    else if (nr == 3) estep_pass(std::integral_constant<int, 3>{});
-    else if (nr == 2) estep_pass(std::integral_constant<int, 2>{});
-    else if (nr == 1) estep_pass(std::integral_constant<int, 1>{});
-    else {  // no row group of this wave in the tile: its slots of the table are zeros for the statistics half
-      for (int k = 0; k < K; ++k) qt[(size_t)k * QS + tid] = 0.0;
+      for (int r = 1; r < R; ++r) t = mfma4(selA[r], d2P[r], t);
+      mymx = fmax(mymx, t);
+      qt[(size_t)(K - 1) * QS + tid] = t;
     }
     // logsumexp and normalisation in the reference's order: max, sum exp(x - max), log + max, exp(x - logZ)
-    if (nr > 0) {
-      double* const ql = qt + tid;  // (the table is indexed by owner thread: 64 consecutive slots per wave, no bank shared)
-      double* const qp = a.qZ + row0 + rowi;
+    {
+      double* const ql = qt + tid;
+      double* const qp = a.qZ + row0 + tid;
       const bool live = myok && myrow;
       if constexpr (!WANT_LL) {
         // ONE exponential per entry -- e = exp(log q~ - max) stays in registers and q = e / sum(e); the same sum and
@@ -369,20 +358,25 @@ __global__ void __launch_bounds__(256, CPW == 4 ? 1 : 2) fused_small_kernel(Fuse
       struct StepOps {
         double qa[NQ], u[NTA], w[NTA], s, one = 0.0;
       };
-      // (row block s4 = row group s4 of the tile belongs to wave s4 % 4 as its group s4 / 4: the slots of its rows in the
-      //  table -- indexed by owner thread -- start at 64 (s4 % 4) + 16 (s4 / 4))
-      auto load = [&](int ro, int qo, StepOps& o) {
+      auto load = [&](auto sc, StepOps& o) {
+        constexpr int s4 = decltype(sc)::value, ro = s4 * 16 * LD;
 #pragma unroll
-        for (int c = 0; c < NQ; ++c) o.qa[c] = qb[4 * c * QS + qo];
+        for (int c = 0; c < NQ; ++c) o.qa[c] = qb[4 * c * QS + s4 * 16];
 #pragma unroll
         for (int i = 0; i < NTA; ++i) o.u[i] = xu[ro + 4 * i], o.w[i] = xw[ro + 4 * i];
         o.s = xs[ro];
         if constexpr (NK_MFMA) o.one = x1[ro];
       };
-      // ALL of a step's products first, then all of its MFMAs: next to the matrix pipe a VALU instruction is paid per
-      // switch between the two kinds, not per instruction (tools/mfma_batch_probe.hip: ~ 12 clocks each when they stand
-      // alone between MFMAs, ~ 5 in a group of eight)
-      auto multiply = [&](const StepOps& cur) {
+      StepOps cur;
+      load(std::integral_constant<int, 0>{}, cur);
+      static_for<FUSED_ROWS / 16>([&](auto sc) {
+        constexpr int s4 = sc;
+        StepOps nxt = cur;
+        if constexpr (s4 + 1 < FUSED_ROWS / 16) load(std::integral_constant<int, s4 + 1>{}, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        // ALL of the step's products first, then all of its MFMAs: next to the matrix pipe a VALU instruction is paid per
+        // switch between the two kinds, not per instruction (tools/mfma_batch_probe.hip: ~ 12 clocks each when they stand
+        // alone between MFMAs, ~ 5 in a group of eight)
         double p[NTLA];
         static_for<NTLA>([&](auto tc) {
           constexpr int t = tc;
@@ -401,30 +395,9 @@ __global__ void __launch_bounds__(256, CPW == 4 ? 1 : 2) fused_small_kernel(Fuse
 #pragma unroll
           for (int c = 0; c < NQ; ++c) acc[t][c] = mfma4(cur.qa[c], p[t], acc[t][c]);
         });
-      };
-      StepOps cur;
-      load(0, 0, cur);
-      if (L == FUSED_ROWS / 16) {  // (uniform) a whole tile: every offset a compile-time constant
-        static_for<FUSED_ROWS / 16>([&](auto sc) {
-          constexpr int s4 = sc, n4 = s4 + 1;
-          StepOps nxt = cur;
-          if constexpr (n4 < FUSED_ROWS / 16) load(n4 * 16 * LD, 64 * (n4 % 4) + 16 * (n4 / 4), nxt);
-          __builtin_amdgcn_sched_barrier(0);
-          multiply(cur);
-          __builtin_amdgcn_sched_barrier(0);
-          cur = nxt;
-        });
-      } else {  // the block's last tile: L < 16 row blocks, the same steps in a loop
-        for (int s4 = 0; s4 < L; ++s4) {
-          const int n4 = s4 + 1;
-          StepOps nxt = cur;
-          if (n4 < L) load(n4 * 16 * LD, 64 * (n4 % 4) + 16 * (n4 / 4), nxt);
-          __builtin_amdgcn_sched_barrier(0);
-          multiply(cur);
-          __builtin_amdgcn_sched_barrier(0);
-          cur = nxt;
-        }
-      }
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+      });
     }
     __syncthreads();  // the next tile overwrites xt and qt
   }

@@ -187,11 +187,11 @@ def test_model_selection_carries_on_when_the_distance_cache_does_not_fit(lib):
     # the shipped library has no fault hooks: the switch does nothing there
     c = _run_snippet({"LC_TEST_CACHE_NO_ROOM": "4", "LC_TRACE_PHASES": "1"}, **kw)
     assert "distance cache given up" not in c["_stderr"] and c["K"] == a["K"]
-    # ... and no schedule switches either (lck::test_switch): the literal schedule's launch count shows only in the hooks build
+    # ... and no schedule switches either (lck::test_switch): the other schedule's launch count shows only in the hooks build
     d = _learn(["60000", "24", "5"], {"LC_SPLIT_NO_DCACHE": "1", "LC_LIB_PATH": str(ROOT / "libcluster_amd" / "lib" / "libcluster_hip.so")})
     e = _learn(["60000", "24", "5"], {})
     f = _learn(["60000", "24", "5"], {"LC_SPLIT_NO_DCACHE": "1"})
-    assert d[4] == e[4] and f[4] > e[4], (d, e, f)
+    assert d[4] == e[4] and f[4] != e[4] and d[:4] == e[:4] == f[:4], (d, e, f)
     assert a["K"] == b["K"] >= 6 and [k for k, _ in a["rounds"]] == [k for k, _ in b["rounds"]]
     for (_, x), (_, y) in zip(a["rounds"], b["rounds"]):
         np.testing.assert_allclose(x, y, rtol=1e-10)
