@@ -5,7 +5,7 @@
 // widths at which the feature-GEMM form of the statistics pass is the default for more than 16 clusters (measured:
 // tools/ssfeat_check.py; LC_SS_FEAT=2 selects it wherever it exists, 0 nowhere)
 #ifndef LC_SS_FEAT_WIDTHS
-#define LC_SS_FEAT_WIDTHS(DP) ((DP) == 32 || (DP) == 48 || (DP) == 64 || (DP) == 128)  // (80, 96, 112: the 8-quad instances spill)
+#define LC_SS_FEAT_WIDTHS(DP) ((DP) >= 32 && (DP) <= 128)  // (every padded width: 80, 96, 112 fit their registers as 8-wave blocks, round 5)
 #endif
 
 namespace lck {
@@ -564,8 +564,12 @@ __host__ __device__ constexpr int ft_tpw_max(int DP, int NQ) {
 #define LC_FT_BR128 32
 #endif
 // tiles whose products are formed together in front of their MFMAs (suffstat_feat_kernel's step loop)
-__host__ __device__ constexpr int ft_group(int DP) { return DP == 48 || DP == 64 ? 2 : 1; }
-__host__ __device__ constexpr int ft_waves(int DP) { return DP == 64 ? LC_FT_WAVES64 : DP == 128 ? LC_FT_WAVES128 : 4; }
+__host__ __device__ constexpr int ft_group(int DP) { return DP >= 48 && DP <= 112 ? 2 : 1; }
+// (round 5: D = 80, 96, 112 as 8-wave blocks too -- half the staging registers per thread, and with them every instance
+//  but <80, 6> free of scratch, where the 4-wave instances spilled 64 ... 136 bytes into the step loop: the feature GEMM
+//  now runs at these widths, N = 4M, K = 32: D = 96 22.9 -> 19.1 ms (0.67 -> 0.81 of the fp64 peak), D = 80 15.0 -> 13.7,
+//  D = 112 (N = 3M) 21.9 -> 19.9; gpurun_out/r05l)
+__host__ __device__ constexpr int ft_waves(int DP) { return DP == 64 ? LC_FT_WAVES64 : DP == 128 ? LC_FT_WAVES128 : DP > 64 ? 8 : 4; }
 __host__ __device__ constexpr int ft_nslice(int DP, int NQ) {  // blocks per row chunk
   return (ft_tiles(DP) + ft_waves(DP) * ft_tpw_max(DP, NQ) - 1) / (ft_waves(DP) * ft_tpw_max(DP, NQ));
 }
@@ -743,7 +747,7 @@ __global__ void __launch_bounds__(64 * ft_waves(DP), 2) suffstat_feat_kernel(Suf
       // during the last tile of a step (as the 16-quad instance does): the second set's 16 registers pay for the group.
       // Measured (N = 10M, D = 64, K = 32; gpurun_out/r05e): pairs 21.61 -> 21.22 ms, threes 21.30, fours 21.51, fives 21.79
       // -- the multiplies were a third of what the step loses, and larger groups expose the fragment reads; D = 48 gains
-      // 1 % with pairs, D = 32 and D = 128 nothing (ft_group).
+      // 1 % with pairs, D = 80 ... 112 1-2 %, D = 32 and D = 128 nothing (ft_group).
       constexpr int G = ft_group(DP), TOT = (BR / 4) * NT;
       double qa[NQ], u[G], w[G], pp[G];
 #pragma unroll
@@ -1045,6 +1049,9 @@ int suffstat_plan(int DP, int64_t NP, int K, int64_t* chunk_rows) {
       case 32: nslice = nq > 7 ? ft_nslice(32, 8) : nq > 6 ? ft_nslice(32, 7) : nq > 5 ? ft_nslice(32, 6) : ft_nslice(32, 5); break;
       case 48: nslice = nq > 7 ? ft_nslice(48, 8) : nq > 6 ? ft_nslice(48, 7) : nq > 5 ? ft_nslice(48, 6) : ft_nslice(48, 5); break;
       case 64: nslice = nq > 7 ? ft_nslice(64, 8) : nq > 6 ? ft_nslice(64, 7) : nq > 5 ? ft_nslice(64, 6) : ft_nslice(64, 5); break;
+      case 80: nslice = nq > 7 ? ft_nslice(80, 8) : nq > 6 ? ft_nslice(80, 7) : nq > 5 ? ft_nslice(80, 6) : ft_nslice(80, 5); break;
+      case 96: nslice = nq > 7 ? ft_nslice(96, 8) : nq > 6 ? ft_nslice(96, 7) : nq > 5 ? ft_nslice(96, 6) : ft_nslice(96, 5); break;
+      case 112: nslice = nq > 7 ? ft_nslice(112, 8) : nq > 6 ? ft_nslice(112, 7) : nq > 5 ? ft_nslice(112, 6) : ft_nslice(112, 5); break;
       case 128: nslice = nq > 8 ? ft_nslice(128, 16) : nq > 7 ? ft_nslice(128, 8) : nq > 6 ? ft_nslice(128, 7) : nq > 5 ? ft_nslice(128, 6) : ft_nslice(128, 5); break;
     }
     if (nslice > 0) {
