@@ -244,7 +244,9 @@ int lc_prune(lc_ctx* ctx, lc_model* model, int verbose, int* removed);
 /* Environment (the frozen learn*() signatures have no room for it): LIBCLUSTER_GPUS = N | "all" shards the
  * observations over N GPUs of this node inside this one call -- row blocks for the single-matrix learners, whole
  * groups for the GMC family -- one host thread and one context per GPU, RCCL all-reduce of the statistics; results
- * (F, rounds, qZ, weights, clusters) are returned exactly as from one GPU.  `device` is then ignored (GPUs 0..N-1). */
+ * (F, rounds, qZ, weights, clusters) are returned exactly as from one GPU.  `device` is then ignored (GPUs 0..N-1).
+ * LIBCLUSTER_COMM = "host" (host-staged sum in rank order, any placement) | "rccl-gather" (ncclAllGather + the same
+ * rank-order additions on every GPU: results independent of RCCL's ring order); default ncclAllReduce. */
 int lc_learn(int algo, int J, const double* const* Xj, const int64_t* Nj, int D, int64_t row_stride,
              int64_t col_stride, double wprior, double clusterprior, int maxclusters, int sparse, int verbose,
              unsigned nthreads, int device, lc_model** out, double* F);
