@@ -1297,6 +1297,8 @@ bool Context::dcache_eligible(int K) const {
 
 void Context::dcache_invalidate() {
   dc_K_ = 0;
+  rm_valid_ = false;
+  dc_ver_.clear();
   dc_slot_.clear();
   std::fill(dc_used_.begin(), dc_used_.end(), (unsigned char)0);
   dc_saved_.clear();
@@ -1311,6 +1313,11 @@ void Context::dcache_release() {
   dc_used_.clear();
   dc_slab_.release();
   dfresh_.release();
+  rm_max_.release();
+  rm_arg_.release();
+  bs_need_.release();
+  bs_x_.release();
+  bs_out_.release();
   dq_.release();
   amax_.release();
   dc_tagA_.clear();
@@ -1348,6 +1355,8 @@ void Context::dcache_rollback() {
     if (cur >= 0 && cur != sv->slot) dc_used_[(size_t)cur] = 0;
     dc_slot_[(size_t)sv->col] = sv->slot;
     dc_used_[(size_t)sv->slot] = 1;
+    if ((int)dc_ver_.size() <= sv->col) dc_ver_.resize((size_t)sv->col + 1, 0);
+    dc_ver_[(size_t)sv->col] = sv->ver;
     dc_tagA_[(size_t)sv->col].swap(sv->A);
     dc_tagm_[(size_t)sv->col].swap(sv->m);
   }
@@ -1355,6 +1364,167 @@ void Context::dcache_rollback() {
   dc_slot_.resize((size_t)dc_K_);
   dc_saved_.clear();
   dc_journal_ = false;
+}
+
+// Recompute the changed columns only for the rows they can reach (lck::BoundSelectLaunch has the argument).  Returns false
+// when the preconditions do not hold -- the caller then runs the ordinary raw pass over all rows, which overwrites whatever
+// this function wrote.  One group, every changed column with a reference column in the slab, few columns, many rows.
+bool Context::recompute_bounded(int K, const std::vector<int>& changed, const std::vector<int>& oldslot,
+                                const std::vector<std::vector<double>>& oldA, const std::vector<std::vector<double>>& oldm,
+                                const std::vector<int>& dest, const double* A, const double* m, const double* c, bool delta) {
+  static const bool off = lck::test_switch("LC_SPLIT_NO_BOUND") != nullptr;  // (tests: every recomputation over all rows)
+  const int nch = (int)changed.size(), D = D_;
+  const size_t AA = (size_t)D * D;
+  static const bool trace = std::getenv("LC_TRACE_PHASES") != nullptr;
+  auto no = [&](const char* why) {
+    if (trace) std::cerr << "[cache] no bounded recomputation at K " << K << " (" << nch << " columns): " << why << std::endl;
+    return false;
+  };
+  if (off || J_ != 1 || distributed() || NP_ < 200000) return false;
+  if (!rm_valid_) return no("no row maxima");
+  if (nch < 1 || nch > lck::BOUND_MAX_COLS || K > lck::BOUND_MAX_K || nch * 3 > K) return no("too many columns");
+  // a reference for every column: its own previous version, else the first previous version any changed column has
+  int fallback = -1;
+  for (int t = 0; t < nch && fallback < 0; ++t)
+    if (oldslot[(size_t)t] >= 0) fallback = t;
+  if (fallback < 0) return no("no reference column");
+  lck::BoundSelectLaunch b;
+  b.ncol = nch;
+  b.K = K;
+  b.NP = NP_;
+  std::vector<double> M(AA), v((size_t)D), w((size_t)D);
+  for (int t = 0; t < nch; ++t) {
+    const int rt = oldslot[(size_t)t] >= 0 ? t : fallback;
+    const double* Ar = oldA[(size_t)rt].data();
+    const double* mr = oldm[(size_t)rt].data();
+    const double* An = A + (size_t)changed[(size_t)t] * AA;
+    const double* mn = m + (size_t)changed[(size_t)t] * D;
+    // M = A_ref A_new^-1 (both lower triangular): row i of M from M A_new = A_ref, right to left
+    std::fill(M.begin(), M.end(), 0.0);
+    for (int i = 0; i < D; ++i)
+      for (int j = i; j >= 0; --j) {
+        double s = Ar[(size_t)i * D + j];
+        for (int l = j + 1; l <= i; ++l) s -= M[(size_t)i * D + l] * An[(size_t)l * D + j];
+        const double d = An[(size_t)j * D + j];
+        if (!(d > 0.0)) return no("singular whitener");
+        M[(size_t)i * D + j] = s / d;
+      }
+    // |M|_2 = 1 / sigma_min(B) by the power method on M^T M; the estimate approaches from below: it has to have settled
+    for (int i = 0; i < D; ++i) v[(size_t)i] = 1.0 + 0.01 * i;
+    double est = 0.0, prev = -1.0;
+    bool settled = false;
+    for (int it = 0; it < 200 && !settled; ++it) {
+      for (int i = 0; i < D; ++i) {  // w = M v
+        double s = 0.0;
+        for (int j = 0; j <= i; ++j) s += M[(size_t)i * D + j] * v[(size_t)j];
+        w[(size_t)i] = s;
+      }
+      double nv = 0.0;
+      for (int j = 0; j < D; ++j) {  // v = M^T w
+        double s = 0.0;
+        for (int i = j; i < D; ++i) s += M[(size_t)i * D + j] * w[(size_t)i];
+        v[(size_t)j] = s;
+        nv += s * s;
+      }
+      nv = std::sqrt(nv);
+      if (!(nv > 0.0) || !std::isfinite(nv)) return no("power method broke down");
+      for (int j = 0; j < D; ++j) v[(size_t)j] /= nv;
+      est = std::sqrt(nv);  // |M^T M v| -> lambda_max = |M|_2^2 for unit v
+      settled = it >= 8 && std::fabs(est - prev) <= 1e-4 * est;
+      prev = est;
+    }
+    if (!settled) return no("power method not settled");
+    double bn = 0.0;
+    for (int i = 0; i < D; ++i) {
+      double s = 0.0;
+      for (int j = 0; j <= i; ++j) s += An[(size_t)i * D + j] * (mr[j] - mn[j]);
+      bn += s * s;
+    }
+    b.ref[t] = dc_slab_.p + (size_t)oldslot[(size_t)rt] * NP_;
+    b.dest[t] = dc_slab_.p + (size_t)dest[(size_t)t] * NP_;
+    b.sigma[t] = 0.97 / est;           // (a lower bound of sigma_min(B): the power method's estimate of |M|_2 is from below)
+    b.bnorm[t] = 1.03 * std::sqrt(bn) + 1e-9;
+    b.cnew[t] = c[changed[(size_t)t]];
+  }
+  std::fill(b.usable, b.usable + lck::BOUND_MAX_K, (unsigned char)0);
+  std::fill(b.dcj, b.dcj + lck::BOUND_MAX_K, 0.0);
+  int nusable = 0;
+  for (int j = 0; j < K && j < rm_K_; ++j) {
+    bool ch = false;
+    for (int k : changed) ch = ch || k == j;
+    if (ch || j >= (int)dc_ver_.size() || dc_ver_[(size_t)j] != rm_ver_[(size_t)j]) continue;
+    b.usable[j] = 1;
+    b.dcj[j] = c[j] - rm_c_[(size_t)j];
+    ++nusable;
+  }
+  if (nusable == 0) return no("no unchanged column");
+  b.rmax = rm_max_.p;
+  b.ramax = rm_arg_.p;
+  b.T = (delta ? 208.0 : 746.0) + 32.0;
+  bs_need_.reserve((size_t)NP_);
+  b.need = bs_need_.p;
+  LC_HIP(lck::launch_bound_select(b, stream_));
+  RowSelection sel;
+  select_rows_col(bs_need_.p, 0.5, sel);
+  if (trace) {
+    std::cerr << "[cache] bounded recomputation: " << sel.M << " of " << NP_ << " rows for " << nch << " columns; usable " << nusable
+              << ", T " << b.T;
+    for (int t = 0; t < nch; ++t) std::cerr << " | col " << changed[(size_t)t] << " sigma " << b.sigma[t] << " |b| " << b.bnorm[t] << " c " << b.cnew[t];
+    std::cerr << std::endl;
+  }
+  if (sel.M * 3 > NP_) return false;  // (most rows: the ordinary pass is the cheaper one, and overwrites the -inf entries)
+  bound_rows_ += sel.M;
+  bound_passes_ += 1;
+  if (sel.M == 0) return true;
+  // the selected rows side by side, the ordinary raw E-step on them, the results back to their rows
+  const int64_t Mp = (sel.M + lck::RG - 1) / lck::RG * lck::RG;
+  bs_x_.reserve((size_t)Mp * DP_);
+  bs_out_.reserve((size_t)Mp * nch);
+  if (Mp > sel.M) LC_HIP(hipMemsetAsync(bs_x_.p + (size_t)sel.M * DP_, 0, (size_t)(Mp - sel.M) * DP_ * sizeof(double), stream_));
+  LC_HIP(lck::launch_gather_rows_plain(X_.p, DP_, sel.idx.p, sel.M, bs_x_.p, stream_));
+  std::vector<double> A2((size_t)nch * AA), m2((size_t)nch * D);
+  for (int t = 0; t < nch; ++t) {
+    std::copy(A + (size_t)changed[(size_t)t] * AA, A + (size_t)(changed[(size_t)t] + 1) * AA, A2.begin() + (size_t)t * AA);
+    std::copy(m + (size_t)changed[(size_t)t] * D, m + (size_t)(changed[(size_t)t] + 1) * D, m2.begin() + (size_t)t * D);
+  }
+  const std::vector<double> zero((size_t)nch, 0.0);
+  const int64_t PS = lck::pstride(DP_);
+  pack_estep_params(nch, A2.data(), m2.data(), zero.data());
+  params_.reserve(hpack_.size());
+  LC_HIP(hipMemcpyAsync(params_.p, hpack_.data(), hpack_.size() * sizeof(double), hipMemcpyHostToDevice, stream_));
+  const int64_t nrg = Mp / lck::RG, grid = lck::estep_grid(DP_, nrg);
+  fzpart_.reserve((size_t)std::max<int64_t>(grid, 1));
+  lck::EstepLaunch a;
+  a.DP = DP_;
+  a.X = bs_x_.p;
+  a.nrg = nrg;
+  a.rginfo = nullptr;
+  a.nrows = sel.M;
+  a.params = params_.p;
+  a.ctab = params_.p + (size_t)nch * PS;
+  a.K = nch;
+  a.qZ = bs_out_.p;
+  a.ldq = Mp;
+  a.fz_part = fzpart_.p;
+  a.ll_part = nullptr;
+  a.raw = 1;
+  EvPair ev{};
+  if (timing_) {
+    ev.a = timing_event();
+    ev.b = timing_event();
+    ev.kind = 0;
+    LC_HIP(hipEventRecord(ev.a, stream_));
+  }
+  LC_HIP(lck::launch_estep(a, stream_));
+  if (timing_) {
+    LC_HIP(hipEventRecord(ev.b, stream_));
+    pending_.push_back(ev);
+  }
+  double* dp[lck::BOUND_MAX_COLS];
+  for (int t = 0; t < nch; ++t) dp[t] = b.dest[t];
+  LC_HIP(lck::launch_scatter_cols(bs_out_.p, Mp, nch, dp, sel.idx.p, sel.M, stream_));
+  LC_HIP(hipStreamSynchronize(stream_));  // (the packed parameters and `sel` are about to go)
+  return true;
 }
 
 int Context::estep_cache(int K, const double* A, const double* m, const double* c, double* Fz, double* LLk, double delta_tol,
@@ -1403,7 +1573,23 @@ int Context::estep_cache(int K, const double* A, const double* m, const double* 
   // for a moment, the move of the responsibilities takes K more columns.
   // (capacities grow geometrically: at tens of millions of rows every one of these blocks is past the block cache's
   // limit, and a hipMalloc / hipFree of ten gigabytes costs seconds)
-  const bool grow = K > dc_cap_ || used + new_needed > dc_cap_;
+  // (the recomputed columns are written side by side: when they cannot stay where they are, a RUN of free slots has to
+  //  exist -- a slab that is nearly full has free slots but no run, and every recomputation would go through the scratch
+  //  buffer and a copy per column: grow it instead, once)
+  bool need_run = nch > 0 && writable[0] < 0;
+  for (int t = 1; t < nch && !need_run; ++t) need_run = writable[(size_t)t] != writable[0] + t;
+  bool have_run = !need_run;
+  if (need_run && dc_cap_ > 0) {
+    std::vector<unsigned char> u(dc_used_);
+    for (int t = 0; t < nch; ++t)
+      if (writable[(size_t)t] >= 0) u[(size_t)writable[(size_t)t]] = 0;
+    int runlen = 0;
+    for (int sl = 0; sl < dc_cap_ && !have_run; ++sl) {
+      runlen = u[(size_t)sl] ? 0 : runlen + 1;
+      have_run = runlen >= nch;
+    }
+  }
+  const bool grow = K > dc_cap_ || used + new_needed > dc_cap_ || !have_run;
   const int grown_cap = std::max(std::max(K, used + new_needed) + 8, 2 * dc_cap_);
   bool ask = K > dc_room_K_ || grow;
 #ifdef LC_TEST_HOOKS  // (libcluster_hip_testhooks.so only: the shipped library has no fault hooks)
@@ -1467,6 +1653,7 @@ int Context::estep_cache(int K, const double* A, const double* m, const double* 
     auto sv = std::make_unique<SavedColumn>();
     sv->col = k;
     sv->slot = dc_slot_[(size_t)k];
+    sv->ver = k < (int)dc_ver_.size() ? dc_ver_[(size_t)k] : 0;
     sv->A = dc_tagA_[(size_t)k];
     sv->m = dc_tagm_[(size_t)k];
     dc_saved_.push_back(std::move(sv));
@@ -1508,6 +1695,17 @@ int Context::estep_cache(int K, const double* A, const double* m, const double* 
       Ap = A2.data();
       mp = m2.data();
     }
+    // the changed columns' previous versions (slot and tags), where they have one: the references of the distance bound
+    std::vector<int> oldslot((size_t)nch, -1);
+    std::vector<std::vector<double>> oldA((size_t)nch), oldm((size_t)nch);
+    for (int t = 0; t < nch; ++t) {
+      const int k = changed[(size_t)t];
+      if (k < dc_K_ && k < (int)dc_slot_.size() && dc_slot_[(size_t)k] >= 0 && dc_tagA_[(size_t)k].size() == AA) {
+        oldslot[(size_t)t] = dc_slot_[(size_t)k];
+        oldA[(size_t)t] = dc_tagA_[(size_t)k];
+        oldm[(size_t)t] = dc_tagm_[(size_t)k];
+      }
+    }
     std::vector<int> dest((size_t)nch, -1);
     if (run >= 0) {
       for (int t = 0; t < nch; ++t) dest[(size_t)t] = run + t;
@@ -1527,7 +1725,11 @@ int Context::estep_cache(int K, const double* A, const double* m, const double* 
     const std::vector<double> zero((size_t)J_ * nch, 0.0);
     double fz0 = 0.0;
     double* target = run >= 0 ? dc_slab_.p + (size_t)run * NP_ : dfresh_.p;
-    if (NP_ > 0) {
+    if ((int)dc_ver_.size() < K) dc_ver_.resize((size_t)K, 0);
+    for (int k : changed) dc_ver_[(size_t)k] = ++dc_vernext_;
+    if (NP_ > 0 && run >= 0 && recompute_bounded(K, changed, oldslot, oldA, oldm, dest, A, m, c, delta_tol >= 0.0)) {
+      // (only the rows the new columns can reach were recomputed; the others hold -inf)
+    } else if (NP_ > 0) {
       estep(nch, Ap, mp, zero.data(), &fz0, nullptr, true, target);
       if (run < 0)
         for (int t = 0; t < nch; ++t)
@@ -1594,6 +1796,19 @@ int Context::estep_cache(int K, const double* A, const double* m, const double* 
     a.ldq = NP_;
     a.fz_part = fzpart_.p;
     a.ll_part = LLk ? llpart_.p : nullptr;
+    if (J_ == 1 && K <= lck::BOUND_MAX_K) {  // (what recompute_bounded needs next time)
+      rm_max_.reserve((size_t)NP_);
+      rm_arg_.reserve((size_t)NP_);
+      a.rmax = rm_max_.p;
+      a.ramax = rm_arg_.p;
+      rm_valid_ = true;
+      rm_K_ = K;
+      rm_ver_.assign(dc_ver_.begin(), dc_ver_.begin() + std::min<size_t>(dc_ver_.size(), (size_t)K));
+      rm_ver_.resize((size_t)K, 0);
+      rm_c_.assign(c, c + K);
+    } else {
+      rm_valid_ = false;
+    }
     if (delta) {
       dq_.reserve((size_t)NP_ * std::max(K, dc_cap_));  // (as wide as the slab: re-allocated only when that grows)
       amax_.reserve((size_t)NP_);
@@ -1603,6 +1818,9 @@ int Context::estep_cache(int K, const double* A, const double* m, const double* 
       a.amax = amax_.p;
       a.dq_tol = delta_tol;
       dq_tol_ = delta_tol;
+      dq_maskd_.reserve(2);
+      LC_HIP(hipMemsetAsync(dq_maskd_.p, 0, 2 * sizeof(int64_t), stream_));
+      a.colmask = reinterpret_cast<unsigned long long*>(dq_maskd_.p);
       static const bool no_hash = lck::test_switch("LC_SPLIT_NO_QHASH") != nullptr;  // (tests: read every old value)
       if (!no_hash) {
         qz_[cur_].hash.reserve((size_t)NP_);
@@ -1635,8 +1853,17 @@ int Context::estep_cache(int K, const double* A, const double* m, const double* 
     allreduce(red_.p, nred);
     LC_HIP(hipMemcpyAsync(hred_.data(), red_.p, (size_t)nred * sizeof(double), hipMemcpyDeviceToHost, stream_));
   }
+  dq_mask_ok_ = false;
+  if (delta && NP_ > 0) {
+    hmask_.resize(2);
+    LC_HIP(hipMemcpyAsync(hmask_.data(), dq_maskd_.p, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, stream_));
+  }
   run_overlap();
   LC_HIP(hipStreamSynchronize(stream_));  // (also covers the host vectors the asynchronous copies read)
+  if (delta && NP_ > 0) {
+    std::memcpy(dq_mask_, hmask_.data(), sizeof(dq_mask_));
+    dq_mask_ok_ = true;
+  }
   if (Fz) *Fz = hred_[0];
   if (LLk) std::copy(hred_.begin() + 1, hred_.begin() + 1 + K, LLk);
   if (delta) dq_K_ = K;  // (a rank without rows keeps an empty delta and still joins delta_suffstat's sums)
@@ -1654,6 +1881,23 @@ bool Context::delta_suffstat(int K1, double max_frac, double* dNk, double* dxs, 
   double cnt[2] = {(double)sel.M, (double)Ntot_};
   allreduce_values(cnt, 2);  // every rank takes the same branch
   if (cnt[0] > max_frac * cnt[1]) return false;
+  // the clusters any moved row moved in (the sweep's column mask): a split trial moves rows between the two halves of one
+  // cluster and, here and there, a neighbour -- 2 to 4 columns of K + 1.  The other clusters' differences are all zero and
+  // so are their statistics: they are not computed (single rank: the mask is this rank's own)
+  std::vector<int> cols;
+  if (dq_mask_ok_ && !distributed() && K1 <= 128) {
+    for (int k = 0; k < K1; ++k)
+      if ((dq_mask_[k >> 6] >> (k & 63)) & 1ull) cols.push_back(k);
+  } else {
+    for (int k = 0; k < K1; ++k) cols.push_back(k);
+  }
+  const int nc = (int)cols.size();
+  const int D = D_;
+  std::fill(dNk, dNk + K1, 0.0);
+  std::fill(dxs, dxs + (size_t)K1 * D, 0.0);
+  std::fill(dxxs, dxxs + (size_t)K1 * D * D, 0.0);
+  std::fill(dNjk, dNjk + (size_t)J_ * K1, 0.0);
+  if (nc == 0) return true;
   Context sub(device_, stream_);
   sub.inherit_comm(*this);
   sub.skip_zero_ = false;
@@ -1661,15 +1905,34 @@ bool Context::delta_suffstat(int K1, double max_frac, double* dNk, double* dxs, 
   QZ& q = sub.qz_[sub.cur_];
   {
     RelaxedFit lend;
-    sub.ensure_qz(q, K1, false);
+    sub.ensure_qz(q, nc, false);
   }
-  q.K = K1;
+  q.K = nc;
   if (sub.NP_ > 0) {
-    LC_HIP(hipMemsetAsync(q.buf.p, 0, (size_t)sub.NP_ * K1 * sizeof(double), stream_));  // padding rows carry nothing
-    LC_HIP(lck::launch_gather_rowmajor(dq_.p, dq_ld_, K1, sel.idx.p, sel.M, sel.starts_d.p, sub.goff_d_.p, J_, q.buf.p,
-                                   sub.NP_, stream_));
+    LC_HIP(hipMemsetAsync(q.buf.p, 0, (size_t)sub.NP_ * nc * sizeof(double), stream_));  // padding rows carry nothing
+    if (nc == K1) {
+      LC_HIP(lck::launch_gather_rowmajor(dq_.p, dq_ld_, K1, sel.idx.p, sel.M, sel.starts_d.p, sub.goff_d_.p, J_, q.buf.p,
+                                         sub.NP_, stream_));
+    } else {
+      dq_colsd_.reserve((size_t)nc);
+      LC_HIP(hipMemcpyAsync(dq_colsd_.p, cols.data(), (size_t)nc * sizeof(int), hipMemcpyHostToDevice, stream_));
+      LC_HIP(lck::launch_gather_rowmajor_cols(dq_.p, dq_ld_, dq_colsd_.p, nc, sel.idx.p, sel.M, sel.starts_d.p, sub.goff_d_.p,
+                                              J_, q.buf.p, sub.NP_, stream_));
+    }
   }
-  sub.suffstat(nullptr, dNk, dxs, dxxs, dNjk);
+  if (nc == K1) {
+    sub.suffstat(nullptr, dNk, dxs, dxxs, dNjk);
+    return true;
+  }
+  std::vector<double> n2((size_t)nc), x2((size_t)nc * D), xx2((size_t)nc * D * D), nj2((size_t)J_ * nc);
+  sub.suffstat(nullptr, n2.data(), x2.data(), xx2.data(), nj2.data());  // (synchronises: `cols` has been read by then)
+  for (int t = 0; t < nc; ++t) {
+    const int k = cols[(size_t)t];
+    dNk[k] = n2[(size_t)t];
+    std::copy(x2.begin() + (size_t)t * D, x2.begin() + (size_t)(t + 1) * D, dxs + (size_t)k * D);
+    std::copy(xx2.begin() + (size_t)t * D * D, xx2.begin() + (size_t)(t + 1) * D * D, dxxs + (size_t)k * D * D);
+    for (int j = 0; j < J_; ++j) dNjk[(size_t)j * K1 + k] = nj2[(size_t)j * nc + t];
+  }
   return true;
 }
 

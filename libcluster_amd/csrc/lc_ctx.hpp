@@ -322,14 +322,33 @@ class Context {
   struct SavedColumn {
     int col = -1;
     int slot = -1;  // where the column's journaled content stays
+    uint64_t ver = 0;
     std::vector<double> A, m;
   };
+  // which rows a recomputed column matters for (lck::BoundSelectLaunch): every sweep leaves each row's largest log q~ and
+  // its cluster; valid for cluster j while column j is the version it was then (dc_ver_)
+  std::vector<uint64_t> dc_ver_;  // [dc_K_] version of cluster k's column (bumped on every recomputation)
+  uint64_t dc_vernext_ = 0;
+  DevBuf<double> rm_max_, bs_need_, bs_x_, bs_out_;
+  DevBuf<int> rm_arg_;
+  bool rm_valid_ = false;
+  int rm_K_ = 0;
+  std::vector<uint64_t> rm_ver_;
+  std::vector<double> rm_c_;
+  int64_t bound_rows_ = 0, bound_passes_ = 0;  // rows recomputed / passes taken by the bounded recomputation (trace)
+  bool recompute_bounded(int K, const std::vector<int>& changed, const std::vector<int>& oldslot,
+                         const std::vector<std::vector<double>>& oldA, const std::vector<std::vector<double>>& oldm,
+                         const std::vector<int>& dest, const double* A, const double* m, const double* c, bool delta);
   int dc_find_run(int n) const;  // first run of n free slots (-1: none)
   std::vector<std::unique_ptr<SavedColumn>> dc_saved_;
   bool dc_journal_ = false;
   int dc_jK0_ = 0;
   DevBuf<double> sink_;  // estep_diag_mfma_kernel's store sink
   DevBuf<double> dq_, amax_;  // estep_cache(delta_tol): q_new - q_old [K x NP] (moved rows), per-row max |.|
+  DevBuf<int64_t> dq_maskd_;  // [2] device: columns with any non-zero difference (CachedNormLaunch::colmask)
+  DevBuf<int> dq_colsd_;
+  uint64_t dq_mask_[2] = {0, 0};
+  bool dq_mask_ok_ = false;
   double dq_tol_ = 0.0;
   int dq_K_ = 0;
   int64_t dq_ld_ = 0;  // row stride of dq_ (row-major: a moved row's differences are contiguous)
@@ -341,7 +360,7 @@ class Context {
   DevBuf<int> selcnt_;
   DevBuf<int64_t> seloff_;
   DevBuf<double> mv_;
-  PinnedBuf hpack_, hred_, hss_;
+  PinnedBuf hpack_, hred_, hss_, hmask_;
   std::function<void()> overlap_;
 
   bool timing_ = false;

@@ -220,6 +220,10 @@ hipError_t launch_gather_cols(const double* src, int64_t lds, int K, const int64
 hipError_t launch_gather_rowmajor(const double* src, int64_t lds, int K, const int64_t* idx, int64_t M,
                                   const int64_t* starts, const int64_t* goff_sub, int J, double* dst, int64_t ldd,
                                   hipStream_t stream);
+// the same for the nc source columns cols[0 .. nc) (device array): dst[c, gathered row of p] = src[idx[p], cols[c]]
+hipError_t launch_gather_rowmajor_cols(const double* src, int64_t lds, const int* cols, int nc, const int64_t* idx, int64_t M,
+                                       const int64_t* starts, const int64_t* goff_sub, int J, double* dst, int64_t ldd,
+                                       hipStream_t stream);
 hipError_t launch_gather_rows(const double* X, int DP, const int64_t* idx, int64_t M, const int64_t* starts,
                               const int64_t* goff_sub, int J, double* Xdst, hipStream_t stream);
 hipError_t launch_split_init(const double* X, int DP, int D, int64_t NP, const int* rginfo, int64_t nrows,
@@ -256,7 +260,46 @@ struct CachedNormLaunch {
   // every row: half of the sweep's traffic)
   int64_t* qhash = nullptr;  // [NP]
   int qhash_in = 0;          // the fingerprints describe the responsibilities being overwritten
+  // optional (both or neither): every row's largest log q~ and the cluster it belongs to -- what the NEXT recomputation of
+  // a few columns needs to tell which rows those columns cannot reach (BoundSelectLaunch)
+  double* rmax = nullptr;  // [NP]
+  int* ramax = nullptr;    // [NP]
+  // optional, with dq: bit j of colmask[j / 64] is set when any row's q_new - q_old is non-zero in column j (two words,
+  // zeroed by the caller): delta_suffstat forms the moved rows' statistics for those clusters only
+  unsigned long long* colmask = nullptr;
 };
+// Model selection: which rows does a recomputed column of -0.5 d^2 matter for?  (Context::estep_cache, round 5.)
+// A split candidate changes two columns and the raw pass that recomputes them reads ALL of X for them (1.7 ms at N = 10M,
+// D = 64: X-bound) -- although, for all but the candidate's own rows and their neighbours, the new responsibilities are
+// exactly 0.0.  For a reference cluster `ref` (the column's own previous version, or the parent of a split) whose column
+// is still in the slab,
+//     d^2_new(x) = |B y + b|^2 >= (sigma_min(B) |y| - |b|)^2,   y = A_ref (x - m_ref), B = A_new A_ref^-1, b = A_new (m_ref - m_new)
+// bounds the new column from ABOVE by a function of the old one:  log q~_new <= c_new - 0.5 (sigma sqrt(d^2_ref) - |b|)_+^2.
+// A row whose largest log q~ over the UNCHANGED columns (rmax + the change of that cluster's constant) exceeds that bound
+// by more than T gets -inf in the new column instead of its true value -- the same bits out of the normalisation sweep:
+// with T > 745.2 exp(log q~ - max) underflows to 0.0 either way; in the moved-row sweeps, which store q < 2^-300 as zero,
+// T > 208 suffices (an addend below 2^-54 of a sum that contains the row's exp(0) = 1 never changes it).  The other rows
+// are flagged in `need` (1.0 / 0.0), gathered, and recomputed by the ordinary raw E-step.
+constexpr int BOUND_MAX_COLS = 8, BOUND_MAX_K = 72;
+struct BoundSelectLaunch {
+  int ncol = 0, K = 0;
+  int64_t NP = 0;
+  const double* ref[BOUND_MAX_COLS];  // [NP] -0.5 d^2 of column t's reference cluster
+  double* dest[BOUND_MAX_COLS];       // [NP] where column t goes: -inf is written for the rows that need no value
+  double sigma[BOUND_MAX_COLS], bnorm[BOUND_MAX_COLS], cnew[BOUND_MAX_COLS];
+  const double* rmax;
+  const int* ramax;
+  double T;
+  unsigned char usable[BOUND_MAX_K];  // cluster j's column (and so rmax of its rows) is what it was when rmax was written
+  double dcj[BOUND_MAX_K];            // change of c_j since then
+  double* need;                       // [NP] out: 1.0 = recompute this row's columns
+};
+hipError_t launch_bound_select(const BoundSelectLaunch& a, hipStream_t stream);
+// Xdst[p] = X[idx[p]] (rows of DP doubles), p < M
+hipError_t launch_gather_rows_plain(const double* X, int DP, const int64_t* idx, int64_t M, double* Xdst, hipStream_t stream);
+// dest[t][idx[p]] = src[t * lds + p], t < ncol, p < M
+hipError_t launch_scatter_cols(const double* src, int64_t lds, int ncol, double* const* dest_host, const int64_t* idx, int64_t M,
+                               hipStream_t stream);
 // Switches of the test suite (the literal schedule of the split search, kernel instances forced on or off): read from
 // the environment by libcluster_hip_testhooks.so ONLY -- in the shipped library this returns nullptr for every name, so
 // no environment variable can change which kernel runs or what a learner returns (defined in lc_ctx.cpp).

@@ -366,6 +366,26 @@ hipError_t launch_gather_rowmajor(const double* src, int64_t lds, int K, const i
   return hipGetLastError();
 }
 
+__global__ void __launch_bounds__(256) gather_rowmajor_cols_kernel(const double* src, int64_t lds, const int* cols, int nc,
+                                                                   const int64_t* idx, int64_t M, const int64_t* starts,
+                                                                   const int64_t* goff_sub, int J, double* dst, int64_t ldd) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= M * nc) return;
+  const int64_t p = t / nc;
+  const int c = (int)(t % nc);
+  const int64_t d = sel_dst_row(p, starts, goff_sub, J);
+  dst[(int64_t)c * ldd + d] = src[idx[p] * lds + cols[c]];
+}
+hipError_t launch_gather_rowmajor_cols(const double* src, int64_t lds, const int* cols, int nc, const int64_t* idx, int64_t M,
+                                       const int64_t* starts, const int64_t* goff_sub, int J, double* dst, int64_t ldd,
+                                       hipStream_t stream) {
+  if (M <= 0 || nc <= 0) return hipSuccess;
+  const int64_t n = M * nc;
+  hipLaunchKernelGGL(gather_rowmajor_cols_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, lds, cols, nc,
+                     idx, M, starts, goff_sub, J, dst, ldd);
+  return hipGetLastError();
+}
+
 hipError_t launch_gather_cols(const double* src, int64_t lds, int K, const int64_t* idx, int64_t M, const int64_t* starts,
                               const int64_t* goff_sub, int J, double* dst, int64_t ldd, hipStream_t stream) {
   if (M <= 0 || K <= 0) return hipSuccess;
@@ -630,8 +650,10 @@ __global__ void __launch_bounds__(256) softmax_cached_kernel(CachedNormLaunch a)
   __shared__ double fzw[4];
   __shared__ double llw[4 * KT];
   __shared__ double etab[64];  // 2^(j / 64) for exp_nonpos
+  __shared__ unsigned long long cmask[2];
   const int tid = threadIdx.x, K = a.K;
   fill_exp_table(etab, tid, 256);
+  if (tid < 2) cmask[tid] = 0ull;
   __syncthreads();
   const int64_t row = (int64_t)blockIdx.x * 256 + tid;
   const bool inb = row < a.NP;
@@ -665,6 +687,14 @@ __global__ void __launch_bounds__(256) softmax_cached_kernel(CachedNormLaunch a)
       v[j] += crow[j];
       mx = fmax(mx, v[j]);
     }
+  if (a.rmax && inb) {  // the row's largest log q~ and its cluster (BoundSelectLaunch)
+    int am = 0;
+#pragma unroll
+    for (int j = 0; j < KT; ++j)
+      if (j < K) am = v[j] == mx ? j : am;
+    a.rmax[row] = mx;
+    a.ramax[row] = am;
+  }
   // (a.dq, a.ll_part: launch-uniform)
   // Without LL_k: ONE exponential per entry -- e = exp(x - max) replaces x in its register and q = e / sum(e) (the same
   // sum and logZ; q within 2 ulp of exp(x - logZ), far inside the tolerance of the moved-row test below, and the same
@@ -723,6 +753,7 @@ __global__ void __launch_bounds__(256) softmax_cached_kernel(CachedNormLaunch a)
     // all K: 33 partial-line writes per such row were a third of a candidate's sweep), and the row's differences go to
     // the row-major table in the same pass (delta_suffstat reads them only where amax > dq_tol).
     double am = 0.0;
+    unsigned long long mlo = 0ull, mhi = 0ull;  // columns in which this row moved at all (a.colmask)
     if (!same && inb) {
       // (all K old values in ONE batch of loads: nearly every wave holds a changed row or two, and with eight registers at
       //  a time it walked five dependent memory round trips for them -- 1.83 against 1.23 ms for a candidate's sweep at
@@ -739,9 +770,17 @@ __global__ void __launch_bounds__(256) softmax_cached_kernel(CachedNormLaunch a)
           if (jb + u < KT && jb + u < K) {
             const double dd = v[jb + u] - o[u];
             am = fmax(am, fabs(dd));
-            if (dd != 0.0) a.qZ[(int64_t)(jb + u) * a.ldq + row] = v[jb + u];
+            if (dd != 0.0) {
+              a.qZ[(int64_t)(jb + u) * a.ldq + row] = v[jb + u];
+              if (jb + u < 64) mlo |= 1ull << ((jb + u) & 63);
+              else mhi |= 1ull << ((jb + u) & 63);
+            }
             a.dq[row * a.ldd + jb + u] = dd;
           }
+      }
+      if (a.colmask) {
+        if (mlo) atomicOr(&cmask[0], mlo);
+        if (mhi) atomicOr(&cmask[1], mhi);
       }
     }
     if (inb) {
@@ -760,6 +799,10 @@ __global__ void __launch_bounds__(256) softmax_cached_kernel(CachedNormLaunch a)
   if (a.ll_part)
     for (int j = tid; j < K; j += 256)
       a.ll_part[(int64_t)blockIdx.x * K + j] = llw[j] + llw[KT + j] + llw[2 * KT + j] + llw[3 * KT + j];
+  if (a.colmask && tid < 2) {  // (an OR: the order of the blocks does not matter; most blocks find their bits set already)
+    const unsigned long long v = cmask[tid];
+    if (v && (__hip_atomic_load(&a.colmask[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & v) != v) atomicOr(&a.colmask[tid], v);
+  }
 }
 // Tests (libcluster_hip_testhooks.so, LC_TEST_VERIFY_QHASH): does every stored fingerprint describe the row it belongs
 // to?  Counts the rows whose fingerprint is neither QHASH_NONE nor that of the K values in the buffer.
@@ -777,6 +820,76 @@ hipError_t launch_qhash_verify(const double* qZ, int64_t ldq, int K, int64_t NP,
                                unsigned long long* bad, hipStream_t stream) {
   if (NP <= 0 || K <= 0) return hipSuccess;
   hipLaunchKernelGGL(qhash_verify_kernel, dim3((unsigned)((NP + 255) / 256)), dim3(256), 0, stream, qZ, ldq, K, NP, qhash, bad);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Model selection: the rows a recomputed column matters for (BoundSelectLaunch, lc_kernels.h)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) bound_select_kernel(BoundSelectLaunch a) {
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (row >= a.NP) return;
+  const int j = a.ramax[row];
+  bool skip = j >= 0 && j < a.K && a.usable[j] != 0;
+  double d2[BOUND_MAX_COLS];
+#pragma unroll
+  for (int t = 0; t < BOUND_MAX_COLS; ++t)
+    if (t < a.ncol) d2[t] = -2.0 * a.ref[t][row];  // (every reference is read before any destination is written)
+  if (skip) {
+    const double low = a.rmax[row] + a.dcj[j] - a.T;  // the row's largest log q~ among the unchanged columns, less the margin
+#pragma unroll
+    for (int t = 0; t < BOUND_MAX_COLS; ++t)
+      if (t < a.ncol) {
+        const double s = fmax(a.sigma[t] * sqrt(fmax(d2[t], 0.0)) - a.bnorm[t], 0.0);
+        skip = skip && (a.cnew[t] - 0.5 * s * s < low);  // (NaN anywhere: false -> the row is recomputed)
+      }
+  }
+  a.need[row] = skip ? 0.0 : 1.0;
+  if (skip) {
+#pragma unroll
+    for (int t = 0; t < BOUND_MAX_COLS; ++t)
+      if (t < a.ncol) a.dest[t][row] = -INFINITY;
+  }
+}
+hipError_t launch_bound_select(const BoundSelectLaunch& a, hipStream_t stream) {
+  if (a.NP <= 0 || a.ncol <= 0) return hipSuccess;
+  if (a.ncol > BOUND_MAX_COLS || a.K > BOUND_MAX_K) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(bound_select_kernel, dim3((unsigned)((a.NP + 255) / 256)), dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
+__global__ void __launch_bounds__(256) gather_rows_plain_kernel(const double* X, int DP, const int64_t* idx, int64_t M, double* Xdst) {
+  const int per = DP / 2;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= M * per) return;
+  const int64_t p = t / per;
+  const int c2 = (int)(t % per);
+  reinterpret_cast<double2*>(Xdst + p * DP)[c2] = reinterpret_cast<const double2*>(X + idx[p] * DP)[c2];
+}
+hipError_t launch_gather_rows_plain(const double* X, int DP, const int64_t* idx, int64_t M, double* Xdst, hipStream_t stream) {
+  if (M <= 0) return hipSuccess;
+  const int64_t n = M * (DP / 2);
+  hipLaunchKernelGGL(gather_rows_plain_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, X, DP, idx, M, Xdst);
+  return hipGetLastError();
+}
+struct ScatterDest {
+  double* p[BOUND_MAX_COLS];
+};
+__global__ void __launch_bounds__(256) scatter_cols_kernel(const double* src, int64_t lds, int ncol, ScatterDest d, const int64_t* idx,
+                                                           int64_t M) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= M) return;
+  const int64_t r = idx[p];
+#pragma unroll
+  for (int t = 0; t < BOUND_MAX_COLS; ++t)
+    if (t < ncol) d.p[t][r] = src[(int64_t)t * lds + p];
+}
+hipError_t launch_scatter_cols(const double* src, int64_t lds, int ncol, double* const* dest_host, const int64_t* idx, int64_t M,
+                               hipStream_t stream) {
+  if (M <= 0 || ncol <= 0) return hipSuccess;
+  if (ncol > BOUND_MAX_COLS) return hipErrorInvalidValue;
+  ScatterDest d{};
+  for (int t = 0; t < ncol; ++t) d.p[t] = dest_host[t];
+  hipLaunchKernelGGL(scatter_cols_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, stream, src, lds, ncol, d, idx, M);
   return hipGetLastError();
 }
 

@@ -227,3 +227,19 @@ def test_every_writer_of_the_responsibilities_keeps_the_fingerprints_honest(lib,
     assert plain["qsha"] == ok["qsha"] and plain["Fhex"] == ok["Fhex"]
     bad = _run_snippet(dict(env, LC_TEST_QHASH_KEEP_STALE="1", _EXPECT_FAILURE="1"), **kw)
     assert bad["rc"] != 0 and "fingerprint that is not theirs" in bad["_stderr"], bad["_stderr"][-1500:]
+
+
+@pytest.mark.parametrize("kw,runs", [(dict(seed=11, K=8, D=24, N=250000, J=1, scale=2.5), True),   # separated enough for the bound to bite
+                                     (dict(seed=12, K=7, D=40, N=220000, J=1, scale=1.0), False),  # heavy overlap: the cache is given up early
+                                     (dict(seed=13, K=9, D=17, N=300000, J=1, scale=4.0), True)])
+def test_bounded_recomputation_changes_no_bit_of_the_result(lib, kw, runs):
+    """A split candidate's recomputed columns are evaluated only for the rows they can reach (Context::recompute_bounded:
+    a lower bound on the new Mahalanobis distance from the reference cluster's cached column; rows whose new
+    responsibility is certain to come out as exactly 0.0 get -inf instead of their true log q~).  With
+    LC_SPLIT_NO_BOUND (test-hooks library) every recomputation runs over all rows: rounds, K, every free energy, F and
+    every bit of qZ must be the same -- and the bounded path must really have run."""
+    on = _run_snippet({"LC_LIB_PATH": HOOKED, "LC_TRACE_PHASES": "1"}, **kw)
+    off = _run_snippet({"LC_LIB_PATH": HOOKED, "LC_SPLIT_NO_BOUND": "1", "LC_TRACE_PHASES": "1"}, **kw)
+    assert ("bounded recomputation:" in on["_stderr"]) == runs and "bounded recomputation:" not in off["_stderr"]
+    assert on["K"] == off["K"] and on["rounds"] == off["rounds"]
+    assert on["Fhex"] == off["Fhex"] and on["qsha"] == off["qsha"]
