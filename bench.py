@@ -460,7 +460,7 @@ def measure(capi, cfg, steps, warmup, rank, world, local_rank, stream, nthreads,
         fn.restype = __import__("ctypes").c_char_p
         fn.argtypes = [__import__("ctypes").c_int, __import__("ctypes").c_int]
         ssname = fn(D, K).decode()
-    dom = "estep_kernel" if est >= sst else ssname
+    dom = ("estep_wide_kernel" if D > 128 else "estep_kernel") if est >= sst else ssname
     if family != "GaussWish":  # the names rocprofv3 lists: the matrix-pipe E-step where the context took it (every launch here)
         dom = ("estep_diag_mfma_kernel" if ka.get("estep_diag_mfma_calls", 0) > 0 else "estep_diag_kernel") if est >= sst \
             else "suffstat_diag_kernel"

@@ -1380,7 +1380,10 @@ bool Context::recompute_bounded(int K, const std::vector<int>& changed, const st
     if (trace) std::cerr << "[cache] no bounded recomputation at K " << K << " (" << nch << " columns): " << why << std::endl;
     return false;
   };
-  if (off || J_ != 1 || distributed() || NP_ < 200000) return false;
+  // (below ~ 200 k rows the selection's two round trips cost what the pass does; tests lower the limit to walk the path on
+  //  small problems)
+  static const int64_t min_rows = lck::test_switch("LC_SPLIT_BOUND_MIN_ROWS") ? std::atoll(lck::test_switch("LC_SPLIT_BOUND_MIN_ROWS")) : 200000;
+  if (off || J_ != 1 || distributed() || NP_ < min_rows) return false;
   if (!rm_valid_) return no("no row maxima");
   if (nch < 1 || nch > lck::BOUND_MAX_COLS || K > lck::BOUND_MAX_K || nch * 3 > K) return no("too many columns");
   // a reference for every column: its own previous version, else the first previous version any changed column has

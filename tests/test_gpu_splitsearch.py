@@ -229,6 +229,29 @@ def test_every_writer_of_the_responsibilities_keeps_the_fingerprints_honest(lib,
     assert bad["rc"] != 0 and "fingerprint that is not theirs" in bad["_stderr"], bad["_stderr"][-1500:]
 
 
+@pytest.mark.parametrize("kw", [dict(seed=21, K=9, D=20, N=9000, J=1, scale=3.0), dict(seed=22, K=12, D=33, N=6000, J=1, scale=5.0),
+                                dict(seed=23, K=8, D=64, N=5000, J=1, scale=2.0), dict(seed=24, K=10, D=17, N=12000, J=1, scale=1.6),
+                                dict(seed=25, K=7, D=100, N=4000, J=1, scale=4.0)])
+def test_bounded_recomputation_on_small_problems_against_all_rows_and_the_oracle(lib, kw):
+    """The same with the row limit of the bounded path lowered (LC_SPLIT_BOUND_MIN_ROWS, test-hooks build), so that many
+    shapes walk it: every bit of the result equal to the all-rows schedule, and rounds / K / F equal to the oracle's."""
+    import lc_oracle as o
+
+    env = {"LC_LIB_PATH": HOOKED, "LC_SPLIT_BOUND_MIN_ROWS": "1000", "LC_SPLIT_DELTA_FORCE": "1", "LC_TRACE_PHASES": "1"}
+    on = _run_snippet(env, **kw)
+    off = _run_snippet(dict(env, LC_SPLIT_NO_BOUND="1"), **kw)
+    assert "bounded recomputation:" in on["_stderr"] and "bounded recomputation:" not in off["_stderr"]
+    assert on["K"] == off["K"] and on["rounds"] == off["rounds"]
+    assert on["Fhex"] == off["Fhex"] and on["qsha"] == off["qsha"]
+    rng = np.random.default_rng(kw["seed"])
+    mu = rng.normal(0, kw["scale"], (kw["K"], kw["D"]))
+    X = mu[rng.integers(0, kw["K"], kw["N"])] + rng.normal(size=(kw["N"], kw["D"]))
+    tr = []
+    Fo, _, _, clo = o.learnVDP(X, trace=tr)
+    assert on["K"] == len(clo) and [k for k, _ in on["rounds"]] == [k for k, _ in tr]
+    assert abs(on["F"] - Fo) <= 1e-9 * abs(Fo)
+
+
 @pytest.mark.parametrize("kw,runs", [(dict(seed=11, K=8, D=24, N=250000, J=1, scale=2.5), True),   # separated enough for the bound to bite
                                      (dict(seed=12, K=7, D=40, N=220000, J=1, scale=1.0), False),  # heavy overlap: the cache is given up early
                                      (dict(seed=13, K=9, D=17, N=300000, J=1, scale=4.0), True)])
