@@ -95,6 +95,9 @@ struct FusedLaunch {
   bool want_ll;          // also the split-ordering data term
   int grid;              // fused_plan(...)
   int ngroups = 1;       // J: rows of ctab (the table waits in LDS when J x K <= FUSED_CT_CAP)
+  // share (per mille) of a CU's tiles that goes to the SECOND of its two blocks (blocks grid / 2 ... grid - 1); 0: every
+  // block the same (launch_fused sets it; the kernel's tile deal is a function of (blockIdx, grid, nrg) alone)
+  int yshare = 0;
 };
 constexpr int FUSED_CT_CAP = 1024;
 inline int64_t fused_record(int DP, int K) { return (int64_t)K * (1 + DP + (int64_t)DP * DP) + 1 + K; }

@@ -142,13 +142,36 @@ __global__ void __launch_bounds__(256, CPW == 4 ? 1 : 2) fused_small_kernel(Fuse
       }
     }
   };
-  fetch(blockIdx.x);
+  // Which tiles are this block's.  With two blocks per CU the SIMD's arbiter serves the wave that arrived first: the
+  // first block of a CU walks a tile in ~ 13 us, the second in ~ 20 (profiles/r05_fused_timeline.log), and with equal
+  // shares the first ones finish 20-30 us early and leave the others alone on a half-empty pipe.  Blocks are dispatched
+  // in index order, the first grid / 2 one per CU: those take the larger share (a.yshare per mille of a CU's tiles go to
+  // the second block) -- a fixed function of (blockIdx, grid, nrg), so every run sums the same rows in the same block,
+  // and if the placement is ever different the only loss is the balance.
+  int64_t tfirst = blockIdx.x, tstride = gridDim.x, tcount = tfirst < ntile ? (ntile - tfirst + tstride - 1) / tstride : 0;
+  {
+    const int64_t G = gridDim.x, H = G / 2;
+    if (a.yshare > 0 && (G & 1) == 0 && ntile >= 4 * G) {
+      const int64_t xy = ntile * 2 * a.yshare / (1000 * G);  // tiles of a second block
+      const int64_t Te = ntile - H * xy;                     // tiles 0 .. Te - 1: dealt to the first blocks in turn
+      tstride = H;
+      if ((int64_t)blockIdx.x < H) {
+        tfirst = blockIdx.x;
+        tcount = tfirst < Te ? (Te - tfirst + H - 1) / H : 0;
+      } else {
+        tfirst = Te + ((int64_t)blockIdx.x - H);
+        tcount = xy;
+      }
+    }
+  }
+  fetch(tcount > 0 ? tfirst : ntile);
   __syncthreads();
   // n-th read of cluster `kk`'s parameter stream relative to the running pointers of the current cluster
   const double* Pt = par + (lane & 3) + 4 * hi;  // this lane's element of every 4x4 tile (cluster 0)
   const double* Pb = par + NTILES * 16 + hi;     // this lane's element of every 4-vector of -b (cluster 0)
   double* const xstage = xt + (tid / C2) * LD + 2 * (tid % C2);
-  for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+  for (int64_t ti = 0; ti < tcount; ++ti) {
+    const int64_t tile = tfirst + ti * tstride;
     const int64_t row0 = tile * FUSED_ROWS;
     // ---- the tile of X -> LDS (its loads were issued a whole tile ago)
     // (one 16-byte store per piece: its 8-lane groups fill one row's 128 bytes; two 8-byte stores put two rows, 36 dwords
@@ -181,7 +204,7 @@ __global__ void __launch_bounds__(256, CPW == 4 ? 1 : 2) fused_small_kernel(Fuse
       myrow = lo4 < (info & 31);
       __builtin_amdgcn_sched_barrier(0);
     }
-    fetch(tile + gridDim.x);  // in flight during both halves of this tile
+    fetch(ti + 1 < tcount ? tile + tstride : ntile);  // in flight during both halves of this tile
     double xf[R][NT];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -505,8 +528,16 @@ static hipError_t launch_fused_t(const FusedLaunch& a, hipStream_t stream, size_
   return a.want_ll ? go(fused_small_kernel<16, CPW, GRP, true>, grants[1]) : go(fused_small_kernel<16, CPW, GRP, false>, grants[0]);
 }
 
-hipError_t launch_fused(const FusedLaunch& a, hipStream_t stream) {
+hipError_t launch_fused(const FusedLaunch& a_, hipStream_t stream) {
+  FusedLaunch a = a_;
   if (a.DP != 16 || a.grid <= 0) return hipErrorInvalidValue;
+  {
+    // two blocks per CU on every CU (fused_plan): the second block of a CU takes 41 % of its tiles (measured pace ratio
+    // 13 : 20 us per tile at K = 8; same-box A/B in profiles/r05_fused_variants.log)
+    static const int ys = test_switch("LC_FUSED_YSHARE") ? atoi(test_switch("LC_FUSED_YSHARE")) : 410;
+    const int cus = current_device_cus();
+    a.yshare = a.grid == 2 * cus ? ys : 0;
+  }
   const size_t shmem = fused_lds_bytes(a.DP, a.K);
   if (!a.rginfo) {
     if (a.K <= 4) return launch_fused_t<1, 0>(a, stream, shmem);

@@ -230,7 +230,7 @@ def test_every_writer_of_the_responsibilities_keeps_the_fingerprints_honest(lib,
 
 
 @pytest.mark.parametrize("kw", [dict(seed=21, K=9, D=20, N=9000, J=1, scale=3.0), dict(seed=22, K=12, D=33, N=6000, J=1, scale=5.0),
-                                dict(seed=23, K=8, D=64, N=5000, J=1, scale=2.0), dict(seed=24, K=10, D=17, N=12000, J=1, scale=1.6),
+                                dict(seed=23, K=8, D=64, N=5000, J=1, scale=2.0), dict(seed=24, K=10, D=17, N=12000, J=1, scale=3.2),
                                 dict(seed=25, K=7, D=100, N=4000, J=1, scale=4.0)])
 def test_bounded_recomputation_on_small_problems_against_all_rows_and_the_oracle(lib, kw):
     """The same with the row limit of the bounded path lowered (LC_SPLIT_BOUND_MIN_ROWS, test-hooks build), so that many
