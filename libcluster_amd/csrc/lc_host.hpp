@@ -65,48 +65,188 @@ inline double lgam(double x) {
 // ---------------------------------------------------------------------------
 // In-place lower Cholesky A = L L^T (only the lower triangle is read/written,
 // the strict upper triangle is zeroed).  Returns false if not positive definite.
-inline bool cholesky(std::vector<double>& A, int n) {
-  // Works on U = L^T (row j of U = column j of L, contiguous): every element still receives its terms
-  // s -= L[i][k] * L[j][k] for k = 0 .. j-1 in that order -- bit for bit the row-by-row dot-product form -- but the
-  // inner loop runs over i (independent elements, unit stride), which the compiler vectorises; a dot product is a
-  // serial chain it may not reorder.  32 clusters at D = 64 are one M-step of the headline configuration.
-  std::vector<double> U((size_t)n * n, 0.0);
-  for (int j = 0; j < n; ++j)
-    for (int i = j; i < n; ++i) U[(size_t)j * n + i] = A[(size_t)i * n + j];
-  for (int j = 0; j < n; ++j) {
-    double* uj = U.data() + (size_t)j * n;
-    for (int k = 0; k < j; ++k) {
-      const double* uk = U.data() + (size_t)k * n;
-      const double ukj = uk[j];
-      for (int i = j; i < n; ++i) uj[i] -= uk[i] * ukj;
+// four doubles side by side (lowered to two SSE2 operations on a baseline x86-64, one with AVX2: the two helpers below
+// are compiled for both and picked at load time; neither target has fused multiply-add, so both give the same bits)
+typedef double lc_v4d __attribute__((vector_size(32), aligned(8)));
+// (hipcc passes every translation unit through a device compilation as well, where function multiversioning does not
+//  exist: the attribute is for the host pass only)
+#if defined(__HIP_DEVICE_COMPILE__) && __HIP_DEVICE_COMPILE__
+#define LC_HOST_CLONES
+#else
+#define LC_HOST_CLONES __attribute__((target_clones("avx2", "default")))
+#endif
+// acc[jj][:] -= li[k][:] * lj[k][jj] for k = 0 .. nk - 1 in that order (li, lj: 4 doubles per k)
+LC_HOST_CLONES inline void chol_block_update(const double* li, const double* lj, int nk,
+                                                                              double (*acc)[4]) {
+  lc_v4d a0, a1, a2, a3;
+  __builtin_memcpy(&a0, acc[0], 32);
+  __builtin_memcpy(&a1, acc[1], 32);
+  __builtin_memcpy(&a2, acc[2], 32);
+  __builtin_memcpy(&a3, acc[3], 32);
+  for (int k = 0; k < nk; ++k) {
+    lc_v4d b;
+    __builtin_memcpy(&b, li + (size_t)k * 4, 32);
+    const double* a = lj + (size_t)k * 4;
+    a0 -= b * a[0];
+    a1 -= b * a[1];
+    a2 -= b * a[2];
+    a3 -= b * a[3];
+  }
+  __builtin_memcpy(acc[0], &a0, 32);
+  __builtin_memcpy(acc[1], &a1, 32);
+  __builtin_memcpy(acc[2], &a2, 32);
+  __builtin_memcpy(acc[3], &a3, 32);
+}
+// r[ii][j] += l[ii][0] rk[0][j] + ... + l[ii][3] rk[3][j] (added in that order) for j = 0 .. nj - 1
+LC_HOST_CLONES inline void trinv_block_update(double* const* r, const double* const* rk,
+                                                                               const double (*l)[4], int nj) {
+  int j = 0;
+  for (; j + 4 <= nj; j += 4) {
+    lc_v4d v0, v1, v2, v3;
+    __builtin_memcpy(&v0, rk[0] + j, 32);
+    __builtin_memcpy(&v1, rk[1] + j, 32);
+    __builtin_memcpy(&v2, rk[2] + j, 32);
+    __builtin_memcpy(&v3, rk[3] + j, 32);
+    for (int ii = 0; ii < 4; ++ii) {
+      lc_v4d s;
+      __builtin_memcpy(&s, r[ii] + j, 32);
+      s += v0 * l[ii][0];
+      s += v1 * l[ii][1];
+      s += v2 * l[ii][2];
+      s += v3 * l[ii][3];
+      __builtin_memcpy(r[ii] + j, &s, 32);
     }
-    if (!(uj[j] > 0.0)) return false;
-    const double ljj = std::sqrt(uj[j]);
-    uj[j] = ljj;
-    for (int i = j + 1; i < n; ++i) uj[i] /= ljj;
+  }
+  for (; j < nj; ++j) {
+    const double v0 = rk[0][j], v1 = rk[1][j], v2 = rk[2][j], v3 = rk[3][j];
+    for (int ii = 0; ii < 4; ++ii) {
+      double s = r[ii][j];
+      s += l[ii][0] * v0;
+      s += l[ii][1] * v1;
+      s += l[ii][2] * v2;
+      s += l[ii][3] * v3;
+      r[ii][j] = s;
+    }
+  }
+}
+
+inline bool cholesky(std::vector<double>& A, int n) {
+  // Every element receives its terms  s -= L[i][k] * L[j][k]  for k = 0 .. j-1 in that order, a multiplication and a
+  // subtraction each -- bit for bit the row-by-row dot-product form (a dot product is a serial chain the compiler may not
+  // reorder).  What is free is WHICH elements advance together: 4 x 4 blocks take the terms of the columns in front of
+  // their block side by side -- sixteen independent chains per two 32-byte loads -- out of a copy of the factor that keeps
+  // four rows interleaved, Lp[panel][k][row in panel], so that both operand streams of a block are contiguous in k
+  // (round 5: the one-element-row form made three memory operations per multiply-subtract and left L1 at D = 128;
+  // 64 clusters at D = 128 were 8 ms of a 143 ms iteration on a two-core host, 16 clusters at D = 256 15 of 61).
+  constexpr int B = 4;
+  const int P = (n + B - 1) / B;
+  std::vector<double> Lp((size_t)P * n * B, 0.0);  // Lp[(p n + k) B + ii] = L[B p + ii][k]
+  std::vector<double> T((size_t)P * B * B);        // the current block column: T[(p B + jj) B + ii] = element (B p + ii, j0 + jj)
+  for (int jb = 0; jb < P; ++jb) {
+    const int j0 = jb * B, jw = n - j0 < B ? n - j0 : B;
+    const double* lj = Lp.data() + (size_t)jb * n * B;
+    for (int ib = jb; ib < P; ++ib) {
+      const int i0 = ib * B;
+      double acc[B][B];
+      for (int jj = 0; jj < B; ++jj)
+        for (int ii = 0; ii < B; ++ii)
+          acc[jj][ii] = (i0 + ii < n && jj < jw) ? A[(size_t)(i0 + ii) * n + j0 + jj] : 0.0;
+      chol_block_update(Lp.data() + (size_t)ib * n * B, lj, j0, acc);
+      for (int jj = 0; jj < B; ++jj)
+        for (int ii = 0; ii < B; ++ii) T[((size_t)ib * B + jj) * B + ii] = acc[jj][ii];
+    }
+    // the block's own columns, one after the other: their terms k = j0 .. j - 1 follow the ones above in order
+    for (int jj = 0; jj < jw; ++jj) {
+      const int j = j0 + jj;
+      for (int ib = jb; ib < P; ++ib) {
+        double* t = T.data() + ((size_t)ib * B + jj) * B;
+        const double* li = Lp.data() + (size_t)ib * n * B;
+        for (int kk = 0; kk < jj; ++kk) {
+          const double ajk = lj[(size_t)(j0 + kk) * B + jj];
+          for (int ii = 0; ii < B; ++ii) t[ii] -= li[(size_t)(j0 + kk) * B + ii] * ajk;
+        }
+      }
+      const double sjj = T[((size_t)jb * B + jj) * B + jj];
+      if (!(sjj > 0.0)) return false;
+      const double ljj = std::sqrt(sjj);
+      for (int ib = jb; ib < P; ++ib) {
+        const double* t = T.data() + ((size_t)ib * B + jj) * B;
+        double* li = Lp.data() + ((size_t)ib * n + j) * B;
+        for (int ii = 0; ii < B; ++ii) {
+          const int i = ib * B + ii;
+          li[ii] = i > j && i < n ? t[ii] / ljj : 0.0;
+        }
+      }
+      Lp[((size_t)jb * n + j) * B + jj] = ljj;
+    }
   }
   for (int i = 0; i < n; ++i) {
-    for (int j = 0; j <= i; ++j) A[(size_t)i * n + j] = U[(size_t)j * n + i];
+    const double* li = Lp.data() + (size_t)(i / B) * n * B + (i % B);
+    for (int j = 0; j <= i; ++j) A[(size_t)i * n + j] = li[(size_t)j * B];
     for (int j = i + 1; j < n; ++j) A[(size_t)i * n + j] = 0.0;
   }
   return true;
 }
 
 // Inverse of a lower-triangular matrix (row-major), result lower-triangular.  Row i accumulates
-// L[i][k] * (row k of the inverse) for k = 0 .. i-1 (unit stride, vectorisable); element j receives its terms for
-// k = j .. i-1 in increasing k, exactly as the element-by-element sum does.
+// L[i][k] * (row k of the inverse) for k = 0 .. i-1; element j receives its terms for k = j .. i-1 in increasing k,
+// exactly as the element-by-element sum does.  Four rows i and four rows k at a time: a piece of the four target rows
+// stays in registers while the four source rows pass over it in order (sixteen multiply-adds per five loads and a store,
+// where the row-by-row form made one per three memory operations).
 inline std::vector<double> tril_inverse(const std::vector<double>& L, int n) {
   std::vector<double> Li((size_t)n * n, 0.0);
-  for (int i = 0; i < n; ++i) {
-    double* ri = Li.data() + (size_t)i * n;
-    for (int k = 0; k < i; ++k) {
-      const double lik = L[(size_t)i * n + k];
-      const double* rk = Li.data() + (size_t)k * n;
-      for (int j = 0; j <= k; ++j) ri[j] += lik * rk[j];
+  constexpr int B = 4;
+  for (int i0 = 0; i0 < n; i0 += B) {
+    const int iw = n - i0 < B ? n - i0 : B;
+    if (iw == B) {
+      double* r[B] = {Li.data() + (size_t)i0 * n, Li.data() + (size_t)(i0 + 1) * n, Li.data() + (size_t)(i0 + 2) * n,
+                      Li.data() + (size_t)(i0 + 3) * n};
+      int k0 = 0;
+      for (; k0 + B <= i0; k0 += B) {
+        double l[B][B];  // l[ii][kk] = L[i0 + ii][k0 + kk]
+        for (int ii = 0; ii < B; ++ii)
+          for (int kk = 0; kk < B; ++kk) l[ii][kk] = L[(size_t)(i0 + ii) * n + k0 + kk];
+        const double* rk[B] = {Li.data() + (size_t)k0 * n, Li.data() + (size_t)(k0 + 1) * n, Li.data() + (size_t)(k0 + 2) * n,
+                               Li.data() + (size_t)(k0 + 3) * n};
+        // columns j <= k0: all four source rows reach them, in the order k0, k0 + 1, k0 + 2, k0 + 3
+        trinv_block_update(r, rk, l, k0 + 1);
+        // columns k0 < j <= k0 + 3: source row k0 + kk reaches column j only for j <= k0 + kk
+        for (int j = k0 + 1; j < k0 + B; ++j)
+          for (int ii = 0; ii < B; ++ii) {
+            double s = r[ii][j];
+            for (int kk = j - k0; kk < B; ++kk) s += l[ii][kk] * rk[kk][j];
+            r[ii][j] = s;
+          }
+      }
+      for (; k0 < i0; ++k0)  // (never taken: i0 is a multiple of B)
+        for (int ii = 0; ii < B; ++ii) {
+          const double lik = L[(size_t)(i0 + ii) * n + k0];
+          const double* rkk = Li.data() + (size_t)k0 * n;
+          for (int j = 0; j <= k0; ++j) r[ii][j] += lik * rkk[j];
+        }
+    } else {
+      for (int ii = 0; ii < iw; ++ii) {
+        double* ri = Li.data() + (size_t)(i0 + ii) * n;
+        for (int k = 0; k < i0; ++k) {
+          const double lik = L[(size_t)(i0 + ii) * n + k];
+          const double* rk = Li.data() + (size_t)k * n;
+          for (int j = 0; j <= k; ++j) ri[j] += lik * rk[j];
+        }
+      }
     }
-    const double lii = L[(size_t)i * n + i];
-    for (int j = 0; j < i; ++j) ri[j] = -ri[j] / lii;
-    ri[i] = 1.0 / lii;
+    // the block's own rows, one after the other
+    for (int ii = 0; ii < iw; ++ii) {
+      const int i = i0 + ii;
+      double* ri = Li.data() + (size_t)i * n;
+      for (int k = i0; k < i; ++k) {
+        const double lik = L[(size_t)i * n + k];
+        const double* rk = Li.data() + (size_t)k * n;
+        for (int j = 0; j <= k; ++j) ri[j] += lik * rk[j];
+      }
+      const double lii = L[(size_t)i * n + i];
+      for (int j = 0; j < i; ++j) ri[j] = -ri[j] / lii;
+      ri[i] = 1.0 / lii;
+    }
   }
   return Li;
 }
