@@ -98,13 +98,6 @@ __global__ void __launch_bounds__(256, CPW == 4 ? 1 : 2) fused_small_kernel(Fuse
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave-uniform: its arithmetic belongs on the scalar unit)
   const int lo4 = lane & 15, hi = lane >> 4, blk = (lane >> 2) & 3, lo2 = lane & 3;
-  for (int i = tid; i < K * PS; i += 256) par[i] = a.params[i];
-  for (int i = tid; i < 4 * K; i += 256) llw[i] = 0.0;
-  if constexpr (CTLDS)
-    for (int i = tid; i < ctrows * K; i += 256) ctl[i] = a.ctab[i];
-  for (int i = tid; i < 4 * NQ * QS; i += 256) qt[i] = 0.0;
-  xt[tid * LD + ONE] = 1.0;  // (the staging below writes columns 0 .. DP - 1 only)
-  fill_exp_table(etab, tid, 256);
   double acc[NTLA][NQ];  // [patches | s_k | N_k]
 #pragma unroll
   for (int t = 0; t < NTLA; ++t)
@@ -165,6 +158,26 @@ __global__ void __launch_bounds__(256, CPW == 4 ? 1 : 2) fused_small_kernel(Fuse
     }
   }
   fetch(tcount > 0 ? tfirst : ntile);
+  // the block's parameters: every load in flight at once, behind the first tile's (the round-4 loop waited for each of its
+  // up to eleven loads in turn -- five L2 round trips in front of the first tile: 4 us of a 40 ... 135 us launch)
+  constexpr int NPV = (4 * CPW * PS + 255) / 256;
+  double pv[NPV];
+#pragma unroll
+  for (int i = 0; i < NPV; ++i) {
+    const int idx = tid + i * 256;
+    pv[i] = idx < K * PS ? a.params[idx] : 0.0;
+  }
+  for (int i = tid; i < 4 * K; i += 256) llw[i] = 0.0;
+  if constexpr (CTLDS)
+    for (int i = tid; i < ctrows * K; i += 256) ctl[i] = a.ctab[i];
+  for (int i = tid; i < 4 * NQ * QS; i += 256) qt[i] = 0.0;
+  xt[tid * LD + ONE] = 1.0;  // (the staging below writes columns 0 .. DP - 1 only)
+  fill_exp_table(etab, tid, 256);
+#pragma unroll
+  for (int i = 0; i < NPV; ++i) {
+    const int idx = tid + i * 256;
+    if (idx < K * PS) par[idx] = pv[i];
+  }
   __syncthreads();
   // n-th read of cluster `kk`'s parameter stream relative to the running pointers of the current cluster
   const double* Pt = par + (lane & 3) + 4 * hi;  // this lane's element of every 4x4 tile (cluster 0)
