@@ -70,7 +70,12 @@ inline double lgam(double x) {
 typedef double lc_v4d __attribute__((vector_size(32), aligned(8)));
 // (hipcc passes every translation unit through a device compilation as well, where function multiversioning does not
 //  exist: the attribute is for the host pass only)
-#if defined(__HIP_DEVICE_COMPILE__) && __HIP_DEVICE_COMPILE__
+#if defined(__has_feature)
+#if __has_feature(thread_sanitizer)
+#define LC_HOST_NO_CLONES 1  // (an ifunc resolver runs before the ThreadSanitizer runtime is up: tools/sanitize_host.sh tsan)
+#endif
+#endif
+#if (defined(__HIP_DEVICE_COMPILE__) && __HIP_DEVICE_COMPILE__) || defined(LC_HOST_NO_CLONES)
 #define LC_HOST_CLONES
 #else
 #define LC_HOST_CLONES __attribute__((target_clones("avx2", "default")))
