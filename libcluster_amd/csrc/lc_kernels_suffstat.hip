@@ -588,8 +588,12 @@ inline int ft_range(int DP, int K) { return DP == 128 && K % 64 == 0 ? 64 : DP =
 inline bool ss_feat_eligible(int DP, int K) {
   // (tests, libcluster_hip_testhooks.so only: 0 off, 1 where it wins, 2 everywhere it exists)
   static const int mode = test_switch("LC_SS_FEAT") ? atoi(test_switch("LC_SS_FEAT")) : 1;
-  if (mode == 0 || K <= 16 || DP < 32 || DP > 128) return false;
+  if (mode == 0 || DP < 32 || DP > 128) return false;
   if (mode == 2) return true;
+  // few clusters (one launch of <= 4 quads): the per-cluster kernel holds its own up to K = 12 everywhere and at D = 64 /
+  // 128 up to 16 (tools/ss_smallk_probe.py, round 5: D = 64, K = 16 0.685 against 0.672 of the peak); a full fourth quad
+  // pays at the widths whose per-cluster instances are the weak ones: D = 96, K = 16 0.64 -> 0.75, D = 32 0.56 -> 0.61
+  if (K <= 16) return K >= 13 && (DP == 32 || DP == 80 || DP == 96 || DP == 112);
   // measured (tools/ssfeat_check.py, MI355X): it wins where EVERY launch carries 7 or 8 cluster quads (one multiply per
   // 7-8 MFMAs): K = 28..32, 60..64, ...; a remainder launch with few quads costs a whole pass over X at a poor ratio
   // (K = 33: 6.8 against 5.8 ms at N = 2M), and with 5-6 quads the two kernels are level

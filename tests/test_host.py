@@ -154,7 +154,7 @@ def test_statistics_kernel_selection_is_a_function_of_the_shape(lib, monkeypatch
     assert fn(128, 40) == per and fn(128, 48) == per
     assert fn(64, 8) == per and fn(64, 16) == per and fn(64, 33) == per and fn(64, 35) == per
     assert fn(80, 32) == feat and fn(96, 32) == feat and fn(112, 40) == feat and fn(96, 20) == feat   # (round 5: 8-wave blocks, no scratch)
-    assert fn(96, 33) == per and fn(80, 16) == per
+    assert fn(96, 33) == per and fn(80, 12) == per and fn(96, 16) == feat and fn(32, 14) == feat and fn(64, 16) == per
     assert fn(16, 32) == per and fn(256, 32) == per
 
 
