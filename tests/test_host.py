@@ -238,3 +238,23 @@ def test_isa_checker_sees_an_asm_read_inside_an_mfma_hazard_window():
 	v_max_f64 v[20:21], v[20:21], v[10:11]
 	;;#ASMEND""" + tail
     assert ci.check_mfma_into_asm(far) == ([], 1)
+
+
+def test_blocked_host_factorisations_are_bit_identical_to_the_element_by_element_forms(tmp_path):
+    """tests/cpp/host_linalg_test.cpp: the M-step's Cholesky and triangular inverse (4 x 4 blocks, four-row-interleaved
+    factor, AVX2 clone where the CPU has it) against the textbook loops with the same order of operations per element, n = 1
+    ... 150, by memcmp -- with g++ and with the compiler the library is built with."""
+    import shutil
+    import subprocess
+
+    src = ROOT / "tests" / "cpp" / "host_linalg_test.cpp"
+    compilers = [["g++", "-O2"]]
+    if shutil.which("/opt/rocm/lib/llvm/bin/clang++"):
+        compilers.append(["/opt/rocm/lib/llvm/bin/clang++", "-O3"])
+    for i, cc in enumerate(compilers):
+        exe = tmp_path / f"host_linalg_{i}"
+        r = subprocess.run([*cc, "-std=c++17", "-Wall", f"-I{ROOT / 'include'}", f"-I{ROOT / 'libcluster_amd' / 'csrc'}", str(src), "-o",
+                            str(exe)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "bit-identical" in r.stdout, r.stdout + r.stderr
