@@ -444,13 +444,18 @@ __host__ __device__ constexpr int wide_nlow() {
   return c;
 }
 constexpr int WIDE_NLOW = wide_nlow();
-template <int R, int WAVES>
-__global__ void __launch_bounds__(WAVES * 64, 2) estep_wide_kernel(EstepLaunch a) {
+// NPX > 0 (round 5): the instance for exactly NPX column panels (D <= 256) keeps ALL of its rows' X fragments in registers
+// -- 2 * 16 * NPX doubles per lane, which takes one block per CU and the wave's full register file -- and selects the
+// panel of a chunk by a switch over NPX copies of the chunk body: nothing but the whitener stream is read inside the
+// cluster loop.  (The streaming instance re-read 64 KB of X per block and chunk: 83 GB per launch from beyond L2 at
+// N = 1M, D = 256, K = 16, under which the part held 2.03 GHz.)
+template <int R, int WAVES, int NPX>
+__global__ void __launch_bounds__(WAVES * 64, NPX ? 1 : 2) estep_wide_kernel(EstepLaunch a) {
   constexpr int CHS = WIDE_CHUNK;  // 256 tiles x 16 + 64
   constexpr int NTHR = WAVES * 64;
   constexpr int NV2 = CHS / 2;
   constexpr int NPRE = (NV2 + NTHR - 1) / NTHR;
-  constexpr int PF = 6;
+  constexpr int PF = NPX ? 8 : 6;  // tile reads in flight (one wave per SIMD in the resident instances: nobody else covers them)
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* pbuf = lds;               // [2][CHS]
   double* llw = lds + 2 * CHS;      // [WAVES][K]
@@ -506,6 +511,20 @@ __global__ void __launch_bounds__(WAVES * 64, 2) estep_wide_kernel(EstepLaunch a
   lstore(0);
   __syncthreads();
 
+  double xres[NPX ? NPX : 1][R][16];  // xres[p][r][4 q + jr] = x[row][64 p + 16 q + 4 hi + jr]
+  if constexpr (NPX > 0) {
+#pragma unroll
+    for (int p = 0; p < NPX; ++p)
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          // (volatile: hipcc otherwise sinks the loads back into the chunk bodies, which is the streaming instance)
+          const volatile double* p2 = xbase[r] + 64 * p + 16 * q;
+          const double2 v0 = make_double2(p2[0], p2[1]), v1 = make_double2(p2[2], p2[3]);
+          xres[p][r][4 * q] = v0.x, xres[p][r][4 * q + 1] = v0.y, xres[p][r][4 * q + 2] = v1.x, xres[p][r][4 * q + 3] = v1.y;
+        }
+  }
   double mx[R], d2[R], acc[16][R];
 #pragma unroll
   for (int r = 0; r < R; ++r) mx[r] = -INFINITY, d2[r] = 0.0;
@@ -513,15 +532,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) estep_wide_kernel(EstepLaunch a
   for (int64_t g = 0; g < total; ++g) {
     const int buf = (int)(g & 1);
     if (g + 1 < total) gload(g + 1);
-    double xf[R][16];  // xf[r][4 q + jr] = x[row][64 J + 16 q + 4 hi + jr]
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const double2* p2 = reinterpret_cast<const double2*>(xbase[r] + 64 * J + 16 * q);
-        const double2 v0 = p2[0], v1 = p2[1];
-        xf[r][4 * q] = v0.x, xf[r][4 * q + 1] = v0.y, xf[r][4 * q + 2] = v1.x, xf[r][4 * q + 3] = v1.y;
-      }
+    auto chunk = [&](const double (&xf)[R][16]) __attribute__((always_inline)) {
     const double* P = pbuf + buf * CHS;
     const double* Pt = P + (lane & 3) + 4 * hi;  // this lane's element of every 4x4 tile
     if (J == 0) {
@@ -549,10 +560,29 @@ __global__ void __launch_bounds__(WAVES * 64, 2) estep_wide_kernel(EstepLaunch a
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[it][r] = mfma4(v, xf[r][jt], acc[it][r]);
+        // (one wave per SIMD: nobody else covers a tile read that hipcc moves next to its use)
+        if constexpr (NPX > 0) __builtin_amdgcn_sched_barrier(0);
       });
     };
     reads(std::integral_constant<int, 0>{}, std::integral_constant<int, WIDE_NLOW>{});
     if (J != I) reads(std::integral_constant<int, WIDE_NLOW>{}, std::integral_constant<int, 256 - WIDE_NLOW>{});
+    };
+    if constexpr (NPX == 0) {
+      double xf[R][16];  // xf[r][4 q + jr] = x[row][64 J + 16 q + 4 hi + jr]
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const double2* p2 = reinterpret_cast<const double2*>(xbase[r] + 64 * J + 16 * q);
+          const double2 v0 = p2[0], v1 = p2[1];
+          xf[r][4 * q] = v0.x, xf[r][4 * q + 1] = v0.y, xf[r][4 * q + 2] = v1.x, xf[r][4 * q + 3] = v1.y;
+        }
+      chunk(xf);
+    } else {
+      static_for<NPX>([&](auto pc) {
+        if (J == decltype(pc)::value) chunk(xres[decltype(pc)::value]);
+      });
+    }
     if (J == I) {  // block row complete
 #pragma unroll
       for (int it = 0; it < 16; ++it)
@@ -638,13 +668,24 @@ constexpr int WIDE_R = 2, WIDE_WAVES = 4;
 static hipError_t launch_estep_wide(const EstepLaunch& a, hipStream_t stream) {
   if (a.DP % 64) return hipErrorInvalidValue;
   const size_t shmem = (size_t)(2 * WIDE_CHUNK + WIDE_WAVES * a.K + WIDE_WAVES) * sizeof(double);
-  auto kern = estep_wide_kernel<WIDE_R, WIDE_WAVES>;
-  static LdsGrant grant;
-  if (hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(kern), shmem, grant); e != hipSuccess) return e;
   const int64_t grid = estep_grid(a.DP, a.nrg);
   if (grid <= 0) return hipSuccess;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WIDE_WAVES * 64), shmem, stream, a);
-  return hipGetLastError();
+  static LdsGrant grants[3];
+  auto go = [&](auto kern, LdsGrant& grant) {
+    if (hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(kern), shmem, grant); e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WIDE_WAVES * 64), shmem, stream, a);
+    return hipGetLastError();
+  };
+  const char* sw = lck::test_switch("LC_WIDE_STREAM");  // tests: the streaming instance at every width
+#ifdef LC_WIDE_FORCE_STREAM  // (tools/variants.py: the A/B of the two instances on one box)
+  const bool stream_only = true;
+  (void)sw;
+#else
+  const bool stream_only = sw && *sw && *sw != '0';
+#endif
+  if (a.DP == 192 && !stream_only) return go(estep_wide_kernel<WIDE_R, WIDE_WAVES, 3>, grants[1]);
+  if (a.DP == 256 && !stream_only) return go(estep_wide_kernel<WIDE_R, WIDE_WAVES, 4>, grants[2]);
+  return go(estep_wide_kernel<WIDE_R, WIDE_WAVES, 0>, grants[0]);
 }
 
 template <int DP>

@@ -548,6 +548,48 @@ def test_half_width_fused_instance_equals_the_full_width_one():
         np.testing.assert_allclose(half[3:], fullw[3:], rtol=1e-11)
 
 
+def test_register_resident_wide_estep_equals_the_streaming_one_bit_for_bit():
+    """D = 129 ... 256 takes estep_wide_kernel's instances that keep the rows' X fragments in registers (three / four column
+    panels); LC_WIDE_STREAM=1 (test-hooks build) takes the streaming instance that serves every width.  Same tiles, same
+    order of MFMAs per accumulator: F traces and responsibilities must agree to the last bit."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    child = (
+        "import sys, json, hashlib, numpy as np\n"
+        f"sys.path.insert(0, {str(root)!r})\n"
+        "from libcluster_amd import capi\n"
+        "out = []\n"
+        "for D, K, N, J in ((129, 3, 700, 1), (192, 5, 1301, 1), (200, 4, 900, 3), (256, 6, 1500, 1)):\n"
+        "    rng = np.random.default_rng(D * 100 + K)\n"
+        "    X = [rng.normal(size=(N // J, D)) * 1.3 + rng.integers(0, K, (N // J, 1)) for _ in range(J)]\n"
+        "    q0 = [rng.dirichlet(np.ones(K) * 0.4, x.shape[0]) for x in X]\n"
+        "    with capi.Context(0) as ctx:\n"
+        "        ctx.set_data(X); ctx.set_qz(q0)\n"
+        "        F, tr, m = ctx.vbem(capi.W_GDIRICHLET if J > 1 else capi.W_STICKBREAK, fixed_iters=4)\n"
+        "        q = ctx.get_qz([x.shape[0] for x in X])\n"
+        "        m.close()\n"
+        "    out.append([[float.hex(float(f)) for f in tr], [hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest() for a in q]])\n"
+        "print('RESULT', json.dumps(out))\n"
+    )
+    res = []
+    for stream in (False, True):
+        env = dict(os.environ)
+        env.pop("LC_WIDE_STREAM", None)
+        env["LC_LIB_PATH"] = str(root / "libcluster_amd" / "lib" / "libcluster_hip_testhooks.so")
+        if stream:  # (a switch of the test-hooks build: lck::test_switch)
+            env["LC_WIDE_STREAM"] = "1"
+        r = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+        res.append(json.loads(line[7:]))
+    assert res[0] == res[1]
+
+
 def test_mahaldist_matches_numpy():
     """probutils::mahaldist (probutils.cpp:113-138) on the GPU: ragged groups, narrow and wide D, SPD A; non-PD is
     refused."""
