@@ -564,10 +564,8 @@ __host__ __device__ constexpr int ft_tpw_max(int DP, int NQ) {
 #define LC_FT_BR128 32
 #endif
 // tiles whose products are formed together in front of their MFMAs (suffstat_feat_kernel's step loop)
-#ifndef LC_FT_G_FEWQ
-#define LC_FT_G_FEWQ 2
-#endif
-__host__ __device__ constexpr int ft_group(int DP, int NQ = 8) { return DP >= 48 && DP <= 112 ? (NQ <= 6 ? LC_FT_G_FEWQ : 2) : 1; }
+// (round 5, K = 20 / 40 at D = 64: threes and fours for the launches of <= 6 quads measure the same as pairs, gpurun_out/r05y2)
+__host__ __device__ constexpr int ft_group(int DP) { return DP >= 48 && DP <= 112 ? 2 : 1; }
 // (round 5: D = 80, 96, 112 as 8-wave blocks too -- half the staging registers per thread, and with them every instance
 //  but <80, 6> free of scratch, where the 4-wave instances spilled 64 ... 136 bytes into the step loop: the feature GEMM
 //  now runs at these widths, N = 4M, K = 32: D = 96 22.9 -> 19.1 ms (0.67 -> 0.81 of the fp64 peak), D = 80 15.0 -> 13.7,
@@ -746,7 +744,7 @@ __global__ void __launch_bounds__(64 * ft_waves(DP), 2) suffstat_feat_kernel(Suf
   constexpr bool ONEQ = NQ > 8;
   auto batch = [&](auto bsel, auto ntsel) {
     constexpr int B = decltype(bsel)::value, XO = B * XBUF, QO = B * QBUF, NT = decltype(ntsel)::value;
-    if constexpr (!ONEQ && ft_group(DP, NQ) > 1) {
+    if constexpr (!ONEQ && ft_group(DP) > 1) {
       // Tiles in groups of G: the group's products first, then its G x NQ MFMAs.  Next to the matrix pipe a VALU
       // instruction is paid per switch between the two kinds, not per instruction (tools/mfma_batch_probe.hip: ~ 12 clocks
       // for a lone multiply between MFMAs, 8 each in pairs, 5.7 in fours); the fragments of the next group are read into
@@ -755,7 +753,7 @@ __global__ void __launch_bounds__(64 * ft_waves(DP), 2) suffstat_feat_kernel(Suf
       // Measured (N = 10M, D = 64, K = 32; gpurun_out/r05e): pairs 21.61 -> 21.22 ms, threes 21.30, fours 21.51, fives 21.79
       // -- the multiplies were a third of what the step loses, and larger groups expose the fragment reads; D = 48 gains
       // 1 % with pairs, D = 80 ... 112 1-2 %, D = 32 and D = 128 nothing (ft_group).
-      constexpr int G = ft_group(DP, NQ), TOT = (BR / 4) * NT;
+      constexpr int G = ft_group(DP), TOT = (BR / 4) * NT;
       double qa[NQ], u[G], w[G], pp[G];
 #pragma unroll
       for (int g = 0; g < G; ++g)
