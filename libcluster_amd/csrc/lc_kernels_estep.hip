@@ -506,9 +506,29 @@ __global__ void __launch_bounds__(WAVES * 64, NPX ? 1 : 2) estep_wide_kernel(Est
     }
   };
 
+  // resident instances: the staging of the whitener stream rides inside the tile loop -- the registers that hold chunk
+  // g + 1 go to the other ring slot one 16-byte store at a time during the first tiles of chunk g (everybody left that
+  // slot before the barrier that ended chunk g - 1), then take the loads of chunk g + 2.  (In bulk at the chunk's end,
+  // with one wave per SIMD and nothing to hide them behind, load addresses, stores and their wait were 10 % of the
+  // launch: gpurun_out/r05y4.)
+  auto gload_part = [&](int64_t g, auto ic) {
+    constexpr int i = decltype(ic)::value;
+    const double2* src = reinterpret_cast<const double2*>(a.params + g * CHS);
+    const int idx = tid + i * NTHR;
+    const double2 v = src[idx < NV2 ? idx : NV2 - 1];
+    pre[i][0] = v.x;
+    pre[i][1] = v.y;
+  };
+  auto lstore_part = [&](int b, auto ic) {
+    constexpr int i = decltype(ic)::value;
+    double2* dst = reinterpret_cast<double2*>(pbuf + b * CHS);
+    const int idx = tid + i * NTHR;
+    if (idx < NV2) dst[idx] = make_double2(pre[i][0], pre[i][1]);
+  };
   const int64_t total = (int64_t)K * NCH;
   gload(0);
   lstore(0);
+  if constexpr (NPX > 0) gload(total > 1 ? 1 : 0);
   __syncthreads();
 
   double xres[NPX ? NPX : 1][R][16];  // xres[p][r][4 q + jr] = x[row][64 p + 16 q + 4 hi + jr]
@@ -531,7 +551,10 @@ __global__ void __launch_bounds__(WAVES * 64, NPX ? 1 : 2) estep_wide_kernel(Est
   int I = 0, J = 0, k = 0;
   for (int64_t g = 0; g < total; ++g) {
     const int buf = (int)(g & 1);
-    if (g + 1 < total) gload(g + 1);
+    if constexpr (NPX == 0) {
+      if (g + 1 < total) gload(g + 1);
+    }
+    const int64_t gn = g + 2 < total ? g + 2 : total - 1;  // (resident instances: the chunk fetched during this one)
     auto chunk = [&](const double (&xf)[R][16]) __attribute__((always_inline)) {
     const double* P = pbuf + buf * CHS;
     const double* Pt = P + (lane & 3) + 4 * hi;  // this lane's element of every 4x4 tile
@@ -560,8 +583,14 @@ __global__ void __launch_bounds__(WAVES * 64, NPX ? 1 : 2) estep_wide_kernel(Est
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[it][r] = mfma4(v, xf[r][jt], acc[it][r]);
-        // (one wave per SIMD: nobody else covers a tile read that hipcc moves next to its use)
-        if constexpr (NPX > 0) __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NPX > 0) {
+          static_assert(NPRE <= 9 && WIDE_NLOW >= 160, "staging slots of the tile loop");
+          if constexpr (n % 12 == 6 && n / 12 < NPRE) lstore_part(buf ^ 1, std::integral_constant<int, n / 12>{});
+          if constexpr (n >= 110 && n < 110 + 5 * NPRE && (n - 110) % 5 == 0)
+            gload_part(gn, std::integral_constant<int, (n - 110) / 5>{});
+          // (one wave per SIMD: nobody else covers a tile read that hipcc moves next to its use)
+          __builtin_amdgcn_sched_barrier(0);
+        }
       });
     };
     reads(std::integral_constant<int, 0>{}, std::integral_constant<int, WIDE_NLOW>{});
@@ -599,7 +628,9 @@ __global__ void __launch_bounds__(WAVES * 64, NPX ? 1 : 2) estep_wide_kernel(Est
         }
       }
     }
-    if (g + 1 < total) lstore(buf ^ 1);
+    if constexpr (NPX == 0) {
+      if (g + 1 < total) lstore(buf ^ 1);
+    }
     __syncthreads();
     if (J == I) {
       J = 0;
