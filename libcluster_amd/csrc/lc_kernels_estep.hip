@@ -506,11 +506,26 @@ __global__ void __launch_bounds__(WAVES * 64, NPX ? 1 : 2) estep_wide_kernel(Est
     }
   };
 
-  // resident instances: the staging of the whitener stream rides inside the tile loop -- the registers that hold chunk
-  // g + 1 go to the other ring slot one 16-byte store at a time during the first tiles of chunk g (everybody left that
-  // slot before the barrier that ended chunk g - 1), then take the loads of chunk g + 2.  (In bulk at the chunk's end,
-  // with one wave per SIMD and nothing to hide them behind, load addresses, stores and their wait were 10 % of the
-  // launch: gpurun_out/r05y4.)
+  // resident instances: the staging of the whitener stream rides inside the tile loop.  Chunk g + 1 goes from global memory
+  // STRAIGHT into the other ring slot (global_load_lds_dwordx4 as in estep_kernel: 16 bytes per lane land at M0 + 16 * lane,
+  // no staging registers, no address arithmetic on the VALU, no ds_write), one instruction every twelve tiles of chunk g --
+  // everybody left that slot before the barrier that ended chunk g - 1, and a vmcnt(0) in front of this chunk's barrier
+  // finds the loads long retired.  (In bulk at the chunk's end, with one wave per SIMD and nothing to hide them behind,
+  // load addresses, stores and their wait were 10 % of the launch: profiles/r05_wide_resident_probe.log.)
+#ifdef LC_WIDE_NO_DMA  // (tools/variants.py: the register-staged form, for the A/B on one box)
+  constexpr bool DMA = false;
+#else
+  constexpr bool DMA = NPX > 0;
+#endif
+  const unsigned dvoff = (unsigned)(wave * 1024 + lane * 16);
+  const unsigned dlds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)pbuf + (unsigned)(wave * 1024));
+  auto dma_part = [&](int64_t g, int bb, auto ic) {
+    constexpr int i = decltype(ic)::value;
+    const char* src = reinterpret_cast<const char*>(a.params + g * CHS) + i * (NTHR * 16);
+    const unsigned dv = dvoff, dl = dlds0 + bb * (CHS * 8) + i * (NTHR * 16);  // (copies: hipcc does not capture asm operands of a generic lambda)
+    if ((i + 1) * (NTHR * 16) <= CHS * 8 || dv + i * (NTHR * 16) < (unsigned)(CHS * 8))  // (only the last round is partial)
+      asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(dv), "s"(src), "s"(dl) : "memory");
+  };
   auto gload_part = [&](int64_t g, auto ic) {
     constexpr int i = decltype(ic)::value;
     const double2* src = reinterpret_cast<const double2*>(a.params + g * CHS);
@@ -526,9 +541,14 @@ __global__ void __launch_bounds__(WAVES * 64, NPX ? 1 : 2) estep_wide_kernel(Est
     if (idx < NV2) dst[idx] = make_double2(pre[i][0], pre[i][1]);
   };
   const int64_t total = (int64_t)K * NCH;
-  gload(0);
-  lstore(0);
-  if constexpr (NPX > 0) gload(total > 1 ? 1 : 0);
+  if constexpr (DMA) {
+    static_for<NPRE>([&](auto ic) { dma_part(0, 0, ic); });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    gload(0);
+    lstore(0);
+    if constexpr (NPX > 0) gload(total > 1 ? 1 : 0);
+  }
   __syncthreads();
 
   double xres[NPX ? NPX : 1][R][16];  // xres[p][r][4 q + jr] = x[row][64 p + 16 q + 4 hi + jr]
@@ -539,11 +559,18 @@ __global__ void __launch_bounds__(WAVES * 64, NPX ? 1 : 2) estep_wide_kernel(Est
       for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          // (volatile: hipcc otherwise sinks the loads back into the chunk bodies, which is the streaming instance)
-          const volatile double* p2 = xbase[r] + 64 * p + 16 * q;
-          const double2 v0 = make_double2(p2[0], p2[1]), v1 = make_double2(p2[2], p2[3]);
+          const double2* p2 = reinterpret_cast<const double2*>(xbase[r] + 64 * p + 16 * q);
+          const double2 v0 = p2[0], v1 = p2[1];
           xres[p][r][4 * q] = v0.x, xres[p][r][4 * q + 1] = v0.y, xres[p][r][4 * q + 2] = v1.x, xres[p][r][4 * q + 3] = v1.y;
         }
+    // opaque from here on: hipcc otherwise sinks the loads back into the chunk bodies, which is the streaming instance
+    // (volatile loads would do too -- one at a time, each waited for: 128 round trips at the head of every block)
+#pragma unroll
+    for (int p = 0; p < NPX; ++p)
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) asm volatile("" : "+v"(xres[p][r][j]));
   }
   double mx[R], d2[R], acc[16][R];
 #pragma unroll
@@ -554,7 +581,8 @@ __global__ void __launch_bounds__(WAVES * 64, NPX ? 1 : 2) estep_wide_kernel(Est
     if constexpr (NPX == 0) {
       if (g + 1 < total) gload(g + 1);
     }
-    const int64_t gn = g + 2 < total ? g + 2 : total - 1;  // (resident instances: the chunk fetched during this one)
+    const int64_t gn = g + 2 < total ? g + 2 : total - 1;  // (resident instances: the chunk fetched during this one,
+    const int64_t g1 = g + 1 < total ? g + 1 : total - 1;  //  through registers / straight into the other slot)
     auto chunk = [&](const double (&xf)[R][16]) __attribute__((always_inline)) {
     const double* P = pbuf + buf * CHS;
     const double* Pt = P + (lane & 3) + 4 * hi;  // this lane's element of every 4x4 tile
@@ -585,9 +613,13 @@ __global__ void __launch_bounds__(WAVES * 64, NPX ? 1 : 2) estep_wide_kernel(Est
         for (int r = 0; r < R; ++r) acc[it][r] = mfma4(v, xf[r][jt], acc[it][r]);
         if constexpr (NPX > 0) {
           static_assert(NPRE <= 9 && WIDE_NLOW >= 160, "staging slots of the tile loop");
-          if constexpr (n % 12 == 6 && n / 12 < NPRE) lstore_part(buf ^ 1, std::integral_constant<int, n / 12>{});
-          if constexpr (n >= 110 && n < 110 + 5 * NPRE && (n - 110) % 5 == 0)
-            gload_part(gn, std::integral_constant<int, (n - 110) / 5>{});
+          if constexpr (DMA) {
+            if constexpr (n % 12 == 6 && n / 12 < NPRE) dma_part(g1, buf ^ 1, std::integral_constant<int, n / 12>{});
+          } else {
+            if constexpr (n % 12 == 6 && n / 12 < NPRE) lstore_part(buf ^ 1, std::integral_constant<int, n / 12>{});
+            if constexpr (n >= 110 && n < 110 + 5 * NPRE && (n - 110) % 5 == 0)
+              gload_part(gn, std::integral_constant<int, (n - 110) / 5>{});
+          }
           // (one wave per SIMD: nobody else covers a tile read that hipcc moves next to its use)
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -631,6 +663,7 @@ __global__ void __launch_bounds__(WAVES * 64, NPX ? 1 : 2) estep_wide_kernel(Est
     if constexpr (NPX == 0) {
       if (g + 1 < total) lstore(buf ^ 1);
     }
+    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (J == I) {
       J = 0;
