@@ -512,11 +512,10 @@ __global__ void __launch_bounds__(WAVES * 64, NPX ? 1 : 2) estep_wide_kernel(Est
   // everybody left that slot before the barrier that ended chunk g - 1, and a vmcnt(0) in front of this chunk's barrier
   // finds the loads long retired.  (In bulk at the chunk's end, with one wave per SIMD and nothing to hide them behind,
   // load addresses, stores and their wait were 10 % of the launch: profiles/r05_wide_resident_probe.log.)
-#ifdef LC_WIDE_NO_DMA  // (tools/variants.py: the register-staged form, for the A/B on one box)
-  constexpr bool DMA = false;
-#else
+  // Same-box A/Bs (profiles/r05_wide_resident_probe.log): against staging through registers inside the tile loop -4.5 % at
+  // D = 256; for the STREAMING instance, whose fragment loads share the vector-memory counter with it, +2 ... 7 % -- that
+  // one keeps its bulk register staging.
   constexpr bool DMA = NPX > 0;
-#endif
   const unsigned dvoff = (unsigned)(wave * 1024 + lane * 16);
   const unsigned dlds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)pbuf + (unsigned)(wave * 1024));
   auto dma_part = [&](int64_t g, int bb, auto ic) {
@@ -526,20 +525,6 @@ __global__ void __launch_bounds__(WAVES * 64, NPX ? 1 : 2) estep_wide_kernel(Est
     if ((i + 1) * (NTHR * 16) <= CHS * 8 || dv + i * (NTHR * 16) < (unsigned)(CHS * 8))  // (only the last round is partial)
       asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(dv), "s"(src), "s"(dl) : "memory");
   };
-  auto gload_part = [&](int64_t g, auto ic) {
-    constexpr int i = decltype(ic)::value;
-    const double2* src = reinterpret_cast<const double2*>(a.params + g * CHS);
-    const int idx = tid + i * NTHR;
-    const double2 v = src[idx < NV2 ? idx : NV2 - 1];
-    pre[i][0] = v.x;
-    pre[i][1] = v.y;
-  };
-  auto lstore_part = [&](int b, auto ic) {
-    constexpr int i = decltype(ic)::value;
-    double2* dst = reinterpret_cast<double2*>(pbuf + b * CHS);
-    const int idx = tid + i * NTHR;
-    if (idx < NV2) dst[idx] = make_double2(pre[i][0], pre[i][1]);
-  };
   const int64_t total = (int64_t)K * NCH;
   if constexpr (DMA) {
     static_for<NPRE>([&](auto ic) { dma_part(0, 0, ic); });
@@ -547,7 +532,6 @@ __global__ void __launch_bounds__(WAVES * 64, NPX ? 1 : 2) estep_wide_kernel(Est
   } else {
     gload(0);
     lstore(0);
-    if constexpr (NPX > 0) gload(total > 1 ? 1 : 0);
   }
   __syncthreads();
 
@@ -578,11 +562,10 @@ __global__ void __launch_bounds__(WAVES * 64, NPX ? 1 : 2) estep_wide_kernel(Est
   int I = 0, J = 0, k = 0;
   for (int64_t g = 0; g < total; ++g) {
     const int buf = (int)(g & 1);
-    if constexpr (NPX == 0) {
+    if constexpr (!DMA) {
       if (g + 1 < total) gload(g + 1);
     }
-    const int64_t gn = g + 2 < total ? g + 2 : total - 1;  // (resident instances: the chunk fetched during this one,
-    const int64_t g1 = g + 1 < total ? g + 1 : total - 1;  //  through registers / straight into the other slot)
+    const int64_t g1 = g + 1 < total ? g + 1 : total - 1;  // (resident instances: the chunk fetched during this one)
     auto chunk = [&](const double (&xf)[R][16]) __attribute__((always_inline)) {
     const double* P = pbuf + buf * CHS;
     const double* Pt = P + (lane & 3) + 4 * hi;  // this lane's element of every 4x4 tile
@@ -611,15 +594,9 @@ __global__ void __launch_bounds__(WAVES * 64, NPX ? 1 : 2) estep_wide_kernel(Est
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[it][r] = mfma4(v, xf[r][jt], acc[it][r]);
-        if constexpr (NPX > 0) {
-          static_assert(NPRE <= 9 && WIDE_NLOW >= 160, "staging slots of the tile loop");
-          if constexpr (DMA) {
-            if constexpr (n % 12 == 6 && n / 12 < NPRE) dma_part(g1, buf ^ 1, std::integral_constant<int, n / 12>{});
-          } else {
-            if constexpr (n % 12 == 6 && n / 12 < NPRE) lstore_part(buf ^ 1, std::integral_constant<int, n / 12>{});
-            if constexpr (n >= 110 && n < 110 + 5 * NPRE && (n - 110) % 5 == 0)
-              gload_part(gn, std::integral_constant<int, (n - 110) / 5>{});
-          }
+        if constexpr (DMA) {
+          static_assert(NPRE <= 9 && WIDE_NLOW >= 12 * NPRE, "staging slots of the tile loop");
+          if constexpr (n % 12 == 6 && n / 12 < NPRE) dma_part(g1, buf ^ 1, std::integral_constant<int, n / 12>{});
           // (one wave per SIMD: nobody else covers a tile read that hipcc moves next to its use)
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -660,7 +637,7 @@ __global__ void __launch_bounds__(WAVES * 64, NPX ? 1 : 2) estep_wide_kernel(Est
         }
       }
     }
-    if constexpr (NPX == 0) {
+    if constexpr (!DMA) {
       if (g + 1 < total) lstore(buf ^ 1);
     }
     if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
