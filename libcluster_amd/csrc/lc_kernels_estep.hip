@@ -554,7 +554,12 @@ __global__ void __launch_bounds__(WAVES * 64, NPX ? 1 : 2) estep_wide_kernel(Est
 #pragma unroll
       for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) asm volatile("" : "+v"(xres[p][r][j]));
+        for (int j = 0; j < 16; ++j) {
+          // (the first two panels in VGPRs, the others in AGPRs, where an MFMA can read its B operand as well: a hint
+          //  that spares the chunk bodies hipcc's copies of a whole panel from one file to the other)
+          if (p < 2) asm volatile("" : "+v"(xres[p][r][j]));
+          else asm volatile("" : "+a"(xres[p][r][j]));
+        }
   }
   double mx[R], d2[R], acc[16][R];
 #pragma unroll
