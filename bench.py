@@ -69,9 +69,14 @@ CONFIGS = {
     "k20": dict(N=5_000_000, D=64, K=20, w="Dirichlet", seed=1020, label="BGMM N=5M D=64 K=20 (ragged cluster count)"),
     "k40": dict(N=5_000_000, D=64, K=40, w="Dirichlet", seed=1040, label="BGMM N=5M D=64 K=40 (ragged cluster count)"),
     "d96": dict(N=4_000_000, D=96, K=32, w="Dirichlet", seed=1096, label="BGMM N=4M D=96 K=32 (in-between width)"),
+    # small and medium Gauss-Wishart shapes (round 6): the widths and cluster counts cluster() walks on every call; D = 23 is
+    # the width of the reference's own data set (test/scott25.dat) -- algorithmic flops are counted on D, not on the padding
+    "d32": dict(N=6_000_000, D=23, K=16, w="Dirichlet", seed=1123, label="BGMM N=6M D=23 K=16 (scott25.dat's width)"),
+    "d48": dict(N=5_000_000, D=48, K=12, w="Dirichlet", seed=1148, label="BGMM N=5M D=48 K=12"),
+    "k8": dict(N=4_000_000, D=64, K=8, w="Dirichlet", seed=1108, label="BGMM N=4M D=64 K=8 (few clusters)"),
 }
 # short runs reported under "other_configs" of the default line
-OTHER_CONFIGS = ["2", "3", "5", "dgmm", "bemm", "wide256", "k20", "k40", "d96"]
+OTHER_CONFIGS = ["2", "3", "5", "dgmm", "bemm", "wide256", "k20", "k40", "d96", "d32", "d48", "k8"]
 
 
 def mixture(D, K, seed, family="GaussWish", overlap=False):
@@ -90,6 +95,43 @@ def mixture(D, K, seed, family="GaussWish", overlap=False):
         B = rng.normal(size=(D, D))
         L[k] = np.linalg.cholesky((0.2 * (B @ B.T) / D + np.eye(D)) if overlap else (B @ B.T / D + 0.5 * np.eye(D)))
     return mu, L
+
+
+def summary_of(line):
+    """{config: [ms_per_step, frac, estep_frac, suffstat_frac, traffic / algorithmic bytes]} for the headline and every
+    entry of other_configs, plus model selection and the drop-in call in seconds -- compact and LAST on the line, so that
+    every configuration survives a record that keeps only the line's tail (the driver kept the last 8 KB)."""
+    def r4(v):
+        return None if v is None else float(f"{v:.4g}")
+
+    def row(ms, roof):
+        tr = roof.get("traffic")
+        tb = None
+        if isinstance(tr, dict):
+            tb = tr.get("bytes_per_launch", tr.get("total_bytes"))
+            if tb is None and "read_bytes" in tr:
+                tb = tr["read_bytes"] + tr.get("write_bytes", 0.0)
+        elif isinstance(tr, (int, float)):
+            tb = float(tr)
+        ratio = tb / roof["alg_bytes_per_launch"] if tb and roof.get("alg_bytes_per_launch") else None
+        if roof.get("mfma_frac") is not None:  # separable families: [ms, frac, mfma_frac, hbm_frac, traffic ratio]
+            return [r4(ms), r4(roof["frac"]), r4(roof["mfma_frac"]), r4(roof["hbm_frac"]), r4(ratio)]
+        if str(roof.get("kernel", "")).startswith("fused"):  # one launch does both passes: `frac` is the figure
+            return [r4(ms), r4(roof["frac"]), None, None, r4(ratio)]
+        return [r4(ms), r4(roof["frac"]), r4(roof.get("estep_frac")), r4(roof.get("suffstat_frac")), r4(ratio)]
+
+    out = {"_columns": "ms_per_step, roofline.frac, estep_frac (separable families: mfma_frac), suffstat_frac (hbm_frac), "
+                       "PMC traffic / algorithmic bytes of the dominant kernel",
+           "headline": row(line["ms_per_step"], line["roofline"])}
+    for o in line.get("other_configs", []):
+        out[o["config"]] = row(o["ms_per_step"], o["roofline"])
+    ms = line.get("model_selection")
+    if isinstance(ms, dict) and "seconds" in ms:
+        out["model_selection_s"] = r4(ms["seconds"])
+    dc = line.get("dropin_call")
+    if isinstance(dc, dict) and "seconds" in dc:
+        out["dropin_call_s"] = r4(dc["seconds"])
+    return out
 
 
 def alg_flops(N, D, K):
@@ -500,12 +542,29 @@ def measure(capi, cfg, steps, warmup, rank, world, local_rank, stream, nthreads,
                              "kernels": dev_ms, "mstep_threads": nthreads, "cpus": len(os.sched_getaffinity(0))}
     if family != "GaussWish":
         # separable families: 8 (D + K) algorithmic bytes per row and launch (X read + q column written / read)
-        gbs = 8.0 * N * (D + K) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        # ... and BOTH passes are products on the matrix pipe: E-step [N x fD] . [fD x K], statistics
+        # Q^T [X | X^2], f = 2 feature blocks for the diagonal Gaussians (x', x'^2), 1 for the exponential family: 2 N f D K
+        # flop per launch.  The roof is whichever demand is the larger at its peak; both fractions are printed.
+        nbytes = 8.0 * N * (D + K)
+        mflop = 2.0 * N * (2 if family == "NormGamma" else 1) * D * K
+        gbs = nbytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        tfl = mflop / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        hbm_floor, mfma_floor = nbytes / (HBM_PEAK_GBS * 1e9) * 1e3, mflop / (FP64_PEAK_TFLOPS * 1e12) * 1e3
         res["config"]["clusters"] = family
         res["kernels"].pop("both_kernels_alg_tflops")
-        res["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": gbs / HBM_PEAK_GBS, "traffic": None,
-                           "alg_bytes_per_launch": 8.0 * N * (D + K), "avg_launch_ms": dom_ms}
+        both = {"hbm_frac": gbs / HBM_PEAK_GBS, "mfma_frac": tfl / FP64_PEAK_TFLOPS, "alg_bytes_per_launch": nbytes,
+                "alg_flops_per_launch": mflop, "avg_launch_ms": dom_ms, "hbm_floor_ms": hbm_floor, "mfma_floor_ms": mfma_floor,
+                # the launch cannot be shorter than the larger of the two demands (the pipe also carries the pass's VALU
+                # work -- subtractions, squares, exponentials: ~0.3 ms at the north-star shape, DESIGN 4.6 -- not counted here)
+                "combined_floor_ms": max(hbm_floor, mfma_floor),
+                "floor_frac": max(hbm_floor, mfma_floor) / dom_ms if dom_ms > 0 else None,
+                "estep_ms": est, "suffstat_ms": sst}
+        if mfma_floor > hbm_floor:
+            res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": tfl, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": tfl / FP64_PEAK_TFLOPS, "traffic": None, **both}
+        else:
+            res["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": gbs / HBM_PEAK_GBS, "traffic": None, **both}
     if model is not None and rank == 0 and family == "GaussWish":
         # what the M-step made of the REDUCED statistics (N_k, the posterior means' and scatter matrices' sums, log|W_k|):
         # a sharded run and the one-rank run over the same rows must agree on these (tests/test_gpu_comm.py, 8 ranks)
@@ -795,6 +854,7 @@ def main():
                     line["dropin_call"] = dropin_call(capi, local_rank)
                 except MemoryError as e:  # (a host with less than ~10 GB to spare: the line says so instead of dying)
                     line["dropin_call"] = {"skipped": f"not enough host memory for a 10M x 64 matrix: {e}"}
+        line["summary"] = summary_of(line)  # LAST key: the driver's record keeps the tail of the line
         print(json.dumps(line), flush=True)
     if model is not None:
         model.close()

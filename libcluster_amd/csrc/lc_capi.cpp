@@ -332,7 +332,7 @@ const char* lc_last_error(void) { return g_err.c_str(); }
 int lc_version(void) { return 300; }
 const char* lc_statistics_kernel_name(int D, int K) {
   const int DP = D <= 128 ? lck::padded_dim(D) : 0;
-  return DP > 0 ? lck::suffstat_kernel_name(DP, K) : "suffstat_kernel";
+  return DP > 0 ? lck::suffstat_kernel_name(DP, K, lck::estep_active_width(D, DP)) : "suffstat_kernel";
 }
 #ifndef LC_SOURCE_HASH
 #define LC_SOURCE_HASH "unknown"

@@ -165,7 +165,7 @@ void DevBuf<T>::reserve(size_t n) {
       e = hipMalloc(&q, n * sizeof(T));
     }
     if (e != hipSuccess)
-      throw HipFailure(std::string("HIP error: hipMalloc of ") + std::to_string(n * sizeof(T)) +
+      throw AllocFailure(std::string("HIP error: hipMalloc of ") + std::to_string(n * sizeof(T)) +
                        " bytes failed: " + hipGetErrorString(e));
     got = n * sizeof(T);
   }
@@ -256,6 +256,7 @@ void Context::build_layout(int J, const int64_t* Nj, int D) {
   J_ = J;
   D_ = D;
   DP_ = DP;
+  DC_ = lck::estep_active_width(D, DP);
   Nj_.assign(Nj, Nj + J);
   goff_.assign(J + 1, 0);
   Ntot_ = 0;
@@ -841,10 +842,10 @@ void Context::allreduce_values(double* v, int n) {
 }
 
 void Context::pack_estep_params(int K, const double* A, const double* m, const double* c) {
-  const int D = D_, DP = DP_, NT = DP / 4;
+  const int D = D_, DP = DP_, DC = DC_, NT = DC / 4;  // (narrow layouts: the tile rows of the active width)
   const bool wide = DP > 128;
-  const int NTILES = wide ? 0 : lck::ntiles(DP);
-  const int64_t PS = wide ? (int64_t)lck::wide_chunks(DP) * lck::WIDE_CHUNK : lck::pstride(DP);
+  const int NTILES = wide ? 0 : lck::ntiles(DC);
+  const int64_t PS = lck::estep_pstride(DP, DC);
   hpack_.assign((size_t)K * PS + (size_t)J_ * K, 0.0);
   std::vector<double> bneg((size_t)DP);
   for (int k = 0; k < K; ++k) {
@@ -868,7 +869,7 @@ void Context::pack_estep_params(int K, const double* A, const double* m, const d
       // ---- tiles of A_k in consumption order, then -b_k = -A_k m_k ------
       for (int it = 0; it < NT; ++it)
         for (int jt = 0; jt <= it; ++jt) fill_tile(P + (size_t)(it * (it + 1) / 2 + jt) * 16, 4 * it, 4 * jt);
-      std::copy(bneg.begin(), bneg.end(), P + (size_t)NTILES * 16);
+      std::copy(bneg.begin(), bneg.begin() + DC, P + (size_t)NTILES * 16);
     } else {
       // ---- 64 x 64 blocks (I, J <= I), row-major; per chunk 16 x 16 tiles, then -b_I (estep_wide_kernel) ------
       double* C = P;
@@ -904,8 +905,7 @@ void Context::estep(int K, const double* A, const double* m, const double* c, do
   }
   LC_HIP(hipSetDevice(device_));
   const int DP = DP_;
-  const bool wide = DP > 128;
-  const int64_t PS = wide ? (int64_t)lck::wide_chunks(DP) * lck::WIDE_CHUNK : lck::pstride(DP);
+  const int64_t PS = lck::estep_pstride(DP, DC_);
   pack_estep_params(K, A, m, c);
   params_.reserve(hpack_.size());
   LC_HIP(hipMemcpyAsync(params_.p, hpack_.data(), hpack_.size() * sizeof(double), hipMemcpyHostToDevice, stream_));
@@ -922,6 +922,7 @@ void Context::estep(int K, const double* A, const double* m, const double* c, do
 
   lck::EstepLaunch a;
   a.DP = DP;
+  a.DC = DC_;
   a.X = X_.p;
   a.nrg = nrg;
   a.rginfo = J_ > 1 ? rginfo_.p : nullptr;
@@ -996,7 +997,8 @@ bool Context::estep_suffstat_fused(int K, const double* A, const double* m, cons
   ensure_qz(qz_[cur_], K, false);  // the E-step overwrites every column
   qz_[cur_].K = K;
   const int64_t W = lck::fused_record(DP, K);
-  sspart_.reserve((size_t)std::max(grid, 1) * W);
+  sspart_reserve((size_t)std::max(grid, 1) * W);
+  sspart_clean_ = false;  // (another record layout)
   // one buffer for everything that is summed over ranks and copied back: [K records | Fz | LL_k | J x K counts]
   // (the first three are the fold of the kernel's per-block records: one reduction launch)
   // (single group without group sharding: the counts ARE the N_k of the records -- no count block at all)
@@ -1149,7 +1151,7 @@ int Context::build_sparse_worklist(const unsigned char* smask, int K, int64_t SS
   a.rginfo = nullptr;
   sskptr_ = kptr_d;
   sskrec_ = krec_d;
-  sspart_.reserve((size_t)std::max(nrec, 1) * SS);
+  sspart_reserve((size_t)std::max(nrec, 1) * SS);
   return nrec;
 }
 
@@ -1171,10 +1173,11 @@ void Context::suffstat(const unsigned char* smask, double* Nk, double* xs, doubl
   hss_.resize(nout);
   if (NP_ > 0) {
     int64_t chunk_rows = 0;
-    const int nchunks = lck::suffstat_plan(DP, NP_, K, &chunk_rows);
-    sspart_.reserve((size_t)nchunks * K * SS);
+    const int nchunks = lck::suffstat_plan(DP, NP_, K, &chunk_rows, DC_);
+    sspart_reserve((size_t)nchunks * K * SS);
     lck::SuffstatLaunch a;
     a.DP = DP;
+    a.DC = DC_;
     a.X = X_.p;
     a.NP = NP_;
     a.qZ = qz_[cur_].buf.p;
@@ -1212,13 +1215,20 @@ void Context::suffstat(const unsigned char* smask, double* Nk, double* xs, doubl
     // ragged K (dense grid only): extra row-split records of the last cluster slice, folded in after the reduction
     int klast0 = K;
     const bool skipping = a.skip_zero > 0 || (a.skip_zero == 0 && a.smask);
-    const int extra = listed ? 0 : lck::suffstat_extra_records(DP, K, skipping, &klast0);
+    const int extra = listed ? 0 : lck::suffstat_extra_records(DP, K, skipping, &klast0, DC_);
     const int KR = K + extra;
     if (extra > 0) {
-      sspart_.reserve((size_t)nchunks * KR * SS);
+      sspart_reserve((size_t)nchunks * KR * SS);
       ssext_.reserve((size_t)KR * SS);
     }
     a.KR = KR;
+    // active width below the padded one: the feature-GEMM kernel never writes the record entries of the idle columns --
+    // they have to BE zero (every other Gauss-Wishart writer of this buffer stores zeros there; the separable families and
+    // the fused pass, which keep other layouts in it, mark it dirty)
+    if (DC_ < DP_ && !sspart_clean_) {
+      LC_HIP(hipMemsetAsync(sspart_.p, 0, sspart_.cap * sizeof(double), stream_));
+      sspart_clean_ = true;
+    }
     a.partial = sspart_.p;
     a.nchunks = nchunks;
     a.chunk_rows = chunk_rows;
@@ -1369,6 +1379,13 @@ void Context::dcache_rollback() {
 // Recompute the changed columns only for the rows they can reach (lck::BoundSelectLaunch has the argument).  Returns false
 // when the preconditions do not hold -- the caller then runs the ordinary raw pass over all rows, which overwrites whatever
 // this function wrote.  One group, every changed column with a reference column in the slab, few columns, many rows.
+bool Context::bound_static_ok() const {
+  // (below ~ 200 k rows the selection's two round trips cost what the pass does; tests lower the limit to walk the path on
+  //  small problems)
+  static const int64_t min_rows = lck::test_switch("LC_SPLIT_BOUND_MIN_ROWS") ? std::atoll(lck::test_switch("LC_SPLIT_BOUND_MIN_ROWS")) : 200000;
+  return J_ == 1 && !distributed() && NP_ >= min_rows;
+}
+
 bool Context::recompute_bounded(int K, const std::vector<int>& changed, const std::vector<int>& oldslot,
                                 const std::vector<std::vector<double>>& oldA, const std::vector<std::vector<double>>& oldm,
                                 const std::vector<int>& dest, const double* A, const double* m, const double* c, bool delta) {
@@ -1380,10 +1397,7 @@ bool Context::recompute_bounded(int K, const std::vector<int>& changed, const st
     if (trace) std::cerr << "[cache] no bounded recomputation at K " << K << " (" << nch << " columns): " << why << std::endl;
     return false;
   };
-  // (below ~ 200 k rows the selection's two round trips cost what the pass does; tests lower the limit to walk the path on
-  //  small problems)
-  static const int64_t min_rows = lck::test_switch("LC_SPLIT_BOUND_MIN_ROWS") ? std::atoll(lck::test_switch("LC_SPLIT_BOUND_MIN_ROWS")) : 200000;
-  if (off || J_ != 1 || distributed() || NP_ < min_rows) return false;
+  if (off || !bound_static_ok()) return false;
   if (!rm_valid_) return no("no row maxima");
   if (nch < 1 || nch > lck::BOUND_MAX_COLS || K > lck::BOUND_MAX_K || nch * 3 > K) return no("too many columns");
   // a reference for every column: its own previous version, else the first previous version any changed column has
@@ -1395,7 +1409,7 @@ bool Context::recompute_bounded(int K, const std::vector<int>& changed, const st
   b.ncol = nch;
   b.K = K;
   b.NP = NP_;
-  std::vector<double> M(AA), v((size_t)D), w((size_t)D);
+  std::vector<double> M(AA), v((size_t)D), w((size_t)D), cert;
   for (int t = 0; t < nch; ++t) {
     const int rt = oldslot[(size_t)t] >= 0 ? t : fallback;
     const double* Ar = oldA[(size_t)rt].data();
@@ -1412,31 +1426,56 @@ bool Context::recompute_bounded(int K, const std::vector<int>& changed, const st
         if (!(d > 0.0)) return no("singular whitener");
         M[(size_t)i * D + j] = s / d;
       }
-    // |M|_2 = 1 / sigma_min(B) by the power method on M^T M; the estimate approaches from below: it has to have settled
-    for (int i = 0; i < D; ++i) v[(size_t)i] = 1.0 + 0.01 * i;
-    double est = 0.0, prev = -1.0;
-    bool settled = false;
-    for (int it = 0; it < 200 && !settled; ++it) {
-      for (int i = 0; i < D; ++i) {  // w = M v
-        double s = 0.0;
-        for (int j = 0; j <= i; ++j) s += M[(size_t)i * D + j] * v[(size_t)j];
-        w[(size_t)i] = s;
+    // |M|_2 = 1 / sigma_min(B).  The power method on M^T M approaches |M|_2 from BELOW (and can sit on the second singular
+    // vector for a while: ADVICE r5), so its estimate only PROPOSES the bound tau = (est / 0.97)^2; the bound is then
+    // PROVED: tau I - M^T M has an LDL^T factorisation with positive pivots iff |M|_2^2 < tau (norm_certified, D^3 / 3
+    // operations -- what the power method's iterations cost).  Not proved: the ordinary pass runs.  Beyond D = 128 the
+    // proof costs more than the column: there sqrt(|M|_1 |M|_inf) >= |M|_2 is taken as it is (looser, never wrong).
+    double upper = 0.0;
+    if (D > 128) {
+      std::fill(v.begin(), v.end(), 0.0);  // column sums
+      double rinf = 0.0;
+      for (int i = 0; i < D; ++i) {
+        double rs = 0.0;
+        for (int j = 0; j <= i; ++j) {
+          const double a = std::fabs(M[(size_t)i * D + j]);
+          rs += a;
+          v[(size_t)j] += a;
+        }
+        rinf = std::max(rinf, rs);
       }
-      double nv = 0.0;
-      for (int j = 0; j < D; ++j) {  // v = M^T w
-        double s = 0.0;
-        for (int i = j; i < D; ++i) s += M[(size_t)i * D + j] * w[(size_t)i];
-        v[(size_t)j] = s;
-        nv += s * s;
+      double r1 = 0.0;
+      for (int j = 0; j < D; ++j) r1 = std::max(r1, v[(size_t)j]);
+      upper = std::sqrt(r1 * rinf) * (1.0 + 1e-12);
+      if (!(upper > 0.0) || !std::isfinite(upper)) return no("norm bound broke down");
+    } else {
+      for (int i = 0; i < D; ++i) v[(size_t)i] = 1.0 + 0.01 * i;
+      double est = 0.0, prev = -1.0;
+      bool settled = false;
+      for (int it = 0; it < 200 && !settled; ++it) {
+        for (int i = 0; i < D; ++i) {  // w = M v
+          double s = 0.0;
+          for (int j = 0; j <= i; ++j) s += M[(size_t)i * D + j] * v[(size_t)j];
+          w[(size_t)i] = s;
+        }
+        double nv = 0.0;
+        for (int j = 0; j < D; ++j) {  // v = M^T w
+          double s = 0.0;
+          for (int i = j; i < D; ++i) s += M[(size_t)i * D + j] * w[(size_t)i];
+          v[(size_t)j] = s;
+          nv += s * s;
+        }
+        nv = std::sqrt(nv);
+        if (!(nv > 0.0) || !std::isfinite(nv)) return no("power method broke down");
+        for (int j = 0; j < D; ++j) v[(size_t)j] /= nv;
+        est = std::sqrt(nv);  // |M^T M v| -> lambda_max = |M|_2^2 for unit v
+        settled = it >= 4 && std::fabs(est - prev) <= 1e-3 * est;
+        prev = est;
       }
-      nv = std::sqrt(nv);
-      if (!(nv > 0.0) || !std::isfinite(nv)) return no("power method broke down");
-      for (int j = 0; j < D; ++j) v[(size_t)j] /= nv;
-      est = std::sqrt(nv);  // |M^T M v| -> lambda_max = |M|_2^2 for unit v
-      settled = it >= 8 && std::fabs(est - prev) <= 1e-4 * est;
-      prev = est;
+      if (!settled) return no("power method not settled");
+      upper = est / 0.97;
+      if (!lch::norm_certified(M.data(), D, upper * upper, cert)) return no("norm estimate not proved");
     }
-    if (!settled) return no("power method not settled");
     double bn = 0.0;
     for (int i = 0; i < D; ++i) {
       double s = 0.0;
@@ -1445,7 +1484,7 @@ bool Context::recompute_bounded(int K, const std::vector<int>& changed, const st
     }
     b.ref[t] = dc_slab_.p + (size_t)oldslot[(size_t)rt] * NP_;
     b.dest[t] = dc_slab_.p + (size_t)dest[(size_t)t] * NP_;
-    b.sigma[t] = 0.97 / est;           // (a lower bound of sigma_min(B): the power method's estimate of |M|_2 is from below)
+    b.sigma[t] = 1.0 / upper;          // (a lower bound of sigma_min(B): `upper` is a proved upper bound of |M|_2)
     b.bnorm[t] = 1.03 * std::sqrt(bn) + 1e-9;
     b.cnew[t] = c[changed[(size_t)t]];
   }
@@ -1464,6 +1503,9 @@ bool Context::recompute_bounded(int K, const std::vector<int>& changed, const st
   b.rmax = rm_max_.p;
   b.ramax = rm_arg_.p;
   b.T = (delta ? 208.0 : 746.0) + 32.0;
+  // The path's own buffers (up to a third of X, gathered) are not part of the room question estep_cache asked: when the
+  // device says no, the ordinary pass runs (it overwrites whatever the selection wrote) -- never an error out of learn*()
+  try {
   bs_need_.reserve((size_t)NP_);
   b.need = bs_need_.p;
   LC_HIP(lck::launch_bound_select(b, stream_));
@@ -1491,7 +1533,7 @@ bool Context::recompute_bounded(int K, const std::vector<int>& changed, const st
     std::copy(m + (size_t)changed[(size_t)t] * D, m + (size_t)(changed[(size_t)t] + 1) * D, m2.begin() + (size_t)t * D);
   }
   const std::vector<double> zero((size_t)nch, 0.0);
-  const int64_t PS = lck::pstride(DP_);
+  const int64_t PS = lck::estep_pstride(DP_, DC_);  // (the wide layout beyond DP = 128: ADVICE r5, high)
   pack_estep_params(nch, A2.data(), m2.data(), zero.data());
   params_.reserve(hpack_.size());
   LC_HIP(hipMemcpyAsync(params_.p, hpack_.data(), hpack_.size() * sizeof(double), hipMemcpyHostToDevice, stream_));
@@ -1499,6 +1541,7 @@ bool Context::recompute_bounded(int K, const std::vector<int>& changed, const st
   fzpart_.reserve((size_t)std::max<int64_t>(grid, 1));
   lck::EstepLaunch a;
   a.DP = DP_;
+  a.DC = DC_;
   a.X = bs_x_.p;
   a.nrg = nrg;
   a.rginfo = nullptr;
@@ -1528,6 +1571,11 @@ bool Context::recompute_bounded(int K, const std::vector<int>& changed, const st
   LC_HIP(lck::launch_scatter_cols(bs_out_.p, Mp, nch, dp, sel.idx.p, sel.M, stream_));
   LC_HIP(hipStreamSynchronize(stream_));  // (the packed parameters and `sel` are about to go)
   return true;
+  } catch (const AllocFailure&) {
+    (void)hipGetLastError();
+    LC_HIP(hipStreamSynchronize(stream_));
+    return no("no room for the gathered rows");
+  }
 }
 
 int Context::estep_cache(int K, const double* A, const double* m, const double* c, double* Fz, double* LLk, double delta_tol,
@@ -1730,8 +1778,9 @@ int Context::estep_cache(int K, const double* A, const double* m, const double* 
     double* target = run >= 0 ? dc_slab_.p + (size_t)run * NP_ : dfresh_.p;
     if ((int)dc_ver_.size() < K) dc_ver_.resize((size_t)K, 0);
     for (int k : changed) dc_ver_[(size_t)k] = ++dc_vernext_;
-    if (NP_ > 0 && run >= 0 && recompute_bounded(K, changed, oldslot, oldA, oldm, dest, A, m, c, delta_tol >= 0.0)) {
-      // (only the rows the new columns can reach were recomputed; the others hold -inf)
+    if (NP_ > 0 && run >= 0 && recompute_bounded(K, changed, oldslot, oldA, oldm, dest, A, m, c, delta_tol >= 0.0 && qz_[cur_].K == K)) {
+      // (only the rows the new columns can reach were recomputed; the others hold an upper bound that the sweep turns
+      //  into exactly 0.0; the margin is the one of the sweep's REAL mode: it flushes only with old responsibilities)
     } else if (NP_ > 0) {
       estep(nch, Ap, mp, zero.data(), &fz0, nullptr, true, target);
       if (run < 0)
@@ -1799,9 +1848,17 @@ int Context::estep_cache(int K, const double* A, const double* m, const double* 
     a.ldq = NP_;
     a.fz_part = fzpart_.p;
     a.ll_part = LLk ? llpart_.p : nullptr;
-    if (J_ == 1 && K <= lck::BOUND_MAX_K) {  // (what recompute_bounded needs next time)
-      rm_max_.reserve((size_t)NP_);
-      rm_arg_.reserve((size_t)NP_);
+    bool rm_room = bound_static_ok() && K <= lck::BOUND_MAX_K;  // (what recompute_bounded needs next time -- where it can run)
+    if (rm_room) {
+      try {
+        rm_max_.reserve((size_t)NP_);
+        rm_arg_.reserve((size_t)NP_);
+      } catch (const AllocFailure&) {
+        (void)hipGetLastError();
+        rm_room = false;
+      }
+    }
+    if (rm_room) {
       a.rmax = rm_max_.p;
       a.ramax = rm_arg_.p;
       rm_valid_ = true;
@@ -2139,7 +2196,8 @@ void Context::suffstat_diag(const unsigned char* smask, double* Nk, double* xs, 
     int64_t rows = ((NP_ + want - 1) / want + 31) / 32 * 32;
     const int nchunks = (int)((NP_ + rows - 1) / rows);
     const int nparts = nchunks * rs;
-    sspart_.reserve((size_t)nparts * K * SS);
+    sspart_reserve((size_t)nparts * K * SS);
+    sspart_clean_ = false;  // (another record layout)
     lck::DiagStatLaunch a;
     a.DP = DP;
     a.X = X_.p;

@@ -19,6 +19,10 @@ namespace lcc {
 struct HipFailure : std::runtime_error {
   explicit HipFailure(const std::string& s) : std::runtime_error(s) {}
 };
+// hipMalloc said no (after the block cache was trimmed): optional accelerations catch this one and take their ordinary path
+struct AllocFailure : HipFailure {
+  explicit AllocFailure(const std::string& s) : HipFailure(s) {}
+};
 // Context::estep_cache: the device has no room for the distance cache at this width (nothing was changed; the caller
 // runs the ordinary E-step instead)
 struct CacheNoRoom : std::runtime_error {
@@ -298,6 +302,7 @@ class Context {
   bool skip_zero_ = false;
 
   int J_ = 0, D_ = 0, DP_ = 0;
+  int DC_ = 0;  // active width of the Gauss-Wishart E-step / feature-GEMM statistics (lck::estep_active_width): DP_ - 8 or DP_
   std::vector<int64_t> Nj_, goff_;  // goff_: padded row offsets, size J+1
   int64_t Ntot_ = 0, NP_ = 0;
   DevBuf<double> X_;
@@ -336,6 +341,7 @@ class Context {
   std::vector<uint64_t> rm_ver_;
   std::vector<double> rm_c_;
   int64_t bound_rows_ = 0, bound_passes_ = 0;  // rows recomputed / passes taken by the bounded recomputation (trace)
+  bool bound_static_ok() const;  // the bounded recomputation's shape preconditions (one group, one rank, enough rows)
   bool recompute_bounded(int K, const std::vector<int>& changed, const std::vector<int>& oldslot,
                          const std::vector<std::vector<double>>& oldA, const std::vector<std::vector<double>>& oldm,
                          const std::vector<int>& dest, const double* A, const double* m, const double* c, bool delta);
@@ -356,6 +362,15 @@ class Context {
   int cur_ = 0;
 
   DevBuf<double> params_, ctab_, fzpart_, llpart_, red_, redtmp_, sspart_, ssout_, ssext_;
+  // sspart_ holds zeros in every Gauss-Wishart record entry of the columns past the active width (suffstat()): true once
+  // it has been cleared and until it is re-allocated or lent to another record layout
+  bool sspart_clean_ = false;
+  void sspart_reserve(size_t n) {
+    if (n > sspart_.cap) {
+      sspart_.reserve(n);
+      sspart_clean_ = false;
+    }
+  }
   DevBuf<unsigned char> smask_;
   DevBuf<int> selcnt_;
   DevBuf<int64_t> seloff_;

@@ -102,6 +102,42 @@ LC_HOST_CLONES inline void chol_block_update(const double* li, const double* lj,
   __builtin_memcpy(acc[2], &a2, 32);
   __builtin_memcpy(acc[3], &a3, 32);
 }
+// Is |M|_2^2 < tau for the lower-triangular M (row-major n x n)?  PROVED, not estimated: tau I - M^T M is factorised as
+// L D L^T without pivoting and every pivot has to stay above 1e-9 tau (rounding is 1e-13 tau at n = 128) -- which holds iff
+// the matrix is positive definite, i.e. iff every singular value of M is below sqrt(tau).  n^3 / 3 multiply-adds in
+// contiguous saxpy loops.  Used by Context::recompute_bounded: the power method proposes tau from below, this decides.
+// (the cloned body touches plain arrays only: hipcc's host pass leaves the members of a std::vector that a multiversioned
+//  function instantiates undefined in the object)
+LC_HOST_CLONES inline bool norm_certified_raw(const double* M, int n, double tau, double* G, double* col) {
+  const size_t N = (size_t)n;
+  for (int i = 0; i < n; ++i) G[(size_t)i * N + i] = tau;
+  for (int l = 0; l < n; ++l) {  // G -= (row l of M)^T (row l of M), lower half
+    const double* r = M + (size_t)l * N;
+    for (int i = 0; i <= l; ++i) {
+      const double a = r[i];
+      double* g = G + (size_t)i * N;
+      for (int j = 0; j <= i; ++j) g[j] -= a * r[j];
+    }
+  }
+  const double floor_ = 1e-9 * tau;
+  for (int k = 0; k < n; ++k) {
+    const double d = G[(size_t)k * N + k];
+    if (!(d > floor_)) return false;  // (NaN: false)
+    for (int i = k + 1; i < n; ++i) col[i] = G[(size_t)i * N + k];
+    for (int i = k + 1; i < n; ++i) {
+      const double f = col[i] / d;
+      double* g = G + (size_t)i * N;
+      for (int j = k + 1; j <= i; ++j) g[j] -= f * col[j];
+    }
+  }
+  return true;
+}
+inline bool norm_certified(const double* M, int n, double tau, std::vector<double>& work) {
+  if (!(tau > 0.0) || !std::isfinite(tau)) return false;
+  const size_t N = (size_t)n;
+  work.assign(N * N + N, 0.0);
+  return norm_certified_raw(M, n, tau, work.data(), work.data() + N * N);
+}
 // r[ii][j] += l[ii][0] rk[0][j] + ... + l[ii][3] rk[3][j] (added in that order) for j = 0 .. nj - 1
 LC_HOST_CLONES inline void trinv_block_update(double* const* r, const double* const* rk,
                                                                                const double (*l)[4], int nj) {

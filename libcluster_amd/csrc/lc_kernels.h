@@ -34,6 +34,21 @@ inline int pstride(int DP) { return ntiles(DP) * 16 + DP; }
 // of 16 doubles + the 64 entries of -b_I
 constexpr int WIDE_CHUNK = 256 * 16 + 64;
 inline int wide_chunks(int DP) { int np = DP / 64; return np * (np + 1) / 2; }
+// doubles per cluster in the packed E-step parameter stream (the constant table c_jk follows K of these): the ONE
+// place that knows both layouts -- every packer and every launch that places `ctab` asks here
+// (narrow layouts: the stream holds the tiles of the ACTIVE width DC <= DP only -- estep_active_width)
+inline int64_t estep_pstride(int DP, int DC) { return DP > 128 ? (int64_t)wide_chunks(DP) * WIDE_CHUNK : (int64_t)pstride(DC); }
+inline int64_t estep_pstride(int DP) { return estep_pstride(DP, DP); }
+// Active width of the Gauss-Wishart E-step and feature-GEMM statistics (round 6): the columns D ... DP - 1 of the padded
+// layout are zero, and both kernels work in 4-column tiles / patches -- they walk the tiles of DC = D rounded up to a
+// multiple of 8 instead of those of DP (D = 23: 21 whitener tiles per cluster instead of 36, 24 feature tiles instead of
+// 39).  Same X layout, same records (the entries of the idle columns are never written: zero), same results bit for bit
+// (the skipped products are 0 * 0).  DP = 16 has the fused pass's own narrow instances (NTA).
+inline int estep_active_width(int D, int DP) {
+  if (DP < 32 || DP > 128) return DP;
+  const int dc = (D + 7) / 8 * 8;
+  return dc < DP ? (dc < DP - 8 ? DP - 8 : dc) : DP;
+}
 // doubles per cluster in a stats record: [N_k, s_k[DP], S_k[DP*DP]]
 inline int64_t stat_stride(int DP) { return 1 + (int64_t)DP + (int64_t)DP * DP; }
 
@@ -57,11 +72,12 @@ inline int rginfo_pack(int group, int nvalid) { return (group << 5) | nvalid; }
 
 struct EstepLaunch {
   int DP;
+  int DC = 0;            // active width (estep_active_width; 0 = DP): tiles of the columns >= DC are neither packed nor walked
   const double* X;       // [NP x DP]
   int64_t nrg;           // number of row-groups (NP / 16)
   const int* rginfo;     // [nrg] or nullptr (single group; nvalid from nrows)
   int64_t nrows;         // valid rows when rginfo == nullptr
-  const double* params;  // [K x pstride(DP)] packed tiles + b
+  const double* params;  // [K x estep_pstride(DP, DC)] packed tiles + b
   const double* ctab;    // [J x K] c_jk (may hold -inf for sparse-inactive)
   int K;
   double* qZ;            // [K x ldq]
@@ -113,6 +129,7 @@ struct SSItem {
 };
 struct SuffstatLaunch {
   int DP;
+  int DC = 0;               // active width (estep_active_width; 0 = DP): the feature-GEMM kernel deals out its patches only
   const double* X;
   int64_t NP;               // padded rows (multiple of 16)
   const double* qZ;
@@ -136,15 +153,15 @@ struct SuffstatLaunch {
   int DPW = 0, colA = 0, colB = 0;  // record width, first column of the A-side / B-side panel
 };
 // choose a chunking for (NP, K); returns nchunks and sets chunk_rows
-int suffstat_plan(int DP, int64_t NP, int K, int64_t* chunk_rows);
+int suffstat_plan(int DP, int64_t NP, int K, int64_t* chunk_rows, int DC = 0);
 hipError_t launch_suffstat(const SuffstatLaunch& a, hipStream_t stream);
 int suffstat_clusters_per_block(int DP, int K);  // 4 waves x clusters per wave
-const char* suffstat_kernel_name(int DP, int K);  // "suffstat_kernel" or "suffstat_feat_kernel" (dense pass of this shape)
+const char* suffstat_kernel_name(int DP, int K, int DC = 0);  // "suffstat_kernel" or "suffstat_feat_kernel" (dense pass of this shape)
 // When the last cluster slice of the dense pass fills only one or two of its four waves, the idle waves take over part
 // of the active waves' rows (2 or 4 row classes) and write partial records of their own: `extra` more records per
 // chunk, laid out after the K regular ones ([row class - 1][cluster of the last slice]).  Returns extra (0: no split);
 // klast0 = first cluster of the last slice.  launch_fold_extra adds them into their clusters after the reduction.
-int suffstat_extra_records(int DP, int K, bool skip_or_items, int* klast0);
+int suffstat_extra_records(int DP, int K, bool skip_or_items, int* klast0, int DC = 0);
 hipError_t launch_fold_extra(double* rec, int64_t SS, int K, int klast0, int extra, hipStream_t stream);
 hipError_t launch_reduce_records(const double* partial, int64_t n, int K, const int* kptr, const int* krec, double* out,
                                  hipStream_t stream);

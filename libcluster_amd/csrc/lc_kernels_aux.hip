@@ -835,20 +835,25 @@ __global__ void __launch_bounds__(256) bound_select_kernel(BoundSelectLaunch a) 
 #pragma unroll
   for (int t = 0; t < BOUND_MAX_COLS; ++t)
     if (t < a.ncol) d2[t] = -2.0 * a.ref[t][row];  // (every reference is read before any destination is written)
+  double ub[BOUND_MAX_COLS];  // -0.5 s^2: an upper bound of the new column's raw value -0.5 d_new^2
   if (skip) {
     const double low = a.rmax[row] + a.dcj[j] - a.T;  // the row's largest log q~ among the unchanged columns, less the margin
 #pragma unroll
     for (int t = 0; t < BOUND_MAX_COLS; ++t)
       if (t < a.ncol) {
         const double s = fmax(a.sigma[t] * sqrt(fmax(d2[t], 0.0)) - a.bnorm[t], 0.0);
-        skip = skip && (a.cnew[t] - 0.5 * s * s < low);  // (NaN anywhere: false -> the row is recomputed)
+        ub[t] = -0.5 * s * s;
+        skip = skip && (a.cnew[t] + ub[t] < low);  // (NaN anywhere: false -> the row is recomputed)
       }
   }
   a.need[row] = skip ? 0.0 : 1.0;
   if (skip) {
+    // A skipped row keeps the BOUND, not -inf: c + ub < max - T, so the sweep's exponential still comes out as
+    // exactly 0.0 (or is flushed, moved-row mode) -- the same bits -- and the column stays a sound reference for the next
+    // bounded pass: d_ref >= s holds for the stored value, where -inf would lock the row out however far the cluster moves.
 #pragma unroll
     for (int t = 0; t < BOUND_MAX_COLS; ++t)
-      if (t < a.ncol) a.dest[t][row] = -INFINITY;
+      if (t < a.ncol) a.dest[t][row] = ub[t];
   }
 }
 hipError_t launch_bound_select(const BoundSelectLaunch& a, hipStream_t stream) {

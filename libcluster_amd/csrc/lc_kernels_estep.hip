@@ -53,13 +53,16 @@ constexpr int ES_PF = 4;  // LDS reads in flight ahead of their use (2...10 are 
 template <int DP>
 struct EstepOcc { static constexpr int BLOCKS = DP == 64 ? 3 : 2; };
 
-template <int DP, int R, int WAVES, bool SPARSE>
+// DC <= DP: the active width (estep_active_width, lc_kernels.h) -- the row stride of X stays DP, the tile rows walked and
+// the parameter record are those of DC columns.
+template <int DP, int DC, int R, int WAVES, bool SPARSE>
 __global__ void __launch_bounds__(WAVES * 64, EstepOcc<DP>::BLOCKS) estep_kernel(EstepLaunch a) {
-  constexpr int NT = DP / 4;
+  static_assert(DC % 4 == 0 && DC <= DP && DC > DP - 16, "active width");
+  constexpr int NT = DC / 4;
   constexpr int NTILES = NT * (NT + 1) / 2;
   constexpr int NREAD = NTILES + NT;  // LDS reads per cluster
   constexpr int PF = ES_PF;
-  constexpr int PS = NTILES * 16 + DP;
+  constexpr int PS = NTILES * 16 + DC;
   constexpr int NTHR = WAVES * 64;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* pbuf = lds;              // [2][PS]
@@ -776,17 +779,17 @@ int64_t estep_grid(int DP, int64_t nrg) {
   return (nrg + rgpb - 1) / rgpb;
 }
 
-template <int DP, bool SPARSE>
+template <int DP, int DC, bool SPARSE>
 static hipError_t launch_estep_s(const EstepLaunch& a, hipStream_t stream) {
   constexpr int R = EstepCfg<DP>::R, WAVES = EstepCfg<DP>::WAVES;
-  size_t shmem = (size_t)(2 * pstride(DP) + WAVES * a.K + WAVES + 64) * sizeof(double) +
+  size_t shmem = (size_t)(2 * pstride(DC) + WAVES * a.K + WAVES + 64) * sizeof(double) +
                  (size_t)(2 * a.K + WAVES * R + 2) * sizeof(int);
   EstepLaunch b = a;
   if (R == 4 && !a.raw && shmem + (size_t)a.K * WAVES * 64 * sizeof(double) <= 40 * 1024) {  // (four blocks per CU still fit; at 74 KB, K = 32, the lost occupancy costs 8 %)
     b.lq_lds = 1;  // log q~ stays in LDS until the normalisation
     shmem += (size_t)a.K * WAVES * 64 * sizeof(double);
   }
-  auto kern = estep_kernel<DP, R, WAVES, SPARSE>;
+  auto kern = estep_kernel<DP, DC, R, WAVES, SPARSE>;
   static LdsGrant grant;  // largest dynamic-LDS size already granted, per device
   if (hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(kern), shmem, grant); e != hipSuccess) return e;
   const int64_t grid = estep_grid(DP, a.nrg);
@@ -797,7 +800,11 @@ static hipError_t launch_estep_s(const EstepLaunch& a, hipStream_t stream) {
 
 template <int DP>
 static hipError_t launch_estep_t(const EstepLaunch& a, hipStream_t stream) {
-  return a.sparse ? launch_estep_s<DP, true>(a, stream) : launch_estep_s<DP, false>(a, stream);
+  if constexpr (DP >= 32) {
+    if (a.DC == DP - 8) return a.sparse ? launch_estep_s<DP, DP - 8, true>(a, stream) : launch_estep_s<DP, DP - 8, false>(a, stream);
+  }
+  if (a.DC != 0 && a.DC != DP) return hipErrorInvalidValue;
+  return a.sparse ? launch_estep_s<DP, DP, true>(a, stream) : launch_estep_s<DP, DP, false>(a, stream);
 }
 
 hipError_t launch_estep(const EstepLaunch& a, hipStream_t stream) {

@@ -4,6 +4,9 @@
 
 // widths at which the feature-GEMM form of the statistics pass is the default for more than 16 clusters (measured:
 // tools/ssfeat_check.py; LC_SS_FEAT=2 selects it wherever it exists, 0 nowhere)
+#ifndef LC_SS_FEAT_MINK_ACTIVE
+#define LC_SS_FEAT_MINK_ACTIVE 5
+#endif
 #ifndef LC_SS_FEAT_WIDTHS
 #define LC_SS_FEAT_WIDTHS(DP) ((DP) >= 32 && (DP) <= 128)  // (every padded width: 80, 96, 112 fit their registers as 8-wave blocks, round 5)
 #endif
@@ -535,7 +538,9 @@ __global__ void __launch_bounds__(256, (DP <= 64 ? (HALF != 0 ? 3 : 2) : (HALF !
 // matrix pipe nothing; no operand sharing to schedule).  More than 32 clusters: one launch per range of <= 32.
 // Same partial records, same reduction, deterministic; the patch on the diagonal computes both halves of its 4 x 4
 // block from commuted products, so S_k comes out exactly symmetric.
-__host__ __device__ constexpr int ft_tiles(int DP) { return (DP / 4) * (DP / 4 + 1) / 2 + DP / 16 + 1; }
+// (DC: the ACTIVE width, estep_active_width in lc_kernels.h -- the patches of the columns past it are products of zeros
+//  and are not dealt out at all; the s_k tiles cover whole 16-column blocks, their idle columns read the staged zeros)
+__host__ __device__ constexpr int ft_tiles(int DC) { return (DC / 4) * (DC / 4 + 1) / 2 + (DC + 15) / 16 + 1; }
 // tiles per wave: as many as the accumulators allow (72 doubles; 64 for 8 quads at D = 80, 96, 112, where 72 spill) -- 9 tiles
 // with 8 cluster quads, 12 with 6, 14 with 5: a launch with fewer quads keeps its MFMAs per step (and has fewer blocks
 // re-staging the same rows)
@@ -571,11 +576,11 @@ __host__ __device__ constexpr int ft_group(int DP) { return DP >= 48 && DP <= 11
 //  now runs at these widths, N = 4M, K = 32: D = 96 22.9 -> 19.1 ms (0.67 -> 0.81 of the fp64 peak), D = 80 15.0 -> 13.7,
 //  D = 112 (N = 3M) 21.9 -> 19.9; gpurun_out/r05l)
 __host__ __device__ constexpr int ft_waves(int DP) { return DP == 64 ? LC_FT_WAVES64 : DP == 128 ? LC_FT_WAVES128 : DP > 64 ? 8 : 4; }
-__host__ __device__ constexpr int ft_nslice(int DP, int NQ) {  // blocks per row chunk
-  return (ft_tiles(DP) + ft_waves(DP) * ft_tpw_max(DP, NQ) - 1) / (ft_waves(DP) * ft_tpw_max(DP, NQ));
+__host__ __device__ constexpr int ft_nslice(int DP, int DC, int NQ) {  // blocks per row chunk
+  return (ft_tiles(DC) + ft_waves(DP) * ft_tpw_max(DP, NQ) - 1) / (ft_waves(DP) * ft_tpw_max(DP, NQ));
 }
-__host__ __device__ constexpr int ft_tpw(int DP, int NQ) {  // tiles of the fuller waves
-  return (ft_tiles(DP) + ft_waves(DP) * ft_nslice(DP, NQ) - 1) / (ft_waves(DP) * ft_nslice(DP, NQ));
+__host__ __device__ constexpr int ft_tpw(int DP, int DC, int NQ) {  // tiles of the fuller waves
+  return (ft_tiles(DC) + ft_waves(DP) * ft_nslice(DP, DC, NQ) - 1) / (ft_waves(DP) * ft_nslice(DP, DC, NQ));
 }
 // (160 KB of LDS per CU: two blocks of 4 waves or one of 8)
 __host__ __device__ constexpr int ft_batch_rows(int DP) {
@@ -586,11 +591,14 @@ __host__ __device__ constexpr int ft_qld(int NQ) { return NQ > 8 ? 68 : 36; }
 // cluster range of one launch: 32 (up to 8 quads), or -- D = 128 -- 64 in ONE pass over X (16 quads, 4 tiles per wave:
 // one multiply per 16 MFMAs; config 5's K = 64 used to take two launches of 8 quads, each re-reading and re-staging X)
 inline int ft_range(int DP, int K) { return DP == 128 && K % 64 == 0 ? 64 : DP == 128 && K % 64 >= 57 ? 64 : 32; }
-inline bool ss_feat_eligible(int DP, int K) {
+inline bool ss_feat_eligible(int DP, int K, int DC) {
   // (tests, libcluster_hip_testhooks.so only: 0 off, 1 where it wins, 2 everywhere it exists)
   static const int mode = test_switch("LC_SS_FEAT") ? atoi(test_switch("LC_SS_FEAT")) : 1;
   if (mode == 0 || DP < 32 || DP > 128) return false;
   if (mode == 2) return true;
+  // active width below the padded one (round 6): this kernel skips the idle patches (D = 23: 24 of 39 tiles), the per-cluster
+  // kernel works in 16 x 16 blocks and cannot -- from two cluster quads up the feature GEMM is the faster one there
+  if (DC > 0 && DC < DP && K >= LC_SS_FEAT_MINK_ACTIVE) return true;
   // few clusters (one launch of <= 4 quads): the per-cluster kernel holds its own up to K = 12 everywhere and at D = 64 /
   // 128 up to 16 (tools/ss_smallk_probe.py, round 5: D = 64, K = 16 0.685 against 0.672 of the peak); a full fourth quad
   // pays at the widths whose per-cluster instances are the weak ones: D = 96, K = 16 0.64 -> 0.75, D = 32 0.56 -> 0.61
@@ -607,11 +615,13 @@ inline bool ss_feat_eligible(int DP, int K) {
   if (DP == 128) return rem == 0 || rem >= 28 || (ft_range(DP, K) == 64 && K >= 57);
   return rem == 0 || rem >= 4;
 }
-template <int DP, int NQ>
+template <int DP, int DC, int NQ>
 __global__ void __launch_bounds__(64 * ft_waves(DP), 2) suffstat_feat_kernel(SuffstatLaunch a) {
+  static_assert(DC % 4 == 0 && DC <= DP && DC > DP - 16, "active width");
   constexpr int FTW = ft_waves(DP);
   constexpr int BR = ft_batch_rows(DP), LD = lds_row_stride(DP), QLD = ft_qld(NQ), XBUF = BR * LD, QBUF = BR * QLD;
-  constexpr int TPW = ft_tpw(DP, NQ), TILES = ft_tiles(DP), NPATCH = (DP / 4) * (DP / 4 + 1) / 2, NSL = ft_nslice(DP, NQ);
+  constexpr int TPW = ft_tpw(DP, DC, NQ), TILES = ft_tiles(DC), NPATCH = (DC / 4) * (DC / 4 + 1) / 2, NSL = ft_nslice(DP, DC, NQ);
+  constexpr int NLIN = (DC + 15) / 16;  // s_k tiles
   constexpr int ONE = DP;  // column of the staged rows that holds 1.0
   static_assert(LD > DP, "the staged rows need a spare column");
   static_assert(TPW * NQ <= 72, "accumulators");
@@ -659,7 +669,7 @@ __global__ void __launch_bounds__(64 * ft_waves(DP), 2) suffstat_feat_kernel(Suf
       const int ia = T - ja * (ja + 1) / 2;
       cu = 4 * ia + lo2;
       cw = 4 * ja + blk;
-    } else if (T < NPATCH + DP / 16) {
+    } else if (T < NPATCH + NLIN) {
       cu = 16 * (T - NPATCH) + 4 * blk + lo2;
     }
     pu[t] = xbuf + hi * LD + cu;
@@ -887,7 +897,7 @@ __global__ void __launch_bounds__(64 * ft_waves(DP), 2) suffstat_feat_kernel(Suf
         double* S = out + 1 + DP;
         S[(int64_t)gi * DP + gj] = v;
         S[(int64_t)gj * DP + gi] = v;
-      } else if (T < NPATCH + DP / 16) {
+      } else if (T < NPATCH + NLIN) {
         out[1 + 16 * (T - NPATCH) + 4 * blk + lo2] = v;
       } else if (blk == 0 && lo2 == 0) {
         out[0] = v;
@@ -896,17 +906,17 @@ __global__ void __launch_bounds__(64 * ft_waves(DP), 2) suffstat_feat_kernel(Suf
   }
 }
 
-template <int DP, int NQ>
+template <int DP, int DC, int NQ>
 static hipError_t launch_ss_feat_q(const SuffstatLaunch& b, hipStream_t stream) {
   constexpr int BR = ft_batch_rows(DP), LD = lds_row_stride(DP);
   const size_t shmem = (size_t)(2 * BR * LD + 2 * BR * ft_qld(NQ)) * sizeof(double);
-  auto kern = suffstat_feat_kernel<DP, NQ>;
+  auto kern = suffstat_feat_kernel<DP, DC, NQ>;
   static LdsGrant grant;
   if (hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(kern), shmem, grant); e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(b.nchunks * ft_nslice(DP, NQ))), dim3(64 * ft_waves(DP)), shmem, stream, b);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(b.nchunks * ft_nslice(DP, DC, NQ))), dim3(64 * ft_waves(DP)), shmem, stream, b);
   return hipGetLastError();
 }
-template <int DP>
+template <int DP, int DC>
 static hipError_t launch_ss_feat_d(const SuffstatLaunch& a, hipStream_t stream) {
   // cluster ranges: as many full ranges of 32 (8 quads: one multiply per 8 MFMAs) as there are, the remainder in a last
   // range of its own -- near-equal ranges (K = 48 as 24 + 24) put BOTH launches at the poor 5-6 quad ratio.  Every range
@@ -920,32 +930,38 @@ static hipError_t launch_ss_feat_d(const SuffstatLaunch& a, hipStream_t stream) 
     hipError_t e = hipErrorInvalidValue;
     if constexpr (DP == 128) {
       if (nq > 8) {
-        e = launch_ss_feat_q<DP, 16>(b, stream);
+        e = launch_ss_feat_q<DP, DC, 16>(b, stream);
         if (e != hipSuccess) return e;
         continue;
       }
     }
     switch (nq) {
-      case 1: case 2: e = launch_ss_feat_q<DP, 2>(b, stream); break;
-      case 3: case 4: e = launch_ss_feat_q<DP, 4>(b, stream); break;
-      case 5: e = launch_ss_feat_q<DP, 5>(b, stream); break;
-      case 6: e = launch_ss_feat_q<DP, 6>(b, stream); break;
-      case 7: e = launch_ss_feat_q<DP, 7>(b, stream); break;
-      case 8: e = launch_ss_feat_q<DP, 8>(b, stream); break;
+      case 1: case 2: e = launch_ss_feat_q<DP, DC, 2>(b, stream); break;
+      case 3: case 4: e = launch_ss_feat_q<DP, DC, 4>(b, stream); break;
+      case 5: e = launch_ss_feat_q<DP, DC, 5>(b, stream); break;
+      case 6: e = launch_ss_feat_q<DP, DC, 6>(b, stream); break;
+      case 7: e = launch_ss_feat_q<DP, DC, 7>(b, stream); break;
+      case 8: e = launch_ss_feat_q<DP, DC, 8>(b, stream); break;
     }
     if (e != hipSuccess) return e;
   }
   return hipSuccess;
 }
+template <int DP>
+static hipError_t launch_ss_feat_w(const SuffstatLaunch& a, hipStream_t stream) {
+  if (a.DC == DP - 8) return launch_ss_feat_d<DP, DP - 8>(a, stream);
+  if (a.DC != 0 && a.DC != DP) return hipErrorInvalidValue;
+  return launch_ss_feat_d<DP, DP>(a, stream);
+}
 static hipError_t launch_ss_feat(const SuffstatLaunch& a, hipStream_t stream) {
   switch (a.DP) {
-    case 32: return launch_ss_feat_d<32>(a, stream);
-    case 48: return launch_ss_feat_d<48>(a, stream);
-    case 64: return launch_ss_feat_d<64>(a, stream);
-    case 80: return launch_ss_feat_d<80>(a, stream);
-    case 96: return launch_ss_feat_d<96>(a, stream);
-    case 112: return launch_ss_feat_d<112>(a, stream);
-    case 128: return launch_ss_feat_d<128>(a, stream);
+    case 32: return launch_ss_feat_w<32>(a, stream);
+    case 48: return launch_ss_feat_w<48>(a, stream);
+    case 64: return launch_ss_feat_w<64>(a, stream);
+    case 80: return launch_ss_feat_w<80>(a, stream);
+    case 96: return launch_ss_feat_w<96>(a, stream);
+    case 112: return launch_ss_feat_w<112>(a, stream);
+    case 128: return launch_ss_feat_w<128>(a, stream);
   }
   return hipErrorInvalidValue;
 }
@@ -978,10 +994,10 @@ static int ss_cpw(int DP, int K) {
 // row classes for a last slice with `active` of its four waves in use
 static int ss_row_classes(int active) { return active == 1 ? 4 : active == 2 ? 2 : 1; }
 
-int suffstat_extra_records(int DP, int K, bool skip_or_items, int* klast0) {
+int suffstat_extra_records(int DP, int K, bool skip_or_items, int* klast0, int DC) {
   if (klast0) *klast0 = K;
   if (DP > 128 || skip_or_items || K < 1) return 0;
-  if (ss_feat_eligible(DP, K)) return 0;  // (the feature-GEMM kernel covers any K of its range with the same 16 waves)
+  if (ss_feat_eligible(DP, K, DC)) return 0;  // (the feature-GEMM kernel covers any K of its range with the same 16 waves)
   const int cpw = ss_cpw(DP, K), kwaves = (K + cpw - 1) / cpw, nslice = (kwaves + 3) / 4;
   const int rs = ss_row_classes(kwaves - (nslice - 1) * 4);
   if (rs == 1) return 0;
@@ -1009,13 +1025,13 @@ hipError_t launch_fold_extra(double* rec, int64_t SS, int K, int klast0, int ext
 }
 
 // which kernel a dense Gauss-Wishart statistics pass of this shape runs (bench.py names the kernel it prices)
-const char* suffstat_kernel_name(int DP, int K) {
-  return DP <= 128 && ss_feat_eligible(DP, K) ? "suffstat_feat_kernel" : "suffstat_kernel";
+const char* suffstat_kernel_name(int DP, int K, int DC) {
+  return DP <= 128 && ss_feat_eligible(DP, K, DC) ? "suffstat_feat_kernel" : "suffstat_kernel";
 }
 
 int suffstat_clusters_per_block(int DP, int K) { return DP > 128 ? 4 : 4 * ss_cpw(DP, K); }
 
-int suffstat_plan(int DP, int64_t NP, int K, int64_t* chunk_rows) {
+int suffstat_plan(int DP, int64_t NP, int K, int64_t* chunk_rows, int DC) {
   const int cpw = DP > 128 ? 1 : ss_cpw(DP, K);  // wide: panel launches, one cluster per wave
   const int kwaves = (K + cpw - 1) / cpw;  // waves needed to cover the clusters
   // aim for ~8 waves per CU on 256 CUs, at least 256 rows per chunk
@@ -1047,18 +1063,10 @@ int suffstat_plan(int DP, int64_t NP, int K, int64_t* chunk_rows) {
   // whose last round of resident blocks is half empty loses that much of the launch.  Config 5 (D = 128, K = 64: 17 blocks
   // per chunk) ran 127 chunks = 2159 blocks = 8.43 rounds of 256 -- 6 % of the pass idle; 120 chunks are 7.97 rounds.
   // Among the chunk counts down to 80 % of the wanted one, take the fullest last round (the larger count on ties).
-  if (DP <= 128 && ss_feat_eligible(DP, K) && NP >= 64 * 1024) {
+  if (DP <= 128 && ss_feat_eligible(DP, K, DC) && NP >= 64 * 1024) {
     const int range = ft_range(DP, K), nq = ((K < range ? K : range) + 3) / 4;
-    int nslice = 0;
-    switch (DP) {
-      case 32: nslice = nq > 7 ? ft_nslice(32, 8) : nq > 6 ? ft_nslice(32, 7) : nq > 5 ? ft_nslice(32, 6) : ft_nslice(32, 5); break;
-      case 48: nslice = nq > 7 ? ft_nslice(48, 8) : nq > 6 ? ft_nslice(48, 7) : nq > 5 ? ft_nslice(48, 6) : ft_nslice(48, 5); break;
-      case 64: nslice = nq > 7 ? ft_nslice(64, 8) : nq > 6 ? ft_nslice(64, 7) : nq > 5 ? ft_nslice(64, 6) : ft_nslice(64, 5); break;
-      case 80: nslice = nq > 7 ? ft_nslice(80, 8) : nq > 6 ? ft_nslice(80, 7) : nq > 5 ? ft_nslice(80, 6) : ft_nslice(80, 5); break;
-      case 96: nslice = nq > 7 ? ft_nslice(96, 8) : nq > 6 ? ft_nslice(96, 7) : nq > 5 ? ft_nslice(96, 6) : ft_nslice(96, 5); break;
-      case 112: nslice = nq > 7 ? ft_nslice(112, 8) : nq > 6 ? ft_nslice(112, 7) : nq > 5 ? ft_nslice(112, 6) : ft_nslice(112, 5); break;
-      case 128: nslice = nq > 8 ? ft_nslice(128, 16) : nq > 7 ? ft_nslice(128, 8) : nq > 6 ? ft_nslice(128, 7) : nq > 5 ? ft_nslice(128, 6) : ft_nslice(128, 5); break;
-    }
+    const int nqi = nq > 8 ? 16 : nq > 4 ? nq : nq > 2 ? 4 : 2;  // the instance launch_ss_feat_d takes
+    const int nslice = ft_nslice(DP, DC > 0 ? DC : DP, nqi);
     if (nslice > 0) {
       const int cus = current_device_cus();
       const int64_t slots = (int64_t)cus * (ft_waves(DP) == 8 ? 1 : 2);
@@ -1164,7 +1172,7 @@ hipError_t launch_suffstat(const SuffstatLaunch& a, hipStream_t stream) {
     const bool skip = a.skip_zero > 0 || (a.skip_zero == 0 && a.smask);
     return skip ? launch_ss_wide<true>(a, stream) : launch_ss_wide<false>(a, stream);
   }
-  if (ss_feat_eligible(a.DP, a.K) && !a.smask && !a.items && a.skip_zero <= 0 && a.KR <= a.K)
+  if (ss_feat_eligible(a.DP, a.K, a.DC) && !a.smask && !a.items && a.skip_zero <= 0 && a.KR <= a.K)
     return launch_ss_feat(a, stream);
   const int cpw = ss_cpw(a.DP, a.K);
   switch (a.DP) {

@@ -80,6 +80,57 @@ int main() {
       ++bad;
     }
   }
+  {  // norm_certified (Context::recompute_bounded's proof of |M|_2^2 < tau): against a norm found the slow way
+    std::vector<double> work;
+    for (int n : {1, 2, 3, 5, 16, 23, 64, 100, 128}) {
+      for (int rep = 0; rep < 4; ++rep) {
+        std::vector<double> M((size_t)n * n, 0.0);
+        for (int i = 0; i < n; ++i)
+          for (int j = 0; j <= i; ++j) M[(size_t)i * n + j] = (i == j ? 1.0 + 0.3 * rep : 0.0) + (rep == 3 ? 1.0 : 0.1) * nd(g);
+        // |M|_2 by 5000 power iterations from eight random starts, the largest wins
+        double best = 0.0;
+        for (int st = 0; st < 8; ++st) {
+          std::vector<double> v((size_t)n), w((size_t)n);
+          for (auto& x : v) x = nd(g);
+          double est = 0.0;
+          for (int it = 0; it < 5000; ++it) {
+            for (int i = 0; i < n; ++i) {
+              double t = 0.0;
+              for (int j = 0; j <= i; ++j) t += M[(size_t)i * n + j] * v[(size_t)j];
+              w[(size_t)i] = t;
+            }
+            double nv = 0.0;
+            for (int j = 0; j < n; ++j) {
+              double t = 0.0;
+              for (int i = j; i < n; ++i) t += M[(size_t)i * n + j] * w[(size_t)i];
+              v[(size_t)j] = t;
+              nv += t * t;
+            }
+            nv = std::sqrt(nv);
+            for (auto& x : v) x /= nv;
+            est = std::sqrt(nv);
+          }
+          best = std::fmax(best, est);
+        }
+        const bool above = lch::norm_certified(M.data(), n, (best * 1.001) * (best * 1.001), work);
+        const bool below = lch::norm_certified(M.data(), n, (best * 0.999) * (best * 0.999), work);
+        // the failure the certificate exists for: a bound proposed from the SECOND singular value must be refused
+        const bool far_below = lch::norm_certified(M.data(), n, 0.5 * best * best, work);
+        if (!above || below || far_below) {
+          std::printf("norm_certified wrong at n = %d rep %d: |M|_2 = %.6g, above %d below %d far below %d\n", n, rep, best,
+                      (int)above, (int)below, (int)far_below);
+          ++bad;
+        }
+      }
+    }
+    const double nan = std::nan("");
+    std::vector<double> one = {1.0};
+    if (lch::norm_certified(one.data(), 1, nan, work) || lch::norm_certified(one.data(), 1, -1.0, work) ||
+        lch::norm_certified(&nan, 1, 4.0, work)) {
+      std::printf("norm_certified accepted a NaN / negative bound\n");
+      ++bad;
+    }
+  }
   std::printf(bad ? "FAILED\n" : "host factorisations: bit-identical to the element-by-element forms for n = 1 .. 150\n");
   return bad ? 1 : 0;
 }

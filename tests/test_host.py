@@ -20,6 +20,19 @@ def test_library_exports_every_declared_symbol(lib):
         assert hasattr(lib, n), f"{n} declared in include/libcluster_hip.h but not exported"
 
 
+def test_library_leaves_no_cxx_template_member_undefined():
+    """Round 6 found hipcc's host pass leaving std::vector members undefined in the object when a multiversioned
+    (target_clones) function instantiates them -- a shared library links anyway and fails at the first call.  Nothing of
+    the C++ library's templates may be an undefined dynamic symbol of the built libraries."""
+    import subprocess
+
+    for name in ("libcluster_hip.so", "libcluster_hip_testhooks.so"):
+        r = subprocess.run(["nm", "-D", "-u", "-C", str(ROOT / "libcluster_amd" / "lib" / name)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        bad = [ln for ln in r.stdout.splitlines() if "std::vector<" in ln or "__normal_iterator<" in ln or "_Vector_base<" in ln]
+        assert not bad, (name, bad)
+
+
 def test_constants(lib):
     assert lib.lc_const_converge() == o.CONVERGE
     assert lib.lc_const_fengydel() == o.FENGYDEL
