@@ -966,6 +966,267 @@ static hipError_t launch_ss_feat(const SuffstatLaunch& a, hipStream_t stream) {
   return hipErrorInvalidValue;
 }
 
+// ===========================================================================
+// Sufficient statistics for FEW clusters (K <= 16) at D <= 64: four clusters in the four blocks of one MFMA (round 6)
+// ===========================================================================
+// Few clusters leave both forms above short of operands to share: suffstat_kernel forms q_k x per cluster and 16 x 16
+// block (D = 32: five fp64 VALU instructions per ten MFMAs), the feature GEMM shares one product among NQ <= 4 cluster
+// quads and reads two LDS fragments for it (NQ = 2: the LDS port is the bound).  Here the MFMA's four blocks are the four
+// CLUSTERS of a quad and its output tile a 4 x 4 patch of the scatter matrix:
+//   A operand = x[row 4 st + hi][4 ia + lo2]                        (the same in all four blocks: one LDS read per ia and step)
+//   B operand = q[row 4 st + hi][cluster 4 c + blk] * x[row][4 ja + lo2]   (ONE v_mul_f64 per ja and step, used by ja + 1 patches;
+//                                                                    s_k adds the same product up on the VALU)
+//   D[i = hi][j = lo2] of block blk = S_{4c + blk}[4 ia + hi][4 ja + lo2]
+// -- NT multiplies, NT + 1 additions and NT + 1 LDS reads per NT (NT + 1) / 2 MFMAs and step (D = 48: 25 : 78, D = 24: 13 : 21), no
+// rotated reads, cross-lane sums in the epilogue only.  A quad's work list (patches ia <= ja in ja-major order, each ja followed by its s_k
+// tile, N_k last) is cut into NPART contiguous parts of equal length, one wave each: K <= 4 runs as 4 parts, K <= 8 as 2 x 2,
+// 12 as 3 x 4 (three blocks per row chunk), 16 as 4 x 1 (D <= 32) or 4 x 2; D = 64 always in 4 parts (39 accumulators).  Same staging, chunks, partial records and
+// fixed-order reduction as the other two kernels; a diagonal patch stores its lower triangle only (and mirrors it): the two
+// halves come from differently rounded products, and the host reads the lower triangle.  Dense only.
+struct SqItem {
+  int kind, ia, ja;  // kind 0: patch (ia, ja); 1: s_k tile of ja; 2: N_k
+};
+__host__ __device__ constexpr int sq_items(int DC) { return (DC / 4) * (DC / 4 + 1) / 2 + DC / 4 + 1; }
+__host__ __device__ constexpr SqItem sq_item(int DC, int n) {
+  for (int ja = 0; ja < DC / 4; ++ja) {
+    if (n <= ja) return SqItem{0, n, ja};
+    n -= ja + 1;
+    if (n == 0) return SqItem{1, 0, ja};
+    n -= 1;
+  }
+  return SqItem{2, 0, 0};
+}
+__host__ __device__ constexpr int sq_part_lo(int DC, int NPART, int p) { return (sq_items(DC) * p + NPART - 1) / NPART; }
+__host__ __device__ constexpr int sq_part_max(int DC, int NPART) {
+  int m = 0;
+  for (int p = 0; p < NPART; ++p) {
+    const int n = sq_part_lo(DC, NPART, p + 1) - sq_part_lo(DC, NPART, p);
+    m = n > m ? n : m;
+  }
+  return m;
+}
+constexpr int SQ_BR = 32, SQ_QLD = 18;
+inline int sq_npart(int DP, int K) {  // parts per cluster quad (the instances launch_ss_quad has)
+  const int nq = (K + 3) / 4;
+  if (DP > 48) return 4;  // (D = 64: two parts per quad need more than 256 registers)
+  return nq == 2 ? 2 : nq == 4 ? (DP <= 32 ? 1 : 2) : 4;
+}
+inline int sq_nslice(int DP, int K) { return (((K + 3) / 4) * sq_npart(DP, K) + 3) / 4; }
+inline bool ss_quad_eligible(int DP, int K) {
+  // (tests, libcluster_hip_testhooks.so only: 0 never, 1 wherever an instance exists)
+  static const int mode = test_switch("LC_SS_QUAD") ? atoi(test_switch("LC_SS_QUAD")) : -1;
+  if (mode == 0 || DP < 32 || DP > 64 || K < 1 || K > 16) return false;
+  return true;
+}
+template <int DP, int DC, int NPART>
+__global__ void __launch_bounds__(256, 2) suffstat_quad_kernel(SuffstatLaunch a) {
+  static_assert(DC % 4 == 0 && DC <= DP && DC > DP - 16, "active width");
+  constexpr int NT = DC / 4, BR = SQ_BR, LD = lds_row_stride(DP), QLD = SQ_QLD, XBUF = BR * LD, QBUF = BR * QLD, NTHR = 256;
+  constexpr int NACC = sq_part_max(DC, NPART);
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* xbuf = lds;             // [2][BR][LD]
+  double* qbuf = lds + 2 * XBUF;  // [2][BR][QLD]: q[row][cluster], clusters past K zero
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hi = lane >> 4, blk = (lane >> 2) & 3, lo2 = lane & 3;
+  const int K = a.K, NQ = (K + 3) / 4;
+  int chunk, slice;
+  {  // (chunk, slice) placement as in suffstat_kernel: the slices of a chunk back-to-back on one XCD
+    const int nslice = a.nslice, nchunks = a.nchunks, b = blockIdx.x, full = (nchunks / 8) * 8;
+    if (b < full * nslice) {
+      const int xcd = b & 7, seq = b >> 3;
+      chunk = (seq / nslice) * 8 + xcd;
+      slice = seq % nslice;
+    } else {
+      const int t = b - full * nslice;
+      chunk = full + t / nslice;
+      slice = t % nslice;
+    }
+  }
+  const int64_t r0 = (int64_t)chunk * a.chunk_rows;
+  const int64_t r1 = (r0 + a.chunk_rows) < a.NP ? (r0 + a.chunk_rows) : a.NP;
+  const int unit = slice * 4 + wave, quad = unit / NPART, part = unit % NPART;
+  const bool busy = quad < NQ;
+
+  // ---- staging (as suffstat_feat_kernel): registers hold the next batch while the current one is consumed
+  constexpr int TPR = DP / 2, NV2 = BR * TPR, NPRE = (NV2 + NTHR - 1) / NTHR;
+  double pre[NPRE][2], qpre[4];
+  const int qcl = tid % 16, qrq = tid / 16;
+  const bool qthr = qrq < BR / 4;
+  auto gload = [&](int64_t b0) {
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) {
+      const int idx = tid + i * NTHR;
+      const int row = idx / TPR, c2 = idx % TPR;
+      double2 v = make_double2(0.0, 0.0);
+      if (row < BR && b0 + row < r1) v = *reinterpret_cast<const double2*>(a.X + (b0 + row) * DP + 2 * c2);
+      pre[i][0] = v.x;
+      pre[i][1] = v.y;
+    }
+    const int64_t qrow = b0 + 4 * qrq;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) qpre[i] = 0.0;
+    if (qthr && qcl < K && qrow < r1) {  // (a row quad lies inside the chunk or outside it: chunk_rows is a multiple of 4)
+      const double2* qp = reinterpret_cast<const double2*>(a.qZ + (int64_t)qcl * a.ldq + qrow);
+      const double2 v0 = qp[0], v1 = qp[1];
+      qpre[0] = v0.x, qpre[1] = v0.y, qpre[2] = v1.x, qpre[3] = v1.y;
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) {
+      const int idx = tid + i * NTHR;
+      const int row = idx / TPR, c2 = idx % TPR;
+      if (row < BR) *reinterpret_cast<double2*>(xbuf + buf * XBUF + row * LD + 2 * c2) = make_double2(pre[i][0], pre[i][1]);
+    }
+    if (qthr) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) qbuf[buf * QBUF + (4 * qrq + i) * QLD + qcl] = qpre[i];
+    }
+  };
+
+  double acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
+  const double* px = xbuf + hi * LD + lo2;
+  const double* pq = qbuf + hi * QLD + 4 * (busy ? quad : 0) + blk;
+
+  // one part's work on one staged batch (buffer B): all BR / 4 steps run (rows past the chunk end were staged as zeros with
+  // q = 0).  The next step's fragments are read before this step's MFMAs (two register sets); the products stand together
+  // in front of them (a VALU instruction next to the matrix pipe is paid per switch).
+  auto batch = [&](auto bsel, auto psel) {
+    constexpr int B = decltype(bsel)::value, P = decltype(psel)::value, XO = B * XBUF, QO = B * QBUF;
+    constexpr int LO = sq_part_lo(DC, NPART, P), HI = sq_part_lo(DC, NPART, P + 1);
+    constexpr int JA0 = sq_item(DC, LO).kind == 2 ? NT - 1 : sq_item(DC, LO).ja;
+    constexpr int JA1 = sq_item(DC, HI - 1).kind == 2 ? NT - 1 : sq_item(DC, HI - 1).ja;  // fragments 0 .. JA1, products JA0 .. JA1
+    double xa[2][JA1 + 1], qa[2];
+#pragma unroll
+    for (int t = 0; t <= JA1; ++t) xa[0][t] = px[XO + 4 * t];
+    qa[0] = pq[QO];
+#pragma unroll
+    for (int st = 0; st < BR / 4; ++st) {
+      const int cur = st & 1, nxt = cur ^ 1;
+      double pr[JA1 - JA0 + 1];
+#pragma unroll
+      for (int j = JA0; j <= JA1; ++j) pr[j - JA0] = qa[cur] * xa[cur][j];
+      if (st + 1 < BR / 4) {
+#pragma unroll
+        for (int t = 0; t <= JA1; ++t) xa[nxt][t] = px[XO + (st + 1) * 4 * LD + 4 * t];
+        qa[nxt] = pq[QO + (st + 1) * 4 * QLD];
+      }
+      // s_k and N_k on the VALU, next to the products (one v_add_f64 each: as MFMA tiles they were 7 of 28 matrix
+      // instructions at D = 24, 13 of 91 at D = 48); the four hi lanes' partial sums meet in the epilogue
+      static_for<HI - LO>([&](auto ic) {
+        constexpr SqItem it = sq_item(DC, LO + ic);
+        if constexpr (it.kind == 1) acc[ic] += pr[it.ja - JA0];
+        else if constexpr (it.kind == 2) acc[ic] += qa[cur];
+      });
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<HI - LO>([&](auto ic) {
+        constexpr SqItem it = sq_item(DC, LO + ic);
+        if constexpr (it.kind == 0) acc[ic] = mfma4(xa[cur][it.ia], pr[it.ja - JA0], acc[ic]);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto run = [&](auto psel) {
+    if (r0 < r1) {
+      gload(r0);
+      lstore(0);
+    }
+    __syncthreads();
+    for (int64_t b0 = r0; b0 < r1; b0 += 2 * BR) {  // two batches per trip: the buffer index is a compile-time constant
+      const bool more1 = b0 + BR < r1, more2 = b0 + 2 * BR < r1;
+      if (more1) gload(b0 + BR);
+      if (busy) batch(std::integral_constant<int, 0>{}, psel);
+      if (more1) lstore(1);
+      __syncthreads();
+      if (!more1) break;
+      if (more2) gload(b0 + 2 * BR);
+      if (busy) batch(std::integral_constant<int, 1>{}, psel);
+      if (more2) lstore(0);
+      __syncthreads();
+    }
+    if (!busy) return;
+    // ---- partial records: [N_k, s_k[DP], S_k[DP x DP]] per (chunk, cluster), as the other kernels write them
+    constexpr int P = decltype(psel)::value, LO = sq_part_lo(DC, NPART, P), HI = sq_part_lo(DC, NPART, P + 1);
+    const int kk = 4 * quad + blk;
+    if (kk >= K) return;
+    const int64_t SS = 1 + (int64_t)DP + (int64_t)DP * DP;
+    double* out = a.partial + ((int64_t)chunk * a.KR + kk) * SS;
+    double* S = out + 1 + DP;
+    static_for<HI - LO>([&](auto ic) {
+      constexpr SqItem it = sq_item(DC, LO + ic);
+      const double v = acc[ic];
+      if constexpr (it.kind == 0) {
+        const int gi = 4 * it.ia + hi, gj = 4 * it.ja + lo2;
+        if constexpr (it.ia == it.ja) {
+          if (hi >= lo2) S[(int64_t)gi * DP + gj] = v;   // lower triangle of the diagonal patch ...
+          if (hi > lo2) S[(int64_t)gj * DP + gi] = v;    // ... and its mirror image
+        } else {
+          S[(int64_t)gi * DP + gj] = v;
+          S[(int64_t)gj * DP + gi] = v;
+        }
+      } else if constexpr (it.kind == 1) {
+        const double t = sum_over_hi(v);
+        if (hi == 0) out[1 + 4 * it.ja + lo2] = t;
+      } else {
+        const double t = sum_over_hi(v);
+        if (hi == 0 && lo2 == 0) out[0] = t;
+      }
+    });
+  };
+  if constexpr (NPART == 1) {
+    run(std::integral_constant<int, 0>{});
+  } else if constexpr (NPART == 2) {
+    if (part == 0) run(std::integral_constant<int, 0>{});
+    else run(std::integral_constant<int, 1>{});
+  } else {
+    static_assert(NPART == 4, "parts per quad");
+    if (part == 0) run(std::integral_constant<int, 0>{});
+    else if (part == 1) run(std::integral_constant<int, 1>{});
+    else if (part == 2) run(std::integral_constant<int, 2>{});
+    else run(std::integral_constant<int, 3>{});
+  }
+}
+
+template <int DP, int DC, int NPART>
+static hipError_t launch_ss_quad_p(const SuffstatLaunch& a, hipStream_t stream) {
+  const size_t shmem = (size_t)(2 * SQ_BR * lds_row_stride(DP) + 2 * SQ_BR * SQ_QLD) * sizeof(double);
+  auto kern = suffstat_quad_kernel<DP, DC, NPART>;
+  static LdsGrant grant;
+  if (hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(kern), shmem, grant); e != hipSuccess) return e;
+  SuffstatLaunch b = a;
+  b.nslice = sq_nslice(DP, a.K);
+  if (b.KR < a.K) b.KR = a.K;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(b.nchunks * b.nslice)), dim3(256), shmem, stream, b);
+  return hipGetLastError();
+}
+template <int DP, int DC>
+static hipError_t launch_ss_quad_d(const SuffstatLaunch& a, hipStream_t stream) {
+  const int np = sq_npart(DP, a.K);  // (only the instances sq_npart can ask for exist)
+  if constexpr (DP <= 32) {
+    if (np == 1) return launch_ss_quad_p<DP, DC, 1>(a, stream);
+  }
+  if constexpr (DP <= 48) {
+    if (np == 2) return launch_ss_quad_p<DP, DC, 2>(a, stream);
+  }
+  return np == 4 ? launch_ss_quad_p<DP, DC, 4>(a, stream) : hipErrorInvalidValue;
+}
+template <int DP>
+static hipError_t launch_ss_quad_w(const SuffstatLaunch& a, hipStream_t stream) {
+  if (a.DC == DP - 8) return launch_ss_quad_d<DP, DP - 8>(a, stream);
+  if (a.DC != 0 && a.DC != DP) return hipErrorInvalidValue;
+  return launch_ss_quad_d<DP, DP>(a, stream);
+}
+static hipError_t launch_ss_quad(const SuffstatLaunch& a, hipStream_t stream) {
+  switch (a.DP) {
+    case 32: return launch_ss_quad_w<32>(a, stream);
+    case 48: return launch_ss_quad_w<48>(a, stream);
+    case 64: return launch_ss_quad_w<64>(a, stream);
+  }
+  return hipErrorInvalidValue;
+}
+
 template <int DP>
 struct SSCfg;
 template <>
@@ -997,6 +1258,7 @@ static int ss_row_classes(int active) { return active == 1 ? 4 : active == 2 ? 2
 int suffstat_extra_records(int DP, int K, bool skip_or_items, int* klast0, int DC) {
   if (klast0) *klast0 = K;
   if (DP > 128 || skip_or_items || K < 1) return 0;
+  if (ss_quad_eligible(DP, K)) return 0;      // (whole quads of clusters per wave: no ragged last slice)
   if (ss_feat_eligible(DP, K, DC)) return 0;  // (the feature-GEMM kernel covers any K of its range with the same 16 waves)
   const int cpw = ss_cpw(DP, K), kwaves = (K + cpw - 1) / cpw, nslice = (kwaves + 3) / 4;
   const int rs = ss_row_classes(kwaves - (nslice - 1) * 4);
@@ -1026,6 +1288,7 @@ hipError_t launch_fold_extra(double* rec, int64_t SS, int K, int klast0, int ext
 
 // which kernel a dense Gauss-Wishart statistics pass of this shape runs (bench.py names the kernel it prices)
 const char* suffstat_kernel_name(int DP, int K, int DC) {
+  if (ss_quad_eligible(DP, K)) return "suffstat_quad_kernel";
   return DP <= 128 && ss_feat_eligible(DP, K, DC) ? "suffstat_feat_kernel" : "suffstat_kernel";
 }
 
@@ -1036,6 +1299,7 @@ int suffstat_plan(int DP, int64_t NP, int K, int64_t* chunk_rows, int DC) {
   const int kwaves = (K + cpw - 1) / cpw;  // waves needed to cover the clusters
   // aim for ~8 waves per CU on 256 CUs, at least 256 rows per chunk
   int64_t want = (256 * 8 + kwaves - 1) / kwaves;
+  if (ss_quad_eligible(DP, K)) want = (256 * 8 / 4 + sq_nslice(DP, K) - 1) / sq_nslice(DP, K);  // blocks of four waves, nslice per chunk
   // four blocks per resident slot: the hardware back-fills slots as blocks retire, which evens out the
   // per-CU / per-XCD speed differences (measured 25.7 -> 24.9 ms at N=10M, D=64, K=32), while the partial
   // records (chunks x K x (1 + DP + DP^2) doubles) stay below 1 GiB
@@ -1172,6 +1436,7 @@ hipError_t launch_suffstat(const SuffstatLaunch& a, hipStream_t stream) {
     const bool skip = a.skip_zero > 0 || (a.skip_zero == 0 && a.smask);
     return skip ? launch_ss_wide<true>(a, stream) : launch_ss_wide<false>(a, stream);
   }
+  if (ss_quad_eligible(a.DP, a.K) && !a.smask && !a.items && a.skip_zero <= 0 && a.KR <= a.K) return launch_ss_quad(a, stream);
   if (ss_feat_eligible(a.DP, a.K, a.DC) && !a.smask && !a.items && a.skip_zero <= 0 && a.KR <= a.K)
     return launch_ss_feat(a, stream);
   const int cpw = ss_cpw(a.DP, a.K);

@@ -752,3 +752,34 @@ def test_feature_gemm_statistics_at_every_width_and_cluster_range(lib):
         for c in cases:
             assert c["sym"], (mode, c)
             assert c["eN"] < 1e-12 and c["es"] < 1e-12 and c["eS"] < 1e-12, (mode, c)
+
+
+
+@pytest.mark.gpu
+def test_quad_statistics_kernel_at_every_instance(lib):
+    """suffstat_quad_kernel (K <= 16, D <= 64: the four clusters of a quad in the four blocks of one MFMA, round 6) on ragged
+    inputs at every instance -- 1, 2 and 4 parts per quad, both active widths of the 32-, 48- and 64-column layouts -- and,
+    with LC_SS_QUAD=0 (test-hooks library), the kernels it replaces on the same inputs: N_k, s_k, S_k of updateSS /
+    GaussWish::addobs (src/cluster.cpp:53-82, src/distributions.cpp:301-313) against numpy to 1e-12 of the largest entry,
+    S_k exactly symmetric."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    sums = []
+    for mode in ("1", "0"):
+        e = dict(os.environ, LC_SS_QUAD=mode, LC_SSFEAT_NOTIME="1", LC_SSCHECK_CASES="quad",
+                 LC_LIB_PATH=str(root / "libcluster_amd" / "lib" / "libcluster_hip_testhooks.so"))  # (lck::test_switch)
+        r = subprocess.run([sys.executable, str(root / "tools" / "ssfeat_check.py"), "child"], capture_output=True, text=True,
+                           env=e, timeout=900, cwd=str(root))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        cases, _ = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+        assert len(cases) >= 20
+        for c in cases:
+            assert c["sym"], (mode, c)
+            assert c["eN"] < 1e-12 and c["es"] < 1e-12 and c["eS"] < 1e-12, (mode, c)
+        sums.append([c["h"] for c in cases])
+    np.testing.assert_allclose(sums[0], sums[1], rtol=1e-11)

@@ -165,10 +165,19 @@ def test_statistics_kernel_selection_is_a_function_of_the_shape(lib, monkeypatch
     assert fn(64, 24) == feat and fn(64, 48) == feat and fn(64, 36) == feat and fn(32, 40) == feat
     assert fn(128, 60) == feat and fn(128, 128) == feat and fn(128, 121) == feat
     assert fn(128, 40) == per and fn(128, 48) == per
-    assert fn(64, 8) == per and fn(64, 16) == per and fn(64, 33) == per and fn(64, 35) == per
+    assert fn(64, 33) == per and fn(64, 35) == per
     assert fn(80, 32) == feat and fn(96, 32) == feat and fn(112, 40) == feat and fn(96, 20) == feat   # (round 5: 8-wave blocks, no scratch)
-    assert fn(96, 33) == per and fn(80, 12) == per and fn(96, 16) == feat and fn(32, 14) == feat and fn(64, 16) == per
+    assert fn(96, 33) == per and fn(80, 12) == per and fn(96, 16) == feat
     assert fn(16, 32) == per and fn(256, 32) == per
+    # round 6: up to 16 clusters at D = 17 ... 64 the four clusters of a quad ride in the four blocks of one MFMA
+    quad = b"suffstat_quad_kernel"
+    for D, K in ((64, 8), (64, 16), (32, 14), (23, 16), (17, 1), (48, 12), (40, 3), (64, 4), (33, 9)):
+        assert fn(D, K) == quad, (D, K)
+    assert fn(64, 17) == feat and fn(16, 8) == per and fn(80, 12) == per and fn(80, 16) == feat
+    # ... and the feature GEMM skips the patches of the padding's idle columns (active width = D rounded up to 8, where that is
+    # below the padded width): from five clusters on it is then the faster one at the wider layouts too
+    assert fn(72, 8) == feat and fn(88, 6) == feat and fn(104, 12) == feat and fn(120, 5) == feat and fn(72, 4) == per
+    assert fn(80, 8) == per and fn(96, 8) == per
 
 
 def test_roofline_traffic_json_is_generated_from_the_committed_summaries():

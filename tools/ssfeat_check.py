@@ -17,6 +17,12 @@ CASES = [(1000, 64, 17), (4099, 64, 20), (777, 50, 24), (30001, 64, 29), (65536,
          (3001, 112, 40), (6000, 128, 32), (5001, 128, 64), (2000, 100, 65), (3000, 64, 64), (2500, 64, 45),
          # D = 128: ranges of 64 clusters in one pass (16 quads), full and ragged, one and two ranges
          (3000, 128, 57), (2777, 120, 60), (2100, 128, 128), (1900, 128, 121)]
+# few clusters (K <= 16) at D <= 64: suffstat_quad_kernel's instances (1, 2, 4 parts per quad; both active widths per layout)
+QUAD_CASES = [(1000, 23, 16), (4099, 32, 8), (777, 20, 4), (30001, 24, 12), (5000, 48, 12), (123, 40, 3), (9001, 33, 16),
+              (7000, 48, 16), (6007, 64, 8), (5003, 56, 4), (4001, 64, 16), (3000, 64, 12), (2500, 17, 1), (40001, 30, 5),
+              (2000, 64, 2), (3001, 47, 9), (65536, 28, 13), (1027, 50, 6), (31, 64, 7), (8000, 57, 15)]
+if os.environ.get("LC_SSCHECK_CASES") == "quad":
+    CASES = QUAD_CASES
 TIMING = [(2000000, 64, 17), (2000000, 64, 20), (2000000, 64, 24), (4000000, 32, 20), (2000000, 48, 24), (4000000, 32, 32), (4000000, 32, 40), (2000000, 48, 32), (2000000, 48, 48), (2000000, 64, 32), (2000000, 64, 28),
           (2000000, 64, 33), (2000000, 64, 36), (2000000, 64, 40), (2000000, 64, 48), (2000000, 64, 56), (2000000, 64, 64),
           (1000000, 128, 32), (1000000, 128, 28), (1000000, 128, 40), (1000000, 128, 48), (1000000, 128, 64)]

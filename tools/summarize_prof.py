@@ -33,7 +33,7 @@ if log.exists():
 
 def short(n):
     """Kernel family + template arguments (every instantiation is reported on its own)."""
-    for k in ("fused_small_kernel", "estep_diag_mfma_kernel", "estep_diag_kernel", "suffstat_diag_kernel", "estep_wide_kernel", "estep_kernel", "suffstat_feat_kernel",
+    for k in ("fused_small_kernel", "estep_diag_mfma_kernel", "estep_diag_kernel", "suffstat_diag_kernel", "estep_wide_kernel", "estep_kernel", "suffstat_feat_kernel", "suffstat_quad_kernel",
               "suffstat_kernel"):
         i = n.find(k)
         if i >= 0:
