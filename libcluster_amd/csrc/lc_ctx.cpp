@@ -652,6 +652,21 @@ void Context::qz_clone_to_alt() {
   use_device();
   QZ& a = qz_[cur_ ^ 1];
   const int Ksave = qz_[cur_].K;
+  // The copy a rejected candidate left behind differs from the original in that candidate's rows only: with fingerprints
+  // on both sides (the moved-row sweeps keep them) only those rows are copied (qz_resync_kernel) -- 0.1 ms instead of
+  // the 1.7 ms a clone of 2.6 GB takes, once per candidate.  LC_SPLIT_NO_QHASH / LC_SPLIT_FULL_CLONE (tests): always the
+  // full copy; the two must agree in every bit (tests/test_gpu_splitsearch.py).
+  static const bool full_only = lck::test_switch("LC_SPLIT_FULL_CLONE") != nullptr;
+  if (!full_only && NP_ > 0 && Ksave >= 1 && qz_[cur_].hash_ok && a.hash_ok && a.buf.p && a.hash.p && qz_[cur_].hash.p &&
+      a.cap >= Ksave + 1 && (a.K == Ksave || a.K == Ksave + 1)) {
+    LC_HIP(lck::launch_qz_resync(a.buf.p, qz_[cur_].buf.p, NP_, Ksave, Ksave + 1, NP_, a.hash.p, qz_[cur_].hash.p, stream_));
+    a.K = Ksave;
+    clone_resyncs_ += 1;
+    return;
+  }
+  clone_fulls_ += 1;
+  static const bool trace = std::getenv("LC_TRACE_PHASES") != nullptr;
+  if (trace) std::cerr << "[clone] full copy at K " << Ksave << " (row-wise so far: " << clone_resyncs_ << ")" << std::endl;
   ensure_qz(a, Ksave + 1, false);
   a.K = Ksave;
   LC_HIP(hipMemcpyAsync(a.buf.p, qz_[cur_].buf.p, (size_t)NP_ * Ksave * sizeof(double), hipMemcpyDeviceToDevice,

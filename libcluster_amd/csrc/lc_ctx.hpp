@@ -340,6 +340,7 @@ class Context {
   int rm_K_ = 0;
   std::vector<uint64_t> rm_ver_;
   std::vector<double> rm_c_;
+  int64_t clone_resyncs_ = 0, clone_fulls_ = 0;  // split trials whose working copy was re-synchronised row by row / copied whole (trace)
   int64_t bound_rows_ = 0, bound_passes_ = 0;  // rows recomputed / passes taken by the bounded recomputation (trace)
   bool bound_static_ok() const;  // the bounded recomputation's shape preconditions (one group, one rank, enough rows)
   bool recompute_bounded(int K, const std::vector<int>& changed, const std::vector<int>& oldslot,

@@ -331,6 +331,9 @@ hipError_t launch_rank_order_sum(const double* gathered, int world, int64_t coun
 // tests: rows whose stored fingerprint is neither QHASH_NONE nor that of the K values in the buffer are counted in *bad
 hipError_t launch_qhash_verify(const double* qZ, int64_t ldq, int K, int64_t NP, const int64_t* qhash,
                                unsigned long long* bad, hipStream_t stream);
+// dst row := src row (K values, zeros in dst's columns K .. Kdst-1, the fingerprint) wherever the rows' fingerprints differ
+hipError_t launch_qz_resync(double* dst, const double* src, int64_t ldq, int K, int Kdst, int64_t NP, int64_t* dhash,
+                            const int64_t* shash, hipStream_t stream);
 int64_t softmax_cached_grid(int64_t NP);
 int softmax_cached_max_k();  // widest K the sweep is built for
 hipError_t launch_softmax_cached(const CachedNormLaunch& a, hipStream_t stream);

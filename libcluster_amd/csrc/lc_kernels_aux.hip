@@ -824,6 +824,34 @@ hipError_t launch_qhash_verify(const double* qZ, int64_t ldq, int K, int64_t NP,
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Model selection: bring a split trial's working copy of the responsibilities back in line with the original, row by row
+// (Context::qz_clone_to_alt, round 6).  After a rejected candidate the copy differs from the original in the candidate's own
+// rows only; both buffers carry row fingerprints (softmax_cached_kernel), so a row is copied -- its K values, its
+// fingerprint, zeros in the copy's columns K ... Kdst-1 -- exactly when the fingerprints differ or either is unknown.  Equal
+// fingerprints = equal rows is the premise the moved-row sweeps already stand on (qhash_step; a zero entry leaves a
+// fingerprint as it is, so a row that is unchanged has zeros in the copy's extra column).  Lanes = consecutive rows of
+// column-major buffers: the copies coalesce whenever neighbouring rows differ together.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) qz_resync_kernel(double* __restrict__ dst, const double* __restrict__ src, int64_t ldq, int K,
+                                                        int Kdst, int64_t NP, int64_t* __restrict__ dhash,
+                                                        const int64_t* __restrict__ shash) {
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (row >= NP) return;
+  const int64_t hs = shash[row], hd = dhash[row];
+  if (hs == hd && hs != QHASH_NONE) return;
+  for (int j = 0; j < K; ++j) dst[(int64_t)j * ldq + row] = src[(int64_t)j * ldq + row];
+  for (int j = K; j < Kdst; ++j) dst[(int64_t)j * ldq + row] = 0.0;
+  dhash[row] = hs;
+}
+hipError_t launch_qz_resync(double* dst, const double* src, int64_t ldq, int K, int Kdst, int64_t NP, int64_t* dhash,
+                            const int64_t* shash, hipStream_t stream) {
+  if (NP <= 0 || K <= 0) return hipSuccess;
+  hipLaunchKernelGGL(qz_resync_kernel, dim3((unsigned)((NP + 255) / 256)), dim3(256), 0, stream, dst, src, ldq, K, Kdst, NP, dhash,
+                     shash);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Model selection: the rows a recomputed column matters for (BoundSelectLaunch, lc_kernels.h)
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) bound_select_kernel(BoundSelectLaunch a) {

@@ -430,11 +430,14 @@ def test_randomised_parity_fuzz():
     import sys
     from pathlib import Path
 
+    import os
+
     root = Path(__file__).resolve().parents[1]
-    r = subprocess.run([sys.executable, str(root / "tools" / "fuzz_parity.py"), "80", "7"], capture_output=True,
+    n = os.environ.get("LC_FUZZ_CASES", "50")  # (the suite's share; tools/fuzz_*.py run thousands per round: profiles/rNN_fuzz.log)
+    r = subprocess.run([sys.executable, str(root / "tools" / "fuzz_parity.py"), n, "7"], capture_output=True,
                        text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert "80 cases" in r.stdout and " 0 failures" in r.stdout
+    assert f"{n} cases" in r.stdout and " 0 failures" in r.stdout
 
 
 def test_randomised_learner_fuzz():

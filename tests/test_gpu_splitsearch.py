@@ -24,7 +24,7 @@ def _with_switches(env):
     """The schedule switches (LC_SPLIT_*, LC_LL_EXTRA_PASS, LC_FUSED_SMALL, ...) exist in the test-hooks build of the library
     only (lck::test_switch): a run that sets one loads that build."""
     e = dict(env)
-    if any(k.startswith(("LC_SPLIT_", "LC_LL_", "LC_FUSED_", "LC_SS_", "LC_ED_")) for k in e):
+    if any(k.startswith(("LC_SPLIT_", "LC_LL_", "LC_FUSED_", "LC_SS_", "LC_ED_", "LC_ES_")) for k in e):
         e.setdefault("LC_LIB_PATH", HOOKED)
     return e
 
@@ -211,6 +211,23 @@ def test_row_fingerprints_change_no_bit_of_the_result(lib, kw):
     b = _run_snippet({"LC_SPLIT_DELTA_FORCE": "1", "LC_SPLIT_NO_QHASH": "1"}, **kw)
     assert a["K"] == b["K"] and a["rounds"] == b["rounds"]
     assert a["Fhex"] == b["Fhex"] and a["qsha"] == b["qsha"]
+
+
+@pytest.mark.parametrize("kw", [_FP_CASES[1], _FP_CASES[3], dict(seed=10, K=8, D=24, N=250000, J=1, scale=2.5)])
+def test_row_wise_resync_of_a_trial_copy_changes_no_bit_of_the_result(lib, kw):
+    """A split candidate works on a copy of the responsibilities (cluster.cpp:468-470).  After a rejected candidate that copy
+    differs from the original in the candidate's rows only, and the next candidate's copy is made by bringing those rows back
+    (Context::qz_clone_to_alt / qz_resync_kernel: rows whose fingerprints differ) instead of copying everything.  With
+    LC_SPLIT_FULL_CLONE (test-hooks library) every candidate gets a full copy: same rounds, same bits -- and the row-wise path
+    must really have carried most candidates."""
+    env = {"LC_LIB_PATH": HOOKED, "LC_SPLIT_DELTA_FORCE": "1", "LC_TRACE_PHASES": "1"}
+    a = _run_snippet(env, **kw)
+    b = _run_snippet(dict(env, LC_SPLIT_FULL_CLONE="1"), **kw)
+    assert a["K"] == b["K"] and a["rounds"] == b["rounds"]
+    assert a["Fhex"] == b["Fhex"] and a["qsha"] == b["qsha"]
+    fa, fb = a["_stderr"].count("[clone] full copy"), b["_stderr"].count("[clone] full copy")
+    # (the first candidate of a round meets a copy of another width -- one full copy per round; every later one is row-wise)
+    assert fa <= len(a["rounds"]) + 1 and fb > fa, (fa, fb, len(a["rounds"]))
 
 
 @pytest.mark.parametrize("kw", _FP_CASES)

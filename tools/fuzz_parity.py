@@ -36,6 +36,10 @@ for case in range(cases):
     sparse = bool(rng.integers(0, 2)) and J > 1
     iters = int(rng.integers(1, 4))
     cent = rng.normal(0, 4.0, (K, D))
+    # a quarter of the cases sit 10 or 100 sigma away from the origin (y = A x - b cancels like eps * offset / sigma;
+    # beyond ~1e3 the reference's own S_k - N_k xbar xbar^T moves by more than this sweep's tolerance: tests/test_gpu_offset.py)
+    offset = float(rng.choice([0.0, 0.0, 0.0, 10.0, 100.0])) * rng.uniform(0.5, 1.5, D)
+    cent = cent + offset
     X, q0 = [], []
     for n in sizes:
         z = rng.integers(0, K, n)
@@ -50,7 +54,7 @@ for case in range(cases):
         else:
             q = rng.dirichlet(np.ones(K) * 0.4, n) if n else q
         q0.append(q)
-    tag = f"case {case}: D={D} K={K} J={J} N={sizes if J < 6 else sum(sizes)} {wf.__name__}/{cf.__name__} sparse={sparse} it={iters}"
+    tag = f"case {case}: offset={offset.max():.0f} D={D} K={K} J={J} N={sizes if J < 6 else sum(sizes)} {wf.__name__}/{cf.__name__} sparse={sparse} it={iters}"
     if os.environ.get("LC_FUZZ_VERBOSE"):
         print(tag, flush=True)
     if os.environ.get("LC_FUZZ_ONLY") and case != int(os.environ["LC_FUZZ_ONLY"]):
