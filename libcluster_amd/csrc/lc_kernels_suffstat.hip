@@ -1016,7 +1016,12 @@ inline bool ss_quad_eligible(int DP, int K) {
   // (tests, libcluster_hip_testhooks.so only: 0 never, 1 wherever an instance exists)
   static const int mode = test_switch("LC_SS_QUAD") ? atoi(test_switch("LC_SS_QUAD")) : -1;
   if (mode == 0 || DP < 32 || DP > 64 || K < 1 || K > 16) return false;
-  return true;
+  if (mode == 1) return true;
+  // a quad's four MFMA blocks are four clusters whether they exist or not: K = 2 does twice the work of the per-cluster
+  // kernel and loses (D = 64: 1.30 against 0.98 ms at N = 4M; cluster()'s two-cluster sub-problems: 403 launches, 107 against
+  // 73 ms); from three clusters on the form wins although blocks idle (D = 48, K = 5: 1.76 against 2.04 ms, D = 32, K = 6:
+  // 1.10 against 1.28; gpurun_out/r06i)
+  return K >= 3;
 }
 template <int DP, int DC, int NPART>
 __global__ void __launch_bounds__(256, 2) suffstat_quad_kernel(SuffstatLaunch a) {

@@ -171,8 +171,10 @@ def test_statistics_kernel_selection_is_a_function_of_the_shape(lib, monkeypatch
     assert fn(16, 32) == per and fn(256, 32) == per
     # round 6: up to 16 clusters at D = 17 ... 64 the four clusters of a quad ride in the four blocks of one MFMA
     quad = b"suffstat_quad_kernel"
-    for D, K in ((64, 8), (64, 16), (32, 14), (23, 16), (17, 1), (48, 12), (40, 3), (64, 4), (33, 9)):
+    # (from three clusters on: the four blocks of a quad work whether their cluster exists or not, and K = 2 loses to that)
+    for D, K in ((64, 8), (64, 16), (23, 16), (48, 12), (64, 4), (33, 7), (17, 11), (40, 15), (40, 3), (64, 6), (32, 14), (33, 9)):
         assert fn(D, K) == quad, (D, K)
+    assert fn(64, 2) == per and fn(17, 1) == per
     assert fn(64, 17) == feat and fn(16, 8) == per and fn(80, 12) == per and fn(80, 16) == feat
     # ... and the feature GEMM skips the patches of the padding's idle columns (active width = D rounded up to 8, where that is
     # below the padded width): from five clusters on it is then the faster one at the wider layouts too
