@@ -838,7 +838,7 @@ def main():
                 # (the 0.18 ms iteration of the small configuration needs more steps for a steady number; so do the 4 ms
                 #  iterations of the separable families: their first five read 5 % above a 20-step run)
                 work = c2["N"] * c2["D"] * c2["K"]
-                st, wu = (200, 20) if work < 1e9 else (20, 3) if c2.get("c", "GaussWish") != "GaussWish" else (5, 1)
+                st, wu = (200, 20) if work < 1e9 else (20, 3) if (c2.get("c", "GaussWish") != "GaussWish" or work < 1e10) else (5, 1)
                 r2, x2, m2, _ = measure(capi, c2, st, wu, 0, 1, local_rank, stream, nthreads, None, None, torch)
                 put_traffic(r2["roofline"], name)
                 others.append({"config": name, "workload": c2["label"], "steps": st, "warmup": wu,

@@ -12,6 +12,9 @@ bash tools/profile_round.sh ${rnd}_wide256 --config wide256
 bash tools/profile_round.sh ${rnd}_d96 --config d96
 bash tools/profile_round.sh ${rnd}_k20 --config k20
 bash tools/profile_round.sh ${rnd}_k40 --config k40
+bash tools/profile_round.sh ${rnd}_d32 --config d32 --steps 20 --warmup 3
+bash tools/profile_round.sh ${rnd}_d48 --config d48 --steps 20 --warmup 3
+bash tools/profile_round.sh ${rnd}_k8 --config k8 --steps 20 --warmup 3
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 out=gpurun_out/prof_${rnd}_learn; mkdir -p $out
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- python3 tools/learn_bench.py 10000000 64 32 > $out/kt.log 2>&1
