@@ -102,5 +102,6 @@ for sname, d in agg.items():
         e["launches_per_step"] = calls[sname] / iters
         e["total_ms_in_run"] = next((float(r["TotalDurationNs"]) / 1e6 for r in rows if short(r["Name"]) == sname), None)
     traffic[sname] = e
-out.append("\n== traffic (machine-readable; tools/pmc_traffic.py) ==\nTRAFFIC " + json.dumps(traffic, sort_keys=True))
+if traffic:
+    out.append("\n== traffic (machine-readable; tools/pmc_traffic.py) ==\nTRAFFIC " + json.dumps(traffic, sort_keys=True))
 print("\n".join(out))
