@@ -308,13 +308,14 @@ __global__ void __launch_bounds__(WAVES * 64, EstepOcc<DP>::BLOCKS) estep_kernel
       // total in every lane (B[k=hi][j=row] is exactly where the partial sums live)
       const double dd = mfma4(1.0, d2[r], 0.0);
       const double lq = cv[r] - 0.5 * dd;
-      mx[r] = max_raw(mx[r], lq);
       if constexpr (ROWLANES) {
         if (hi == r) lqsel = lq;
       } else {
+        mx[r] = max_raw(mx[r], lq);
         lqprev[r] = lq;
       }
     }
+    if constexpr (ROWLANES) mx[0] = max_raw(mx[0], lqsel);  // (the lane's own row group only: one maximum per cluster, not R)
     kprev = k;
     // R == 4: lane (lo4, hi) keeps row group hi -- ONE 512-byte store per cluster column instead of four
     // 128-byte ones, and the normalisation below needs no cross-lane sums
@@ -338,14 +339,36 @@ __global__ void __launch_bounds__(WAVES * 64, EstepOcc<DP>::BLOCKS) estep_kernel
   double fz = 0.0;
   if constexpr (ROWLANES) {
     // every lane owns one row (row group hi, row lo4) and walks all K columns it wrote itself
-    double mymx = mx[0];
+    const double mymx = mx[0];
     int mygrp = grp[0];
     bool myrow = rowok[0];
 #pragma unroll
     for (int r = 1; r < R; ++r)
-      if (hi == r) mymx = mx[r], mygrp = grp[r], myrow = rowok[r];
+      if (hi == r) mygrp = grp[r], myrow = rowok[r];
     double* qp = a.qZ + (rg0 + hi) * RG + lo4;
     double s = 0.0;
+    if (lqm && !a.ll_part) {  // (launch-uniform)
+      // log q~ waits in LDS and the split-ordering term is not asked for: ONE exponential per entry, as fused_small_kernel
+      // and the separable families' sweeps do -- e = exp(log q~ - max) goes back into the lane's slot and q = e / sum(e):
+      // the same sum and logZ, q within two ulp of exp(log q~ - logZ) (cluster.cpp:130-131).  At D = 23 the second
+      // exponential and its loop were 25 of the 90 VALU instructions a cluster costs next to 88 MFMAs.
+      if (myok) {
+#pragma unroll 8
+        for (int k = 0; k < K; ++k) {
+          const double e = exp_nonpos(lql[k * NTHR + tid] - mymx, etab);
+          s += e;
+          lql[k * NTHR + tid] = e;
+        }
+        const double inv = rcp_pos(s);
+#pragma unroll 8
+        for (int k = 0; k < K; ++k) {
+          double q = lql[k * NTHR + tid] * inv;
+          if (!myrow) q = 0.0;
+          qp[(int64_t)k * a.ldq] = q;
+        }
+      }
+      fz = (myok && myrow) ? log(s) + mymx : 0.0;
+    } else {
     if (myok) {
 #pragma unroll 8
       for (int k = 0; k < K; ++k) s += exp_nonpos((lqm ? lql[k * NTHR + tid] : qp[(int64_t)k * a.ldq]) - mymx, etab);
@@ -366,6 +389,7 @@ __global__ void __launch_bounds__(WAVES * 64, EstepOcc<DP>::BLOCKS) estep_kernel
       }
     }
     fz = (myok && myrow) ? logZ : 0.0;
+    }
   } else {
   double logZ[R];
 #pragma unroll
@@ -794,13 +818,18 @@ int64_t estep_grid(int DP, int64_t nrg) {
   return (nrg + rgpb - 1) / rgpb;
 }
 
+// log q~ waits in LDS up to this block size (LC_ES_LQLDS_KB, test-hooks library: A/B).  Round 6: 40 -> 80 KB, two blocks per CU.
+// With ONE exponential per entry on that path the table pays although the occupancy halves: D = 32, K = 16 2.16 -> 2.00 ms
+// (N = 6M), K = 32 4.07 -> 3.86; D = 48, K = 12 2.68 -> 2.51 (N = 5M), K = 28 5.75 -> 5.45; D = 23, K = 24 2.26 -> 2.13 (gpurun_out/r06m)
+constexpr size_t ES_LQ_LDS_CAP = 80 * 1024;
 template <int DP, int DC, bool SPARSE>
 static hipError_t launch_estep_s(const EstepLaunch& a, hipStream_t stream) {
   constexpr int R = EstepCfg<DP>::R, WAVES = EstepCfg<DP>::WAVES;
   size_t shmem = (size_t)(2 * pstride(DC) + WAVES * a.K + WAVES + 64) * sizeof(double) +
                  (size_t)(2 * a.K + WAVES * R + 2) * sizeof(int);
   EstepLaunch b = a;
-  if (R == 4 && !a.raw && shmem + (size_t)a.K * WAVES * 64 * sizeof(double) <= 40 * 1024) {  // (four blocks per CU still fit; at 74 KB, K = 32, the lost occupancy costs 8 %)
+  static const size_t lq_cap = test_switch("LC_ES_LQLDS_KB") ? (size_t)atoi(test_switch("LC_ES_LQLDS_KB")) * 1024 : ES_LQ_LDS_CAP;
+  if (R == 4 && !a.raw && shmem + (size_t)a.K * WAVES * 64 * sizeof(double) <= lq_cap) {
     b.lq_lds = 1;  // log q~ stays in LDS until the normalisation
     shmem += (size_t)a.K * WAVES * 64 * sizeof(double);
   }
