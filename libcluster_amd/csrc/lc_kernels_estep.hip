@@ -191,9 +191,6 @@ __global__ void __launch_bounds__(WAVES * 64, EstepOcc<DP>::BLOCKS) estep_kernel
   double lqprev[R];
   int kprev = -1;
   auto flush_lq = [&]() {  // the previous cluster's log q~: stored one pass late (see the top of the file)
-#ifdef LC_ABL_NOLQSTORE  // (timing-only builds of tools/variants.py: profiles/r06_headline_ablation.log; results are wrong)
-    return;
-#endif
     if constexpr (SADDR) {
       if (kprev >= 0) {
         const char* qk = qwave + (int64_t)kprev * a.ldq * 8;
@@ -220,11 +217,7 @@ __global__ void __launch_bounds__(WAVES * 64, EstepOcc<DP>::BLOCKS) estep_kernel
     const int k = SPARSE ? klist[ii] : ii;
     const int buf = ii & 1;
     flush_lq();
-#ifdef LC_ABL_NODMA
-    if (ii + 1 < nact && ii < 1) dma_record(SPARSE ? klist[ii + 1] : ii + 1, buf ^ 1);
-#else
     if (ii + 1 < nact) dma_record(SPARSE ? klist[ii + 1] : ii + 1, buf ^ 1);
-#endif
     const double* P = pbuf + buf * PS;
     const double* Pt = P + (lane & 3) + 4 * hi;  // this lane's element of every 4x4 tile
     const double* Pb = P + NTILES * 16 + hi;     // this lane's element of every 4-vector of -b
@@ -258,11 +251,6 @@ __global__ void __launch_bounds__(WAVES * 64, EstepOcc<DP>::BLOCKS) estep_kernel
       for (int r = 0; r < R; ++r) cv[r] = a.ctab[(int64_t)grp[r] * K + k];
     }
     auto square = [&](int set) {
-#ifdef LC_ABL_NOSQUARE
-#pragma unroll
-      for (int r = 0; r < R; ++r) asm volatile("" : "+v"(d2[r]) : "v"(acc[set][r]));
-      return;
-#endif
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         d2[r] = fma(acc[set][r], acc[set][r], d2[r]);
@@ -331,9 +319,6 @@ __global__ void __launch_bounds__(WAVES * 64, EstepOcc<DP>::BLOCKS) estep_kernel
   if constexpr (SADDR) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (asm stores: re-read below by the same lanes)
 
   if (a.raw) return;  // GaussWish::Eloglike: leave c_k - 0.5 d^2 in qZ, no normalisation
-#ifdef LC_ABL_NONORM
-  return;
-#endif
 
   // ---- normalise (probutils.cpp:141-150, cluster.cpp:124-131) -------------
   double fz = 0.0;
