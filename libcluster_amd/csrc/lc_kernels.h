@@ -41,13 +41,16 @@ inline int64_t estep_pstride(int DP, int DC) { return DP > 128 ? (int64_t)wide_c
 inline int64_t estep_pstride(int DP) { return estep_pstride(DP, DP); }
 // Active width of the Gauss-Wishart E-step and feature-GEMM statistics (round 6): the columns D ... DP - 1 of the padded
 // layout are zero, and both kernels work in 4-column tiles / patches -- they walk the tiles of DC = D rounded up to a
-// multiple of 8 instead of those of DP (D = 23: 21 whitener tiles per cluster instead of 36, 24 feature tiles instead of
+// multiple of 8 (of 4 up to 48 columns) instead of those of DP (D = 23: 21 whitener tiles per cluster instead of 36, 24 feature tiles instead of
 // 39).  Same X layout, same records (the entries of the idle columns are never written: zero), same results bit for bit
 // (the skipped products are 0 * 0).  DP = 16 has the fused pass's own narrow instances (NTA).
+// (granularity: 4 columns at the 32- and 48-column layouts, where the padding is the larger share -- D = 17 walks 20 columns,
+//  not 24 --, 8 columns beyond: one more instance per layout there instead of three)
 inline int estep_active_width(int D, int DP) {
   if (DP < 32 || DP > 128) return DP;
-  const int dc = (D + 7) / 8 * 8;
-  return dc < DP ? (dc < DP - 8 ? DP - 8 : dc) : DP;
+  const int g = DP <= 48 ? 4 : 8, lo = DP <= 48 ? DP - 12 : DP - 8;
+  const int dc = (D + g - 1) / g * g;
+  return dc < DP ? (dc < lo ? lo : dc) : DP;
 }
 // doubles per cluster in a stats record: [N_k, s_k[DP], S_k[DP*DP]]
 inline int64_t stat_stride(int DP) { return 1 + (int64_t)DP + (int64_t)DP * DP; }

@@ -832,6 +832,10 @@ static hipError_t launch_estep_t(const EstepLaunch& a, hipStream_t stream) {
   if constexpr (DP >= 32) {
     if (a.DC == DP - 8) return a.sparse ? launch_estep_s<DP, DP - 8, true>(a, stream) : launch_estep_s<DP, DP - 8, false>(a, stream);
   }
+  if constexpr (DP == 32 || DP == 48) {  // (active widths in steps of four columns at the two narrowest layouts)
+    if (a.DC == DP - 4) return a.sparse ? launch_estep_s<DP, DP - 4, true>(a, stream) : launch_estep_s<DP, DP - 4, false>(a, stream);
+    if (a.DC == DP - 12) return a.sparse ? launch_estep_s<DP, DP - 12, true>(a, stream) : launch_estep_s<DP, DP - 12, false>(a, stream);
+  }
   if (a.DC != 0 && a.DC != DP) return hipErrorInvalidValue;
   return a.sparse ? launch_estep_s<DP, DP, true>(a, stream) : launch_estep_s<DP, DP, false>(a, stream);
 }

@@ -949,6 +949,10 @@ static hipError_t launch_ss_feat_d(const SuffstatLaunch& a, hipStream_t stream) 
 }
 template <int DP>
 static hipError_t launch_ss_feat_w(const SuffstatLaunch& a, hipStream_t stream) {
+  if constexpr (DP <= 48) {
+    if (a.DC == DP - 4) return launch_ss_feat_d<DP, DP - 4>(a, stream);
+    if (a.DC == DP - 12) return launch_ss_feat_d<DP, DP - 12>(a, stream);
+  }
   if (a.DC == DP - 8) return launch_ss_feat_d<DP, DP - 8>(a, stream);
   if (a.DC != 0 && a.DC != DP) return hipErrorInvalidValue;
   return launch_ss_feat_d<DP, DP>(a, stream);
@@ -1219,6 +1223,10 @@ static hipError_t launch_ss_quad_d(const SuffstatLaunch& a, hipStream_t stream) 
 }
 template <int DP>
 static hipError_t launch_ss_quad_w(const SuffstatLaunch& a, hipStream_t stream) {
+  if constexpr (DP <= 48) {
+    if (a.DC == DP - 4) return launch_ss_quad_d<DP, DP - 4>(a, stream);
+    if (a.DC == DP - 12) return launch_ss_quad_d<DP, DP - 12>(a, stream);
+  }
   if (a.DC == DP - 8) return launch_ss_quad_d<DP, DP - 8>(a, stream);
   if (a.DC != 0 && a.DC != DP) return hipErrorInvalidValue;
   return launch_ss_quad_d<DP, DP>(a, stream);

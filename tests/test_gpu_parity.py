@@ -86,6 +86,9 @@ def test_vbem_fixed_matches_golden(estep_cases):
                                       # the in-between layouts (48, 80, 96 and 112 columns)
                                       (600, 40, 7, 2), (901, 48, 9, 1), (450, 80, 5, 3), (500, 96, 4, 1),
                                       (333, 70, 6, 1), (512, 110, 3, 2),
+                                      # active widths (round 6): 20, 28, 36, 44 columns of the 32- / 48-column layouts, 56, 72, 104 beyond
+                                      (700, 18, 6, 1), (650, 27, 11, 2), (800, 35, 5, 1), (500, 42, 14, 1), (600, 53, 7, 1), (480, 66, 4, 2),
+                                      (400, 100, 3, 1),
                                       # ragged K: the last cluster slice of the statistics pass runs row-split
                                       (1500, 64, 9, 1), (900, 64, 10, 3), (700, 128, 9, 1), (640, 96, 5, 2),
                                       (800, 32, 17, 1), (4000, 16, 33, 1), (300, 64, 1, 1), (500, 48, 2, 2),

@@ -20,7 +20,7 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 fails, t0 = [], time.time()
 for case in range(cases):
-    D = int(rng.choice([1, 3, 8, 16, 17, 32, 33, 47, 64, 65, 96, 128, 130, 192, 300]))
+    D = int(rng.choice([1, 3, 8, 16, 17, 23, 27, 32, 33, 42, 47, 53, 64, 65, 85, 96, 128, 130, 192, 300]))
     K = int(rng.choice([1, 2, 3, 5, 8, 9, 16, 17, 32, 33, 47, 64, 65, 100]))
     J = int(rng.choice([1, 1, 2, 3, 7, 31]))
     Ntot = int(rng.integers(1, max(2, int(3e8 / (K * D * D + 2000)))))

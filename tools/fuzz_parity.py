@@ -110,6 +110,23 @@ for case in range(cases):
         if any(near_tie(w.Nk) for w in wo):
             skipped_ties += 1
             continue
+    if (not ok or not dq < 1e-6) and wf is not o.Dirichlet and iters > 1 and np.all(np.isfinite(tro)):
+        # ... and a tie in an EARLIER iteration reaches F one iteration later (the two sides then run on different E[log pi]
+        # from there on: seed 202 case 465, hard assignments, counts 4, 4, 3, 3, 3, 2, ...).  The traces have to agree up to
+        # and including the first iteration whose counts tie; what follows says nothing about the kernels.
+        def near_tie2(nk):
+            v = np.sort(np.asarray(nk, dtype=float))[::-1]
+            a, b = v[:-1], v[1:]
+            return bool(np.any((np.abs(a - b) <= 1e-9 * np.maximum(np.abs(a), 1e-300)) & (a > 1e-12)))
+        tied_at = None
+        for t in range(1, iters):
+            _, _, _, wt, _ = o.vbem_fixed(X, q0, wf, 1.0, t, sparse, cf)
+            if any(near_tie2(w.Nk) for w in wt):
+                tied_at = t
+                break
+        if tied_at is not None and np.allclose(tr[:tied_at], tro[:tied_at], rtol=1e-8, atol=0):
+            skipped_ties += 1
+            continue
     if not ok or not dq < 1e-6:
         if os.environ.get("LC_FUZZ_ONLY"):
             np.savez("gpurun_out/fuzz_case.npz", **{f"X{g}": x for g, x in enumerate(X)}, **{f"q0{g}": x for g, x in enumerate(q0)},

@@ -8,7 +8,7 @@
 #   * tools/sanitize/host_hammer.cpp: M-step pool, block cache / cache_release_thread, heap and shared-memory all-reduce
 #     with 1-8 ranks incl. one rank aborting and a left-over rendezvous object, the failing-shard path of learn_sharded;
 #   * (asan) pytest -m "not gpu" with the sanitized library loaded through LC_LIB_PATH.
-# Logs: profiles/r05_sanitize_{asan_ubsan,tsan}.log.  Exit status 0 = both clean.
+# Logs: profiles/r06_sanitize_{asan_ubsan,tsan}.log.  Exit status 0 = both clean.
 set -u
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="$ROOT/tools/sanitize/_build"
@@ -49,7 +49,7 @@ build() {  # $1 = tag, $2 = sanitizer flags
 }
 
 if [ "$WHAT" = asan ] || [ "$WHAT" = all ]; then
-  LOG="$ROOT/profiles/r05_sanitize_asan_ubsan.log"
+  LOG="$ROOT/profiles/r06_sanitize_asan_ubsan.log"
   {
     echo "# tools/sanitize_host.sh asan -- $(date -u +%FT%TZ) -- source hash $HASH"
     echo "# -fsanitize=address,undefined over the host translation units + host halves of the .hip files, HIP runtime = tools/sanitize/hip_host_stub.cpp"
@@ -70,7 +70,7 @@ if [ "$WHAT" = asan ] || [ "$WHAT" = all ]; then
 fi
 
 if [ "$WHAT" = tsan ] || [ "$WHAT" = all ]; then
-  LOG="$ROOT/profiles/r05_sanitize_tsan.log"
+  LOG="$ROOT/profiles/r06_sanitize_tsan.log"
   {
     echo "# tools/sanitize_host.sh tsan -- $(date -u +%FT%TZ) -- source hash $HASH"
     echo "# -fsanitize=thread over the same objects"

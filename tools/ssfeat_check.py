@@ -16,11 +16,14 @@ CASES = [(1000, 64, 17), (4099, 64, 20), (777, 50, 24), (30001, 64, 29), (65536,
          (5000, 32, 17), (9001, 20, 33), (7000, 48, 32), (6007, 40, 70), (5003, 80, 24), (4001, 70, 64), (4999, 96, 32),
          (3001, 112, 40), (6000, 128, 32), (5001, 128, 64), (2000, 100, 65), (3000, 64, 64), (2500, 64, 45),
          # D = 128: ranges of 64 clusters in one pass (16 quads), full and ragged, one and two ranges
-         (3000, 128, 57), (2777, 120, 60), (2100, 128, 128), (1900, 128, 121)]
+         (3000, 128, 57), (2777, 120, 60), (2100, 128, 128), (1900, 128, 121),
+         # active widths below the padded one (round 6): 28, 36, 44 columns (20 is the (9001, 20, 33) case above), 56, 88
+         (5000, 27, 20), (4000, 35, 24), (4000, 44, 28), (3000, 55, 32), (2500, 85, 20)]
 # few clusters (K <= 16) at D <= 64: suffstat_quad_kernel's instances (1, 2, 4 parts per quad; both active widths per layout)
 QUAD_CASES = [(1000, 23, 16), (4099, 32, 8), (777, 20, 4), (30001, 24, 12), (5000, 48, 12), (123, 40, 3), (9001, 33, 16),
               (7000, 48, 16), (6007, 64, 8), (5003, 56, 4), (4001, 64, 16), (3000, 64, 12), (2500, 17, 1), (40001, 30, 5),
-              (2000, 64, 2), (3001, 47, 9), (65536, 28, 13), (1027, 50, 6), (31, 64, 7), (8000, 57, 15)]
+              (2000, 64, 2), (3001, 47, 9), (65536, 28, 13), (1027, 50, 6), (31, 64, 7), (8000, 57, 15), (3000, 43, 8), (2222, 18, 10),
+              (1500, 36, 16)]
 if os.environ.get("LC_SSCHECK_CASES") == "quad":
     CASES = QUAD_CASES
 TIMING = [(2000000, 64, 17), (2000000, 64, 20), (2000000, 64, 24), (4000000, 32, 20), (2000000, 48, 24), (4000000, 32, 32), (4000000, 32, 40), (2000000, 48, 32), (2000000, 48, 48), (2000000, 64, 32), (2000000, 64, 28),
