@@ -52,8 +52,9 @@ typedef struct lc_tmodel lc_tmodel; /* two-level (SCM / MCM) model: qY, qZ, weig
 const char* lc_last_error(void);
 int lc_version(void);
 /* Name of the device kernel a dense Gauss-Wishart statistics pass (updateSS, src/cluster.cpp:53-82) runs for D columns
- * and K clusters: "suffstat_kernel" (per-cluster form) or "suffstat_feat_kernel" (feature GEMM) -- what a profiler will
- * list; bench.py prices that kernel. */
+ * and K clusters: "suffstat_kernel" (per-cluster form), "suffstat_feat_kernel" (feature GEMM) or "suffstat_quad_kernel"
+ * (3 <= K <= 16 at D = 17 ... 64: four clusters in the four blocks of one matrix instruction) -- what a profiler will list;
+ * bench.py prices that kernel. */
 const char* lc_statistics_kernel_name(int D, int K);
 /* hash of the sources this binary was built from (libcluster_amd/build.py::source_hash); the Python loader compares it
  * with the tree it sits in and rebuilds or refuses a stale binary */
