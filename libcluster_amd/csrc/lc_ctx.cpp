@@ -1521,71 +1521,71 @@ bool Context::recompute_bounded(int K, const std::vector<int>& changed, const st
   // The path's own buffers (up to a third of X, gathered) are not part of the room question estep_cache asked: when the
   // device says no, the ordinary pass runs (it overwrites whatever the selection wrote) -- never an error out of learn*()
   try {
-  bs_need_.reserve((size_t)NP_);
-  b.need = bs_need_.p;
-  LC_HIP(lck::launch_bound_select(b, stream_));
-  RowSelection sel;
-  select_rows_col(bs_need_.p, 0.5, sel);
-  if (trace) {
-    std::cerr << "[cache] bounded recomputation: " << sel.M << " of " << NP_ << " rows for " << nch << " columns; usable " << nusable
-              << ", T " << b.T;
-    for (int t = 0; t < nch; ++t) std::cerr << " | col " << changed[(size_t)t] << " sigma " << b.sigma[t] << " |b| " << b.bnorm[t] << " c " << b.cnew[t];
-    std::cerr << std::endl;
-  }
-  if (sel.M * 3 > NP_) return false;  // (most rows: the ordinary pass is the cheaper one, and overwrites the -inf entries)
-  bound_rows_ += sel.M;
-  bound_passes_ += 1;
-  if (sel.M == 0) return true;
-  // the selected rows side by side, the ordinary raw E-step on them, the results back to their rows
-  const int64_t Mp = (sel.M + lck::RG - 1) / lck::RG * lck::RG;
-  bs_x_.reserve((size_t)Mp * DP_);
-  bs_out_.reserve((size_t)Mp * nch);
-  if (Mp > sel.M) LC_HIP(hipMemsetAsync(bs_x_.p + (size_t)sel.M * DP_, 0, (size_t)(Mp - sel.M) * DP_ * sizeof(double), stream_));
-  LC_HIP(lck::launch_gather_rows_plain(X_.p, DP_, sel.idx.p, sel.M, bs_x_.p, stream_));
-  std::vector<double> A2((size_t)nch * AA), m2((size_t)nch * D);
-  for (int t = 0; t < nch; ++t) {
-    std::copy(A + (size_t)changed[(size_t)t] * AA, A + (size_t)(changed[(size_t)t] + 1) * AA, A2.begin() + (size_t)t * AA);
-    std::copy(m + (size_t)changed[(size_t)t] * D, m + (size_t)(changed[(size_t)t] + 1) * D, m2.begin() + (size_t)t * D);
-  }
-  const std::vector<double> zero((size_t)nch, 0.0);
-  const int64_t PS = lck::estep_pstride(DP_, DC_);  // (the wide layout beyond DP = 128: ADVICE r5, high)
-  pack_estep_params(nch, A2.data(), m2.data(), zero.data());
-  params_.reserve(hpack_.size());
-  LC_HIP(hipMemcpyAsync(params_.p, hpack_.data(), hpack_.size() * sizeof(double), hipMemcpyHostToDevice, stream_));
-  const int64_t nrg = Mp / lck::RG, grid = lck::estep_grid(DP_, nrg);
-  fzpart_.reserve((size_t)std::max<int64_t>(grid, 1));
-  lck::EstepLaunch a;
-  a.DP = DP_;
-  a.DC = DC_;
-  a.X = bs_x_.p;
-  a.nrg = nrg;
-  a.rginfo = nullptr;
-  a.nrows = sel.M;
-  a.params = params_.p;
-  a.ctab = params_.p + (size_t)nch * PS;
-  a.K = nch;
-  a.qZ = bs_out_.p;
-  a.ldq = Mp;
-  a.fz_part = fzpart_.p;
-  a.ll_part = nullptr;
-  a.raw = 1;
-  EvPair ev{};
-  if (timing_) {
-    ev.a = timing_event();
-    ev.b = timing_event();
-    ev.kind = 0;
-    LC_HIP(hipEventRecord(ev.a, stream_));
-  }
-  LC_HIP(lck::launch_estep(a, stream_));
-  if (timing_) {
-    LC_HIP(hipEventRecord(ev.b, stream_));
-    pending_.push_back(ev);
-  }
-  double* dp[lck::BOUND_MAX_COLS];
-  for (int t = 0; t < nch; ++t) dp[t] = b.dest[t];
-  LC_HIP(lck::launch_scatter_cols(bs_out_.p, Mp, nch, dp, sel.idx.p, sel.M, stream_));
-  LC_HIP(hipStreamSynchronize(stream_));  // (the packed parameters and `sel` are about to go)
-  return true;
+    bs_need_.reserve((size_t)NP_);
+    b.need = bs_need_.p;
+    LC_HIP(lck::launch_bound_select(b, stream_));
+    RowSelection sel;
+    select_rows_col(bs_need_.p, 0.5, sel);
+    if (trace) {
+      std::cerr << "[cache] bounded recomputation: " << sel.M << " of " << NP_ << " rows for " << nch << " columns; usable " << nusable
+                << ", T " << b.T;
+      for (int t = 0; t < nch; ++t) std::cerr << " | col " << changed[(size_t)t] << " sigma " << b.sigma[t] << " |b| " << b.bnorm[t] << " c " << b.cnew[t];
+      std::cerr << std::endl;
+    }
+    if (sel.M * 3 > NP_) return false;  // (most rows: the ordinary pass is the cheaper one, and overwrites the -inf entries)
+    bound_rows_ += sel.M;
+    bound_passes_ += 1;
+    if (sel.M == 0) return true;
+    // the selected rows side by side, the ordinary raw E-step on them, the results back to their rows
+    const int64_t Mp = (sel.M + lck::RG - 1) / lck::RG * lck::RG;
+    bs_x_.reserve((size_t)Mp * DP_);
+    bs_out_.reserve((size_t)Mp * nch);
+    if (Mp > sel.M) LC_HIP(hipMemsetAsync(bs_x_.p + (size_t)sel.M * DP_, 0, (size_t)(Mp - sel.M) * DP_ * sizeof(double), stream_));
+    LC_HIP(lck::launch_gather_rows_plain(X_.p, DP_, sel.idx.p, sel.M, bs_x_.p, stream_));
+    std::vector<double> A2((size_t)nch * AA), m2((size_t)nch * D);
+    for (int t = 0; t < nch; ++t) {
+      std::copy(A + (size_t)changed[(size_t)t] * AA, A + (size_t)(changed[(size_t)t] + 1) * AA, A2.begin() + (size_t)t * AA);
+      std::copy(m + (size_t)changed[(size_t)t] * D, m + (size_t)(changed[(size_t)t] + 1) * D, m2.begin() + (size_t)t * D);
+    }
+    const std::vector<double> zero((size_t)nch, 0.0);
+    const int64_t PS = lck::estep_pstride(DP_, DC_);  // (the wide layout beyond DP = 128: ADVICE r5, high)
+    pack_estep_params(nch, A2.data(), m2.data(), zero.data());
+    params_.reserve(hpack_.size());
+    LC_HIP(hipMemcpyAsync(params_.p, hpack_.data(), hpack_.size() * sizeof(double), hipMemcpyHostToDevice, stream_));
+    const int64_t nrg = Mp / lck::RG, grid = lck::estep_grid(DP_, nrg);
+    fzpart_.reserve((size_t)std::max<int64_t>(grid, 1));
+    lck::EstepLaunch a;
+    a.DP = DP_;
+    a.DC = DC_;
+    a.X = bs_x_.p;
+    a.nrg = nrg;
+    a.rginfo = nullptr;
+    a.nrows = sel.M;
+    a.params = params_.p;
+    a.ctab = params_.p + (size_t)nch * PS;
+    a.K = nch;
+    a.qZ = bs_out_.p;
+    a.ldq = Mp;
+    a.fz_part = fzpart_.p;
+    a.ll_part = nullptr;
+    a.raw = 1;
+    EvPair ev{};
+    if (timing_) {
+      ev.a = timing_event();
+      ev.b = timing_event();
+      ev.kind = 0;
+      LC_HIP(hipEventRecord(ev.a, stream_));
+    }
+    LC_HIP(lck::launch_estep(a, stream_));
+    if (timing_) {
+      LC_HIP(hipEventRecord(ev.b, stream_));
+      pending_.push_back(ev);
+    }
+    double* dp[lck::BOUND_MAX_COLS];
+    for (int t = 0; t < nch; ++t) dp[t] = b.dest[t];
+    LC_HIP(lck::launch_scatter_cols(bs_out_.p, Mp, nch, dp, sel.idx.p, sel.M, stream_));
+    LC_HIP(hipStreamSynchronize(stream_));  // (the packed parameters and `sel` are about to go)
+    return true;
   } catch (const AllocFailure&) {
     (void)hipGetLastError();
     LC_HIP(hipStreamSynchronize(stream_));
