@@ -1009,7 +1009,7 @@ __host__ __device__ constexpr int sq_part_max(int DC, int NPART) {
   }
   return m;
 }
-constexpr int SQ_BR = 32, SQ_QLD = 18;
+constexpr int SQ_BR = 32, SQ_QLD = 18;  // (rows per staged batch: 16 measures 1-7 % slower, 64 3-20 % -- the blocks a CU holds)
 inline int sq_npart(int DP, int K) {  // parts per cluster quad (the instances launch_ss_quad has)
   const int nq = (K + 3) / 4;
   if (DP > 48) return 4;  // (D = 64: two parts per quad need more than 256 registers)
