@@ -107,9 +107,18 @@ __global__ void __launch_bounds__(WAVES * 64, EstepOcc<DP>::BLOCKS) estep_kernel
     for (int jt = 0; jt < NT; ++jt) xf[r][jt] = xr[4 * jt];
   }
   bool myok = false;  // ROWLANES: this lane's row group exists
+  int owngrp = 0;     // ROWLANES: ... and its group
 #pragma unroll
   for (int r = 0; r < R; ++r)
-    if (hi == r) myok = rgok[r];
+    if (hi == r) myok = rgok[r], owngrp = grp[r];
+  // ROWLANES: selector operands of the epilogue's chain (A[i][k] = 1 for i == r: D[i = hi][j] += sum_k d2_r[k][j] lands in
+  // the lanes of row group hi == r only) -- four registers for the whole kernel, as fused_small_kernel keeps them
+  double selA[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    selA[r] = (lane & 3) == r ? 1.0 : 0.0;
+    asm volatile("" : "+v"(selA[r]));
+  }
 
   // The next cluster's record, global -> LDS without staging registers: 16 bytes per lane and instruction land at LDS
   // address M0 + 16 * lane; a round of the block moves NTHR * 16 bytes.  M0 is written here behind the compiler's back (it
@@ -246,6 +255,8 @@ __global__ void __launch_bounds__(WAVES * 64, EstepOcc<DP>::BLOCKS) estep_kernel
       const double* ck = a.ctab + k;  // (scalar)
 #pragma unroll
       for (int r = 0; r < R; ++r) asm volatile("global_load_dwordx2 %0, %1, %2" : "=&v"(cv[r]) : "v"(coff[r]), "s"(ck) : "memory");
+    } else if constexpr (ROWLANES) {
+      cv[0] = a.ctab[(int64_t)owngrp * K + k];  // (the lane's own row group's constant: one load, not R)
     } else {
 #pragma unroll
       for (int r = 0; r < R; ++r) cv[r] = a.ctab[(int64_t)grp[r] * K + k];
@@ -290,20 +301,26 @@ __global__ void __launch_bounds__(WAVES * 64, EstepOcc<DP>::BLOCKS) estep_kernel
       if constexpr (R == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(cv[0]), "+v"(cv[1]), "+v"(cv[2])::"memory");
       else asm volatile("s_waitcnt vmcnt(0)" : "+v"(cv[0]), "+v"(cv[R > 1 ? 1 : 0])::"memory");
     }
+    if constexpr (ROWLANES) {
+      // Lane (lo4, hi) wants row group hi's distance: four CHAINED selector MFMAs leave sum_k d2_r[k][row] in the lanes with
+      // hi == r and nothing else (round 6; four independent sums + four selects + four multiply-adds before).  The sum of a
+      // row group is the one mfma4(1.0, d2[r], 0.0) forms -- the chain adds exact zeros to it: the same bits.
+      double t = mfma4(selA[0], d2[0], 0.0);
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      // sum over the four hi lanes on the matrix pipe: D[i][j] = sum_k 1 * B[k][j] leaves the
-      // total in every lane (B[k=hi][j=row] is exactly where the partial sums live)
-      const double dd = mfma4(1.0, d2[r], 0.0);
-      const double lq = cv[r] - 0.5 * dd;
-      if constexpr (ROWLANES) {
-        if (hi == r) lqsel = lq;
-      } else {
+      for (int r = 1; r < R; ++r) t = mfma4(selA[r], d2[r], t);
+      lqsel = cv[0] - 0.5 * t;
+      mx[0] = fmax(mx[0], lqsel);  // (one maximum per cluster; fmax: lqsel is one instruction behind an MFMA result -- see max_raw)
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        // sum over the four hi lanes on the matrix pipe: D[i][j] = sum_k 1 * B[k][j] leaves the
+        // total in every lane (B[k=hi][j=row] is exactly where the partial sums live)
+        const double dd = mfma4(1.0, d2[r], 0.0);
+        const double lq = cv[r] - 0.5 * dd;
         mx[r] = max_raw(mx[r], lq);
         lqprev[r] = lq;
       }
     }
-    if constexpr (ROWLANES) mx[0] = max_raw(mx[0], lqsel);  // (the lane's own row group only: one maximum per cluster, not R)
     kprev = k;
     // R == 4: lane (lo4, hi) keeps row group hi -- ONE 512-byte store per cluster column instead of four
     // 128-byte ones, and the normalisation below needs no cross-lane sums
