@@ -783,7 +783,7 @@ struct EstepCfg;
 template <>
 struct EstepCfg<16> { static constexpr int R = 4, WAVES = 4; };
 template <>
-struct EstepCfg<32> { static constexpr int R = 4, WAVES = 4; };  // (8-wave blocks: 15-30 % slower at every narrow shape, round 6)
+struct EstepCfg<32> { static constexpr int R = 4, WAVES = 4; };  // (8-wave blocks: 15-30 % slower at every narrow shape, 2-wave blocks 0-20 %: round 6)
 template <>
 struct EstepCfg<48> { static constexpr int R = 4, WAVES = 4; };
 template <>
