@@ -653,8 +653,8 @@ void Context::qz_clone_to_alt() {
   QZ& a = qz_[cur_ ^ 1];
   const int Ksave = qz_[cur_].K;
   // The copy a rejected candidate left behind differs from the original in that candidate's rows only: with fingerprints
-  // on both sides (the moved-row sweeps keep them) only those rows are copied (qz_resync_kernel) -- 0.1 ms instead of
-  // the 1.7 ms a clone of 2.6 GB takes, once per candidate.  LC_SPLIT_NO_QHASH / LC_SPLIT_FULL_CLONE (tests): always the
+  // on both sides (the moved-row sweeps keep them) only those rows are copied (qz_resync_kernel) -- 0.6 ms instead of
+  // the 1.2-1.7 ms a clone of 2.6 GB takes, once per candidate (N = 10M, K = 32: the candidate's 312 k rows lie scattered).  LC_SPLIT_NO_QHASH / LC_SPLIT_FULL_CLONE (tests): always the
   // full copy; the two must agree in every bit (tests/test_gpu_splitsearch.py).
   static const bool full_only = lck::test_switch("LC_SPLIT_FULL_CLONE") != nullptr;
   if (!full_only && NP_ > 0 && Ksave >= 1 && qz_[cur_].hash_ok && a.hash_ok && a.buf.p && a.hash.p && qz_[cur_].hash.p &&
@@ -1532,7 +1532,7 @@ bool Context::recompute_bounded(int K, const std::vector<int>& changed, const st
       for (int t = 0; t < nch; ++t) std::cerr << " | col " << changed[(size_t)t] << " sigma " << b.sigma[t] << " |b| " << b.bnorm[t] << " c " << b.cnew[t];
       std::cerr << std::endl;
     }
-    if (sel.M * 3 > NP_) return false;  // (most rows: the ordinary pass is the cheaper one, and overwrites the -inf entries)
+    if (sel.M * 3 > NP_) return false;  // (most rows: the ordinary pass is the cheaper one, and overwrites the bounds just written)
     bound_rows_ += sel.M;
     bound_passes_ += 1;
     if (sel.M == 0) return true;

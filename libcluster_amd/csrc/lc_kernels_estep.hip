@@ -830,8 +830,7 @@ static hipError_t launch_estep_s(const EstepLaunch& a, hipStream_t stream) {
   size_t shmem = (size_t)(2 * pstride(DC) + WAVES * a.K + WAVES + 64) * sizeof(double) +
                  (size_t)(2 * a.K + WAVES * R + 2) * sizeof(int);
   EstepLaunch b = a;
-  static const size_t lq_cap0 = test_switch("LC_ES_LQLDS_KB") ? (size_t)atoi(test_switch("LC_ES_LQLDS_KB")) * 1024 : ES_LQ_LDS_CAP;
-  const size_t lq_cap = lq_cap0;
+  static const size_t lq_cap = test_switch("LC_ES_LQLDS_KB") ? (size_t)atoi(test_switch("LC_ES_LQLDS_KB")) * 1024 : ES_LQ_LDS_CAP;
   if (R == 4 && !a.raw && shmem + (size_t)a.K * WAVES * 64 * sizeof(double) <= lq_cap) {
     b.lq_lds = 1;  // log q~ stays in LDS until the normalisation
     shmem += (size_t)a.K * WAVES * 64 * sizeof(double);
