@@ -930,11 +930,6 @@ void Context::estep(int K, const double* A, const double* m, const double* c, do
     qz_[cur_].K = K;
   }
   const int64_t nrg = NP_ / lck::RG;
-  const int64_t grid = lck::estep_grid(DP, nrg);
-  fzpart_.reserve((size_t)std::max<int64_t>(grid, 1));
-  llpart_.reserve((size_t)std::max<int64_t>(grid, 1) * K);
-  red_.reserve((size_t)1 + K);
-
   lck::EstepLaunch a;
   a.DP = DP;
   a.DC = DC_;
@@ -947,11 +942,15 @@ void Context::estep(int K, const double* A, const double* m, const double* c, do
   a.K = K;
   a.qZ = target ? target : qz_[cur_].buf.p;
   a.ldq = NP_;
-  a.fz_part = fzpart_.p;
-  a.ll_part = LLk ? llpart_.p : nullptr;
   a.raw = raw ? 1 : 0;
   for (size_t t = 0; t < (size_t)J_ * K && !a.sparse; ++t)
     if (c[t] == -std::numeric_limits<double>::infinity()) a.sparse = 1;
+  const int64_t grid = lck::estep_grid(a);  // (a function of the whole launch: shape, raw, sparse)
+  fzpart_.reserve((size_t)std::max<int64_t>(grid, 1));
+  llpart_.reserve((size_t)std::max<int64_t>(grid, 1) * K);
+  red_.reserve((size_t)1 + K);
+  a.fz_part = fzpart_.p;
+  a.ll_part = LLk ? llpart_.p : nullptr;
   EvPair ev{};
   if (timing_) {
     ev.a = timing_event();
@@ -1552,8 +1551,7 @@ bool Context::recompute_bounded(int K, const std::vector<int>& changed, const st
     pack_estep_params(nch, A2.data(), m2.data(), zero.data());
     params_.reserve(hpack_.size());
     LC_HIP(hipMemcpyAsync(params_.p, hpack_.data(), hpack_.size() * sizeof(double), hipMemcpyHostToDevice, stream_));
-    const int64_t nrg = Mp / lck::RG, grid = lck::estep_grid(DP_, nrg);
-    fzpart_.reserve((size_t)std::max<int64_t>(grid, 1));
+    const int64_t nrg = Mp / lck::RG;
     lck::EstepLaunch a;
     a.DP = DP_;
     a.DC = DC_;
@@ -1566,9 +1564,11 @@ bool Context::recompute_bounded(int K, const std::vector<int>& changed, const st
     a.K = nch;
     a.qZ = bs_out_.p;
     a.ldq = Mp;
-    a.fz_part = fzpart_.p;
     a.ll_part = nullptr;
     a.raw = 1;
+    const int64_t grid = lck::estep_grid(a);
+    fzpart_.reserve((size_t)std::max<int64_t>(grid, 1));
+    a.fz_part = fzpart_.p;
     EvPair ev{};
     if (timing_) {
       ev.a = timing_event();

@@ -92,7 +92,9 @@ struct EstepLaunch {
   int lq_lds = 0;        // filled in by launch_estep: log q~ waits in LDS (D <= 48, small K) instead of in qZ
 };
 int estep_rows_per_block(int DP);
-int64_t estep_grid(int DP, int64_t nrg);
+// blocks of the launch (and partial sums the caller provides): a function of the WHOLE launch -- DP, DC, K, raw, sparse, nrg
+// have to be set (D = 64 / 80 run four row groups per wave where the log q~ table fits in LDS: other rows per block)
+int64_t estep_grid(const EstepLaunch& a);
 hipError_t launch_estep(const EstepLaunch& a, hipStream_t stream);
 
 // ---- small observations: E-step + the next iteration's statistics in one persistent pass (lc_kernels_fused.hip) ----

@@ -50,13 +50,13 @@ constexpr int ES_PF = 4;  // LDS reads in flight ahead of their use (2...10 are 
 // sum exp(x-max), log+max, exp(x - logZ).
 // blocks per CU the register budget is set for.  D = 64: three row groups per wave (96 VGPRs of X fragments) at
 // three waves per SIMD measured 22.2 ms against 22.6 for four row groups at two waves per SIMD (N=10M, K=32).
-template <int DP>
-struct EstepOcc { static constexpr int BLOCKS = DP == 64 ? 3 : 2; };
+template <int DP, int R>
+struct EstepOcc { static constexpr int BLOCKS = DP == 64 && R == 3 ? 3 : 2; };
 
 // DC <= DP: the active width (estep_active_width, lc_kernels.h) -- the row stride of X stays DP, the tile rows walked and
 // the parameter record are those of DC columns.
 template <int DP, int DC, int R, int WAVES, bool SPARSE>
-__global__ void __launch_bounds__(WAVES * 64, EstepOcc<DP>::BLOCKS) estep_kernel(EstepLaunch a) {
+__global__ void __launch_bounds__(WAVES * 64, (EstepOcc<DP, R>::BLOCKS)) estep_kernel(EstepLaunch a) {
   static_assert(DC % 4 == 0 && DC <= DP && DC > DP - 16, "active width");
   constexpr int NT = DC / 4;
   constexpr int NTILES = NT * (NT + 1) / 2;
@@ -758,7 +758,7 @@ constexpr int WIDE_R = 2, WIDE_WAVES = 4;
 static hipError_t launch_estep_wide(const EstepLaunch& a, hipStream_t stream) {
   if (a.DP % 64) return hipErrorInvalidValue;
   const size_t shmem = (size_t)(2 * WIDE_CHUNK + WIDE_WAVES * a.K + WIDE_WAVES) * sizeof(double);
-  const int64_t grid = estep_grid(a.DP, a.nrg);
+  const int64_t grid = estep_grid(a);
   if (grid <= 0) return hipSuccess;
   static LdsGrant grants[3];
   auto go = [&](auto kern, LdsGrant& grant) {
@@ -815,30 +815,45 @@ int estep_rows_per_block(int DP) {
   return -1;
 }
 
-int64_t estep_grid(int DP, int64_t nrg) {
-  const int64_t rgpb = estep_rows_per_block(DP) / RG;
-  return (nrg + rgpb - 1) / rgpb;
-}
-
 // log q~ waits in LDS up to this block size (LC_ES_LQLDS_KB, test-hooks library: A/B).  Round 6: 40 -> 80 KB, two blocks per CU.
 // With ONE exponential per entry on that path the table pays although the occupancy halves: D = 32, K = 16 2.16 -> 2.00 ms
 // (N = 6M), K = 32 4.07 -> 3.86; D = 48, K = 12 2.68 -> 2.51 (N = 5M), K = 28 5.75 -> 5.45; D = 23, K = 24 2.26 -> 2.13 (gpurun_out/r06m)
 constexpr size_t ES_LQ_LDS_CAP = 80 * 1024;
-template <int DP, int DC, bool SPARSE>
+static size_t estep_lq_cap() {
+  static const size_t cap = test_switch("LC_ES_LQLDS_KB") ? (size_t)atoi(test_switch("LC_ES_LQLDS_KB")) * 1024 : ES_LQ_LDS_CAP;
+  return cap;
+}
+static size_t estep_lds_base(int DC, int K, int R, int WAVES) {
+  return (size_t)(2 * pstride(DC) + WAVES * K + WAVES + 64) * sizeof(double) + (size_t)(2 * K + WAVES * R + 2) * sizeof(int);
+}
+// D = 64 and 80 (three row groups per wave by default): the FOUR-row-group scheme with its log q~ table in LDS, one
+// exponential per entry and the selector-chain epilogue wins where that table fits next to the two parameter records (D = 64:
+// K <= 21, D = 80: K <= 12) from six clusters on -- D = 64, N = 4M: K = 8 2.30 -> 2.25 ms, K = 12 3.35 -> 3.25, K = 16 4.31 -> 4.19
+// (0.82 -> 0.85 of the peak), K = 20 5.31 -> 5.19; K = 4 loses 2 % and keeps three (gpurun_out/r06r).  Dense, normalising
+// launches only.  ONE decision for the launch and for the grid the caller sizes its partial sums by (estep_grid).
+static bool estep_four_groups(const EstepLaunch& a) {
+  static const bool off = test_switch("LC_ES_R4") && atoi(test_switch("LC_ES_R4")) == 0;  // (tests: the default scheme everywhere)
+  if (off || (a.DP != 64 && a.DP != 80) || a.raw || a.sparse || a.K < 6) return false;
+  const int DC = a.DC > 0 ? a.DC : a.DP;
+  return estep_lds_base(DC, a.K, 4, 4) + (size_t)a.K * 4 * 64 * sizeof(double) <= estep_lq_cap();
+}
+int64_t estep_grid(const EstepLaunch& a) {
+  const int64_t rgpb = (a.DP <= 128 && estep_four_groups(a) ? 4 * 4 * RG : estep_rows_per_block(a.DP)) / RG;
+  return (a.nrg + rgpb - 1) / rgpb;
+}
+
+template <int DP, int DC, bool SPARSE, int R = EstepCfg<DP>::R, int WAVES = EstepCfg<DP>::WAVES>
 static hipError_t launch_estep_s(const EstepLaunch& a, hipStream_t stream) {
-  constexpr int R = EstepCfg<DP>::R, WAVES = EstepCfg<DP>::WAVES;
-  size_t shmem = (size_t)(2 * pstride(DC) + WAVES * a.K + WAVES + 64) * sizeof(double) +
-                 (size_t)(2 * a.K + WAVES * R + 2) * sizeof(int);
+  size_t shmem = estep_lds_base(DC, a.K, R, WAVES);
   EstepLaunch b = a;
-  static const size_t lq_cap = test_switch("LC_ES_LQLDS_KB") ? (size_t)atoi(test_switch("LC_ES_LQLDS_KB")) * 1024 : ES_LQ_LDS_CAP;
-  if (R == 4 && !a.raw && shmem + (size_t)a.K * WAVES * 64 * sizeof(double) <= lq_cap) {
+  if (R == 4 && !a.raw && shmem + (size_t)a.K * WAVES * 64 * sizeof(double) <= estep_lq_cap()) {
     b.lq_lds = 1;  // log q~ stays in LDS until the normalisation
     shmem += (size_t)a.K * WAVES * 64 * sizeof(double);
   }
   auto kern = estep_kernel<DP, DC, R, WAVES, SPARSE>;
   static LdsGrant grant;  // largest dynamic-LDS size already granted, per device
   if (hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(kern), shmem, grant); e != hipSuccess) return e;
-  const int64_t grid = estep_grid(DP, a.nrg);
+  const int64_t grid = estep_grid(a);
   if (grid <= 0) return hipSuccess;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVES * 64), shmem, stream, b);
   return hipGetLastError();
@@ -846,6 +861,12 @@ static hipError_t launch_estep_s(const EstepLaunch& a, hipStream_t stream) {
 
 template <int DP>
 static hipError_t launch_estep_t(const EstepLaunch& a, hipStream_t stream) {
+  if constexpr (DP == 64 || DP == 80) {
+    if (estep_four_groups(a)) {
+      if (a.DC == DP - 8) return launch_estep_s<DP, DP - 8, false, 4, 4>(a, stream);
+      if (a.DC == 0 || a.DC == DP) return launch_estep_s<DP, DP, false, 4, 4>(a, stream);
+    }
+  }
   if constexpr (DP >= 32) {
     if (a.DC == DP - 8) return a.sparse ? launch_estep_s<DP, DP - 8, true>(a, stream) : launch_estep_s<DP, DP - 8, false>(a, stream);
   }

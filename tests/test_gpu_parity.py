@@ -89,6 +89,8 @@ def test_vbem_fixed_matches_golden(estep_cases):
                                       # active widths (round 6): 20, 28, 36, 44 columns of the 32- / 48-column layouts, 56, 72, 104 beyond
                                       (700, 18, 6, 1), (650, 27, 11, 2), (800, 35, 5, 1), (500, 42, 14, 1), (600, 53, 7, 1), (480, 66, 4, 2),
                                       (400, 100, 3, 1),
+                                      # D = 64 / 80: four row groups per wave where the log q~ table fits in LDS (K = 6 ... 21 / 12), three beyond
+                                      (700, 64, 16, 2), (640, 64, 21, 1), (500, 64, 22, 1), (520, 80, 12, 1), (520, 72, 8, 2), (400, 80, 13, 1),
                                       # ragged K: the last cluster slice of the statistics pass runs row-split
                                       (1500, 64, 9, 1), (900, 64, 10, 3), (700, 128, 9, 1), (640, 96, 5, 2),
                                       (800, 32, 17, 1), (4000, 16, 33, 1), (300, 64, 1, 1), (500, 48, 2, 2),
