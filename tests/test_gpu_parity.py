@@ -438,7 +438,7 @@ def test_randomised_parity_fuzz():
     import os
 
     root = Path(__file__).resolve().parents[1]
-    n = os.environ.get("LC_FUZZ_CASES", "50")  # (the suite's share; tools/fuzz_*.py run thousands per round: profiles/rNN_fuzz.log)
+    n = os.environ.get("LC_FUZZ_CASES", "30")  # (the suite's share; tools/fuzz_*.py run thousands per round: profiles/rNN_fuzz.log)
     r = subprocess.run([sys.executable, str(root / "tools" / "fuzz_parity.py"), n, "7"], capture_output=True,
                        text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
