@@ -154,6 +154,7 @@ struct SuffstatLaunch {
   int KR = 0;
   int slice0 = 0, rs = 1, klast0 = 0, nklast = 0;  // filled in by launch_suffstat for the row-split launch of the last slice
   // wide observations (DP > 128), filled in by launch_suffstat: the kernel works on 64-column panels
+  int* occ_out = nullptr;         // suffstat_plan's question to the few-cluster kernel: resident blocks per CU of the instance this launch would take (nothing is launched)
   int64_t ldx = 0;                // row stride of X
   int DPW = 0, colA = 0, colB = 0;  // record width, first column of the A-side / B-side panel
 };

@@ -1204,6 +1204,12 @@ static hipError_t launch_ss_quad_p(const SuffstatLaunch& a, hipStream_t stream) 
   auto kern = suffstat_quad_kernel<DP, DC, NPART>;
   static LdsGrant grant;
   if (hipError_t e = grant_dynamic_lds(reinterpret_cast<const void*>(kern), shmem, grant); e != hipSuccess) return e;
+  if (a.occ_out) {  // (suffstat_plan: how many blocks of this instance a CU holds)
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, shmem) != hipSuccess || per_cu < 1) per_cu = 2;
+    *a.occ_out = per_cu;
+    return hipSuccess;
+  }
   SuffstatLaunch b = a;
   b.nslice = sq_nslice(DP, a.K);
   if (b.KR < a.K) b.KR = a.K;
@@ -1340,7 +1346,7 @@ int suffstat_plan(int DP, int64_t NP, int K, int64_t* chunk_rows, int DC) {
   // whose last round of resident blocks is half empty loses that much of the launch.  Config 5 (D = 128, K = 64: 17 blocks
   // per chunk) ran 127 chunks = 2159 blocks = 8.43 rounds of 256 -- 6 % of the pass idle; 120 chunks are 7.97 rounds.
   // Among the chunk counts down to 80 % of the wanted one, take the fullest last round (the larger count on ties).
-  if (DP <= 128 && ss_feat_eligible(DP, K, DC) && NP >= 64 * 1024) {
+  if (DP <= 128 && !ss_quad_eligible(DP, K) && ss_feat_eligible(DP, K, DC) && NP >= 64 * 1024) {
     const int range = ft_range(DP, K), nq = ((K < range ? K : range) + 3) / 4;
     const int nqi = nq > 8 ? 16 : nq > 4 ? nq : nq > 2 ? 4 : 2;  // the instance launch_ss_feat_d takes
     const int nslice = ft_nslice(DP, DC > 0 ? DC : DP, nqi);
@@ -1358,6 +1364,41 @@ int suffstat_plan(int DP, int64_t NP, int K, int64_t* chunk_rows, int DC) {
         if (fill(n2) > best + 1e-9) best = fill(n2), n = n2, rows = r2;
       }
     }
+  }
+  // ... and the few-cluster kernel (sq_nslice blocks per chunk, 2 - 4 resident per CU): N = 5M, D = 48, K = 12 ran 684 chunks = 2052
+  // blocks = 2.67 rounds of 768
+  if (ss_quad_eligible(DP, K) && NP >= 64 * 1024) {
+    static std::atomic<int> occ_cache[8 * 16 * 4];  // [layout][active-width step][parts]: resident blocks per CU, asked once
+    const int dc = DC > 0 ? DC : DP, np = sq_npart(DP, K);
+    const int slot = ((DP / 16) % 8) * 64 + (((DP - dc) / 4) % 16) * 4 + (np == 1 ? 0 : np == 2 ? 1 : 2);
+    int per_cu = occ_cache[slot].load(std::memory_order_relaxed);
+    if (per_cu <= 0) {
+      SuffstatLaunch q{};
+      q.DP = DP;
+      q.DC = dc;
+      q.K = K;
+      q.nchunks = 1;
+      q.occ_out = &per_cu;
+      if (launch_ss_quad(q, nullptr) != hipSuccess || per_cu < 1) per_cu = 2;
+      occ_cache[slot].store(per_cu, std::memory_order_relaxed);
+    }
+    const int nslice = sq_nslice(DP, K);
+    const int64_t slots = (int64_t)current_device_cus() * per_cu;
+    auto fill = [&](int64_t chunks) {
+      const int64_t blocks = chunks * nslice, rounds = (blocks + slots - 1) / slots;
+      return (double)blocks / (double)(rounds * slots);
+    };
+    // (chunk counts from 80 % to 125 % of the wanted one, the nearest first: three blocks per chunk on 768 slots have no
+    //  full round between 512 and 768 chunks)
+    double best = fill(n);
+    for (int64_t d = 1; best < 0.985 && d * 4 <= want; ++d)
+      for (int sgn = -1; sgn <= 1; sgn += 2) {
+        const int64_t w = want + sgn * d;
+        if (w < 1 || (sgn < 0 && w * 5 < want * 4) || w > maxchunks || (sgn > 0 && w > cap)) continue;  // (cap: the partial records' memory)
+        int64_t r2 = 0;
+        const int64_t n2 = plan(w, &r2);
+        if (fill(n2) > best + 1e-9) best = fill(n2), n = n2, rows = r2;
+      }
   }
   *chunk_rows = rows;
   return (int)n;
