@@ -121,6 +121,10 @@ hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) {
   return hipSuccess;
 }
 hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* numBlocks, const void*, int, size_t) {  // (suffstat_plan's question)
+  if (numBlocks) *numBlocks = 2;
+  return hipSuccess;
+}
 hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t*, void*) { return hipErrorNotSupported; }
 hipError_t hipMemcpyFromSymbol(void*, const void*, size_t, size_t, hipMemcpyKind) { return hipErrorNotSupported; }
 hipError_t hipGetDevicePropertiesR0600(hipDeviceProp_tR0600* prop, int) {
