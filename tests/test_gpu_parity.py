@@ -791,3 +791,55 @@ def test_quad_statistics_kernel_at_every_instance(lib):
             assert c["eN"] < 1e-12 and c["es"] < 1e-12 and c["eS"] < 1e-12, (mode, c)
         sums.append([c["h"] for c in cases])
     np.testing.assert_allclose(sums[0], sums[1], rtol=1e-11)
+
+
+_R4_SNIPPET = r"""
+import json, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from libcluster_amd import capi
+rng = np.random.default_rng({seed})
+N, D, K = {N}, {D}, {K}
+mu = rng.normal(0, 1.2, (K, D))
+z = rng.integers(0, K, N)
+X = mu[z] + rng.normal(size=(N, D))
+q0 = rng.dirichlet(np.ones(K) * 0.5, N)
+with capi.Context(0) as ctx:
+    ctx.set_data(X)
+    ctx.set_qz(q0)
+    F, tr, model = ctx.vbem(capi.W_STICKBREAK, 1.0, 1.0, fixed_iters=3)
+    q = ctx.get_qz([N])[0]
+    model.close()
+np.save({out!r}, q)
+print(json.dumps(dict(F=[float(v) for v in tr])))
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,D,K", [(150_000, 64, 16), (120_000, 57, 8), (100_000, 80, 12), (90_000, 72, 7), (100_001, 64, 21)])
+def test_four_row_group_estep_at_64_and_80_columns_agrees_with_the_three_row_group_one(N, D, K, tmp_path):
+    """D = 64 / 80 with 6 ... 21 / 12 clusters run estep_kernel's four-row-group scheme (log q~ table in LDS, one
+    exponential per entry, selector-chain epilogue: lc_kernels_estep.hip, estep_four_groups) since round 6; LC_ES_R4=0
+    (test-hooks library) keeps three row groups per wave.  On inputs far beyond the oracle's reach the two must agree to
+    rounding (one against two exponentials per entry: a few ulp in q) over three whole iterations -- both are held to the
+    oracle at small sizes by the random-shape test above."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    hooked = str(root / "libcluster_amd" / "lib" / "libcluster_hip_testhooks.so")
+    res = []
+    for tag, env in (("r4", {}), ("r3", {"LC_LIB_PATH": hooked, "LC_ES_R4": "0"})):
+        out = str(tmp_path / f"q_{tag}.npy")
+        r = subprocess.run([sys.executable, "-c", _R4_SNIPPET.format(root=str(root), seed=N + D + K, N=N, D=D, K=K, out=out)],
+                           capture_output=True, text=True, timeout=600, env=dict(os.environ, **env), cwd=str(root))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        res.append((json.loads(r.stdout.strip().splitlines()[-1])["F"], np.load(out)))
+    (Fa, qa), (Fb, qb) = res
+    np.testing.assert_allclose(Fa, Fb, rtol=1e-13)
+    big = qb > 1e-200
+    assert np.max(np.abs(qa[big] - qb[big]) / qb[big]) < 1e-11
+    assert not np.array_equal(qa, qb) or K < 6  # (two different sweeps: if every bit agreed the switch would not have switched)
