@@ -257,6 +257,7 @@ void Context::build_layout(int J, const int64_t* Nj, int D) {
   D_ = D;
   DP_ = DP;
   DC_ = lck::estep_active_width(D, DP);
+  if (lck::test_switch("LC_FULL_WIDTH")) DC_ = DP;  // (tests, libcluster_hip_testhooks.so only: every kernel walks the padded width)
   Nj_.assign(Nj, Nj + J);
   goff_.assign(J + 1, 0);
   Ntot_ = 0;

@@ -843,3 +843,33 @@ def test_four_row_group_estep_at_64_and_80_columns_agrees_with_the_three_row_gro
     big = qb > 1e-200
     assert np.max(np.abs(qa[big] - qb[big]) / qb[big]) < 1e-11
     assert not np.array_equal(qa, qb) or K < 6  # (two different sweeps: if every bit agreed the switch would not have switched)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,D,K", [(120_000, 23, 16), (150_000, 18, 8), (100_000, 40, 20), (90_000, 56, 8), (60_000, 72, 24), (80_000, 35, 5),
+                                   (50_000, 104, 12)])
+def test_active_width_agrees_with_the_padded_width(N, D, K, tmp_path):
+    """The E-step and the statistics kernels walk the 4-column tiles of D rounded up to 8 (to 4 up to 48 columns), not those
+    of the 16-column padding (lc_kernels.h, estep_active_width; round 6).  LC_FULL_WIDTH (test-hooks library) makes every
+    kernel walk the padded width as round 5 did: the skipped products are 0 x 0, so three whole iterations must agree to
+    the rounding of sums taken over another number of row chunks -- on inputs far beyond the oracle's reach (the oracle
+    holds both at small sizes)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    hooked = str(root / "libcluster_amd" / "lib" / "libcluster_hip_testhooks.so")
+    res = []
+    for tag, env in (("active", {}), ("padded", {"LC_LIB_PATH": hooked, "LC_FULL_WIDTH": "1"})):
+        out = str(tmp_path / f"q_{tag}.npy")
+        r = subprocess.run([sys.executable, "-c", _R4_SNIPPET.format(root=str(root), seed=N + D + K, N=N, D=D, K=K, out=out)],
+                           capture_output=True, text=True, timeout=600, env=dict(os.environ, **env), cwd=str(root))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        res.append((json.loads(r.stdout.strip().splitlines()[-1])["F"], np.load(out)))
+    (Fa, qa), (Fb, qb) = res
+    np.testing.assert_allclose(Fa, Fb, rtol=1e-12)
+    big = qb > 1e-200
+    assert np.max(np.abs(qa[big] - qb[big]) / qb[big]) < 1e-9
