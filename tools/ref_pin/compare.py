@@ -15,6 +15,10 @@ import numpy as np
 ROOT = Path(__file__).resolve().parents[2]
 ref = json.loads(Path(sys.argv[1]).read_text())
 ora = json.loads((ROOT / "tests" / "golden" / "xcat_traces.json").read_text())
+# the separable families' learners on the same data (round 6): their oracle records live in family_traces.json
+fam = json.loads((ROOT / "tests" / "golden" / "family_traces.json").read_text())
+for _name in ("learnDGMM", "learnDGMC", "learnBEMM", "learnEGMC"):
+    ora.setdefault(_name, fam[_name])
 worst, bad = 0.0, []
 for name, r in ref.items():
     o = ora.get(name)
@@ -29,7 +33,7 @@ for name, r in ref.items():
     dF = abs(r["F"] - o["F"]) / max(1.0, abs(o["F"]))
     line.append(f"rel dF {dF:.2e}")
     errs = {"F": dF}
-    for key in ("N", "means", "covs", "Elogweight", "qZ"):
+    for key in ("N", "means", "covs", "rates", "Elogweight", "qZ"):
         if key not in o:
             continue
         if key in ("Elogweight", "qZ"):  # per group (the single-matrix learners have one)
